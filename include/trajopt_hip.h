@@ -1,0 +1,302 @@
+/*
+ * trajopt_hip.h — C-ABI of libtrajopt_hip.so: MI355X-native batched trajectory-optimisation
+ * hot path (RK4 rollout -> dynamics/cost/constraint expansion -> backward Riccati ->
+ * forward line-search rollout -> iLQR / augmented-Lagrangian loop) for a BATCH of
+ * independent trajectories.
+ *
+ * This header is the drop-in boundary.  The reference (TrajectoryOptimization.jl v0.7.1,
+ * pure Julia) has no FFI; the entry points below are what a Julia `ccall` shim keeping the
+ * reference's type names (Problem / Objective / ConstraintList / KnotPoint) binds, one per
+ * operator of the reference's solver-facing API (see INTEGRATION.md for the shim):
+ *
+ *   to_rollout                  <- rollout!(prob)                       src/problem.jl:330-340
+ *   to_cost / to_stage_costs    <- cost(prob) / cost!(obj,Z)            src/problem.jl:321, src/objective.jl:89-106
+ *   to_cost_expansion           <- RD.gradient!/RD.hessian! per knot    src/cost_functions.jl:137-233, src/lie_costs.jl:78-95
+ *   to_evaluate_constraints     <- evaluate_constraints!                src/abstract_constraint.jl:200-225
+ *   to_constraint_jacobians     <- constraint_jacobians!                src/abstract_constraint.jl:236-248
+ *   to_cone_projection{,_jacobian,_hessian} <- projection!/∇projection!/∇²projection!  src/cones.jl:96-276
+ *   to_expand / to_backward / to_forward / to_ilqr_solve / to_al_solve
+ *                               <- the Altro.jl iLQR / AL loops that consume a Problem
+ *                                  (out of tree; SURVEY.md §8a rows E1,S1-S4)
+ *   to_set_* / to_get_*         <- initial_controls!/initial_states!/set_initial_state!/states/controls
+ *                                  src/problem.jl:198-310
+ *
+ * Conventions
+ *   - All floating point is IEEE double (reference: Problem{T<:AbstractFloat}, Float64 everywhere).
+ *   - Host arrays are CALLER-OWNED, in the reference's native layout: column-major, state index
+ *     fastest, then knot, then trajectory:   X[i + n*(k + N*b)],  U[j + m*(k + (N-1)*b)].
+ *     Knot indices inside descriptors are 1-based inclusive ranges like Julia `inds::UnitRange`
+ *     (src/constraint_list.jl:38); state/control indices (`inds`, `q_ind`) are 1-based too.
+ *   - Device memory is library-owned behind the handle, batch-fastest SoA.
+ *   - Every function returns int: 0 = ok, negative = error class mirroring the reference's
+ *     exception (to_status_code); text via to_last_error().  Nothing throws across the boundary.
+ *   - Integer outputs (iterations, status, line-search index, active flags) are int32.
+ *   - A handle owns one HIP stream and is not thread-safe (like Objective.J / tmpu scratch in
+ *     the reference, src/objective.jl:29, src/cost_functions.jl:431).
+ *   - There is NO CPU fallback: every compute entry point fails with TO_ERR_HIP when no HIP
+ *     device is usable.
+ */
+#ifndef TRAJOPT_HIP_H
+#define TRAJOPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TO_ABI_VERSION 1
+
+#define TO_MAX_N 16       /* max state dimension            */
+#define TO_MAX_M 8        /* max control dimension          */
+#define TO_MAX_P 40       /* max rows of one constraint     */
+#define TO_MAX_CON_PARAMS 400
+#define TO_MAX_CON_INDS 48
+
+/* ---- return codes ---------------------------------------------------------------------- */
+typedef enum {
+  TO_OK = 0,
+  TO_ERR_DIMENSION_MISMATCH = -1, /* Julia DimensionMismatch (src/problem.jl:64-68, src/constraint_list.jl:109) */
+  TO_ERR_ARGUMENT = -2,           /* Julia ArgumentError     (src/problem.jl:88, src/constraints.jl:712)       */
+  TO_ERR_ASSERTION = -3,          /* Julia AssertionError    (src/problem.jl:49-55)                            */
+  TO_ERR_HIP = -4,                /* HIP runtime failure / no device                                           */
+  TO_ERR_UNSUPPORTED = -5,        /* descriptor combination outside the hot-path scope                         */
+  TO_ERR_NULL = -6,               /* null pointer                                                              */
+  TO_ERR_CONE = -7                /* ErrorException("Invalid second-order cone projection") src/cones.jl:124    */
+} to_status_code;
+
+/* ---- per-trajectory solver status (Altro.jl TerminationStatus order) --------------------- */
+typedef enum {
+  TO_UNSOLVED = 0,
+  TO_LINESEARCH_FAIL = 1,
+  TO_SOLVE_SUCCEEDED = 2,
+  TO_MAX_ITERATIONS = 3,
+  TO_MAX_ITERATIONS_OUTER = 4,
+  TO_MAXIMUM_COST = 5,
+  TO_STATE_LIMIT = 6,
+  TO_CONTROL_LIMIT = 7,
+  TO_NO_PROGRESS = 8,
+  TO_COST_INCREASE = 9,
+  TO_REGULARIZATION_MAX = 10
+} to_solver_status;
+
+/* ---- models (RobotZoo.jl / examples, restated; SURVEY.md §8a R2,R3) ----------------------- */
+typedef enum {
+  TO_MODEL_DOUBLE_INTEGRATOR = 0, /* examples/quickstart.jl:11-23; n=2D, m=D; params[0]=mass, params[1]=D (1,2,3) */
+  TO_MODEL_CARTPOLE = 1,          /* docs/src/model.md:20-51; params = mc, mp, l, g                               */
+  TO_MODEL_QUADROTOR = 2          /* examples/Quadrotor.ipynb cells 4,8; params = mass, Jx,Jy,Jz, gx,gy,gz,
+                                     motor_dist, kf, km                                                           */
+} to_model_id;
+
+typedef enum { TO_RK4 = 0, TO_RK3 = 1, TO_EULER = 2 } to_integrator; /* default RK4: src/problem.jl:120 */
+
+/* ---- cost functions (src/cost_functions.jl, src/lie_costs.jl) ----------------------------- */
+typedef enum {
+  TO_COST_DIAGONAL = 0,      /* DiagonalCost      src/cost_functions.jl:326-346: Q,R hold diagonals     */
+  TO_COST_QUADRATIC = 1,     /* QuadraticCost     src/cost_functions.jl:422-453: dense Q (n x n), R (m x m), H (m x n), column-major */
+  TO_COST_DIAGONAL_QUAT = 2  /* DiagonalQuatCost  src/lie_costs.jl:34-55: diagonal + w*min(1 +/- q_ref'q) */
+} to_cost_kind;
+
+typedef struct {
+  int32_t kind;                     /* to_cost_kind */
+  int32_t terminal;                 /* the reference's `terminal` field; informational (terminal-ness of a knot is dt==0) */
+  double Q[TO_MAX_N * TO_MAX_N];    /* diagonal kinds: first n entries; QUADRATIC: n*n col-major (ld = n) */
+  double R[TO_MAX_M * TO_MAX_M];    /* diagonal kinds: first m entries; QUADRATIC: m*m col-major (ld = m) */
+  double H[TO_MAX_M * TO_MAX_N];    /* QUADRATIC only: m*n col-major (ld = m); cost term u'Hx            */
+  double q[TO_MAX_N];
+  double r[TO_MAX_M];
+  double c;
+  double w;                         /* DIAGONAL_QUAT */
+  double q_ref[4];                  /* DIAGONAL_QUAT: reference quaternion (w,x,y,z) */
+  int32_t q_ind[4];                 /* DIAGONAL_QUAT: 1-based state indices of the quaternion (default 4:7) */
+} to_cost_desc;
+
+/* ---- cones / constraint sense (src/cones.jl:17-61) --------------------------------------- */
+typedef enum {
+  TO_CONE_ZERO = 0,              /* Equality         */
+  TO_CONE_NEGATIVE_ORTHANT = 1,  /* Inequality c<=0  */
+  TO_CONE_SECOND_ORDER = 2,      /* [v; s], |v|<=s, scalar LAST */
+  TO_CONE_POSITIVE_ORTHANT = 3,
+  TO_CONE_IDENTITY = 4
+} to_cone;
+
+/* ---- constraints (src/constraints.jl) ----------------------------------------------------- */
+typedef enum {
+  TO_CON_GOAL = 0,    /* GoalConstraint  :22-87   sense Equality; inds[p] = state indices, params[0..p) = xf[inds]          */
+  TO_CON_BOUND = 1,   /* BoundConstraint :644-783 sense Inequality; params[0..n+m) = z_max, params[n+m..2(n+m)) = z_min
+                         (+/-inf allowed); rows ordered [finite max rows; finite min rows]                                  */
+  TO_CON_NORM = 2,    /* NormConstraint  :438-521 params[0] = val; inds[D] = indices into z=[x;u]; sense Equality /
+                         Inequality (c = |z[inds]|^2 - val^2, p=1) or SecondOrder (c = [z[inds]; val], p=D+1)                */
+  TO_CON_CIRCLE = 3,  /* CircleConstraint :168-233 sense Inequality; inds[0]=xi, inds[1]=yi; params = x[P], y[P], r[P]; p=P  */
+  TO_CON_SPHERE = 4,  /* SphereConstraint :249-326 inds = xi,yi,zi; params = x[P], y[P], z[P], r[P]                          */
+  TO_CON_LINEAR = 5   /* LinearConstraint :103-150 params = A (p x D col-major), then b[p]; inds[D] into z; sense Eq/Ineq    */
+} to_con_kind;
+
+typedef struct {
+  int32_t kind;     /* to_con_kind */
+  int32_t sense;    /* to_cone */
+  int32_t k_first;  /* 1-based inclusive knot range (ConstraintList.inds, src/constraint_list.jl:38) */
+  int32_t k_last;
+  int32_t p;        /* output dimension; 0 = let the library derive it; otherwise validated */
+  int32_t n_inds;
+  int32_t inds[TO_MAX_CON_INDS];
+  int32_t n_params;
+  double params[TO_MAX_CON_PARAMS];
+} to_constraint_desc;
+
+/* ---- problem (src/problem.jl:36-73) -------------------------------------------------------- */
+typedef struct {
+  int32_t abi_version; /* TO_ABI_VERSION */
+  int32_t model;       /* to_model_id   */
+  int32_t integrator;  /* to_integrator */
+  int32_t n, m;        /* state / control dims; validated against the model (RD.dims) */
+  int32_t N;           /* knot points  (N-1 models, src/problem.jl:49) */
+  int32_t B;           /* batch: number of independent trajectories held by this handle */
+  double model_params[16];
+  double t0, tf;       /* tf > t0 asserted (src/problem.jl:50); uniform dt = (tf-t0)/(N-1) unless dt given */
+  const double* dt;    /* optional [N-1] step sizes (test/problems_tests.jl:78-85), must sum to tf-t0; NULL = uniform */
+  int32_t n_costs;           /* number of distinct cost functions */
+  const to_cost_desc* costs; /* [n_costs] */
+  const int32_t* cost_index; /* [N] 0-based index into costs per knot (Objective.cost, src/objective.jl:28);
+                                NULL = Objective(stage, terminal, N): costs[0] for k<N, costs[1] at k=N (src/objective.jl:74-77) */
+  int32_t n_constraints;
+  const to_constraint_desc* constraints; /* ConstraintList order (src/constraint_list.jl:103-134) */
+} to_problem_desc;
+
+/* ---- solver options (names follow Altro.jl SolverOptions; examples/Cartpole.ipynb cell 17) -- */
+typedef struct {
+  /* iLQR */
+  double cost_tolerance;              /* 1e-4 */
+  double gradient_tolerance;          /* 10.0 */
+  int32_t iterations;                 /* 300: max inner iterations per iLQR solve */
+  int32_t dJ_counter_limit;           /* 10 */
+  int32_t iterations_linesearch;      /* 20 */
+  int32_t reserved0;
+  double line_search_lower_bound;     /* 1e-8 */
+  double line_search_upper_bound;     /* 10.0 */
+  double line_search_decrease_factor; /* 0.5 */
+  double bp_reg_initial;              /* 0.0 */
+  double bp_reg_increase_factor;      /* 1.6 */
+  double bp_reg_min;                  /* 1e-8 */
+  double bp_reg_max;                  /* 1e8 */
+  double bp_reg_fp;                   /* 10.0 */
+  double max_cost_value;              /* 1e8 */
+  double max_state_value;             /* 1e8 */
+  double max_control_value;           /* 1e8 */
+  /* augmented Lagrangian */
+  double constraint_tolerance;        /* 1e-6 */
+  double cost_tolerance_intermediate; /* 1e-4 */
+  double penalty_initial;             /* 1.0 */
+  double penalty_scaling;             /* 10.0 */
+  double penalty_max;                 /* 1e8 */
+  double dual_max;                    /* 1e8 */
+  int32_t iterations_outer;           /* 30 */
+  int32_t cost_dt_scaling;            /* 0 (v0.7 semantics, NEWS.md:11-12); 1 = legacy: stage costs multiplied by dt */
+  int32_t iterations_total;           /* 1000: cap on inner iterations summed over AL outer loops */
+  int32_t reserved1;
+} to_solver_opts;
+
+/* caller-allocated outputs of a solve; any pointer may be NULL */
+typedef struct {
+  int32_t* iterations;        /* [B] inner iLQR iterations performed by each trajectory */
+  int32_t* iterations_outer;  /* [B] AL outer iterations (0 for to_ilqr_solve) */
+  int32_t* status;            /* [B] to_solver_status */
+  double* cost;               /* [B] objective cost J at the solution (cost(prob), no AL terms) */
+  double* dJ;                 /* [B] last accepted cost decrease */
+  double* gradient;           /* [B] last iLQR gradient metric */
+  double* c_max;              /* [B] max constraint violation (0 without constraints) */
+  double* penalty_max;        /* [B] largest penalty used */
+  /* aggregates written by the library */
+  int64_t total_iterations;   /* sum_b iterations[b] (the numerator of the headline metric) */
+  int32_t batch_steps;        /* batch-synchronous device iterations executed */
+  int32_t reserved;
+  double solve_ms;            /* device time of the solve loop (hipEvent) */
+} to_solve_stats;
+
+typedef struct to_handle_s to_handle;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int to_abi_version(void);
+const char* to_last_error(void);
+int to_device_count(int* count);           /* number of usable HIP devices */
+int to_default_options(to_solver_opts* o); /* fill with the defaults documented above */
+
+/* ---- handle lifecycle --------------------------------------------------------------------- */
+/* Validates the descriptor exactly as the reference's constructors do (Problem inner ctor
+ * src/problem.jl:44-72, add_constraint! src/constraint_list.jl:103-134, BoundConstraint ctor
+ * src/constraints.jl:660-687, NormConstraint ctor :442-455) and allocates device storage on
+ * `device` (HIP ordinal).  opts may be NULL (defaults). */
+int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int device, to_handle** out);
+int to_destroy(to_handle* h);
+int to_set_options(to_handle* h, const to_solver_opts* opts);
+int to_get_options(const to_handle* h, to_solver_opts* opts);
+int to_sync(to_handle* h);                 /* block until the handle's stream is idle */
+void* to_stream(to_handle* h);             /* the hipStream_t the handle launches on */
+
+/* sizes */
+int to_dims(const to_handle* h, int32_t* n, int32_t* m, int32_t* n_err, int32_t* N, int32_t* B);
+int to_num_constraints(const to_handle* h, int32_t* p_per_knot /* [N], ConstraintList.p src/constraint_list.jl:44 */);
+
+/* ---- trajectory I/O (host layout (n,N,B) / (m,N-1,B) column-major) ------------------------- */
+int to_set_initial_state(to_handle* h, const double* x0 /* [n*B] */);  /* set_initial_state! src/problem.jl:275 */
+int to_set_controls(to_handle* h, const double* U /* [m*(N-1)*B] */);  /* initial_controls!  src/problem.jl:255-268 */
+int to_set_states(to_handle* h, const double* X /* [n*N*B] */);        /* initial_states!    src/problem.jl:242-253 */
+int to_set_controls_uniform(to_handle* h, const double* u /* [m] */);  /* initial_controls!(prob, u0) for every k and b */
+int to_get_states(to_handle* h, double* X);
+int to_get_controls(to_handle* h, double* U);
+int to_get_initial_state(to_handle* h, double* x0);
+/* device-to-device copies into caller-provided DEVICE buffers (same (n,N,B) layout), for RCCL all-gather */
+int to_get_states_device(to_handle* h, void* dX);
+int to_get_controls_device(to_handle* h, void* dU);
+/* goal / reference updates between solves (set_goal_state! src/problem.jl:294-310; set_LQR_goal! src/cost_functions.jl:249-258) */
+int to_set_cost(to_handle* h, int32_t cost_id, const to_cost_desc* cost);
+int to_set_constraint(to_handle* h, int32_t con_id, const to_constraint_desc* con);
+
+/* ---- the hot path, phase by phase ----------------------------------------------------------- */
+int to_rollout(to_handle* h);                                   /* rollout!  src/problem.jl:330-340 */
+int to_cost(to_handle* h, double* J /* [B] */);                  /* cost      src/objective.jl:89-93  */
+int to_stage_costs(to_handle* h, double* Jk /* [N*B], Objective.J */);
+int to_expand(to_handle* h);     /* dynamics Jacobians (error-state) + cost expansion (+AL terms) at the current (X,U) */
+int to_backward(to_handle* h);   /* Riccati recursion -> K, d, dV; regularises per trajectory */
+int to_forward(to_handle* h, int32_t* ls_index /* [B], -1 = failed */, double* J_new /* [B] */);
+int to_ilqr_solve(to_handle* h, to_solve_stats* stats);
+int to_al_solve(to_handle* h, to_solve_stats* stats);
+
+/* expansion / gain getters (parity + solver introspection); host layouts column-major:
+ *   A[ne,ne,N-1,B]  Bm[ne,m,N-1,B]  Qxx[ne,ne,N,B] Quu[m,m,N,B] Qux[m,ne,N,B] qx[ne,N,B] qu[m,N,B]
+ *   K[m,ne,N-1,B]   d[m,N-1,B]  dV[2,B]  rho[B]                                       */
+int to_get_dynamics_jacobians(to_handle* h, double* A, double* Bm);
+int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, double* qx, double* qu);
+int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho);
+
+/* raw (non error-state) per-knot cost derivatives of the objective at the current trajectory
+ * (RD.gradient! / RD.hessian!): grad[(n+m),N,B], hess[(n+m),(n+m),N,B] */
+int to_cost_expansion(to_handle* h, double* grad, double* hess);
+/* raw RK Jacobian [A B] of the discrete dynamics (RD.jacobian! on DiscretizedDynamics): F[n,(n+m),N-1,B] */
+int to_discrete_jacobian(to_handle* h, double* F);
+
+/* ---- constraints --------------------------------------------------------------------------- */
+/* evaluate_constraints! / constraint_jacobians! for constraint `con_id` over its knot range.
+ * vals[p, nk, B], jac[p, w, nk, B] with w = n (state constraints: GOAL, CIRCLE, SPHERE) or n+m (stage constraints),
+ * nk = k_last-k_first+1.  jac is fully written (zeros included). */
+int to_evaluate_constraints(to_handle* h, int32_t con_id, double* vals);
+int to_constraint_jacobians(to_handle* h, int32_t con_id, double* jac);
+int to_constraint_info(const to_handle* h, int32_t con_id, int32_t* p, int32_t* width, int32_t* nk, int32_t* sense);
+int to_max_violation(to_handle* h, double* c_max /* [B] */);
+int to_get_duals(to_handle* h, int32_t con_id, double* lambda /* [p,nk,B] */, double* mu /* [B] */);
+int to_set_duals(to_handle* h, int32_t con_id, const double* lambda, const double* mu);
+int to_reset_duals(to_handle* h);            /* lambda = 0, mu = penalty_initial */
+int to_dual_update(to_handle* h);            /* one AL dual + penalty update at the current trajectory */
+int to_al_cost(to_handle* h, double* J_al /* [B] objective + AL terms */);
+
+/* ---- cones, batched and stateless (src/cones.jl) --------------------------------------------- */
+/* x[dim,count] column-major. px[dim,count]; jac[dim,dim,count]; hess[dim,dim,count] with b[dim,count].
+ * status[count] (nullable): SOC branch 0=below 1=in 2=outside (cone_status src/cones.jl:278-291). */
+int to_cone_projection(int device, int32_t cone, int32_t dim, int64_t count, const double* x, double* px, int32_t* status);
+int to_cone_projection_jacobian(int device, int32_t cone, int32_t dim, int64_t count, const double* x, double* jac);
+int to_cone_projection_hessian(int device, int32_t cone, int32_t dim, int64_t count, const double* x, const double* b, double* hess);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAJOPT_HIP_H */

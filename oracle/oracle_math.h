@@ -1,0 +1,594 @@
+/*
+ * oracle_math.h — TEST INFRASTRUCTURE ONLY (CPU oracle).  Not part of the product; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build/load anything under oracle/.
+ *
+ * Plain scalar restatement of the arithmetic on the hot path:
+ *   - models:      double integrator (examples/quickstart.jl:11-23), Cartpole (docs/src/model.md:20-51),
+ *                  Quadrotor / RigidBody (examples/Quadrotor.ipynb cells 4,8)
+ *   - integrators: RK4 / RK3 / Euler (default RK4 src/problem.jl:120)
+ *   - analytic continuous Jacobians + exact RK Jacobian by the chain rule
+ *   - error-state maps for the quaternion model
+ *   - cones (src/cones.jl), costs (src/cost_functions.jl, src/lie_costs.jl), constraints (src/constraints.jl)
+ * Everything is runtime-dimensioned, dense, loop-based: deliberately the opposite of the GPU code's
+ * compile-time-specialised forward-mode implementation, so the two check each other.
+ */
+#ifndef ORACLE_MATH_H
+#define ORACLE_MATH_H
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../include/trajopt_hip.h"
+
+namespace oracle {
+
+constexpr int MAXN = TO_MAX_N;
+constexpr int MAXM = TO_MAX_M;
+constexpr int MAXZ = TO_MAX_N + TO_MAX_M;
+
+struct Model {
+  int id = 0;
+  int n = 0, m = 0, ne = 0; /* ne = error-state dim (RD.errstate_dim): n, or 12 for the quadrotor */
+  double p[16];
+};
+
+inline int model_dims(int id, const double* params, int* n, int* m, int* ne) {
+  switch (id) {
+    case TO_MODEL_DOUBLE_INTEGRATOR: {
+      int D = (int)params[1];
+      if (D < 1 || D > 3) return -1;
+      *n = 2 * D; *m = D; *ne = 2 * D; return 0;
+    }
+    case TO_MODEL_CARTPOLE: *n = 4; *m = 1; *ne = 4; return 0;
+    case TO_MODEL_QUADROTOR: *n = 13; *m = 4; *ne = 12; return 0;
+  }
+  return -1;
+}
+
+/* ---------------------------------------------------------------- continuous dynamics xdot = f(x,u) */
+inline void dynamics(const Model& M, const double* x, const double* u, double* xd) {
+  switch (M.id) {
+    case TO_MODEL_DOUBLE_INTEGRATOR: { /* examples/quickstart.jl:15-20 */
+      int D = M.m; double mass = M.p[0];
+      for (int i = 0; i < D; ++i) { xd[i] = x[D + i]; xd[D + i] = u[i] / mass; }
+      return;
+    }
+    case TO_MODEL_CARTPOLE: { /* docs/src/model.md:34-50 */
+      double mc = M.p[0], mp = M.p[1], l = M.p[2], g = M.p[3];
+      double qd1 = x[2], qd2 = x[3];
+      double s = std::sin(x[1]), c = std::cos(x[1]);
+      double h11 = mc + mp, h12 = mp * l * c, h21 = mp * l * c, h22 = mp * l * l;
+      double c12 = -mp * qd2 * l * s;
+      /* b = C*qd + G - B*u */
+      double b1 = (0.0 * qd1 + c12 * qd2) + 0.0 - 1.0 * u[0];
+      double b2 = (0.0 * qd1 + 0.0 * qd2) + mp * g * l * s - 0.0 * u[0];
+      /* StaticArrays 2x2 solve: x = ((a22 b1 - a12 b2)/d, (a11 b2 - a21 b1)/d) */
+      double d = h11 * h22 - h12 * h21;
+      double s1 = (h22 * b1 - h12 * b2) / d;
+      double s2 = (h11 * b2 - h21 * b1) / d;
+      xd[0] = qd1; xd[1] = qd2; xd[2] = -s1; xd[3] = -s2;
+      return;
+    }
+    case TO_MODEL_QUADROTOR: { /* RigidBody dynamics, world-frame velocity (bodyframe=false) */
+      double mass = M.p[0], J1 = M.p[1], J2 = M.p[2], J3 = M.p[3];
+      double g1 = M.p[4], g2 = M.p[5], g3 = M.p[6];
+      double L = M.p[7], kf = M.p[8], km = M.p[9];
+      double qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+      double w1 = x[10], w2 = x[11], w3 = x[12];
+      double F1 = std::fmax(0.0, kf * u[0]), F2 = std::fmax(0.0, kf * u[1]);
+      double F3 = std::fmax(0.0, kf * u[2]), F4 = std::fmax(0.0, kf * u[3]);
+      double Fz = F1 + F2 + F3 + F4; /* body-frame thrust [0,0,Fz] */
+      /* q*F, NOT normalised: (w^2 - v'v) r + 2 v (v'r) + 2 w (v x r) with r=(0,0,Fz) */
+      double vv = qx * qx + qy * qy + qz * qz;
+      double sc = qw * qw - vv;
+      double vr = qz * Fz;
+      double qF1 = sc * 0.0 + 2.0 * qx * vr + 2.0 * qw * (qy * Fz - qz * 0.0);
+      double qF2 = sc * 0.0 + 2.0 * qy * vr + 2.0 * qw * (qz * 0.0 - qx * Fz);
+      double qF3 = sc * Fz + 2.0 * qz * vr + 2.0 * qw * (qx * 0.0 - qy * 0.0);
+      double Fw1 = mass * g1 + qF1, Fw2 = mass * g2 + qF2, Fw3 = mass * g3 + qF3;
+      double t1 = L * (F2 - F4), t2 = L * (F3 - F1);
+      double t3 = km * u[0] - km * u[1] + km * u[2] - km * u[3];
+      /* rdot = v */
+      xd[0] = x[7]; xd[1] = x[8]; xd[2] = x[9];
+      /* qdot = 0.5 * q (x) (0, omega) */
+      xd[3] = 0.5 * (-qx * w1 - qy * w2 - qz * w3);
+      xd[4] = 0.5 * (qw * w1 + qy * w3 - qz * w2);
+      xd[5] = 0.5 * (qw * w2 - qx * w3 + qz * w1);
+      xd[6] = 0.5 * (qw * w3 + qx * w2 - qy * w1);
+      /* vdot = F/m */
+      xd[7] = Fw1 / mass; xd[8] = Fw2 / mass; xd[9] = Fw3 / mass;
+      /* omegadot = Jinv (tau - omega x J omega) */
+      double Jw1 = J1 * w1, Jw2 = J2 * w2, Jw3 = J3 * w3;
+      xd[10] = (1.0 / J1) * (t1 - (w2 * Jw3 - w3 * Jw2));
+      xd[11] = (1.0 / J2) * (t2 - (w3 * Jw1 - w1 * Jw3));
+      xd[12] = (1.0 / J3) * (t3 - (w1 * Jw2 - w2 * Jw1));
+      return;
+    }
+  }
+}
+
+/* analytic continuous Jacobians fx (n x n), fu (n x m), row-major [i*n + j] / [i*m + j] */
+inline void dynamics_jacobian(const Model& M, const double* x, const double* u, double* fx, double* fu) {
+  const int n = M.n, m = M.m;
+  std::memset(fx, 0, sizeof(double) * n * n);
+  std::memset(fu, 0, sizeof(double) * n * m);
+  switch (M.id) {
+    case TO_MODEL_DOUBLE_INTEGRATOR: {
+      int D = M.m; double mass = M.p[0];
+      for (int i = 0; i < D; ++i) { fx[i * n + D + i] = 1.0; fu[(D + i) * m + i] = 1.0 / mass; }
+      return;
+    }
+    case TO_MODEL_CARTPOLE: {
+      double mc = M.p[0], mp = M.p[1], l = M.p[2], g = M.p[3];
+      double om = x[3];
+      double s = std::sin(x[1]), c = std::cos(x[1]);
+      double a11 = mc + mp, a12 = mp * l * c, a22 = mp * l * l;
+      double b1 = -mp * l * s * om * om - u[0];
+      double b2 = mp * g * l * s;
+      double d = a11 * a22 - a12 * a12;
+      double x1 = (a22 * b1 - a12 * b2) / d;
+      double x2 = (a11 * b2 - a12 * b1) / d;
+      /* d/dtheta */
+      double db1 = -mp * l * c * om * om, db2 = mp * g * l * c, da12 = -mp * l * s;
+      double dd = -2.0 * a12 * da12;
+      double dx1_t = (a22 * db1 - da12 * b2 - a12 * db2) / d - x1 * dd / d;
+      double dx2_t = (a11 * db2 - da12 * b1 - a12 * db1) / d - x2 * dd / d;
+      /* d/domega */
+      double db1_o = -2.0 * mp * l * s * om;
+      double dx1_o = a22 * db1_o / d, dx2_o = -a12 * db1_o / d;
+      fx[0 * 4 + 2] = 1.0; fx[1 * 4 + 3] = 1.0;
+      fx[2 * 4 + 1] = -dx1_t; fx[2 * 4 + 3] = -dx1_o;
+      fx[3 * 4 + 1] = -dx2_t; fx[3 * 4 + 3] = -dx2_o;
+      /* d/du: db1/du = -1 */
+      fu[2] = a22 / d; fu[3] = -a12 / d;
+      return;
+    }
+    case TO_MODEL_QUADROTOR: {
+      double mass = M.p[0], J1 = M.p[1], J2 = M.p[2], J3 = M.p[3];
+      double L = M.p[7], kf = M.p[8], km = M.p[9];
+      double qw = x[3], qx = x[4], qy = x[5], qz = x[6];
+      double w1 = x[10], w2 = x[11], w3 = x[12];
+      double dF[4], Fz = 0.0;
+      for (int i = 0; i < 4; ++i) { dF[i] = (kf * u[i] > 0.0) ? kf : 0.0; Fz += std::fmax(0.0, kf * u[i]); }
+      /* rdot = v */
+      fx[0 * 13 + 7] = 1.0; fx[1 * 13 + 8] = 1.0; fx[2 * 13 + 9] = 1.0;
+      /* qdot wrt q */
+      fx[3 * 13 + 4] = -0.5 * w1; fx[3 * 13 + 5] = -0.5 * w2; fx[3 * 13 + 6] = -0.5 * w3;
+      fx[4 * 13 + 3] = 0.5 * w1;  fx[4 * 13 + 5] = 0.5 * w3;  fx[4 * 13 + 6] = -0.5 * w2;
+      fx[5 * 13 + 3] = 0.5 * w2;  fx[5 * 13 + 4] = -0.5 * w3; fx[5 * 13 + 6] = 0.5 * w1;
+      fx[6 * 13 + 3] = 0.5 * w3;  fx[6 * 13 + 4] = 0.5 * w2;  fx[6 * 13 + 5] = -0.5 * w1;
+      /* qdot wrt omega */
+      fx[3 * 13 + 10] = -0.5 * qx; fx[3 * 13 + 11] = -0.5 * qy; fx[3 * 13 + 12] = -0.5 * qz;
+      fx[4 * 13 + 10] = 0.5 * qw;  fx[4 * 13 + 11] = -0.5 * qz; fx[4 * 13 + 12] = 0.5 * qy;
+      fx[5 * 13 + 10] = 0.5 * qz;  fx[5 * 13 + 11] = 0.5 * qw;  fx[5 * 13 + 12] = -0.5 * qx;
+      fx[6 * 13 + 10] = -0.5 * qy; fx[6 * 13 + 11] = 0.5 * qx;  fx[6 * 13 + 12] = 0.5 * qw;
+      /* vdot = g + a(q) Fz/m, a = q*(0,0,1) = (2(xz+wy), 2(yz-wx), w^2-x^2-y^2+z^2) */
+      double k = Fz / mass;
+      fx[7 * 13 + 3] = k * 2.0 * qy;  fx[7 * 13 + 4] = k * 2.0 * qz;  fx[7 * 13 + 5] = k * 2.0 * qw;  fx[7 * 13 + 6] = k * 2.0 * qx;
+      fx[8 * 13 + 3] = -k * 2.0 * qx; fx[8 * 13 + 4] = -k * 2.0 * qw; fx[8 * 13 + 5] = k * 2.0 * qz;  fx[8 * 13 + 6] = k * 2.0 * qy;
+      fx[9 * 13 + 3] = k * 2.0 * qw;  fx[9 * 13 + 4] = -k * 2.0 * qx; fx[9 * 13 + 5] = -k * 2.0 * qy; fx[9 * 13 + 6] = k * 2.0 * qz;
+      double a1 = 2.0 * (qx * qz + qw * qy), a2 = 2.0 * (qy * qz - qw * qx);
+      double a3 = qw * qw - qx * qx - qy * qy + qz * qz;
+      for (int i = 0; i < 4; ++i) {
+        fu[7 * 4 + i] = a1 * dF[i] / mass; fu[8 * 4 + i] = a2 * dF[i] / mass; fu[9 * 4 + i] = a3 * dF[i] / mass;
+      }
+      /* omegadot */
+      fx[10 * 13 + 11] = -(J3 - J2) * w3 / J1; fx[10 * 13 + 12] = -(J3 - J2) * w2 / J1;
+      fx[11 * 13 + 10] = -(J1 - J3) * w3 / J2; fx[11 * 13 + 12] = -(J1 - J3) * w1 / J2;
+      fx[12 * 13 + 10] = -(J2 - J1) * w2 / J3; fx[12 * 13 + 11] = -(J2 - J1) * w1 / J3;
+      /* tau = [L(F2-F4), L(F3-F1), km(u1-u2+u3-u4)] */
+      fu[10 * 4 + 1] = L * dF[1] / J1; fu[10 * 4 + 3] = -L * dF[3] / J1;
+      fu[11 * 4 + 2] = L * dF[2] / J2; fu[11 * 4 + 0] = -L * dF[0] / J2;
+      fu[12 * 4 + 0] = km / J3; fu[12 * 4 + 1] = -km / J3; fu[12 * 4 + 2] = km / J3; fu[12 * 4 + 3] = -km / J3;
+      return;
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- discrete dynamics */
+inline void discrete_dynamics(const Model& M, int integrator, const double* x, const double* u, double h, double* xn) {
+  const int n = M.n;
+  double k1[MAXN], k2[MAXN], k3[MAXN], k4[MAXN], xt[MAXN];
+  if (integrator == TO_EULER) {
+    dynamics(M, x, u, k1);
+    for (int i = 0; i < n; ++i) xn[i] = x[i] + k1[i] * h;
+    return;
+  }
+  if (integrator == TO_RK3) {
+    dynamics(M, x, u, k1); for (int i = 0; i < n; ++i) k1[i] *= h;
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] / 2;
+    dynamics(M, xt, u, k2); for (int i = 0; i < n; ++i) k2[i] *= h;
+    for (int i = 0; i < n; ++i) xt[i] = x[i] - k1[i] + 2 * k2[i];
+    dynamics(M, xt, u, k3); for (int i = 0; i < n; ++i) k3[i] *= h;
+    for (int i = 0; i < n; ++i) xn[i] = x[i] + (k1[i] + 4 * k2[i] + k3[i]) / 6;
+    return;
+  }
+  dynamics(M, x, u, k1); for (int i = 0; i < n; ++i) k1[i] *= h;
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] / 2;
+  dynamics(M, xt, u, k2); for (int i = 0; i < n; ++i) k2[i] *= h;
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] / 2;
+  dynamics(M, xt, u, k3); for (int i = 0; i < n; ++i) k3[i] *= h;
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i];
+  dynamics(M, xt, u, k4); for (int i = 0; i < n; ++i) k4[i] *= h;
+  for (int i = 0; i < n; ++i) xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+}
+
+/* C (r x c) = A (r x k) * B (k x c), all row-major */
+inline void matmul(const double* A, const double* B, double* C, int r, int k, int c) {
+  for (int i = 0; i < r; ++i)
+    for (int j = 0; j < c; ++j) {
+      double s = 0.0;
+      for (int t = 0; t < k; ++t) s += A[i * k + t] * B[t * c + j];
+      C[i * c + j] = s;
+    }
+}
+
+/* exact Jacobian of the RK step: A (n x n), Bm (n x m), row-major */
+inline void discrete_jacobian(const Model& M, int integrator, const double* x, const double* u, double h,
+                              double* A, double* Bm) {
+  const int n = M.n, m = M.m;
+  std::vector<double> fx(n * n), fu(n * m), T(n * n), Tu(n * m);
+  std::vector<double> D1x(n * n), D1u(n * m), D2x(n * n), D2u(n * m), D3x(n * n), D3u(n * m), D4x(n * n), D4u(n * m);
+  double k1[MAXN], k2[MAXN], k3[MAXN], xt[MAXN];
+  auto eye_plus = [&](const double* D, double scale, double* out) { /* out = I + scale*D */
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = (i == j ? 1.0 : 0.0) + scale * D[i * n + j];
+  };
+  /* stage 1 */
+  dynamics(M, x, u, k1);
+  dynamics_jacobian(M, x, u, fx.data(), fu.data());
+  for (int i = 0; i < n * n; ++i) D1x[i] = h * fx[i];
+  for (int i = 0; i < n * m; ++i) D1u[i] = h * fu[i];
+  if (integrator == TO_EULER) {
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = (i == j ? 1.0 : 0.0) + D1x[i * n + j];
+    for (int i = 0; i < n * m; ++i) Bm[i] = D1u[i];
+    return;
+  }
+  for (int i = 0; i < n; ++i) k1[i] *= h;
+  /* stage 2 at x + k1/2 */
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k1[i] / 2;
+  dynamics(M, xt, u, k2); for (int i = 0; i < n; ++i) k2[i] *= h;
+  dynamics_jacobian(M, xt, u, fx.data(), fu.data());
+  eye_plus(D1x.data(), 0.5, T.data());
+  matmul(fx.data(), T.data(), D2x.data(), n, n, n);
+  matmul(fx.data(), D1u.data(), Tu.data(), n, n, m);
+  for (int i = 0; i < n * n; ++i) D2x[i] *= h;
+  for (int i = 0; i < n * m; ++i) D2u[i] = h * (0.5 * Tu[i] + fu[i]);
+  if (integrator == TO_RK3) {
+    /* stage 3 at x - k1 + 2 k2 */
+    for (int i = 0; i < n; ++i) xt[i] = x[i] - k1[i] + 2 * k2[i];
+    dynamics_jacobian(M, xt, u, fx.data(), fu.data());
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+      T[i * n + j] = (i == j ? 1.0 : 0.0) - D1x[i * n + j] + 2.0 * D2x[i * n + j];
+    matmul(fx.data(), T.data(), D3x.data(), n, n, n);
+    std::vector<double> Du(n * m);
+    for (int i = 0; i < n * m; ++i) Du[i] = -D1u[i] + 2.0 * D2u[i];
+    matmul(fx.data(), Du.data(), Tu.data(), n, n, m);
+    for (int i = 0; i < n * n; ++i) D3x[i] *= h;
+    for (int i = 0; i < n * m; ++i) D3u[i] = h * (Tu[i] + fu[i]);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+      A[i * n + j] = (i == j ? 1.0 : 0.0) + (D1x[i * n + j] + 4.0 * D2x[i * n + j] + D3x[i * n + j]) / 6.0;
+    for (int i = 0; i < n * m; ++i) Bm[i] = (D1u[i] + 4.0 * D2u[i] + D3u[i]) / 6.0;
+    return;
+  }
+  /* stage 3 at x + k2/2 */
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k2[i] / 2;
+  dynamics(M, xt, u, k3); for (int i = 0; i < n; ++i) k3[i] *= h;
+  dynamics_jacobian(M, xt, u, fx.data(), fu.data());
+  eye_plus(D2x.data(), 0.5, T.data());
+  matmul(fx.data(), T.data(), D3x.data(), n, n, n);
+  matmul(fx.data(), D2u.data(), Tu.data(), n, n, m);
+  for (int i = 0; i < n * n; ++i) D3x[i] *= h;
+  for (int i = 0; i < n * m; ++i) D3u[i] = h * (0.5 * Tu[i] + fu[i]);
+  /* stage 4 at x + k3 */
+  for (int i = 0; i < n; ++i) xt[i] = x[i] + k3[i];
+  dynamics_jacobian(M, xt, u, fx.data(), fu.data());
+  eye_plus(D3x.data(), 1.0, T.data());
+  matmul(fx.data(), T.data(), D4x.data(), n, n, n);
+  matmul(fx.data(), D3u.data(), Tu.data(), n, n, m);
+  for (int i = 0; i < n * n; ++i) D4x[i] *= h;
+  for (int i = 0; i < n * m; ++i) D4u[i] = h * (Tu[i] + fu[i]);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+    A[i * n + j] = (i == j ? 1.0 : 0.0) + (D1x[i * n + j] + 2.0 * D2x[i * n + j] + 2.0 * D3x[i * n + j] + D4x[i * n + j]) / 6.0;
+  for (int i = 0; i < n * m; ++i) Bm[i] = (D1u[i] + 2.0 * D2u[i] + 2.0 * D3u[i] + D4u[i]) / 6.0;
+}
+
+/* ---------------------------------------------------------------- error state */
+/* G(x): n x ne row-major.  Identity for vector-space models. */
+inline void errstate_jacobian(const Model& M, const double* x, double* G) {
+  const int n = M.n, ne = M.ne;
+  std::memset(G, 0, sizeof(double) * n * ne);
+  if (M.id != TO_MODEL_QUADROTOR) { for (int i = 0; i < n; ++i) G[i * ne + i] = 1.0; return; }
+  for (int i = 0; i < 3; ++i) G[i * ne + i] = 1.0;
+  double w = x[3], a = x[4], b = x[5], c = x[6];
+  /* L(q) H : 4x3, no 1/2 factor (Cayley map) */
+  double LH[12] = {-a, -b, -c,  w, -c, b,  c, w, -a,  -b, a, w};
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) G[(3 + i) * ne + 3 + j] = LH[i * 3 + j];
+  for (int i = 0; i < 6; ++i) G[(7 + i) * ne + 6 + i] = 1.0;
+}
+
+/* dx (ne) = x (-) x0  (RD.state_diff with the Cayley map) */
+inline void state_diff(const Model& M, const double* x, const double* x0, double* dx) {
+  if (M.id != TO_MODEL_QUADROTOR) { for (int i = 0; i < M.n; ++i) dx[i] = x[i] - x0[i]; return; }
+  for (int i = 0; i < 3; ++i) dx[i] = x[i] - x0[i];
+  double w0 = x0[3], a0 = x0[4], b0 = x0[5], c0 = x0[6];
+  double w = x[3], a = x[4], b = x[5], c = x[6];
+  /* dq = conj(q0) (x) q */
+  double s = w0 * w + a0 * a + b0 * b + c0 * c;
+  double v1 = w0 * a - a0 * w - (b0 * c - c0 * b);
+  double v2 = w0 * b - b0 * w - (c0 * a - a0 * c);
+  double v3 = w0 * c - c0 * w - (a0 * b - b0 * a);
+  dx[3] = v1 / s; dx[4] = v2 / s; dx[5] = v3 / s;
+  for (int i = 0; i < 6; ++i) dx[6 + i] = x[7 + i] - x0[7 + i];
+}
+
+/* ---------------------------------------------------------------- cones (src/cones.jl) */
+/* returns SOC branch: 0 below, 1 in, 2 outside, -1 invalid (NaN) */
+inline int soc_status(const double* x, int dim) {
+  double s = x[dim - 1], a2 = 0.0;
+  for (int i = 0; i < dim - 1; ++i) a2 += x[i] * x[i];
+  double a = std::sqrt(a2);
+  if (a <= -s) return 0;
+  if (a <= s) return 1;
+  if (a >= std::fabs(s)) return 2;
+  return -1;
+}
+
+inline int cone_projection(int cone, const double* x, double* px, int dim) { /* src/cones.jl:96-127 */
+  switch (cone) {
+    case TO_CONE_IDENTITY: for (int i = 0; i < dim; ++i) px[i] = x[i]; return 0;
+    case TO_CONE_ZERO: for (int i = 0; i < dim; ++i) px[i] = 0.0; return 0;
+    case TO_CONE_NEGATIVE_ORTHANT: for (int i = 0; i < dim; ++i) px[i] = std::fmin(0.0, x[i]); return 0;
+    case TO_CONE_POSITIVE_ORTHANT: for (int i = 0; i < dim; ++i) px[i] = std::fmax(0.0, x[i]); return 0;
+    case TO_CONE_SECOND_ORDER: {
+      double s = x[dim - 1], a2 = 0.0;
+      for (int i = 0; i < dim - 1; ++i) a2 += x[i] * x[i];
+      double a = std::sqrt(a2);
+      if (a <= -s) { for (int i = 0; i < dim; ++i) px[i] = 0.0; return 0; }
+      if (a <= s) { for (int i = 0; i < dim; ++i) px[i] = x[i]; return 1; }
+      if (a >= std::fabs(s)) {
+        double c = 0.5 * (1 + s / a);
+        for (int i = 0; i < dim - 1; ++i) px[i] = x[i] * c;
+        px[dim - 1] = a * c;
+        return 2;
+      }
+      return -1;
+    }
+  }
+  return -1;
+}
+
+/* J (dim x dim, row-major), fully written. src/cones.jl:129-188.  NOTE the reference's NegativeOrthant
+ * method only writes the diagonal; the oracle writes the full (zero off-diagonal) matrix. */
+inline int cone_projection_jacobian(int cone, const double* x, double* J, int dim) {
+  std::memset(J, 0, sizeof(double) * dim * dim);
+  switch (cone) {
+    case TO_CONE_IDENTITY: for (int i = 0; i < dim; ++i) J[i * dim + i] = 1.0; return 0;
+    case TO_CONE_ZERO: return 0;
+    case TO_CONE_NEGATIVE_ORTHANT: for (int i = 0; i < dim; ++i) J[i * dim + i] = x[i] <= 0 ? 1.0 : 0.0; return 0;
+    case TO_CONE_POSITIVE_ORTHANT: for (int i = 0; i < dim; ++i) J[i * dim + i] = x[i] >= 0 ? 1.0 : 0.0; return 0;
+    case TO_CONE_SECOND_ORDER: {
+      int n = dim;
+      double s = x[n - 1], a2 = 0.0;
+      for (int i = 0; i < n - 1; ++i) a2 += x[i] * x[i];
+      double a = std::sqrt(a2);
+      if (a <= -s) return 0;
+      if (a <= s) { for (int i = 0; i < n; ++i) J[i * n + i] = 1.0; return 1; }
+      if (a >= std::fabs(s)) {
+        double c = 0.5 * (1 + s / a);
+        for (int i = 0; i < n - 1; ++i)
+          for (int j = 0; j < n - 1; ++j) {
+            J[i * n + j] = -0.5 * s / (a * a * a) * x[i] * x[j];
+            if (i == j) J[i * n + j] += c;
+          }
+        for (int i = 0; i < n - 1; ++i) J[i * n + (n - 1)] = 0.5 * x[i] / a;
+        for (int i = 0; i < n - 1; ++i) J[(n - 1) * n + i] = ((-0.5 * s / (a * a)) + c / a) * x[i];
+        J[(n - 1) * n + (n - 1)] = 0.5;
+        return 2;
+      }
+      return -1;
+    }
+  }
+  return -1;
+}
+
+/* hess (dim x dim) = Hessian of b' Pi(x). src/cones.jl:201-276 */
+inline int cone_projection_hessian(int cone, const double* x, const double* b, double* H, int dim) {
+  std::memset(H, 0, sizeof(double) * dim * dim);
+  if (cone != TO_CONE_SECOND_ORDER) return 0;
+  int n = dim - 1;
+  double s = x[n], bs = b[n], a2 = 0.0, vbv = 0.0;
+  for (int i = 0; i < n; ++i) { a2 += x[i] * x[i]; vbv += x[i] * b[i]; }
+  double a = std::sqrt(a2);
+  if (a <= -s) return 0;
+  if (a <= s) return 1;
+  if (a > std::fabs(s)) {
+    for (int i = 0; i < n; ++i) {
+      double hi = 0.0;
+      for (int j = 0; j < n; ++j) {
+        double Hij = -x[i] * x[j] / (a * a);
+        if (i == j) Hij += 1;
+        hi += Hij * b[j];
+      }
+      H[i * dim + n] = hi / (2 * a);
+      H[n * dim + i] = H[i * dim + n];
+      for (int j = 0; j <= i; ++j) {
+        double vij = x[i] * x[j];
+        double H1 = hi * x[j] * (-s / (a * a * a));
+        double H2 = vij * (2 * vbv) / (a * a * a * a) - x[i] * b[j] / (a * a);
+        double H3 = -vij / (a * a);
+        if (i == j) { H2 -= vbv / (a * a); H3 += 1; }
+        H2 *= s / a;
+        H3 *= bs / a;
+        H[i * dim + j] = (H1 + H2 + H3) / 2;
+        H[j * dim + i] = H[i * dim + j];
+      }
+    }
+    H[n * dim + n] = 0.0;
+    return 2;
+  }
+  return -1;
+}
+
+/* ---------------------------------------------------------------- costs */
+/* J = 0.5 x'Qx + q'x + c (+ 0.5 u'Ru + r'u) (+ u'Hx) (+ w min(1+dq,1-dq)); src/cost_functions.jl:89-104, src/lie_costs.jl:68-76.
+ * `with_u`: the reference adds the control terms whenever u is non-empty. */
+inline double cost_evaluate(const to_cost_desc& C, int n, int m, const double* x, const double* u) {
+  double J = 0.0;
+  if (C.kind == TO_COST_QUADRATIC) {
+    double xQx = 0.0;
+    for (int j = 0; j < n; ++j) { double t = 0.0; for (int i = 0; i < n; ++i) t += x[i] * C.Q[i + n * j]; xQx += t * x[j]; }
+    J = 0.5 * xQx;
+  } else {
+    double xQx = 0.0;
+    for (int i = 0; i < n; ++i) xQx += x[i] * C.Q[i] * x[i];
+    J = 0.5 * xQx;
+  }
+  double qx = 0.0; for (int i = 0; i < n; ++i) qx += C.q[i] * x[i];
+  J = J + qx + C.c;
+  if (u) {
+    double uRu = 0.0, ru = 0.0;
+    if (C.kind == TO_COST_QUADRATIC) {
+      for (int j = 0; j < m; ++j) { double t = 0.0; for (int i = 0; i < m; ++i) t += u[i] * C.R[i + m * j]; uRu += t * u[j]; }
+    } else {
+      for (int i = 0; i < m; ++i) uRu += u[i] * C.R[i] * u[i];
+    }
+    for (int i = 0; i < m; ++i) ru += C.r[i] * u[i];
+    J += 0.5 * uRu + ru;
+    if (C.kind == TO_COST_QUADRATIC) {
+      double uHx = 0.0;
+      for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) uHx += u[i] * C.H[i + m * j] * x[j];
+      J += uHx;
+    }
+  }
+  if (C.kind == TO_COST_DIAGONAL_QUAT) {
+    double dq = 0.0;
+    for (int i = 0; i < 4; ++i) dq += C.q_ref[i] * x[C.q_ind[i] - 1];
+    J += C.w * std::fmin(1 + dq, 1 - dq);
+  }
+  return J;
+}
+
+/* grad (n+m) and hess ((n+m)^2 row-major) wrt z=[x;u]; u-parts are zero when terminal.
+ * src/cost_functions.jl:137-233; quaternion term src/lie_costs.jl:82-90 (the intended gradient). */
+inline void cost_expansion(const to_cost_desc& C, int n, int m, const double* x, const double* u, bool terminal,
+                           double* grad, double* hess) {
+  const int nz = n + m;
+  std::memset(grad, 0, sizeof(double) * nz);
+  std::memset(hess, 0, sizeof(double) * nz * nz);
+  if (C.kind == TO_COST_QUADRATIC) {
+    for (int i = 0; i < n; ++i) { double t = C.q[i]; for (int j = 0; j < n; ++j) t += C.Q[i + n * j] * x[j]; grad[i] = t; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) hess[i * nz + j] = C.Q[i + n * j];
+  } else {
+    for (int i = 0; i < n; ++i) { grad[i] = C.Q[i] * x[i] + C.q[i]; hess[i * nz + i] = C.Q[i]; }
+  }
+  if (C.kind == TO_COST_DIAGONAL_QUAT) {
+    double dq = 0.0;
+    for (int i = 0; i < 4; ++i) dq += C.q_ref[i] * x[C.q_ind[i] - 1];
+    for (int i = 0; i < 4; ++i) {
+      if (dq < 0) grad[C.q_ind[i] - 1] += C.w * C.q_ref[i];
+      else grad[C.q_ind[i] - 1] -= C.w * C.q_ref[i];
+    }
+  }
+  if (!terminal) {
+    if (C.kind == TO_COST_QUADRATIC) {
+      for (int i = 0; i < m; ++i) { double t = C.r[i]; for (int j = 0; j < m; ++j) t += C.R[i + m * j] * u[j]; grad[n + i] = t; }
+      for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) hess[(n + i) * nz + n + j] = C.R[i + m * j];
+      /* cross term u'Hx: grad_x += H'u, grad_u += Hx; hess[iu,ix] = H (and its transpose for the symmetric full Hessian) */
+      for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) {
+        grad[j] += C.H[i + m * j] * u[i];
+        grad[n + i] += C.H[i + m * j] * x[j];
+        hess[(n + i) * nz + j] = C.H[i + m * j];
+        hess[j * nz + n + i] = C.H[i + m * j];
+      }
+    } else {
+      for (int i = 0; i < m; ++i) { grad[n + i] = C.R[i] * u[i] + C.r[i]; hess[(n + i) * nz + n + i] = C.R[i]; }
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- constraints (src/constraints.jl) */
+/* z = [x; u] (u = zeros at the terminal knot).  c (p), jac (p x (n+m) row-major, fully written). */
+inline int constraint_output_dim(const to_constraint_desc& K, int n, int m) {
+  switch (K.kind) {
+    case TO_CON_GOAL: return K.n_inds;
+    case TO_CON_BOUND: {
+      int p = 0;
+      for (int i = 0; i < n + m; ++i) if (std::isfinite(K.params[i])) ++p;
+      for (int i = 0; i < n + m; ++i) if (std::isfinite(K.params[n + m + i])) ++p;
+      return p;
+    }
+    case TO_CON_NORM: return K.sense == TO_CONE_SECOND_ORDER ? K.n_inds + 1 : 1;
+    case TO_CON_CIRCLE: return K.n_params / 3;
+    case TO_CON_SPHERE: return K.n_params / 4;
+    case TO_CON_LINEAR: return K.n_params / (K.n_inds + 1);
+  }
+  return -1;
+}
+
+inline void constraint_evaluate(const to_constraint_desc& K, int n, int m, const double* z, double* c, double* jac) {
+  const int nz = n + m;
+  const int p = constraint_output_dim(K, n, m);
+  if (jac) std::memset(jac, 0, sizeof(double) * p * nz);
+  switch (K.kind) {
+    case TO_CON_GOAL: /* :55-68 */
+      for (int i = 0; i < p; ++i) {
+        int j = K.inds[i] - 1;
+        c[i] = z[j] - K.params[i];
+        if (jac) jac[i * nz + j] = 1.0;
+      }
+      return;
+    case TO_CON_BOUND: { /* :738-765: [(z - z_max); (z_min - z)][finite] */
+      int r = 0;
+      for (int j = 0; j < nz; ++j) if (std::isfinite(K.params[j])) { c[r] = z[j] - K.params[j]; if (jac) jac[r * nz + j] = 1.0; ++r; }
+      for (int j = 0; j < nz; ++j) if (std::isfinite(K.params[nz + j])) { c[r] = K.params[nz + j] - z[j]; if (jac) jac[r * nz + j] = -1.0; ++r; }
+      return;
+    }
+    case TO_CON_NORM: { /* :462-517 */
+      double val = K.params[0];
+      if (K.sense == TO_CONE_SECOND_ORDER) {
+        for (int i = 0; i < K.n_inds; ++i) { int j = K.inds[i] - 1; c[i] = z[j]; if (jac) jac[i * nz + j] = 1.0; }
+        c[K.n_inds] = val;
+      } else {
+        double s = 0.0;
+        for (int i = 0; i < K.n_inds; ++i) { int j = K.inds[i] - 1; s += z[j] * z[j]; if (jac) jac[j] = 2 * z[j]; }
+        c[0] = s - val * val;
+      }
+      return;
+    }
+    case TO_CON_CIRCLE: { /* :199-228 */
+      int P = p; int xi = K.inds[0] - 1, yi = K.inds[1] - 1;
+      for (int i = 0; i < P; ++i) {
+        double xc = K.params[i], yc = K.params[P + i], r = K.params[2 * P + i];
+        double dx = z[xi] - xc, dy = z[yi] - yc;
+        c[i] = -(dx * dx) - dy * dy + r * r;
+        if (jac) { jac[i * nz + xi] = -2 * dx; jac[i * nz + yi] = -2 * dy; }
+      }
+      return;
+    }
+    case TO_CON_SPHERE: { /* :283-321 */
+      int P = p; int xi = K.inds[0] - 1, yi = K.inds[1] - 1, zi = K.inds[2] - 1;
+      for (int i = 0; i < P; ++i) {
+        double xc = K.params[i], yc = K.params[P + i], zc = K.params[2 * P + i], r = K.params[3 * P + i];
+        double dx = z[xi] - xc, dy = z[yi] - yc, dz = z[zi] - zc;
+        c[i] = -(dx * dx) - dy * dy - dz * dz + r * r;
+        if (jac) { jac[i * nz + xi] = -2 * dx; jac[i * nz + yi] = -2 * dy; jac[i * nz + zi] = -2 * dz; }
+      }
+      return;
+    }
+    case TO_CON_LINEAR: { /* :134-144: A z[inds] - b */
+      int D = K.n_inds;
+      for (int i = 0; i < p; ++i) {
+        double s = 0.0;
+        for (int t = 0; t < D; ++t) { int j = K.inds[t] - 1; s += K.params[i + p * t] * z[j]; if (jac) jac[i * nz + j] = K.params[i + p * t]; }
+        c[i] = s - K.params[p * D + i];
+      }
+      return;
+    }
+  }
+}
+
+inline bool constraint_is_state_only(int kind) { return kind == TO_CON_GOAL || kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE; }
+
+}  // namespace oracle
+#endif

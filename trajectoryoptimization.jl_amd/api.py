@@ -1,0 +1,997 @@
+"""Host-side mirror of the reference's solver-facing API, over the C-ABI.
+
+The reference is Julia; Julia is not available in this image, so the host side is written in Python
+with the reference's names and argument meaning (``!`` dropped from mutating functions).  Everything
+here is descriptor plumbing: all arithmetic runs in ``libtrajopt_hip.so`` on the GPU.
+
+Index conventions follow the reference (Julia): knot ranges and state/control indices are **1-based
+and inclusive**.  A knot range may be given as an ``int`` (``N``), a ``(first, last)`` tuple, or a
+Python ``range`` whose *values* are the 1-based knots (``range(1, N)`` == Julia ``1:N-1``).
+
+Mirrored reference API (file:line in /root/reference):
+  costs        DiagonalCost, QuadraticCost, LQRCost, DiagonalQuatCost, QuatLQRCost
+               src/cost_functions.jl:326-346,422-453,532-547; src/lie_costs.jl:34-55,133-142
+  objective    Objective, LQRObjective, TrackingObjective          src/objective.jl:27-45,137-196
+  cones        Equality/ZeroCone, Inequality/NegativeOrthant, SecondOrderCone, projection, ∇projection,
+               ∇²projection, cone_status                           src/cones.jl
+  constraints  GoalConstraint, BoundConstraint, NormConstraint, CircleConstraint, SphereConstraint,
+               LinearConstraint, ConstraintList, add_constraint!   src/constraints.jl, src/constraint_list.jl
+  problem      Problem, rollout!, cost, states, controls, initial_controls!, initial_states!,
+               set_initial_state!, set_goal_state!, get_* getters   src/problem.jl
+  solvers      iLQRSolver, ALSolver (=Altro's AL-iLQR), SolverOptions, solve!, iterations, status,
+               max_violation (Altro.jl, out of tree; examples/Cartpole.ipynb cells 17-25)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, ProblemDesc,
+                    SolverOpts, SolveStats)
+
+__all__ = [
+    "DoubleIntegrator", "Cartpole", "Quadrotor", "RK4", "RK3", "Euler",
+    "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "QuatLQRCost",
+    "Objective", "LQRObjective", "TrackingObjective",
+    "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
+    "projection", "grad_projection", "hess_projection", "cone_status", "dualcone",
+    "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint",
+    "LinearConstraint", "ConstraintList", "add_constraint", "num_constraints",
+    "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
+    "set_initial_state", "set_goal_state", "get_constraints", "get_objective", "get_model",
+    "get_initial_state", "get_final_state", "get_trajectory", "gettimes",
+    "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "solve", "iterations", "status", "max_violation",
+    "evaluate_constraints", "constraint_jacobians", "sense", "upper_bound", "lower_bound", "is_bound",
+    "DimensionMismatch", "ArgumentError",
+]
+
+RK4, RK3, Euler = capi.RK4, capi.RK3, capi.EULER
+
+
+def _vec(x, n=None, name="vector"):
+    a = np.atleast_1d(np.asarray(x, dtype=np.float64)).ravel()
+    if n is not None and a.size != n:
+        raise DimensionMismatch(f"{name} has length {a.size}, expected {n}")
+    return a
+
+
+def _diag_or_vec(Q):
+    """Accept Diagonal-as-vector or a square matrix; return (is_diag, array)."""
+    a = np.asarray(Q, dtype=np.float64)
+    if a.ndim <= 1:
+        return True, np.atleast_1d(a).ravel()
+    if a.shape[0] != a.shape[1]:
+        raise DimensionMismatch("weight matrix must be square")
+    if np.count_nonzero(a - np.diag(np.diag(a))) == 0:
+        return True, np.diag(a).copy()
+    return False, a.copy()
+
+
+# --------------------------------------------------------------------------------------------- models
+class _Model:
+    model_id = -1
+    n = m = 0
+
+    def params(self):
+        raise NotImplementedError
+
+    def dims(self):
+        return self.n, self.m
+
+    @property
+    def errstate_dim(self):
+        return self.n
+
+
+class DoubleIntegrator(_Model):
+    """examples/quickstart.jl:11-23 generalised to D dimensions (D=2 there)."""
+    model_id = capi.MODEL_DOUBLE_INTEGRATOR
+
+    def __init__(self, mass=1.0, D=2):
+        if D not in (1, 2, 3):
+            raise ArgumentError("DoubleIntegrator dimension must be 1, 2 or 3")
+        self.mass, self.D = float(mass), int(D)
+        self.n, self.m = 2 * D, D
+
+    def params(self):
+        return [self.mass, float(self.D)]
+
+
+class Cartpole(_Model):
+    """RobotZoo.Cartpole, restated at docs/src/model.md:20-51."""
+    model_id = capi.MODEL_CARTPOLE
+    n, m = 4, 1
+
+    def __init__(self, mc=1.0, mp=0.2, l=0.5, g=9.81):
+        self.mc, self.mp, self.l, self.g = float(mc), float(mp), float(l), float(g)
+
+    def params(self):
+        return [self.mc, self.mp, self.l, self.g]
+
+
+class Quadrotor(_Model):
+    """RobotZoo.Quadrotor / examples/Quadrotor.ipynb cells 4 and 8.  State [r, q(w,x,y,z), v, ω]."""
+    model_id = capi.MODEL_QUADROTOR
+    n, m = 13, 4
+
+    def __init__(self, mass=0.5, J=(0.0023, 0.0023, 0.004), gravity=(0.0, 0.0, -9.81),
+                 motor_dist=0.1750, kf=1.0, km=0.0245):
+        self.mass, self.J, self.gravity = float(mass), tuple(map(float, J)), tuple(map(float, gravity))
+        self.motor_dist, self.kf, self.km = float(motor_dist), float(kf), float(km)
+
+    def params(self):
+        return [self.mass, *self.J, *self.gravity, self.motor_dist, self.kf, self.km]
+
+    @property
+    def errstate_dim(self):
+        return 12
+
+    def hover_control(self):
+        """``zeros(model)[2]``: thrust that cancels gravity, -g_z*m/4 per motor."""
+        return np.full(4, -self.gravity[2] * self.mass / 4.0 / self.kf)
+
+
+# --------------------------------------------------------------------------------------------- costs
+class QuadraticCostFunction:
+    """½xᵀQx + ½uᵀRu + uᵀHx + qᵀx + rᵀu + c  (src/cost_functions.jl:19-34)."""
+    kind = capi.COST_QUADRATIC
+
+    def __init__(self, Q, R, H=None, q=None, r=None, c=0.0, terminal=False):
+        self.Q = np.asarray(Q, dtype=np.float64)
+        self.R = np.asarray(R, dtype=np.float64)
+        self.n, self.m = self.Q.shape[0], self.R.shape[0]
+        self.H = np.zeros((self.m, self.n)) if H is None else np.asarray(H, dtype=np.float64)
+        if self.H.shape != (self.m, self.n):
+            raise DimensionMismatch("H must be m x n")
+        self.q = np.zeros(self.n) if q is None else _vec(q, self.n, "q")
+        self.r = np.zeros(self.m) if r is None else _vec(r, self.m, "r")
+        self.c, self.terminal = float(c), bool(terminal)
+
+    def state_dim(self):
+        return self.n
+
+    def control_dim(self):
+        return self.m
+
+    def is_diag(self):
+        return self.kind != capi.COST_QUADRATIC
+
+    def _desc(self):
+        d = CostDesc()
+        n, m = self.n, self.m
+        if n > capi.TO_MAX_N or m > capi.TO_MAX_M:
+            raise DimensionMismatch("cost dimensions exceed TO_MAX_N/TO_MAX_M")
+        d.kind, d.terminal = self.kind, int(self.terminal)
+        if self.kind == capi.COST_QUADRATIC:
+            d.Q[: n * n] = list(self.Q.ravel(order="F"))
+            d.R[: m * m] = list(self.R.ravel(order="F"))
+            d.H[: m * n] = list(self.H.ravel(order="F"))
+        else:
+            d.Q[:n] = list(self.Q)
+            d.R[:m] = list(self.R)
+        d.q[:n] = list(self.q)
+        d.r[:m] = list(self.r)
+        d.c = self.c
+        d.w = getattr(self, "w", 0.0)
+        d.q_ref[:] = list(getattr(self, "q_ref", np.array([1.0, 0, 0, 0])))
+        d.q_ind[:] = list(getattr(self, "q_ind", (4, 5, 6, 7)))
+        return d
+
+
+class QuadraticCost(QuadraticCostFunction):
+    """src/cost_functions.jl:422-453."""
+
+
+class DiagonalCost(QuadraticCostFunction):
+    """src/cost_functions.jl:326-346.  Q, R given as diagonals (vectors) or diagonal matrices."""
+    kind = capi.COST_DIAGONAL
+
+    def __init__(self, Q, R, q=None, r=None, c=0.0, terminal=False):
+        dq, Qd = _diag_or_vec(Q)
+        dr, Rd = _diag_or_vec(R)
+        if not (dq and dr):
+            raise ArgumentError("DiagonalCost needs diagonal Q and R")
+        self.Q, self.R = Qd, Rd
+        self.n, self.m = Qd.size, Rd.size
+        self.H = np.zeros((self.m, self.n))
+        self.q = np.zeros(self.n) if q is None else _vec(q, self.n, "q")
+        self.r = np.zeros(self.m) if r is None else _vec(r, self.m, "r")
+        self.c, self.terminal = float(c), bool(terminal)
+
+
+def LQRCost(Q, R, xf, uf=None, terminal=False):
+    """½(x-xf)ᵀQ(x-xf) + ½(u-uf)ᵀR(u-uf)  (src/cost_functions.jl:532-547)."""
+    dq, Qa = _diag_or_vec(Q)
+    dr, Ra = _diag_or_vec(R)
+    n, m = Qa.shape[0], Ra.shape[0]
+    xf = _vec(xf, n, "xf")
+    uf = np.zeros(m) if uf is None else _vec(uf, m, "uf")
+    if dq and dr:
+        q, r = -Qa * xf, -Ra * uf
+        c = 0.5 * xf @ (Qa * xf) + 0.5 * uf @ (Ra * uf)
+        return DiagonalCost(Qa, Ra, q, r, c, terminal=terminal)
+    Qm = np.diag(Qa) if dq else Qa
+    Rm = np.diag(Ra) if dr else Ra
+    return QuadraticCost(Qm, Rm, None, -Qm @ xf, -Rm @ uf, 0.5 * xf @ Qm @ xf + 0.5 * uf @ Rm @ uf, terminal=terminal)
+
+
+class DiagonalQuatCost(DiagonalCost):
+    """src/lie_costs.jl:34-55: diagonal quadratic + w·min(1 ± q_refᵀ x[q_ind])."""
+    kind = capi.COST_DIAGONAL_QUAT
+
+    def __init__(self, Q, R, q=None, r=None, c=0.0, w=1.0, q_ref=(1.0, 0, 0, 0), q_ind=(4, 5, 6, 7), terminal=False):
+        super().__init__(Q, R, q, r, c, terminal)
+        self.w = float(w)
+        self.q_ref = _vec(q_ref, 4, "q_ref")
+        if len(q_ind) != 4:
+            raise AssertionError("quat_ind argument must be of length 4")
+        self.q_ind = tuple(int(i) for i in q_ind)
+
+
+def QuatLQRCost(Q, R, xf, uf=None, w=1.0, quat_ind=(4, 5, 6, 7), terminal=False):
+    """src/lie_costs.jl:133-142."""
+    _, Qd = _diag_or_vec(Q)
+    _, Rd = _diag_or_vec(R)
+    xf = _vec(xf, Qd.size, "xf")
+    uf = np.zeros(Rd.size) if uf is None else _vec(uf, Rd.size, "uf")
+    if len(quat_ind) != 4:
+        raise AssertionError("quat_ind argument must be of length 4")
+    q_ref = xf[[i - 1 for i in quat_ind]]
+    c = 0.5 * xf @ (Qd * xf) + 0.5 * uf @ (Rd * uf)
+    return DiagonalQuatCost(Qd, Rd, -Qd * xf, -Rd * uf, c, w, q_ref, quat_ind, terminal=terminal)
+
+
+class Objective:
+    """Vector of N cost functions (src/objective.jl:27-45)."""
+
+    def __init__(self, costs, terminal_cost=None, N=None):
+        if terminal_cost is not None:  # Objective(cost, cost_terminal, N)  src/objective.jl:74-77
+            self.cost = [costs] * (N - 1) + [terminal_cost]
+        elif isinstance(costs, QuadraticCostFunction):  # Objective(cost, N)
+            self.cost = [costs] * N
+        else:
+            self.cost = list(costs)
+        n, m = self.cost[0].n, self.cost[0].m
+        for c in self.cost:
+            if (c.n, c.m) != (n, m):
+                raise DimensionMismatch("all cost functions must share state/control dimensions")
+        self.J = np.zeros(len(self.cost))
+
+    def __len__(self):
+        return len(self.cost)
+
+    def __getitem__(self, k):
+        return self.cost[k]
+
+    def dims(self):
+        return self.cost[0].n, self.cost[0].m
+
+    def _descs(self):
+        """Deduplicate by identity -> (list of CostDesc, cost_index[N])."""
+        uniq, index = [], []
+        for c in self.cost:
+            for i, u in enumerate(uniq):
+                if u is c:
+                    index.append(i)
+                    break
+            else:
+                uniq.append(c)
+                index.append(len(uniq) - 1)
+        return uniq, index
+
+
+def LQRObjective(Q, R, Qf, xf, N, uf=None, checks=True):
+    """src/objective.jl:137-183: stage LQRCost(Q,R,xf,uf); terminal uses Qf, the SAME R and r, cf=½xfᵀQf xf."""
+    dq, Qa = _diag_or_vec(Q)
+    dr, Ra = _diag_or_vec(R)
+    df, Qfa = _diag_or_vec(Qf)
+    n, m = Qa.shape[0], Ra.shape[0]
+    xf = _vec(xf)
+    assert Qa.shape[0] == xf.size and Qfa.shape[0] == xf.size
+    uf = np.zeros(m) if uf is None else _vec(uf)
+    assert Ra.shape[0] == uf.size
+    if dq and dr and df:
+        q, r = -Qa * xf, -Ra * uf
+        c = 0.5 * xf @ (Qa * xf) + 0.5 * uf @ (Ra * uf)
+        stage = DiagonalCost(Qa, Ra, q, r, c, terminal=False)
+        term = DiagonalCost(Qfa, Ra, -Qfa * xf, r, 0.5 * xf @ (Qfa * xf), terminal=True)
+    else:
+        Qm = np.diag(Qa) if dq else Qa
+        Rm = np.diag(Ra) if dr else Ra
+        Qfm = np.diag(Qfa) if df else Qfa
+        r = -Rm @ uf
+        stage = QuadraticCost(Qm, Rm, None, -Qm @ xf, r, 0.5 * xf @ Qm @ xf + 0.5 * uf @ Rm @ uf)
+        term = QuadraticCost(Qfm, Rm, None, -Qfm @ xf, r, 0.5 * xf @ Qfm @ xf, terminal=True)
+    return Objective(stage, term, N)
+
+
+def TrackingObjective(Q, R, X, U, Qf=None):
+    """src/objective.jl:190-196: per-knot LQRCost tracking the reference (X[k], U[k])."""
+    X = np.asarray(X, dtype=np.float64)
+    U = np.asarray(U, dtype=np.float64)
+    N = X.shape[1]
+    costs = [LQRCost(Q, R, X[:, k], U[:, k] if k < U.shape[1] else None) for k in range(N)]
+    costs[-1] = LQRCost(Q if Qf is None else Qf, R, X[:, -1], terminal=True)
+    return Objective(costs)
+
+
+# --------------------------------------------------------------------------------------------- cones
+class _Cone:
+    code = -1
+
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __hash__(self):
+        return hash(type(self))
+
+    def __repr__(self):
+        return type(self).__name__ + "()"
+
+
+class ZeroCone(_Cone):
+    code = capi.CONE_ZERO
+
+
+class NegativeOrthant(_Cone):
+    code = capi.CONE_NEGATIVE_ORTHANT
+
+
+class SecondOrderCone(_Cone):
+    code = capi.CONE_SECOND_ORDER
+
+
+class PositiveOrthant(_Cone):
+    code = capi.CONE_POSITIVE_ORTHANT
+
+
+class IdentityCone(_Cone):
+    code = capi.CONE_IDENTITY
+
+
+Equality = ZeroCone
+Inequality = NegativeOrthant
+
+
+def dualcone(cone):
+    """src/cones.jl:65-69."""
+    return {IdentityCone: ZeroCone, ZeroCone: IdentityCone}.get(type(cone), type(cone))()
+
+
+def _cone_call(name, cone, x, b=None, lib=None, device=0):
+    lib = lib or capi.load_hip_library()
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    single = x.ndim == 1
+    xs = x.reshape(1, -1) if single else x
+    count, dim = xs.shape
+    xs = np.ascontiguousarray(xs)
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    if name == "cone_projection":
+        out = np.empty_like(xs)
+        st = np.zeros(count, dtype=np.int32)
+        lib.call(name, device, cone.code, dim, count, pd(xs), pd(out), st.ctypes.data_as(C.POINTER(C.c_int32)))
+        return (out[0], int(st[0])) if single else (out, st)
+    out = np.empty((count, dim, dim))
+    if name == "cone_projection_jacobian":
+        lib.call(name, device, cone.code, dim, count, pd(xs), pd(out))
+    else:
+        bs = np.ascontiguousarray(np.asarray(b, dtype=np.float64).reshape(count, dim))
+        lib.call(name, device, cone.code, dim, count, pd(xs), pd(bs), pd(out))
+    out = out.transpose(0, 2, 1)  # column-major blocks -> numpy [count, row, col]
+    return out[0] if single else out
+
+
+def projection(cone, x, lib=None):
+    """Π_K(x)  (src/cones.jl:71-127).  x: [dim] or [count, dim]."""
+    return _cone_call("cone_projection", cone, x, lib=lib)[0]
+
+
+def cone_status(cone, x, lib=None):
+    """:below / :in / :outside  (src/cones.jl:278-291)."""
+    st = _cone_call("cone_projection", cone, x, lib=lib)[1]
+    names = {0: "below", 1: "in", 2: "outside"}
+    return names[st] if np.isscalar(st) or isinstance(st, int) else [names[int(s)] for s in st]
+
+
+def grad_projection(cone, x, lib=None):
+    """∇projection!  (src/cones.jl:129-188)."""
+    return _cone_call("cone_projection_jacobian", cone, x, lib=lib)
+
+
+def hess_projection(cone, x, b, lib=None):
+    """∇²projection!: Hessian of bᵀΠ(x)  (src/cones.jl:201-276)."""
+    return _cone_call("cone_projection_hessian", cone, x, b, lib=lib)
+
+
+# --------------------------------------------------------------------------------------------- constraints
+class AbstractConstraint:
+    kind = -1
+    state_only = False
+
+    def sense(self):
+        return self._sense
+
+    def output_dim(self):
+        return self.p
+
+    def check_dims(self, n, m):
+        """src/abstract_constraint.jl:146-149."""
+        if self.state_only:
+            return self.n == n
+        return self.n == n and self.m == m
+
+    def _fill(self, d):
+        raise NotImplementedError
+
+    def _desc(self, k1, k2):
+        d = ConstraintDesc()
+        d.kind, d.sense, d.k_first, d.k_last, d.p = self.kind, self._sense.code, k1, k2, self.p
+        inds, params = self._fill()
+        if len(inds) > capi.TO_MAX_CON_INDS or len(params) > capi.TO_MAX_CON_PARAMS:
+            raise DimensionMismatch("constraint exceeds TO_MAX_CON_INDS/TO_MAX_CON_PARAMS")
+        d.n_inds, d.n_params = len(inds), len(params)
+        d.inds[: len(inds)] = [int(i) for i in inds]
+        d.params[: len(params)] = [float(v) for v in params]
+        return d
+
+
+def sense(con):
+    return con.sense()
+
+
+def upper_bound(con):
+    """src/abstract_constraint.jl:107-123."""
+    s = con.sense()
+    if isinstance(con, BoundConstraint):
+        return con.z_max
+    return np.full(con.p, 0.0 if not isinstance(s, SecondOrderCone) else np.inf)
+
+
+def lower_bound(con):
+    s = con.sense()
+    if isinstance(con, BoundConstraint):
+        return con.z_min
+    return np.full(con.p, 0.0 if isinstance(s, ZeroCone) else -np.inf)
+
+
+def is_bound(con):
+    return isinstance(con, (GoalConstraint, BoundConstraint))
+
+
+class GoalConstraint(AbstractConstraint):
+    """x[inds] − xf[inds] = 0  (src/constraints.jl:22-87)."""
+    kind = capi.CON_GOAL
+    state_only = True
+
+    def __init__(self, xf, inds=None):
+        xf = _vec(xf)
+        self.n = xf.size
+        self.inds = list(range(1, self.n + 1)) if inds is None else [int(i) for i in inds]
+        self.xf = xf[[i - 1 for i in self.inds]].copy()
+        self.p = len(self.inds)
+        self._sense = Equality()
+
+    def _fill(self):
+        return self.inds, list(self.xf)
+
+
+class BoundConstraint(AbstractConstraint):
+    """x_min ≤ x ≤ x_max, u_min ≤ u ≤ u_max  (src/constraints.jl:644-783)."""
+    kind = capi.CON_BOUND
+
+    def __init__(self, n, m, x_max=np.inf, x_min=-np.inf, u_max=np.inf, u_min=-np.inf):
+        self.n, self.m = int(n), int(m)
+
+        def check(k, hi, lo):  # checkBounds, src/constraints.jl:708-719
+            hi = np.full(k, float(hi)) if np.isscalar(hi) else _vec(hi, k, "upper bound")
+            lo = np.full(k, float(lo)) if np.isscalar(lo) else _vec(lo, k, "lower bound")
+            if not np.all(hi >= lo):
+                raise ArgumentError("Upper bounds must be greater than or equal to lower bounds")
+            return hi, lo
+
+        xh, xl = check(n, x_max, x_min)
+        uh, ul = check(m, u_max, u_min)
+        self.z_max = np.concatenate([xh, uh])
+        self.z_min = np.concatenate([xl, ul])
+        b = np.concatenate([-self.z_max, self.z_min])
+        self.inds = [i + 1 for i in np.flatnonzero(np.isfinite(b))]
+        self.p = len(self.inds)
+        self._sense = Inequality()
+
+    def _fill(self):
+        return [], list(self.z_max) + list(self.z_min)
+
+
+class NormConstraint(AbstractConstraint):
+    """‖z[inds]‖ (=,≤) a, or the second-order-cone form [z[inds]; a] ∈ SOC  (src/constraints.jl:438-521)."""
+    kind = capi.CON_NORM
+
+    def __init__(self, n, m, val, sense, inds=None):
+        self.n, self.m = int(n), int(m)
+        if isinstance(inds, str):
+            inds = {"state": range(1, n + 1), "control": range(n + 1, n + m + 1)}[inds]
+        self.inds = list(range(1, n + m + 1)) if inds is None else [int(i) for i in inds]
+        if not val >= 0:
+            raise AssertionError("Value must be greater than or equal to zero")
+        self.val = float(val)
+        self._sense = sense
+        self.p = len(self.inds) + 1 if isinstance(sense, SecondOrderCone) else 1
+
+    def _fill(self):
+        return self.inds, [self.val]
+
+
+class CircleConstraint(AbstractConstraint):
+    """(x−xc)²+(y−yc)² ≥ r²  (src/constraints.jl:168-233)."""
+    kind = capi.CON_CIRCLE
+    state_only = True
+
+    def __init__(self, n, xc, yc, radius, xi=1, yi=2):
+        self.n = int(n)
+        self.x, self.y, self.radius = _vec(xc), _vec(yc), _vec(radius)
+        if not (self.x.size == self.y.size == self.radius.size):
+            raise AssertionError("Lengths of xc, yc, and radius must be equal.")
+        self.xi, self.yi = int(xi), int(yi)
+        self.p = self.x.size
+        self._sense = Inequality()
+
+    def _fill(self):
+        return [self.xi, self.yi], list(self.x) + list(self.y) + list(self.radius)
+
+
+class SphereConstraint(AbstractConstraint):
+    """src/constraints.jl:249-326."""
+    kind = capi.CON_SPHERE
+    state_only = True
+
+    def __init__(self, n, xc, yc, zc, radius, xi=1, yi=2, zi=3):
+        self.n = int(n)
+        self.x, self.y, self.z, self.radius = _vec(xc), _vec(yc), _vec(zc), _vec(radius)
+        if not (self.x.size == self.y.size == self.z.size == self.radius.size):
+            raise AssertionError("Lengths of xc, yc, zc, and radius must be equal.")
+        self.xi, self.yi, self.zi = int(xi), int(yi), int(zi)
+        self.p = self.x.size
+        self._sense = Inequality()
+
+    def _fill(self):
+        return [self.xi, self.yi, self.zi], list(self.x) + list(self.y) + list(self.z) + list(self.radius)
+
+
+class LinearConstraint(AbstractConstraint):
+    """A z[inds] − b (=,≤) 0  (src/constraints.jl:103-150)."""
+    kind = capi.CON_LINEAR
+
+    def __init__(self, n, m, A, b, sense, inds=None):
+        self.n, self.m = int(n), int(m)
+        self.A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+        self.b = _vec(b)
+        if self.A.shape[0] != self.b.size:
+            raise AssertionError("size(A,1) == length(b)")
+        self.inds = list(range(1, n + m + 1)) if inds is None else [int(i) for i in inds]
+        if len(self.inds) != self.A.shape[1]:
+            raise AssertionError("length(inds) == size(A,2)")
+        self._sense = sense
+        self.p = self.b.size
+
+    def check_dims(self, n, m):
+        return self.n == n and self.m == m
+
+    def _fill(self):
+        return self.inds, list(self.A.ravel(order="F")) + list(self.b)
+
+
+def _knot_range(inds, N):
+    if isinstance(inds, (int, np.integer)):
+        return int(inds), int(inds)
+    if isinstance(inds, range):
+        if inds.step != 1 or len(inds) == 0:
+            raise ArgumentError("knot range must be a non-empty unit range")
+        return inds[0], inds[-1]
+    a, b = inds
+    return int(a), int(b)
+
+
+class ConstraintList:
+    """src/constraint_list.jl:35-52."""
+
+    def __init__(self, n, m, N):
+        self.n, self.m, self.N = int(n), int(m), int(N)
+        self.nx, self.nu = [self.n] * N, [self.m] * N
+        self.constraints, self.inds = [], []
+        self.p = [0] * N
+
+    def __len__(self):
+        return len(self.constraints)
+
+    def __getitem__(self, i):
+        return self.constraints[i]
+
+    def __iter__(self):
+        return iter(self.constraints)
+
+    def zip(self):
+        return list(zip(self.inds, self.constraints))
+
+    def copy(self):
+        c = ConstraintList(self.n, self.m, self.N)
+        for con, (a, b) in zip(self.constraints, self.inds):
+            add_constraint(c, con, (a, b))
+        return c
+
+    def _descs(self):
+        arr = (ConstraintDesc * max(1, len(self)))()
+        for i, (con, (a, b)) in enumerate(zip(self.constraints, self.inds)):
+            arr[i] = con._desc(a, b)
+        return arr
+
+
+def add_constraint(cons, con, inds, idx=-1):
+    """add_constraint!  (src/constraint_list.jl:103-134).  ``idx`` is 1-based like the reference."""
+    k1, k2 = _knot_range(inds, cons.N)
+    if not con.check_dims(cons.n, cons.m):
+        raise DimensionMismatch(f"New constraint not consistent with n={cons.n} and m={cons.m} at time step {k1}.")
+    assert 1 <= k1 <= k2 <= cons.N, f"Invalid inds, inds[end] must be less than number of knotpoints, {cons.N}"
+    if len(cons) == 0:
+        idx = -1
+    if idx == -1:
+        cons.constraints.append(con)
+        cons.inds.append((k1, k2))
+    elif 0 < idx <= len(cons):
+        cons.constraints.insert(idx - 1, con)
+        cons.inds.insert(idx - 1, (k1, k2))
+    else:
+        raise ArgumentError(f"cannot insert constraint at index={idx}. Length = {len(cons)}")
+    cons.p = [0] * cons.N
+    for c, (a, b) in zip(cons.constraints, cons.inds):
+        for k in range(a, b + 1):
+            cons.p[k - 1] += c.p
+    return cons
+
+
+def num_constraints(obj):
+    """src/constraint_list.jl:198 / src/problem.jl:203: total constraint rows per knot."""
+    return obj.p if isinstance(obj, ConstraintList) else obj.constraints.p
+
+
+# --------------------------------------------------------------------------------------------- problem
+class KnotPoint:
+    """z=[x;u], t, dt; terminal ⇔ dt == 0 (RobotDynamics.KnotPoint as built at src/problem.jl:58-61)."""
+
+    def __init__(self, x, u, t, dt):
+        self.x, self.u = _vec(x), _vec(u)
+        self.z = np.concatenate([self.x, self.u])
+        self.t, self.dt = float(t), float(dt)
+
+    def is_terminal(self):
+        return self.dt == 0.0
+
+
+class SolverOptions:
+    """Altro.jl ``SolverOptions`` subset (examples/Cartpole.ipynb cell 17); fields of ``to_solver_opts``."""
+
+    _names = [f[0] for f in SolverOpts._fields_ if not f[0].startswith("reserved")]
+
+    def __init__(self, lib=None, **kw):
+        lib = lib or capi.load_hip_library()
+        self._o = lib.default_options()
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def __getattr__(self, k):
+        if k in SolverOptions._names:
+            return getattr(self._o, k)
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if k in SolverOptions._names:
+            setattr(self._o, k, v)
+        elif k.startswith("_"):
+            object.__setattr__(self, k, v)
+        else:
+            raise ArgumentError(f"unknown solver option {k}")
+
+
+class Problem:
+    """Trajectory-optimisation problem for a BATCH of trajectories (src/problem.jl:36-73).
+
+    ``Problem(model, obj, x0, tf; xf, constraints, t0, X0, U0, dt, integration)`` as in the reference,
+    plus ``batch`` (number of independent trajectories sharing model/objective/constraints) and
+    ``device``.  ``x0`` may be [n] (replicated) or [n, B] / [B, n]-shaped via ``set_initial_state``.
+    """
+
+    def __init__(self, model, obj, x0, tf, xf=None, constraints=None, t0=0.0, X0=None, U0=None, dt=None,
+                 integration=RK4, batch=1, device=0, options=None, lib=None, **kwargs):
+        if "x0" in kwargs:
+            raise ArgumentError("Cannot pass x0 as a keyword argument. It is now a positional argument, "
+                                "and xf is a keyword argument.")
+        self._lib = lib or capi.load_hip_library()
+        self.model, self.obj = model, obj
+        n, m = model.dims()
+        self.n, self.m, self.N, self.B = n, m, len(obj), int(batch)
+        self.constraints = constraints if constraints is not None else ConstraintList(n, m, self.N)
+        if (self.constraints.n, self.constraints.N) != (n, self.N):
+            raise DimensionMismatch("Constraint state dimensions don't match model")
+        if self.constraints.m != m:
+            raise DimensionMismatch("Constraint control dimensions don't match model")
+        if obj.dims()[0] != n:
+            raise DimensionMismatch("Objective state dimensions don't match model.")
+        if obj.dims()[1] != m:
+            raise DimensionMismatch("Objective control dimensions don't match model.")
+        self.t0, self.tf = float(t0), float(tf)
+        self.xf = np.full(n, np.nan) if xf is None else _vec(xf, n, "xf")
+        self.integration = integration
+        self._dt = None if dt is None else np.ascontiguousarray(_vec(dt, self.N - 1, "dt"))
+
+        uniq, index = obj._descs()
+        self._cost_objs = uniq
+        self._costs = (CostDesc * len(uniq))(*[c._desc() for c in uniq])
+        self._cost_index = (C.c_int32 * self.N)(*index)
+        self._cons = self.constraints._descs()
+        d = ProblemDesc()
+        d.abi_version, d.model, d.integrator = capi.TO_ABI_VERSION, model.model_id, integration
+        d.n, d.m, d.N, d.B = n, m, self.N, self.B
+        p = model.params()
+        d.model_params[: len(p)] = p
+        d.t0, d.tf = self.t0, self.tf
+        d.dt = self._dt.ctypes.data_as(C.POINTER(C.c_double)) if self._dt is not None else None
+        d.n_costs, d.costs, d.cost_index = len(uniq), self._costs, self._cost_index
+        d.n_constraints = len(self.constraints)
+        d.constraints = self._cons
+        self._desc = d
+        self._h = C.c_void_p()
+        opts = options._o if isinstance(options, SolverOptions) else options
+        self._lib.call("create", C.byref(d), C.byref(opts) if opts is not None else None, int(device), C.byref(self._h))
+        self.set_initial_state(x0)
+        if U0 is not None:
+            initial_controls(self, U0)
+        if X0 is not None:
+            initial_states(self, X0)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.raw("destroy")(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    # ---- helpers
+    def _call(self, name, *args):
+        return self._lib.call(name, self._h, *args)
+
+    @staticmethod
+    def _pd(a):
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    @staticmethod
+    def _pi(a):
+        return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def _batch(self, a, inner, name):
+        """Coerce to C-contiguous [B, *inner_reversed] memory == column-major (inner..., B)."""
+        a = np.asarray(a, dtype=np.float64)
+        tgt = (self.B,) + tuple(reversed(inner))
+        if a.shape == tuple(inner):  # single trajectory in Julia (n, N) layout -> replicate
+            a = np.broadcast_to(a.T, tgt)
+        elif a.shape == tuple(reversed(inner)):
+            a = np.broadcast_to(a, tgt)
+        elif a.shape != tgt:
+            raise DimensionMismatch(f"{name}: expected shape {tgt} ([B, knot, dim]) or {tuple(inner)}, got {a.shape}")
+        return np.ascontiguousarray(a)
+
+    # ---- setters / getters (src/problem.jl:198-310)
+    def set_initial_state(self, x0):
+        a = np.asarray(x0, dtype=np.float64)
+        if a.ndim == 1:
+            a = np.broadcast_to(_vec(a, self.n, "x0"), (self.B, self.n))
+        elif a.shape != (self.B, self.n):
+            raise DimensionMismatch(f"x0 must be [n] or [B, n]; got {a.shape}")
+        a = np.ascontiguousarray(a)
+        self._call("set_initial_state", self._pd(a))
+        self.x0 = a.copy()
+
+    def dims(self):
+        return self.n, self.m, self.N
+
+    @property
+    def errstate_dim(self):
+        return self.model.errstate_dim
+
+    def gettimes(self):
+        dt = self._dt if self._dt is not None else np.full(self.N - 1, (self.tf - self.t0) / (self.N - 1))
+        return self.t0 + np.concatenate([[0.0], np.cumsum(dt)])
+
+
+def initial_controls(prob, U0):
+    """initial_controls!(prob, U0): U0 is [m] (all knots), [m, N-1] / [N-1, m], or [B, N-1, m]."""
+    a = np.asarray(U0, dtype=np.float64)
+    if a.ndim == 1 and a.size == prob.m:
+        a = np.ascontiguousarray(a)
+        prob._call("set_controls_uniform", prob._pd(a))
+        return
+    if a.ndim == 2 and prob.m == prob.N - 1 and a.shape == (prob.m, prob.N - 1):
+        raise ArgumentError("ambiguous U0 shape; pass [B, N-1, m]")
+    a = prob._batch(a, (prob.m, prob.N - 1), "U0")
+    prob._call("set_controls", prob._pd(a))
+
+
+def initial_states(prob, X0):
+    a = prob._batch(X0, (prob.n, prob.N), "X0")
+    prob._call("set_states", prob._pd(a))
+
+
+def set_initial_state(prob, x0):
+    prob.set_initial_state(x0)
+
+
+def states(prob):
+    """states(prob) -> [B, N, n]."""
+    X = np.empty((prob.B, prob.N, prob.n))
+    prob._call("get_states", prob._pd(X))
+    return X
+
+
+def controls(prob):
+    """controls(prob) -> [B, N-1, m]."""
+    U = np.empty((prob.B, prob.N - 1, prob.m))
+    prob._call("get_controls", prob._pd(U))
+    return U
+
+
+def rollout(prob):
+    """rollout!(prob)  (src/problem.jl:330-340)."""
+    prob._call("rollout")
+
+
+def cost(prob):
+    """cost(prob) -> [B]  (src/problem.jl:321, src/objective.jl:89-93).  Also fills Objective.J (first trajectory)."""
+    J = np.empty(prob.B)
+    prob._call("cost", prob._pd(J))
+    return J
+
+
+def stage_costs(prob):
+    """cost!(obj, Z): per-knot costs [B, N] (Objective.J, src/objective.jl:104-106)."""
+    Jk = np.empty((prob.B, prob.N))
+    prob._call("stage_costs", prob._pd(Jk))
+    prob.obj.J = Jk[0].copy()
+    return Jk
+
+
+def get_constraints(prob):
+    return prob.constraints
+
+
+def get_objective(prob):
+    return prob.obj
+
+
+def get_model(prob, k=None):
+    return prob.model
+
+
+def get_initial_state(prob):
+    x = np.empty((prob.B, prob.n))
+    prob._call("get_initial_state", prob._pd(x))
+    return x
+
+
+def get_final_state(prob):
+    return prob.xf
+
+
+def get_trajectory(prob):
+    return states(prob), controls(prob)
+
+
+def gettimes(prob):
+    return prob.gettimes()
+
+
+def set_goal_state(prob, xf, objective=True, constraint=True):
+    """set_goal_state!  (src/problem.jl:294-310): set_LQR_goal! on every cost, update GoalConstraints."""
+    xf = _vec(xf, prob.n, "xf")
+    if objective:
+        for i, c in enumerate(prob._cost_objs):
+            if c.kind == capi.COST_QUADRATIC:
+                c.q = -c.Q @ xf  # set_LQR_goal!: only q changes (src/cost_functions.jl:249-252)
+            else:
+                c.q = -c.Q * xf
+            d = c._desc()
+            prob._call("set_cost", i, C.byref(d))
+    if constraint:
+        for i, (con, (a, b)) in enumerate(zip(prob.constraints.constraints, prob.constraints.inds)):
+            if isinstance(con, GoalConstraint):
+                con.xf = xf[[j - 1 for j in con.inds]].copy()
+                d = con._desc(a, b)
+                prob._call("set_constraint", i, C.byref(d))
+    prob.xf = xf.copy()
+
+
+def evaluate_constraints(prob, i):
+    """evaluate_constraints! for constraint ``i`` (0-based list position) -> [B, nk, p]  (src/abstract_constraint.jl:200-225)."""
+    con = prob.constraints[i]
+    a, b = prob.constraints.inds[i]
+    vals = np.empty((prob.B, b - a + 1, con.p))
+    prob._call("evaluate_constraints", i, prob._pd(vals))
+    return vals
+
+
+def constraint_jacobians(prob, i):
+    """constraint_jacobians! -> [B, nk, p, w]  (src/abstract_constraint.jl:236-248)."""
+    con = prob.constraints[i]
+    a, b = prob.constraints.inds[i]
+    w = prob.n if con.state_only else prob.n + prob.m
+    jac = np.empty((prob.B, b - a + 1, w, con.p))
+    prob._call("constraint_jacobians", i, prob._pd(jac))
+    return jac.transpose(0, 1, 3, 2)
+
+
+# --------------------------------------------------------------------------------------------- solvers
+class _Solver:
+    _entry = "ilqr_solve"
+
+    def __init__(self, prob, opts=None, **kw):
+        self.prob = prob
+        if opts is None:  # start from the options the Problem was created with
+            opts = SolverOptions(lib=prob._lib)
+            prob._call("get_options", C.byref(opts._o))
+        for k, v in kw.items():
+            setattr(opts, k, v)
+        self.opts = opts
+        B = prob.B
+        self.stats = dict(
+            iterations=np.zeros(B, np.int32), iterations_outer=np.zeros(B, np.int32), status=np.zeros(B, np.int32),
+            cost=np.zeros(B), dJ=np.zeros(B), gradient=np.zeros(B), c_max=np.zeros(B), penalty_max=np.zeros(B))
+        self.total_iterations = 0
+        self.batch_steps = 0
+        self.solve_ms = 0.0
+
+    def solve(self):
+        p = self.prob
+        p._call("set_options", C.byref(self.opts._o))
+        st = SolveStats()
+        for k, a in self.stats.items():
+            ptr = a.ctypes.data_as(C.POINTER(C.c_int32 if a.dtype == np.int32 else C.c_double))
+            setattr(st, k, ptr)
+        p._call(self._entry, C.byref(st))
+        self.total_iterations, self.batch_steps, self.solve_ms = st.total_iterations, st.batch_steps, st.solve_ms
+        return self
+
+
+class iLQRSolver(_Solver):
+    """Altro.iLQRSolver(prob, opts): unconstrained iLQR on the batch (examples/Cartpole.ipynb cell 25)."""
+    _entry = "ilqr_solve"
+
+
+class ALSolver(_Solver):
+    """Altro's augmented-Lagrangian iLQR (the AL stage of ALTROSolver; projected-Newton polish is out of scope)."""
+    _entry = "al_solve"
+
+
+ALTROSolver = ALSolver
+
+
+def solve(solver):
+    """solve!(solver)."""
+    return solver.solve()
+
+
+def iterations(solver):
+    return solver.stats["iterations"]
+
+
+def status(solver):
+    return solver.stats["status"]
+
+
+def max_violation(obj):
+    """max_violation(solver) or max_violation(prob) -> [B]."""
+    prob = obj.prob if isinstance(obj, _Solver) else obj
+    c = np.empty(prob.B)
+    prob._call("max_violation", prob._pd(c))
+    return c

@@ -1,0 +1,117 @@
+"""The BASELINE.json workloads as Problem builders with synthetic,
+reproducible inputs.  Host-side input generation only; shared by tests/, bench.py and smoke()."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import api as T
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64_uniform(seed, index):
+    """U[0,1) doubles from the counter-based splitmix64 stream: element ``i`` is output number ``i`` of
+    splitmix64(seed).  Indexed by the GLOBAL trajectory number so shards draw identical inputs."""
+    idx = np.asarray(index, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (idx + np.uint64(1)) * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _shard(batch, b_offset):
+    return np.arange(b_offset, b_offset + batch, dtype=np.uint64)
+
+
+def cartpole_x0(batch, b_offset=0, seed=1):
+    """C2: x0_b = [ξ1, ξ2, 0, 0], ξ1~U(-0.5,0.5), ξ2~U(-0.3,0.3); global b=0 is exactly zero."""
+    b = _shard(batch, b_offset)
+    x0 = np.zeros((batch, 4))
+    x0[:, 0] = splitmix64_uniform(seed, 2 * b) - 0.5
+    x0[:, 1] = (splitmix64_uniform(seed, 2 * b + np.uint64(1)) - 0.5) * 0.6
+    x0[b == 0] = 0.0
+    return x0
+
+
+def cartpole_problem(batch=1024, N=101, tf=5.0, b_offset=0, constrained=False, integration=T.RK4,
+                     u_bnd=3.0, device=0, lib=None, options=None):
+    """C2 (examples/Cartpole.ipynb cells 3-15; docs/src/creating_problems.md:34-53): Q=1e-2 I, R=1e-1, Qf=100 I,
+    xf=[0,π,0,0], U0≡0.01.  ``constrained`` adds the notebook's |u|≤3 bound and goal constraint."""
+    model = T.Cartpole()
+    n, m = model.dims()
+    xf = np.array([0.0, math.pi, 0.0, 0.0])
+    obj = T.LQRObjective(np.full(n, 1e-2), np.full(m, 1e-1), np.full(n, 100.0), xf, N)
+    cons = T.ConstraintList(n, m, N)
+    if constrained:
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=-u_bnd, u_max=u_bnd), range(1, N))
+        T.add_constraint(cons, T.GoalConstraint(xf), N)
+    prob = T.Problem(model, obj, np.zeros(n), tf, xf=xf, constraints=cons, batch=batch, integration=integration,
+                     device=device, lib=lib, options=options)
+    prob.set_initial_state(cartpole_x0(batch, b_offset))
+    T.initial_controls(prob, np.full(m, 0.01))
+    return prob
+
+
+def quadrotor_x0(batch, b_offset=0, seed=2):
+    """C3: r0 = ζ_b ~ U(-1,1)^3, q = identity, v = ω = 0; global b=0 unperturbed."""
+    b = _shard(batch, b_offset)
+    x0 = np.zeros((batch, 13))
+    for j in range(3):
+        x0[:, j] = 2.0 * splitmix64_uniform(seed, 3 * b + np.uint64(j)) - 1.0
+    x0[b == 0, :3] = 0.0
+    x0[:, 3] = 1.0
+    return x0
+
+
+def quadrotor_problem(batch=4096, N=201, tf=5.0, b_offset=0, constrained=False, goal_inds=None, u_norm_max=6.0,
+                      integration=T.RK4, device=0, lib=None, options=None):
+    """C3/C4 (shape from test/quatcosts.jl:152-168 + src/lie_costs.jl:133-142): point-to-point with QuatLQRCost,
+    xf = (r=[2,3,1], yaw 135°), stage Q=diag(1,1,1, 0,0,0,0, .1×6), R=1e-2 I, terminal Q×100, U0≡hover.
+    ``constrained`` = C5: GoalConstraint(xf)@N + NormConstraint(‖u‖₂≤6, SecondOrderCone)@1..N-1."""
+    model = T.Quadrotor()
+    n, m = model.dims()
+    th = math.radians(135.0) / 2
+    xf = np.zeros(n)
+    xf[:3] = [2.0, 3.0, 1.0]
+    xf[3:7] = [math.cos(th), 0.0, 0.0, math.sin(th)]
+    Qd = np.array([1.0, 1, 1, 0, 0, 0, 0, .1, .1, .1, .1, .1, .1])
+    Rd = np.full(m, 1e-2)
+    uhover = model.hover_control()
+    stage = T.QuatLQRCost(Qd, Rd, xf, uhover, w=1.0)
+    term = T.QuatLQRCost(100.0 * Qd, Rd, xf, uhover, w=1.0, terminal=True)
+    obj = T.Objective(stage, term, N)
+    cons = T.ConstraintList(n, m, N)
+    if constrained:
+        T.add_constraint(cons, T.NormConstraint(n, m, u_norm_max, T.SecondOrderCone(), "control"), range(1, N))
+        T.add_constraint(cons, T.GoalConstraint(xf, goal_inds), N)
+    prob = T.Problem(model, obj, np.zeros(n), tf, xf=xf, constraints=cons, batch=batch, integration=integration,
+                     device=device, lib=lib, options=options)
+    prob.set_initial_state(quadrotor_x0(batch, b_offset))
+    T.initial_controls(prob, uhover)
+    return prob
+
+
+def quickstart_problem(N=21, tf=3.0, batch=1, device=0, lib=None, options=None):
+    """C1 = examples/quickstart.jl:28-59: 2-D double integrator, Goal@N, Circle(0,1,r=.5)@2:N-1,
+    Norm-SOC(5,:control)@1:N-1, Bound(|u|≤10)@1:N-1, U0≡0."""
+    model = T.DoubleIntegrator(1.0, 2)
+    n, m = model.dims()
+    xf = np.array([0.0, 2.0, 0.0, 0.0])
+    obj = T.LQRObjective(np.ones(n), np.ones(m), np.ones(n) * (N - 1), xf, N)
+    cons = T.ConstraintList(n, m, N)
+    T.add_constraint(cons, T.GoalConstraint(xf), N)
+    T.add_constraint(cons, T.CircleConstraint(n, [0.0], [1.0], [0.5]), range(2, N))
+    T.add_constraint(cons, T.NormConstraint(n, m, 5.0, T.SecondOrderCone(), "control"), range(1, N))
+    T.add_constraint(cons, T.BoundConstraint(n, m, u_min=-10, u_max=10), range(1, N))
+    return T.Problem(model, obj, np.zeros(n), tf, xf=xf, constraints=cons, batch=batch, device=device, lib=lib,
+                     options=options)
+
+
+def algorithmic_bytes_per_iteration(n, m, ne, N, duals=0):
+    """FP64 bytes one trajectory-iteration must move (X,U read + X̄,Ū write, Ā/B̄ write+read,
+    K/d write+read, dual reads).  C2 = 48 064 B, C3 = 835 408 B, C5 = 851 616 B."""
+    return 8 * (2 * (N * n + (N - 1) * m) + 2 * (N - 1) * (ne * ne + ne * m) + 2 * (N - 1) * (m * ne + m)) + 16 * duals
