@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: batched iLQR trajectory-iterations per second (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W            (N=1 default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete pass of the hot path over one batch of synthetic input: the batch's controls are
+reset on the device to the initial guess (inputs stay resident in HBM) and the whole batch is solved with
+iLQR (rollout -> [expansion -> backward Riccati -> forward line search]* until every trajectory converges).
+The workload at N=1 is BASELINE.json configs[1]: Cartpole swing-up (n=4, m=1), N=101 knot points,
+batch=1024 trajectories.  Every rank owns its own 1024-trajectory shard (weak scaling; inputs are drawn
+from the global trajectory index so shards are disjoint); with N>1 each step ends with the north-star's
+RCCL all-gather of the converged trajectories.
+
+value = total trajectory-iterations of all ranks over the K timed steps / max-over-ranks wall time.
+roofline: algorithmic bytes (48 064 B per Cartpole trajectory-iteration, split per kernel as
+DESIGN.md §4 states) / kernel time from hipEvents recorded on the library's own stream inside the timed
+region.  cpu_baseline: the CPU oracle (a port; the Julia reference cannot run here) on the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (builder kwargs, description)
+    "cartpole": dict(batch=1024, N=101, solver="ilqr",
+                     desc="C2 Cartpole swing-up iLQR (n=4,m=1), N=101, batch=1024 per GPU"),
+    "quadrotor": dict(batch=4096, N=201, solver="ilqr",
+                      desc="C3 Quadrotor point-to-point iLQR (n=13,m=4,ne=12), N=201, batch=4096 per GPU"),
+    "quadrotor_al": dict(batch=8192, N=201, solver="al",
+                         desc="C5 Quadrotor + GoalConstraint + NormConstraint(SOC) AL-iLQR, N=201, batch=8192 per GPU"),
+}
+
+
+def build_problem(T, configs, name, batch, b_offset, device, lib):
+    if name == "cartpole":
+        return configs.cartpole_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
+    if name == "quadrotor":
+        return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
+    if name == "quadrotor_al":
+        return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib, constrained=True)
+    raise ValueError(name)
+
+
+def initial_controls_value(T, prob, name):
+    return np.full(prob.m, 0.01) if name == "cartpole" else prob.model.hover_control()
+
+
+def kernel_split_bytes(n, m, ne, N, duals):
+    """Per trajectory-iteration algorithmic bytes attributed to each kernel (sums to SURVEY §8d's W)."""
+    xu = 8 * (N * n + (N - 1) * m)
+    ab = 8 * (N - 1) * (ne * ne + ne * m)
+    kd = 8 * (N - 1) * (m * ne + m)
+    return {"expand": xu + ab + 8 * duals, "backward": ab + kd, "forward": kd + xu + 8 * duals}
+
+
+def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
+    """Oracle (port) on the host cores, bounded sample of the same workload."""
+    from oracle_binding import load_oracle, set_threads
+    o = load_oracle()
+    threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
+    sample = min(batch, 1024 if name == "cartpole" else 256 if name == "quadrotor" else 128)
+    prob = build_problem(T, configs, name, sample, 0, 0, o)
+    set_threads(prob, threads)
+    solver = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(prob)
+    t0 = time.perf_counter()
+    solver.solve()
+    dt = time.perf_counter() - t0
+    return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{WORKLOADS[name]['desc'].split(',')[0]}: first {sample} trajectories of the batch, 1 solve, "
+                      f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cartpole", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/scaling studies only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import trajopt_amd as T
+    from trajectoryoptimization_jl_amd import configs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    lib = T.load_hip_library()
+    if lib.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libtrajopt_hip.so has no CPU fallback")
+    name = args.workload
+    W = WORKLOADS[name]
+    batch = args.batch or W["batch"]
+    prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
+    solver = (T.ALSolver if W["solver"] == "al" else T.iLQRSolver)(prob)
+    u0 = initial_controls_value(T, prob, name)
+    n, m, N = prob.dims()
+    ne = prob.errstate_dim
+    duals = sum(prob.constraints.p)
+
+    gather = None
+    if world > 1:  # RCCL all-gather buffers for the converged trajectories (host layout (n,N,B) per rank)
+        xs = torch.empty(batch * N * n, dtype=torch.float64, device="cuda")
+        us = torch.empty(batch * (N - 1) * m, dtype=torch.float64, device="cuda")
+        xg = torch.empty(world * xs.numel(), dtype=torch.float64, device="cuda")
+        ug = torch.empty(world * us.numel(), dtype=torch.float64, device="cuda")
+        gather = (xs, us, xg, ug)
+
+    def one_step():
+        T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
+        solver.solve()
+        if gather is not None:
+            xs, us, xg, ug = gather
+            prob._call("get_states_device", C.c_void_p(xs.data_ptr()))
+            prob._call("get_controls_device", C.c_void_p(us.data_ptr()))
+            dist.all_gather_into_tensor(xg, xs)
+            dist.all_gather_into_tensor(ug, us)
+        return solver.total_iterations, solver.batch_steps
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    profile = not args.no_profile
+    prob._call("reset_profile")
+    prob._call("set_profiling", 1 if profile else 0)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    bsteps = 0
+    for _ in range(args.steps):
+        it, bs = one_step()
+        iters += it
+        bsteps += bs
+    barrier()
+    dt = time.perf_counter() - t0
+    prob._call("set_profiling", 0)
+    kms = (C.c_double * 4)()
+    kln = (C.c_int64 * 4)()
+    prob._call("get_profile", kms, kln)
+
+    if dist is not None:
+        t = torch.tensor([dt, float(iters)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, iters_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, iters_all = dt, float(iters)
+
+    if rank == 0:
+        value = iters_all / dt_max
+        bytes_it = configs.algorithmic_bytes_per_iteration(n, m, ne, N, duals)
+        split = kernel_split_bytes(n, m, ne, N, duals)
+        names = ["expand", "backward", "forward"]
+        kern = {}
+        for i, kn in enumerate(names):
+            if kln[i] > 0:
+                kern[kn] = {"ms_total": kms[i], "launches": int(kln[i]), "avg_us": 1e3 * kms[i] / kln[i]}
+        roof = None
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["ms_total"])
+            # a launch processes, on average, (trajectory-iterations of this rank) / launches units
+            units_per_launch = iters / kern[dom]["launches"]
+            achieved = split[dom] * units_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_unit": split[dom], "units_per_launch": units_per_launch,
+                    "avg_launch_us": kern[dom]["avg_us"], "kernels": kern,
+                    "whole_iteration": {"algorithmic_bytes_per_unit": bytes_it,
+                                        "achieved": bytes_it * value / world / 1e9,
+                                        "frac": bytes_it * value / world / 1e9 / HBM_PEAK_GBS}}
+        out = {
+            "metric": "iLQR iterations/sec (batched trajectories)", "value": value, "unit": "trajectory-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
+                       "trajectory_iterations_per_step": iters_all / args.steps,
+                       "batch_steps_per_solve": bsteps / args.steps,
+                       "collective": "RCCL all_gather of converged (X,U)" if world > 1 else "none"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(T, configs, name, batch)
+            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -275,6 +275,14 @@ int to_cost_expansion(to_handle* h, double* grad, double* hess);
 /* raw RK Jacobian [A B] of the discrete dynamics (RD.jacobian! on DiscretizedDynamics): F[n,(n+m),N-1,B] */
 int to_discrete_jacobian(to_handle* h, double* F);
 
+/* ---- measurement: per-kernel device time of the solve loop, from hipEvents recorded on the handle's stream ----
+ * slots: 0 expansion, 1 backward pass, 2 forward pass (+ state machine), 3 fused whole-solve kernel (when used).
+ * Accumulates over solves until reset.  Enabling it adds two event records per launch. */
+#define TO_PROFILE_SLOTS 4
+int to_set_profiling(to_handle* h, int enable);
+int to_get_profile(to_handle* h, double* kernel_ms /* [TO_PROFILE_SLOTS] */, int64_t* launches /* [TO_PROFILE_SLOTS] */);
+int to_reset_profile(to_handle* h);
+
 /* ---- constraints --------------------------------------------------------------------------- */
 /* evaluate_constraints! / constraint_jacobians! for constraint `con_id` over its knot range.
  * vals[p, nk, B], jac[p, w, nk, B] with w = n (state constraints: GOAL, CIRCLE, SPHERE) or n+m (stage constraints),

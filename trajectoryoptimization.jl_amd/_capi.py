@@ -183,6 +183,9 @@ SIGNATURES = {
 HIP_ONLY = {
     "get_states_device": [_H, C.c_void_p],
     "get_controls_device": [_H, C.c_void_p],
+    "set_profiling": [_H, C.c_int],
+    "get_profile": [_H, _PD, C.POINTER(C.c_int64)],
+    "reset_profile": [_H],
 }
 
 

@@ -1,0 +1,359 @@
+// problem_dev.h — device-side problem description and the per-knot cost / constraint / cone
+// arithmetic.  All descriptor data is wave-uniform (scalar loads); the
+// per-trajectory data (x, u, duals) lives in registers, one trajectory per lane.
+//
+// Restated from src/cost_functions.jl:89-233, src/lie_costs.jl:68-95, src/constraints.jl (Goal :55-68,
+// Bound :738-765, Norm :462-517, Circle :199-228, Sphere :283-321, Linear :134-144), src/cones.jl:96-276.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/trajopt_hip.h"
+
+namespace to {
+
+struct DevCon {
+  to_constraint_desc d;
+  int p, width, k1, k2;     // k1,k2 0-based inclusive
+  long long dual_off;       // row offset of this constraint's duals in the per-trajectory dual array
+  int selector;             // 1: every row is s*(z[idx]-off) or a constant (GOAL, BOUND, NORM-SOC)
+  int sidx[TO_MAX_P];       // selector rows: 0-based index into z, or -1 for a constant row (value = soff)
+  double ssgn[TO_MAX_P];
+  double soff[TO_MAX_P];
+};
+
+struct DevProblem {
+  int n, m, ne, N, B, Bp, integrator, n_costs, n_cons;
+  long long n_duals;
+  double mp[16];
+  to_solver_opts opts;
+  const double* dt;          // [N-1]
+  const int* cost_index;     // [N]
+  const to_cost_desc* costs; // [n_costs]
+  const DevCon* cons;        // [n_cons]
+};
+
+// register-array helpers with a wave-uniform runtime index (no scratch: unrolled selects)
+template <int N_>
+__device__ __forceinline__ double pick(const double* a, int idx) {
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < N_; ++i) r = (i == idx) ? a[i] : r;
+  return r;
+}
+template <int N_>
+__device__ __forceinline__ void add_at(double* a, int idx, double v) {
+#pragma unroll
+  for (int i = 0; i < N_; ++i) a[i] += (i == idx) ? v : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------ costs
+// J = ½x'Qx + q'x + c (+ ½u'Ru + r'u whenever u is given) (+ u'Hx) (+ w·min(1±dq))
+template <int n, int m>
+__device__ __forceinline__ double cost_eval(const to_cost_desc& C, const double* x, const double* u) {
+  double J;
+  if (C.kind == TO_COST_QUADRATIC) {
+    double xQx = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) t += x[i] * C.Q[i + n * j];
+      xQx += t * x[j];
+    }
+    J = 0.5 * xQx;
+  } else {
+    double xQx = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) xQx += x[i] * C.Q[i] * x[i];
+    J = 0.5 * xQx;
+  }
+  double qx = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) qx += C.q[i] * x[i];
+  J = J + qx + C.c;
+  {
+    double uRu = 0.0, ru = 0.0;
+    if (C.kind == TO_COST_QUADRATIC) {
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < m; ++i) t += u[i] * C.R[i + m * j];
+        uRu += t * u[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < m; ++i) uRu += u[i] * C.R[i] * u[i];
+    }
+#pragma unroll
+    for (int i = 0; i < m; ++i) ru += C.r[i] * u[i];
+    J += 0.5 * uRu + ru;
+    if (C.kind == TO_COST_QUADRATIC) {
+      double uHx = 0.0;
+#pragma unroll
+      for (int j = 0; j < n; ++j)
+#pragma unroll
+        for (int i = 0; i < m; ++i) uHx += u[i] * C.H[i + m * j] * x[j];
+      J += uHx;
+    }
+  }
+  if (C.kind == TO_COST_DIAGONAL_QUAT) {
+    double dq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq += C.q_ref[i] * pick<n>(x, C.q_ind[i] - 1);
+    J += C.w * fmin(1 + dq, 1 - dq);
+  }
+  return J;
+}
+
+// gradient g (n+m) and Hessian-vector product y = H v (n+m) of the cost at (x,u); u-parts zero if terminal
+template <int n, int m>
+__device__ __forceinline__ void cost_grad_hvp(const to_cost_desc& C, const double* x, const double* u, bool terminal,
+                                              const double* v, double* g, double* y) {
+  if (C.kind == TO_COST_QUADRATIC) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      double t = C.q[i], h = 0.0;
+#pragma unroll
+      for (int j = 0; j < n; ++j) { t += C.Q[i + n * j] * x[j]; h += C.Q[i + n * j] * v[j]; }
+      g[i] = t; y[i] = h;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < n; ++i) { g[i] = C.Q[i] * x[i] + C.q[i]; y[i] = C.Q[i] * v[i]; }
+  }
+  if (C.kind == TO_COST_DIAGONAL_QUAT) {  // the intended gradient src/lie_costs.jl:82-90
+    double dq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq += C.q_ref[i] * pick<n>(x, C.q_ind[i] - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) add_at<n>(g, C.q_ind[i] - 1, dq < 0 ? C.w * C.q_ref[i] : -(C.w * C.q_ref[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < m; ++i) { g[n + i] = 0.0; y[n + i] = 0.0; }
+  if (!terminal) {
+    if (C.kind == TO_COST_QUADRATIC) {
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        double t = C.r[i], h = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) { t += C.R[i + m * j] * u[j]; h += C.R[i + m * j] * v[n + j]; }
+        g[n + i] = t; y[n + i] = h;
+      }
+#pragma unroll
+      for (int j = 0; j < n; ++j)
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          const double Hij = C.H[i + m * j];
+          g[j] += Hij * u[i]; g[n + i] += Hij * x[j];
+          y[j] += Hij * v[n + i]; y[n + i] += Hij * v[j];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < m; ++i) { g[n + i] = C.R[i] * u[i] + C.r[i]; y[n + i] = C.R[i] * v[n + i]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ constraints
+// One row of a non-selector constraint: value c and the gradient coefficients on z[inds[t]], t < n_inds.
+template <int nz>
+__device__ __forceinline__ double con_row(const DevCon& K, const double* z, int r, double* coef /* [nz] */) {
+  const to_constraint_desc& d = K.d;
+  double c = 0.0;
+  switch (d.kind) {
+    case TO_CON_NORM: {  // quadratic form: |z[inds]|² − val²
+#pragma unroll
+      for (int t = 0; t < nz; ++t)
+        if (t < d.n_inds) { double zj = pick<nz>(z, d.inds[t] - 1); c += zj * zj; coef[t] = 2 * zj; }
+      c -= d.params[0] * d.params[0];
+      break;
+    }
+    case TO_CON_CIRCLE: {
+      const int P = K.p;
+      const double dx = pick<nz>(z, d.inds[0] - 1) - d.params[r], dy = pick<nz>(z, d.inds[1] - 1) - d.params[P + r];
+      const double rad = d.params[2 * P + r];
+      c = -(dx * dx) - dy * dy + rad * rad;
+      coef[0] = -2 * dx; coef[1] = -2 * dy;
+      break;
+    }
+    case TO_CON_SPHERE: {
+      const int P = K.p;
+      const double dx = pick<nz>(z, d.inds[0] - 1) - d.params[r], dy = pick<nz>(z, d.inds[1] - 1) - d.params[P + r];
+      const double dz = pick<nz>(z, d.inds[2] - 1) - d.params[2 * P + r], rad = d.params[3 * P + r];
+      c = -(dx * dx) - dy * dy - dz * dz + rad * rad;
+      coef[0] = -2 * dx; coef[1] = -2 * dy;
+      if constexpr (nz > 2) coef[2] = -2 * dz;
+      break;
+    }
+    case TO_CON_LINEAR: {
+      const int p = K.p;
+#pragma unroll
+      for (int t = 0; t < nz; ++t)
+        if (t < d.n_inds) { const double a = d.params[r + p * t]; c += a * pick<nz>(z, d.inds[t] - 1); coef[t] = a; }
+      c -= d.params[p * d.n_inds + r];
+      break;
+    }
+    default: break;
+  }
+  return c;
+}
+
+// value of row r of a selector constraint
+template <int nz>
+__device__ __forceinline__ double sel_row(const DevCon& K, const double* z, int r) {
+  const int j = K.sidx[r];
+  return j < 0 ? K.soff[r] : K.ssgn[r] * (pick<nz>(z, j) - K.soff[r]);
+}
+
+// SOC pieces for the vector lb = lam − mu·c of a NORM-SOC selector constraint (p = D+1, last row constant).
+struct SocState { double a, s, coef; int branch; };  // Π(lb) = coef·[v; a] (branch 2), lb (1), 0 (0)
+
+// AL penalty of one constraint at one knot.  lam: pointer to row 0 of this knot's duals
+// (batch-fastest: row r at lam[r*stride]).
+template <int nz>
+__device__ __forceinline__ double al_term(const DevCon& K, const double* z, const double* lam, size_t stride, double mu) {
+  const int p = K.p;
+  double J = 0.0;
+  if (K.d.sense == TO_CONE_SECOND_ORDER) {
+    // psi = (|Π(lb)|² − |lam|²)/(2mu);  |Π|² = 0 | |lb|² | 2·coef²·a²
+    double a2 = 0.0, l2 = 0.0, s = 0.0;
+    for (int r = 0; r < p; ++r) {
+      const double l = lam[r * stride];
+      const double lb = l - mu * sel_row<nz>(K, z, r);
+      l2 += l * l;
+      if (r < p - 1) a2 += lb * lb; else s = lb;
+    }
+    const double a = sqrt(a2);
+    double pn;
+    if (a <= -s) pn = 0.0;
+    else if (a <= s) pn = a2 + s * s;
+    else { const double cf = 0.5 * (1 + s / a); pn = (cf * cf) * a2 + (a * cf) * (a * cf); }
+    J = (pn - l2) / (2.0 * mu);
+  } else if (K.selector) {
+    for (int r = 0; r < p; ++r) {
+      const double l = lam[r * stride], c = sel_row<nz>(K, z, r);
+      const bool active = (K.d.sense == TO_CONE_ZERO) || (c >= 0.0) || (l > 0.0);
+      J += l * c + (active ? 0.5 * mu * c * c : 0.0);
+    }
+  } else {
+    double coef[nz];
+    for (int r = 0; r < p; ++r) {
+      const double l = lam[r * stride], c = con_row<nz>(K, z, r, coef);
+      const bool active = (K.d.sense == TO_CONE_ZERO) || (c >= 0.0) || (l > 0.0);
+      J += l * c + (active ? 0.5 * mu * c * c : 0.0);
+    }
+  }
+  return J;
+}
+
+// adds the AL gradient (g += ∇c' y) and Gauss-Newton Hessian-vector product (y += ∇c' W ∇c v) of one constraint.
+// For the SOC the reference composes ∇Π'∇Π + ∇²Π[Π] (src/cones.jl); since ∇(½|Π(x)|²) = Π(x) this equals ∇Π(x), and
+// ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
+template <int nz>
+__device__ __forceinline__ void al_grad_hvp(const DevCon& K, const double* z, const double* lam, size_t stride, double mu,
+                                            const double* v, double* g, double* y) {
+  const int p = K.p;
+  if (K.d.sense == TO_CONE_SECOND_ORDER) {
+    double a2 = 0.0, s = 0.0, lw = 0.0;  // lw = lb_v · w_v with w = ∇c v
+    for (int r = 0; r < p; ++r) {
+      const double lb = lam[r * stride] - mu * sel_row<nz>(K, z, r);
+      if (r < p - 1) { a2 += lb * lb; lw += lb * (K.ssgn[r] * pick<nz>(v, K.sidx[r])); } else s = lb;
+    }
+    const double a = sqrt(a2);
+    if (a <= -s) return;  // Π = 0, ∇Π = 0
+    const bool inside = (a <= s);
+    const double cf = inside ? 1.0 : 0.5 * (1 + s / a);
+    const double k3 = inside ? 0.0 : 0.5 * s / (a * a * a);
+    for (int r = 0; r < p - 1; ++r) {
+      const int j = K.sidx[r];
+      const double sg = K.ssgn[r];
+      const double lb = lam[r * stride] - mu * sel_row<nz>(K, z, r);
+      add_at<nz>(g, j, -sg * (cf * lb));                       // −∇c'Π(lb)
+      const double w = sg * pick<nz>(v, j);
+      add_at<nz>(y, j, mu * sg * (cf * w - k3 * lb * lw));     // µ ∇c' ∇Π(lb) ∇c v  (the s-row of ∇c is zero)
+    }
+  } else if (K.selector) {
+    for (int r = 0; r < p; ++r) {
+      const int j = K.sidx[r];
+      const double l = lam[r * stride], c = sel_row<nz>(K, z, r);
+      const bool active = (K.d.sense == TO_CONE_ZERO) || (c >= 0.0) || (l > 0.0);
+      const double sg = K.ssgn[r];
+      add_at<nz>(g, j, sg * (l + (active ? mu * c : 0.0)));
+      add_at<nz>(y, j, active ? mu * pick<nz>(v, j) : 0.0);
+    }
+  } else {
+    double coef[nz];
+    for (int r = 0; r < p; ++r) {
+      const double l = lam[r * stride], c = con_row<nz>(K, z, r, coef);
+      const bool active = (K.d.sense == TO_CONE_ZERO) || (c >= 0.0) || (l > 0.0);
+      const double yr = l + (active ? mu * c : 0.0);
+      double cv = 0.0;
+#pragma unroll
+      for (int t = 0; t < nz; ++t) if (t < K.d.n_inds) cv += coef[t] * pick<nz>(v, K.d.inds[t] - 1);
+      const double wv = active ? mu * cv : 0.0;
+#pragma unroll
+      for (int t = 0; t < nz; ++t)
+        if (t < K.d.n_inds) { add_at<nz>(g, K.d.inds[t] - 1, coef[t] * yr); add_at<nz>(y, K.d.inds[t] - 1, coef[t] * wv); }
+    }
+  }
+}
+
+// max violation of one constraint at one knot
+template <int nz>
+__device__ __forceinline__ double con_violation(const DevCon& K, const double* z) {
+  const int p = K.p;
+  double vmax = 0.0;
+  if (K.d.sense == TO_CONE_SECOND_ORDER) {
+    double a2 = 0.0, s = 0.0;
+    for (int r = 0; r < p; ++r) { const double c = sel_row<nz>(K, z, r); if (r < p - 1) a2 += c * c; else s = c; }
+    const double a = sqrt(a2);
+    if (a <= -s) { for (int r = 0; r < p; ++r) { const double v = fabs(sel_row<nz>(K, z, r)); if (!(v <= vmax)) vmax = v; } }
+    else if (a <= s) vmax = 0.0;
+    else {
+      const double cf = 0.5 * (1 + s / a);
+      for (int r = 0; r < p; ++r) {
+        const double c = sel_row<nz>(K, z, r);
+        const double pc = (r < p - 1) ? c * cf : a * cf;
+        const double v = fabs(c - pc);
+        if (!(v <= vmax)) vmax = v;
+      }
+    }
+    return vmax;
+  }
+  double coef[nz];
+  for (int r = 0; r < p; ++r) {
+    const double c = K.selector ? sel_row<nz>(K, z, r) : con_row<nz>(K, z, r, coef);
+    const double v = (K.d.sense == TO_CONE_ZERO) ? fabs(c) : fmax(0.0, c);
+    if (!(v <= vmax)) vmax = v;
+  }
+  return vmax;
+}
+
+// dual update of one constraint at one knot (lam in place)
+template <int nz>
+__device__ __forceinline__ void con_dual_update(const DevCon& K, const double* z, double* lam, size_t stride, double mu, double dual_max) {
+  const int p = K.p;
+  if (K.d.sense == TO_CONE_SECOND_ORDER) {
+    double a2 = 0.0, s = 0.0;
+    for (int r = 0; r < p; ++r) { const double lb = lam[r * stride] - mu * sel_row<nz>(K, z, r); if (r < p - 1) a2 += lb * lb; else s = lb; }
+    const double a = sqrt(a2);
+    for (int r = 0; r < p; ++r) {
+      const double lb = lam[r * stride] - mu * sel_row<nz>(K, z, r);
+      double out;
+      if (a <= -s) out = 0.0;
+      else if (a <= s) out = lb;
+      else { const double cf = 0.5 * (1 + s / a); out = (r < p - 1) ? lb * cf : a * cf; }
+      lam[r * stride] = out;
+    }
+    return;
+  }
+  double coef[nz];
+  for (int r = 0; r < p; ++r) {
+    const double c = K.selector ? sel_row<nz>(K, z, r) : con_row<nz>(K, z, r, coef);
+    const double l = lam[r * stride] + mu * c;
+    lam[r * stride] = (K.d.sense == TO_CONE_ZERO) ? fmax(-dual_max, fmin(dual_max, l)) : fmin(dual_max, fmax(0.0, l));
+  }
+}
+
+}  // namespace to

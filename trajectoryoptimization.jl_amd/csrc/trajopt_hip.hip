@@ -1,0 +1,830 @@
+// trajopt_hip.hip — host side of libtrajopt_hip.so: descriptor validation, device storage, kernel
+// launches and the C-ABI declared in include/trajopt_hip.h.  gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace to;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHECK(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(TO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+#define CHECK_H(h) do { if (!(h)) return fail(TO_ERR_NULL, "null handle"); } while (0)
+#define CHECK_P(p) do { if (!(p)) return fail(TO_ERR_NULL, "null pointer"); } while (0)
+#define TRY(expr) do { int r_ = (expr); if (r_ != TO_OK) return r_; } while (0)
+
+constexpr int BLOCK = 64;  // one wave per workgroup: a small batch is spread over as many CUs as possible
+
+void default_opts(to_solver_opts* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->cost_tolerance = 1e-4; o->gradient_tolerance = 10.0; o->iterations = 300; o->dJ_counter_limit = 10;
+  o->iterations_linesearch = 20; o->line_search_lower_bound = 1e-8; o->line_search_upper_bound = 10.0;
+  o->line_search_decrease_factor = 0.5; o->bp_reg_initial = 0.0; o->bp_reg_increase_factor = 1.6;
+  o->bp_reg_min = 1e-8; o->bp_reg_max = 1e8; o->bp_reg_fp = 10.0; o->max_cost_value = 1e8;
+  o->max_state_value = 1e8; o->max_control_value = 1e8; o->constraint_tolerance = 1e-6;
+  o->cost_tolerance_intermediate = 1e-4; o->penalty_initial = 1.0; o->penalty_scaling = 10.0;
+  o->penalty_max = 1e8; o->dual_max = 1e8; o->iterations_outer = 30; o->cost_dt_scaling = 0;
+  o->iterations_total = 1000;
+}
+
+int model_dims(int id, const double* params, int* n, int* m, int* ne, int* key) {
+  switch (id) {
+    case TO_MODEL_DOUBLE_INTEGRATOR: {
+      const int D = (int)params[1];
+      if (D < 1 || D > 3) return -1;
+      *n = 2 * D; *m = D; *ne = 2 * D; *key = D - 1; return 0;
+    }
+    case TO_MODEL_CARTPOLE: *n = 4; *m = 1; *ne = 4; *key = 3; return 0;
+    case TO_MODEL_QUADROTOR: *n = 13; *m = 4; *ne = 12; *key = 4; return 0;
+  }
+  return -1;
+}
+
+}  // namespace
+
+struct to_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int model_key = -1;
+  KArgs a;  // host copy of the kernel argument block (device pointers inside)
+  std::vector<to_cost_desc> costs;
+  std::vector<DevCon> cons;
+  std::vector<double> dt;
+  std::vector<int> cost_index;
+  std::vector<void*> allocs;
+  double* stage = nullptr;  // device staging buffer in host layout
+  size_t stage_bytes = 0;
+  int* counter_host = nullptr;  // pinned
+  int counter_len = 0;
+  // device copies of the descriptor tables
+  to_cost_desc* d_costs = nullptr;
+  DevCon* d_cons = nullptr;
+  double* d_dt = nullptr;
+  int* d_cost_index = nullptr;
+  double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
+  double* d_tmp2 = nullptr;
+  // measurement
+  bool profile = false;
+  std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
+  double prof_ms[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
+  int64_t prof_launches[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
+};
+
+namespace {
+
+#define DISPATCH(h, ...)                                                                        \
+  switch ((h)->model_key) {                                                                     \
+    case 0: { using M = DoubleIntegratorModel<1>; __VA_ARGS__; } break;                         \
+    case 1: { using M = DoubleIntegratorModel<2>; __VA_ARGS__; } break;                         \
+    case 2: { using M = DoubleIntegratorModel<3>; __VA_ARGS__; } break;                         \
+    case 3: { using M = CartpoleModel; __VA_ARGS__; } break;                                    \
+    case 4: { using M = QuadrotorModel; __VA_ARGS__; } break;                                   \
+    default: return fail(TO_ERR_UNSUPPORTED, "unknown model");                                  \
+  }
+
+int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon* out) {
+  const int nz = n + m;
+  DevCon ci;
+  std::memset(&ci, 0, sizeof(ci));
+  ci.d = d;
+  if (d.k_first < 1 || d.k_last > N || d.k_first > d.k_last)
+    return fail(TO_ERR_ASSERTION, "Invalid inds, inds[end] must be less than number of knotpoints");  // src/constraint_list.jl:112
+  if (d.n_inds < 0 || d.n_inds > TO_MAX_CON_INDS || d.n_params < 0 || d.n_params > TO_MAX_CON_PARAMS)
+    return fail(TO_ERR_ARGUMENT, "constraint inds/params count out of range");
+  auto dimerr = [&](const char* what) {
+    return fail(TO_ERR_DIMENSION_MISMATCH, std::string("New constraint not consistent with n=") + std::to_string(n) +
+                                               " and m=" + std::to_string(m) + ": " + what);  // src/constraint_list.jl:109
+  };
+  int p = 0;
+  switch (d.kind) {
+    case TO_CON_GOAL:
+      if (d.sense != TO_CONE_ZERO) return fail(TO_ERR_ARGUMENT, "GoalConstraint sense must be Equality");
+      if (d.n_params != d.n_inds) return dimerr("GoalConstraint length(xf) != length(inds)");
+      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return dimerr("GoalConstraint index outside the state");
+      ci.width = n; p = d.n_inds; ci.selector = 1;
+      for (int r = 0; r < p && r < TO_MAX_P; ++r) { ci.sidx[r] = d.inds[r] - 1; ci.ssgn[r] = 1.0; ci.soff[r] = d.params[r]; }
+      break;
+    case TO_CON_BOUND: {
+      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "BoundConstraint sense must be Inequality");
+      if (d.n_params != 2 * nz) return dimerr("BoundConstraint needs z_max and z_min of length n+m");
+      for (int i = 0; i < nz; ++i)
+        if (!(d.params[i] >= d.params[nz + i])) return fail(TO_ERR_ARGUMENT, "Upper bounds must be greater than or equal to lower bounds");  // src/constraints.jl:712
+      ci.width = nz; ci.selector = 1;
+      for (int j = 0; j < nz; ++j) if (std::isfinite(d.params[j])) { if (p < TO_MAX_P) { ci.sidx[p] = j; ci.ssgn[p] = 1.0; ci.soff[p] = d.params[j]; } ++p; }
+      for (int j = 0; j < nz; ++j) if (std::isfinite(d.params[nz + j])) { if (p < TO_MAX_P) { ci.sidx[p] = j; ci.ssgn[p] = -1.0; ci.soff[p] = d.params[nz + j]; } ++p; }
+      break;
+    }
+    case TO_CON_NORM:
+      if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "NormConstraint needs one parameter (val)");
+      if (!(d.params[0] >= 0)) return fail(TO_ERR_ASSERTION, "Value must be greater than or equal to zero");  // src/constraints.jl:453
+      if (d.sense != TO_CONE_ZERO && d.sense != TO_CONE_NEGATIVE_ORTHANT && d.sense != TO_CONE_SECOND_ORDER)
+        return fail(TO_ERR_ARGUMENT, "NormConstraint sense must be Equality, Inequality or SecondOrderCone");
+      if (d.n_inds < 1 || d.n_inds > nz) return dimerr("NormConstraint needs 1..n+m indices");
+      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > nz) return dimerr("NormConstraint index outside [x;u]");
+      ci.width = nz;
+      if (d.sense == TO_CONE_SECOND_ORDER) {
+        p = d.n_inds + 1; ci.selector = 1;
+        for (int r = 0; r < d.n_inds; ++r) { ci.sidx[r] = d.inds[r] - 1; ci.ssgn[r] = 1.0; ci.soff[r] = 0.0; }
+        ci.sidx[d.n_inds] = -1; ci.ssgn[d.n_inds] = 0.0; ci.soff[d.n_inds] = d.params[0];
+      } else p = 1;
+      break;
+    case TO_CON_CIRCLE:
+      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "CircleConstraint sense must be Inequality");
+      if (d.n_inds != 2 || d.n_params % 3 != 0 || d.n_params == 0) return fail(TO_ERR_ASSERTION, "Lengths of xc, yc, and radius must be equal.");
+      for (int i = 0; i < 2; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return dimerr("CircleConstraint index outside the state");
+      ci.width = n; p = d.n_params / 3;
+      break;
+    case TO_CON_SPHERE:
+      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "SphereConstraint sense must be Inequality");
+      if (d.n_inds != 3 || d.n_params % 4 != 0 || d.n_params == 0) return fail(TO_ERR_ASSERTION, "Lengths of xc, yc, zc, and radius must be equal.");
+      for (int i = 0; i < 3; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return dimerr("SphereConstraint index outside the state");
+      ci.width = n; p = d.n_params / 4;
+      break;
+    case TO_CON_LINEAR:
+      if (d.sense != TO_CONE_ZERO && d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "LinearConstraint sense must be Equality or Inequality");
+      if (d.n_inds < 1 || d.n_inds > nz || d.n_params == 0 || d.n_params % (d.n_inds + 1) != 0) return fail(TO_ERR_ASSERTION, "size(A,1) == length(b)");
+      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > nz) return dimerr("LinearConstraint index outside [x;u]");
+      ci.width = nz; p = d.n_params / (d.n_inds + 1);
+      break;
+    default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
+  }
+  if (p < 1 || p > TO_MAX_P) return fail(TO_ERR_UNSUPPORTED, "constraint output dimension outside 1..TO_MAX_P");
+  if (d.p != 0 && d.p != p) return fail(TO_ERR_DIMENSION_MISMATCH, "constraint output dimension does not match its descriptor");
+  ci.p = p; ci.k1 = d.k_first - 1; ci.k2 = d.k_last - 1;
+  *out = ci;
+  return TO_OK;
+}
+
+int validate_cost(int n, const to_cost_desc& c) {
+  if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT)
+    return fail(TO_ERR_UNSUPPORTED, "unknown cost kind");
+  if (c.kind == TO_COST_DIAGONAL_QUAT)
+    for (int i = 0; i < 4; ++i) if (c.q_ind[i] < 1 || c.q_ind[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "quat_ind outside the state");
+  return TO_OK;
+}
+
+template <class T>
+int dev_alloc(to_handle* h, T** p, size_t count, bool zero = true) {
+  void* q = nullptr;
+  HIPCHECK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  if (zero) HIPCHECK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
+  *p = (T*)q;
+  return TO_OK;
+}
+
+int ensure_stage(to_handle* h, size_t bytes) {
+  if (h->stage_bytes >= bytes) return TO_OK;
+  if (h->stage) { HIPCHECK(hipStreamSynchronize(h->stream)); HIPCHECK(hipFree(h->stage)); h->stage = nullptr; h->stage_bytes = 0; }
+  HIPCHECK(hipMalloc((void**)&h->stage, bytes));
+  h->stage_bytes = bytes;
+  return TO_OK;
+}
+
+int use_device(to_handle* h) { HIPCHECK(hipSetDevice(h->device)); return TO_OK; }
+
+dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
+
+// host (dim, K, B) -> device [k][i][Bp] through the staging buffer
+int upload_vec(to_handle* h, const double* host, double* d0, double* d1, int dim, int K, bool use_cur) {
+  const size_t cnt = (size_t)dim * K * h->a.P.B;
+  TRY(ensure_stage(h, cnt * sizeof(double)));
+  HIPCHECK(hipMemcpyAsync(h->stage, host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (use_cur) hipLaunchKernelGGL(k_to_device_cur, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, h->stage, d0, d1, h->a.cur, dim, K, h->a.P.B, h->a.P.Bp);
+  else hipLaunchKernelGGL(k_to_device, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, h->stage, d0, dim, K, h->a.P.B, h->a.P.Bp);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int download_vec(to_handle* h, double* host, const double* d0, const double* d1, int dim, int K, bool use_cur, void* dev_dst = nullptr) {
+  const size_t cnt = (size_t)dim * K * h->a.P.B;
+  double* dst = (double*)dev_dst;
+  if (!dst) { TRY(ensure_stage(h, cnt * sizeof(double))); dst = h->stage; }
+  if (use_cur) hipLaunchKernelGGL(k_to_host_cur, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, d0, d1, h->a.cur, dst, dim, K, h->a.P.B, h->a.P.Bp);
+  else hipLaunchKernelGGL(k_to_host, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, d0, dst, dim, K, h->a.P.B, h->a.P.Bp);
+  HIPCHECK(hipGetLastError());
+  if (host) HIPCHECK(hipMemcpyAsync(host, dst, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int download_mat(to_handle* h, double* host, const double* d, int R, int Cc, int K) {
+  if (!host) return TO_OK;
+  const size_t cnt = (size_t)R * Cc * K * h->a.P.B;
+  TRY(ensure_stage(h, cnt * sizeof(double)));
+  hipLaunchKernelGGL(k_mat_to_host, grid_b(h, R * Cc * K), dim3(BLOCK), 0, h->stream, d, h->stage, R, Cc, K, h->a.P.B, h->a.P.Bp);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int download_scalar(to_handle* h, double* host, const double* d) {
+  if (!host) return TO_OK;
+  HIPCHECK(hipMemcpyAsync(host, d, sizeof(double) * h->a.P.B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int download_int(to_handle* h, int32_t* host, const int* d) {
+  if (!host) return TO_OK;
+  HIPCHECK(hipMemcpyAsync(host, d, sizeof(int) * h->a.P.B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+
+int upload_tables(to_handle* h) {
+  HIPCHECK(hipMemcpyAsync(h->d_costs, h->costs.data(), h->costs.size() * sizeof(to_cost_desc), hipMemcpyHostToDevice, h->stream));
+  if (!h->cons.empty()) HIPCHECK(hipMemcpyAsync(h->d_cons, h->cons.data(), h->cons.size() * sizeof(DevCon), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+
+int launch_set_active(to_handle* h, int v) {
+  hipLaunchKernelGGL(k_set_active, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, v);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_rollout(to_handle* h) {
+  DISPATCH(h, hipLaunchKernelGGL(k_rollout<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_cost(to_handle* h, int with_al, double* out, double* Jk) {
+  DISPATCH(h, hipLaunchKernelGGL(k_cost<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, with_al, out, Jk));
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_expand(to_handle* h) {
+  const DevProblem& P = h->a.P;
+  DISPATCH(h, hipLaunchKernelGGL(k_expand<M>, grid_b(h, P.N, P.ne + P.m), dim3(BLOCK), 0, h->stream, h->a));
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_backward(to_handle* h) {
+  DISPATCH(h, hipLaunchKernelGGL(k_backward<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_forward(to_handle* h) {
+  DISPATCH(h, hipLaunchKernelGGL(k_forward<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_violation(to_handle* h, double* out) {
+  DISPATCH(h, hipLaunchKernelGGL(k_violation<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, out));
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+
+int solve(to_handle* h, to_solve_stats* st, int al_mode) {
+  TRY(use_device(h));
+  KArgs& a = h->a;
+  const DevProblem& P = a.P;
+  a.al_mode = al_mode;
+  a.control = 1;
+  const int max_steps = (al_mode ? P.opts.iterations_total : P.opts.iterations) + 1;
+  if (h->counter_len < max_steps) {
+    int* c = nullptr;
+    HIPCHECK(hipMalloc((void**)&c, sizeof(int) * max_steps));
+    h->allocs.push_back(c);
+    a.counter = c;
+    if (h->counter_host) HIPCHECK(hipHostFree(h->counter_host));
+    HIPCHECK(hipHostMalloc((void**)&h->counter_host, sizeof(int) * max_steps));
+    h->counter_len = max_steps;
+  }
+  HIPCHECK(hipMemsetAsync(a.counter, 0, sizeof(int) * max_steps, h->stream));
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  HIPCHECK(hipEventRecord(e0, h->stream));
+  hipLaunchKernelGGL(k_solve_init, grid_b(h), dim3(BLOCK), 0, h->stream, a, al_mode);
+  HIPCHECK(hipGetLastError());
+  TRY(launch_rollout(h));
+  TRY(launch_cost(h, 1, a.J, nullptr));
+  int steps = 0;
+  if (h->profile) {
+    while ((int)h->ev.size() < 4 * max_steps) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); h->ev.push_back(e); }
+  }
+  for (int step = 0; step < max_steps; ++step) {
+    a.step = step;
+    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 0], h->stream));
+    TRY(launch_expand(h));
+    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
+    TRY(launch_backward(h));
+    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
+    TRY(launch_forward(h));
+    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
+    ++steps;
+    HIPCHECK(hipMemcpyAsync(&h->counter_host[step], &a.counter[step], sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->counter_host[step] == 0) break;
+  }
+  HIPCHECK(hipEventRecord(e1, h->stream));
+  HIPCHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHECK(hipEventDestroy(e0));
+  HIPCHECK(hipEventDestroy(e1));
+  if (h->profile) {
+    for (int step = 0; step < steps; ++step)
+      for (int s = 0; s < 3; ++s) {
+        float t = 0.f;
+        HIPCHECK(hipEventElapsedTime(&t, h->ev[4 * step + s], h->ev[4 * step + s + 1]));
+        h->prof_ms[s] += t;
+        h->prof_launches[s] += 1;
+      }
+  }
+  a.control = 0;
+  if (st) {
+    const int B = P.B;
+    std::vector<int32_t> its(B);
+    TRY(download_int(h, its.data(), a.iterations));
+    int64_t tot = 0;
+    for (int b = 0; b < B; ++b) tot += its[b];
+    if (st->iterations) std::memcpy(st->iterations, its.data(), sizeof(int32_t) * B);
+    TRY(download_int(h, st->iterations_outer, a.outer));
+    TRY(download_int(h, st->status, a.status));
+    if (st->cost) { TRY(launch_cost(h, 0, h->d_tmp, nullptr)); TRY(download_scalar(h, st->cost, h->d_tmp)); }
+    TRY(download_scalar(h, st->dJ, a.dJ));
+    TRY(download_scalar(h, st->gradient, a.grad));
+    if (st->c_max) {
+      if (P.n_cons > 0) { TRY(launch_violation(h, h->d_tmp)); TRY(download_scalar(h, st->c_max, h->d_tmp)); }
+      else std::memset(st->c_max, 0, sizeof(double) * B);
+    }
+    if (st->penalty_max) {
+      hipLaunchKernelGGL(k_penalty_max, grid_b(h), dim3(BLOCK), 0, h->stream, a, h->d_tmp);
+      HIPCHECK(hipGetLastError());
+      TRY(download_scalar(h, st->penalty_max, h->d_tmp));
+    }
+    st->total_iterations = tot;
+    st->batch_steps = steps;
+    st->solve_ms = ms;
+  }
+  return TO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int to_abi_version(void) { return TO_ABI_VERSION; }
+const char* to_last_error(void) { return g_err.c_str(); }
+int to_device_count(int* count) {
+  CHECK_P(count);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(TO_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *count = n;
+  return TO_OK;
+}
+int to_default_options(to_solver_opts* o) { CHECK_P(o); default_opts(o); return TO_OK; }
+
+int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int device, to_handle** out) {
+  CHECK_P(out);
+  if (!desc) return fail(TO_ERR_NULL, "null descriptor");
+  if (desc->abi_version != TO_ABI_VERSION) return fail(TO_ERR_ARGUMENT, "ABI version mismatch");
+  int n, m, ne, key;
+  if (model_dims(desc->model, desc->model_params, &n, &m, &ne, &key)) return fail(TO_ERR_UNSUPPORTED, "unknown model");
+  if (desc->n != n || desc->m != m) return fail(TO_ERR_DIMENSION_MISMATCH, "Objective state/control dimensions don't match model.");  // src/problem.jl:65-68
+  if (desc->N < 2) return fail(TO_ERR_ASSERTION, "length(models) == N-1 requires N >= 2");                                         // src/problem.jl:49
+  if (desc->B < 1) return fail(TO_ERR_ARGUMENT, "batch must be positive");
+  if (!(desc->tf > desc->t0)) return fail(TO_ERR_ASSERTION, "tf > t0");                                                             // src/problem.jl:50
+  if (desc->integrator < TO_RK4 || desc->integrator > TO_EULER) return fail(TO_ERR_UNSUPPORTED, "unknown integrator");
+  const int N = desc->N, B = desc->B;
+  std::vector<double> dt(N - 1);
+  if (desc->dt) {
+    double s = 0;
+    for (int k = 0; k < N - 1; ++k) { dt[k] = desc->dt[k]; s += dt[k]; if (!(dt[k] > 0)) return fail(TO_ERR_ASSERTION, "dt must be positive"); }
+    if (std::fabs(s - (desc->tf - desc->t0)) > 1e-8 * std::fmax(1.0, std::fabs(desc->tf - desc->t0)))
+      return fail(TO_ERR_ASSERTION, "time(Z[end]) ≈ tf: time steps are inconsistent with the final time");                          // src/problem.jl:52
+  } else {
+    for (int k = 0; k < N - 1; ++k) dt[k] = (desc->tf - desc->t0) / (N - 1);
+  }
+  if (desc->n_costs < 1 || !desc->costs) return fail(TO_ERR_ARGUMENT, "objective needs at least one cost function");
+  for (int i = 0; i < desc->n_costs; ++i) TRY(validate_cost(n, desc->costs[i]));
+  std::vector<int> cost_index(N);
+  if (desc->cost_index) {
+    for (int k = 0; k < N; ++k) {
+      if (desc->cost_index[k] < 0 || desc->cost_index[k] >= desc->n_costs) return fail(TO_ERR_DIMENSION_MISMATCH, "cost_index outside the cost list");
+      cost_index[k] = desc->cost_index[k];
+    }
+  } else {
+    if (desc->n_costs < 2) return fail(TO_ERR_ARGUMENT, "Objective(stage, terminal, N) needs two cost functions");
+    for (int k = 0; k < N; ++k) cost_index[k] = (k == N - 1) ? 1 : 0;
+  }
+  if (desc->n_constraints < 0 || (desc->n_constraints > 0 && !desc->constraints)) return fail(TO_ERR_ARGUMENT, "bad constraint list");
+  std::vector<DevCon> cons;
+  long long n_duals = 0;
+  for (int i = 0; i < desc->n_constraints; ++i) {
+    DevCon ci;
+    TRY(validate_constraint(n, m, N, desc->constraints[i], &ci));
+    ci.dual_off = n_duals;
+    n_duals += (long long)ci.p * (ci.k2 - ci.k1 + 1);
+    cons.push_back(ci);
+  }
+  int ndev = 0;
+  {
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) return fail(TO_ERR_HIP, "no usable HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TO_ERR_ARGUMENT, "device ordinal out of range");
+  }
+  to_handle* h = new to_handle();
+  h->device = device;
+  h->model_key = key;
+  h->costs.assign(desc->costs, desc->costs + desc->n_costs);
+  h->cons = cons; h->dt = dt; h->cost_index = cost_index;
+  auto bail = [&](int rc) { std::string e = g_err; to_destroy(h); g_err = e; return rc; };
+#define TRYB(expr) do { int r_ = (expr); if (r_ != TO_OK) return bail(r_); } while (0)
+#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(TO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
+  HIPB(hipSetDevice(device));
+  HIPB(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  KArgs& a = h->a;
+  std::memset(&a, 0, sizeof(a));
+  DevProblem& P = a.P;
+  P.n = n; P.m = m; P.ne = ne; P.N = N; P.B = B; P.Bp = ((B + BLOCK - 1) / BLOCK) * BLOCK;
+  P.integrator = desc->integrator; P.n_costs = desc->n_costs; P.n_cons = (int)cons.size(); P.n_duals = n_duals;
+  std::memcpy(P.mp, desc->model_params, sizeof(P.mp));
+  if (opts) P.opts = *opts; else default_opts(&P.opts);
+  const size_t Bp = P.Bp;
+  TRYB(dev_alloc(h, &h->d_costs, h->costs.size()));
+  TRYB(dev_alloc(h, &h->d_cons, cons.size()));
+  TRYB(dev_alloc(h, &h->d_dt, (size_t)N - 1));
+  TRYB(dev_alloc(h, &h->d_cost_index, (size_t)N));
+  HIPB(hipMemcpyAsync(h->d_dt, dt.data(), sizeof(double) * (N - 1), hipMemcpyHostToDevice, h->stream));
+  HIPB(hipMemcpyAsync(h->d_cost_index, cost_index.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+  TRYB(upload_tables(h));
+  P.dt = h->d_dt; P.cost_index = h->d_cost_index; P.costs = h->d_costs; P.cons = h->d_cons;
+  for (int c = 0; c < 2; ++c) { TRYB(dev_alloc(h, &a.X[c], (size_t)N * n * Bp)); TRYB(dev_alloc(h, &a.U[c], (size_t)(N - 1) * m * Bp)); }
+  TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
+  TRYB(dev_alloc(h, &a.cur, Bp));
+  TRYB(dev_alloc(h, &a.A, (size_t)(N - 1) * ne * ne * Bp));
+  TRYB(dev_alloc(h, &a.Bm, (size_t)(N - 1) * ne * m * Bp));
+  TRYB(dev_alloc(h, &a.Qxx, (size_t)N * ne * ne * Bp));
+  TRYB(dev_alloc(h, &a.Quu, (size_t)N * m * m * Bp));
+  TRYB(dev_alloc(h, &a.Qux, (size_t)N * m * ne * Bp));
+  TRYB(dev_alloc(h, &a.qx, (size_t)N * ne * Bp));
+  TRYB(dev_alloc(h, &a.qu, (size_t)N * m * Bp));
+  TRYB(dev_alloc(h, &a.K, (size_t)(N - 1) * m * ne * Bp));
+  TRYB(dev_alloc(h, &a.d, (size_t)(N - 1) * m * Bp));
+  TRYB(dev_alloc(h, &a.lam, (size_t)n_duals * Bp));
+  TRYB(dev_alloc(h, &a.mu, cons.size() * Bp));
+  TRYB(dev_alloc(h, &a.J, Bp)); TRYB(dev_alloc(h, &a.dJ, Bp)); TRYB(dev_alloc(h, &a.grad, Bp));
+  TRYB(dev_alloc(h, &a.rho, Bp)); TRYB(dev_alloc(h, &a.drho, Bp)); TRYB(dev_alloc(h, &a.dV, 2 * Bp));
+  TRYB(dev_alloc(h, &a.cmax, Bp)); TRYB(dev_alloc(h, &a.Jout, Bp));
+  TRYB(dev_alloc(h, &a.status, Bp)); TRYB(dev_alloc(h, &a.iterations, Bp)); TRYB(dev_alloc(h, &a.it_inner, Bp));
+  TRYB(dev_alloc(h, &a.outer, Bp)); TRYB(dev_alloc(h, &a.dJzero, Bp)); TRYB(dev_alloc(h, &a.ls_index, Bp));
+  TRYB(dev_alloc(h, &a.active, Bp)); TRYB(dev_alloc(h, &a.budget, Bp)); TRYB(dev_alloc(h, &a.bpfail, Bp));
+  TRYB(dev_alloc(h, &h->d_tmp, Bp)); TRYB(dev_alloc(h, &h->d_tmp2, Bp));
+  // reference defaults: X0 = NaN, U0 = 0 (src/problem.jl:83-84); duals 0, penalties penalty_initial
+  {
+    std::vector<double> nanv((size_t)N * n * Bp, std::nan(""));
+    HIPB(hipMemcpyAsync(a.X[0], nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPB(hipStreamSynchronize(h->stream));
+    if (!cons.empty()) {
+      std::vector<double> mu(cons.size() * Bp, P.opts.penalty_initial);
+      HIPB(hipMemcpyAsync(a.mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIPB(hipStreamSynchronize(h->stream));
+    }
+  }
+  HIPB(hipStreamSynchronize(h->stream));
+#undef TRYB
+#undef HIPB
+  *out = h;
+  return TO_OK;
+}
+
+int to_destroy(to_handle* h) {
+  if (!h) return TO_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->stage) hipFree(h->stage);
+  if (h->counter_host) hipHostFree(h->counter_host);
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return TO_OK;
+}
+
+int to_set_options(to_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_P(o); h->a.P.opts = *o; return TO_OK; }
+int to_get_options(const to_handle* h, to_solver_opts* o) { CHECK_H(h); CHECK_P(o); *o = h->a.P.opts; return TO_OK; }
+int to_sync(to_handle* h) { CHECK_H(h); TRY(use_device(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
+void* to_stream(to_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int to_set_profiling(to_handle* h, int enable) { CHECK_H(h); h->profile = enable != 0; return TO_OK; }
+int to_reset_profile(to_handle* h) {
+  CHECK_H(h);
+  for (int i = 0; i < TO_PROFILE_SLOTS; ++i) { h->prof_ms[i] = 0; h->prof_launches[i] = 0; }
+  return TO_OK;
+}
+int to_get_profile(to_handle* h, double* ms, int64_t* launches) {
+  CHECK_H(h);
+  for (int i = 0; i < TO_PROFILE_SLOTS; ++i) { if (ms) ms[i] = h->prof_ms[i]; if (launches) launches[i] = h->prof_launches[i]; }
+  return TO_OK;
+}
+
+int to_dims(const to_handle* h, int32_t* n, int32_t* m, int32_t* ne, int32_t* N, int32_t* B) {
+  CHECK_H(h);
+  const DevProblem& P = h->a.P;
+  if (n) *n = P.n; if (m) *m = P.m; if (ne) *ne = P.ne; if (N) *N = P.N; if (B) *B = P.B;
+  return TO_OK;
+}
+int to_num_constraints(const to_handle* h, int32_t* p) {
+  CHECK_H(h); CHECK_P(p);
+  for (int k = 0; k < h->a.P.N; ++k) p[k] = 0;
+  for (const DevCon& ci : h->cons) for (int k = ci.k1; k <= ci.k2; ++k) p[k] += ci.p;
+  return TO_OK;
+}
+
+int to_set_initial_state(to_handle* h, const double* x0) {
+  CHECK_H(h); CHECK_P(x0); TRY(use_device(h));
+  return upload_vec(h, x0, h->a.x0, nullptr, h->a.P.n, 1, false);
+}
+int to_get_initial_state(to_handle* h, double* x0) {
+  CHECK_H(h); CHECK_P(x0); TRY(use_device(h));
+  return download_vec(h, x0, h->a.x0, nullptr, h->a.P.n, 1, false);
+}
+int to_set_controls(to_handle* h, const double* U) {
+  CHECK_H(h); CHECK_P(U); TRY(use_device(h));
+  return upload_vec(h, U, h->a.U[0], h->a.U[1], h->a.P.m, h->a.P.N - 1, true);
+}
+int to_set_states(to_handle* h, const double* X) {
+  CHECK_H(h); CHECK_P(X); TRY(use_device(h));
+  return upload_vec(h, X, h->a.X[0], h->a.X[1], h->a.P.n, h->a.P.N, true);
+}
+int to_set_controls_uniform(to_handle* h, const double* u) {
+  CHECK_H(h); CHECK_P(u); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  TRY(ensure_stage(h, sizeof(double) * P.m));
+  HIPCHECK(hipMemcpyAsync(h->stage, u, sizeof(double) * P.m, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_fill_uniform, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.U[0], h->a.U[1], h->a.cur, h->stage, P.m, P.N - 1, P.B, P.Bp);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_get_states(to_handle* h, double* X) {
+  CHECK_H(h); CHECK_P(X); TRY(use_device(h));
+  return download_vec(h, X, h->a.X[0], h->a.X[1], h->a.P.n, h->a.P.N, true);
+}
+int to_get_controls(to_handle* h, double* U) {
+  CHECK_H(h); CHECK_P(U); TRY(use_device(h));
+  return download_vec(h, U, h->a.U[0], h->a.U[1], h->a.P.m, h->a.P.N - 1, true);
+}
+int to_get_states_device(to_handle* h, void* dX) {
+  CHECK_H(h); CHECK_P(dX); TRY(use_device(h));
+  return download_vec(h, nullptr, h->a.X[0], h->a.X[1], h->a.P.n, h->a.P.N, true, dX);
+}
+int to_get_controls_device(to_handle* h, void* dU) {
+  CHECK_H(h); CHECK_P(dU); TRY(use_device(h));
+  return download_vec(h, nullptr, h->a.U[0], h->a.U[1], h->a.P.m, h->a.P.N - 1, true, dU);
+}
+int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
+  CHECK_H(h); CHECK_P(c); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
+  TRY(validate_cost(h->a.P.n, *c));
+  h->costs[id] = *c;
+  return upload_tables(h);
+}
+int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
+  CHECK_H(h); CHECK_P(c); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  DevCon ci;
+  TRY(validate_constraint(h->a.P.n, h->a.P.m, h->a.P.N, *c, &ci));
+  const DevCon& old = h->cons[id];
+  if (ci.p != old.p || ci.k1 != old.k1 || ci.k2 != old.k2) return fail(TO_ERR_DIMENSION_MISMATCH, "replacement constraint must keep p and the knot range");
+  ci.dual_off = old.dual_off;
+  h->cons[id] = ci;
+  return upload_tables(h);
+}
+
+int to_rollout(to_handle* h) { CHECK_H(h); TRY(use_device(h)); TRY(launch_rollout(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
+int to_cost(to_handle* h, double* J) {
+  CHECK_H(h); CHECK_P(J); TRY(use_device(h));
+  TRY(launch_cost(h, 0, h->d_tmp, nullptr));
+  return download_scalar(h, J, h->d_tmp);
+}
+int to_al_cost(to_handle* h, double* J) {
+  CHECK_H(h); CHECK_P(J); TRY(use_device(h));
+  TRY(launch_cost(h, 1, h->d_tmp, nullptr));
+  return download_scalar(h, J, h->d_tmp);
+}
+int to_stage_costs(to_handle* h, double* Jk) {
+  CHECK_H(h); CHECK_P(Jk); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  // per-knot values land in device layout [N][Bp] in the upper half of the staging buffer, then transpose to host (N,B)
+  const size_t cnt = (size_t)P.N * P.Bp;
+  TRY(ensure_stage(h, 2 * cnt * sizeof(double)));
+  double* dJk = h->stage + cnt;
+  TRY(launch_cost(h, 0, nullptr, dJk));
+  hipLaunchKernelGGL(k_to_host, grid_b(h, P.N), dim3(BLOCK), 0, h->stream, dJk, h->stage, 1, P.N, P.B, P.Bp);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(Jk, h->stage, sizeof(double) * P.N * P.B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_expand(to_handle* h) {
+  CHECK_H(h); TRY(use_device(h));
+  TRY(launch_set_active(h, 1)); TRY(launch_expand(h));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_backward(to_handle* h) {
+  CHECK_H(h); TRY(use_device(h));
+  TRY(launch_set_active(h, 1)); TRY(launch_backward(h));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
+  CHECK_H(h); TRY(use_device(h));
+  h->a.control = 0;
+  // keep bpfail from a preceding to_backward: set active without clearing it
+  TRY(launch_cost(h, 1, h->a.J, nullptr));
+  {
+    std::vector<int> ones(h->a.P.Bp, 0);
+    for (int b = 0; b < h->a.P.B; ++b) ones[b] = 1;
+    HIPCHECK(hipMemcpyAsync(h->a.active, ones.data(), sizeof(int) * h->a.P.Bp, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  }
+  TRY(launch_forward(h));
+  TRY(download_int(h, ls_index, h->a.ls_index));
+  TRY(download_scalar(h, J_new, h->a.Jout));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_ilqr_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 0); }
+int to_al_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 1); }
+
+int to_get_dynamics_jacobians(to_handle* h, double* A, double* Bm) {
+  CHECK_H(h); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  TRY(download_mat(h, A, h->a.A, P.ne, P.ne, P.N - 1));
+  TRY(download_mat(h, Bm, h->a.Bm, P.ne, P.m, P.N - 1));
+  return TO_OK;
+}
+int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, double* qx, double* qu) {
+  CHECK_H(h); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  TRY(download_mat(h, Qxx, h->a.Qxx, P.ne, P.ne, P.N));
+  TRY(download_mat(h, Quu, h->a.Quu, P.m, P.m, P.N));
+  TRY(download_mat(h, Qux, h->a.Qux, P.m, P.ne, P.N));
+  if (qx) TRY(download_vec(h, qx, h->a.qx, nullptr, P.ne, P.N, false));
+  if (qu) TRY(download_vec(h, qu, h->a.qu, nullptr, P.m, P.N, false));
+  return TO_OK;
+}
+int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
+  CHECK_H(h); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  TRY(download_mat(h, K, h->a.K, P.m, P.ne, P.N - 1));
+  if (d) TRY(download_vec(h, d, h->a.d, nullptr, P.m, P.N - 1, false));
+  if (dV) TRY(download_vec(h, dV, h->a.dV, nullptr, 2, 1, false));
+  TRY(download_scalar(h, rho, h->a.rho));
+  return TO_OK;
+}
+int to_cost_expansion(to_handle* h, double* grad, double* hess) {
+  CHECK_H(h); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  const size_t nz = P.n + P.m, ng = nz * P.N * P.B, nh = nz * nz * P.N * P.B;
+  TRY(ensure_stage(h, (ng + nh) * sizeof(double)));
+  double* dg = h->stage; double* dh = h->stage + ng;
+  DISPATCH(h, hipLaunchKernelGGL(k_cost_derivs<M>, grid_b(h, P.N), dim3(BLOCK), 0, h->stream, h->a, dg, dh));
+  HIPCHECK(hipGetLastError());
+  if (grad) HIPCHECK(hipMemcpyAsync(grad, dg, ng * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (hess) HIPCHECK(hipMemcpyAsync(hess, dh, nh * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_discrete_jacobian(to_handle* h, double* F) {
+  CHECK_H(h); CHECK_P(F); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  const size_t cnt = (size_t)P.n * (P.n + P.m) * (P.N - 1) * P.B;
+  TRY(ensure_stage(h, cnt * sizeof(double)));
+  DISPATCH(h, hipLaunchKernelGGL(k_discrete_jacobian<M>, grid_b(h, P.N - 1, P.n + P.m), dim3(BLOCK), 0, h->stream, h->a, h->stage));
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(F, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+
+int to_constraint_info(const to_handle* h, int32_t id, int32_t* p, int32_t* width, int32_t* nk, int32_t* sense) {
+  CHECK_H(h);
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const DevCon& ci = h->cons[id];
+  if (p) *p = ci.p; if (width) *width = ci.width; if (nk) *nk = ci.k2 - ci.k1 + 1; if (sense) *sense = ci.d.sense;
+  return TO_OK;
+}
+static int constraint_eval(to_handle* h, int32_t id, double* vals, double* jac) {
+  TRY(use_device(h));
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const DevCon& ci = h->cons[id];
+  const DevProblem& P = h->a.P;
+  const int nk = ci.k2 - ci.k1 + 1;
+  const size_t nv = (size_t)ci.p * nk * P.B, nj = (size_t)ci.p * ci.width * nk * P.B;
+  TRY(ensure_stage(h, (nv + nj) * sizeof(double)));
+  double* dv = h->stage; double* dj = h->stage + nv;
+  DISPATCH(h, hipLaunchKernelGGL(k_constraint_eval<M>, grid_b(h, nk), dim3(BLOCK), 0, h->stream, h->a, (int)id, vals ? dv : nullptr, jac ? dj : nullptr));
+  HIPCHECK(hipGetLastError());
+  if (vals) HIPCHECK(hipMemcpyAsync(vals, dv, nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (jac) HIPCHECK(hipMemcpyAsync(jac, dj, nj * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_evaluate_constraints(to_handle* h, int32_t id, double* vals) { CHECK_H(h); CHECK_P(vals); return constraint_eval(h, id, vals, nullptr); }
+int to_constraint_jacobians(to_handle* h, int32_t id, double* jac) { CHECK_H(h); CHECK_P(jac); return constraint_eval(h, id, nullptr, jac); }
+int to_max_violation(to_handle* h, double* c_max) {
+  CHECK_H(h); CHECK_P(c_max); TRY(use_device(h));
+  if (h->a.P.n_cons == 0) { std::memset(c_max, 0, sizeof(double) * h->a.P.B); return TO_OK; }
+  TRY(launch_violation(h, h->d_tmp));
+  return download_scalar(h, c_max, h->d_tmp);
+}
+int to_get_duals(to_handle* h, int32_t id, double* lambda, double* mu) {
+  CHECK_H(h); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const DevCon& ci = h->cons[id];
+  const DevProblem& P = h->a.P;
+  if (lambda) TRY(download_vec(h, lambda, h->a.lam + (size_t)ci.dual_off * P.Bp, nullptr, ci.p, ci.k2 - ci.k1 + 1, false));
+  if (mu) TRY(download_scalar(h, mu, h->a.mu + (size_t)id * P.Bp));
+  return TO_OK;
+}
+int to_set_duals(to_handle* h, int32_t id, const double* lambda, const double* mu) {
+  CHECK_H(h); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const DevCon& ci = h->cons[id];
+  const DevProblem& P = h->a.P;
+  if (lambda) TRY(upload_vec(h, lambda, h->a.lam + (size_t)ci.dual_off * P.Bp, nullptr, ci.p, ci.k2 - ci.k1 + 1, false));
+  if (mu) { HIPCHECK(hipMemcpyAsync(h->a.mu + (size_t)id * P.Bp, mu, sizeof(double) * P.B, hipMemcpyHostToDevice, h->stream)); HIPCHECK(hipStreamSynchronize(h->stream)); }
+  return TO_OK;
+}
+int to_reset_duals(to_handle* h) {
+  CHECK_H(h); TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  if (P.n_cons == 0) return TO_OK;
+  HIPCHECK(hipMemsetAsync(h->a.lam, 0, sizeof(double) * (size_t)P.n_duals * P.Bp, h->stream));
+  std::vector<double> mu((size_t)P.n_cons * P.Bp, P.opts.penalty_initial);
+  HIPCHECK(hipMemcpyAsync(h->a.mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int to_dual_update(to_handle* h) {
+  CHECK_H(h); TRY(use_device(h));
+  if (h->a.P.n_cons == 0) return TO_OK;
+  DISPATCH(h, hipLaunchKernelGGL(k_dual_update<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+
+// ---- cones: stateless batched ops on `device` ------------------------------------------------------
+static int cone_op(int device, int which, int32_t cone, int32_t dim, int64_t count, const double* x, const double* b, double* out, int32_t* status) {
+  CHECK_P(x); CHECK_P(out);
+  if (dim < 1 || dim > TO_MAX_P) return fail(TO_ERR_ARGUMENT, "cone dimension out of range");
+  if (cone < TO_CONE_ZERO || cone > TO_CONE_IDENTITY) return fail(TO_ERR_ARGUMENT, "unknown cone");
+  if (count <= 0) return TO_OK;
+  HIPCHECK(hipSetDevice(device));
+  const size_t nx = (size_t)dim * count, no = which == 0 ? nx : nx * dim;
+  double *dx = nullptr, *db = nullptr, *dout = nullptr;
+  int* dst = nullptr;
+  HIPCHECK(hipMalloc((void**)&dx, nx * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&dout, no * sizeof(double)));
+  HIPCHECK(hipMalloc((void**)&dst, count * sizeof(int)));
+  HIPCHECK(hipMemcpy(dx, x, nx * sizeof(double), hipMemcpyHostToDevice));
+  if (which == 2) { HIPCHECK(hipMalloc((void**)&db, nx * sizeof(double))); HIPCHECK(hipMemcpy(db, b, nx * sizeof(double), hipMemcpyHostToDevice)); }
+  const unsigned blocks = (unsigned)((count + 255) / 256);
+  if (which == 0) hipLaunchKernelGGL(k_cone_projection, dim3(blocks), dim3(256), 0, 0, cone, dim, (long long)count, dx, dout, dst);
+  else if (which == 1) hipLaunchKernelGGL(k_cone_jacobian, dim3(blocks), dim3(256), 0, 0, cone, dim, (long long)count, dx, dout, dst);
+  else hipLaunchKernelGGL(k_cone_hessian, dim3(blocks), dim3(256), 0, 0, cone, dim, (long long)count, dx, db, dout, dst);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpy(out, dout, no * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<int> st(count);
+  HIPCHECK(hipMemcpy(st.data(), dst, count * sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(dx); hipFree(dout); hipFree(dst); if (db) hipFree(db);
+  for (int64_t i = 0; i < count; ++i) {
+    if (st[i] < 0) return fail(TO_ERR_CONE, "Invalid second-order cone projection");
+    if (status) status[i] = st[i];
+  }
+  return TO_OK;
+}
+int to_cone_projection(int device, int32_t cone, int32_t dim, int64_t count, const double* x, double* px, int32_t* status) {
+  return cone_op(device, 0, cone, dim, count, x, nullptr, px, status);
+}
+int to_cone_projection_jacobian(int device, int32_t cone, int32_t dim, int64_t count, const double* x, double* jac) {
+  return cone_op(device, 1, cone, dim, count, x, nullptr, jac, nullptr);
+}
+int to_cone_projection_hessian(int device, int32_t cone, int32_t dim, int64_t count, const double* x, const double* b, double* hess) {
+  CHECK_P(b);
+  return cone_op(device, 2, cone, dim, count, x, b, hess, nullptr);
+}
+
+}  // extern "C"
