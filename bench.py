@@ -127,22 +127,15 @@ def main():
     duals = sum(prob.constraints.p)
 
     gather = None
-    if world > 1:  # RCCL all-gather buffers for the converged trajectories (host layout (n,N,B) per rank)
-        xs = torch.empty(batch * N * n, dtype=torch.float64, device="cuda")
-        us = torch.empty(batch * (N - 1) * m, dtype=torch.float64, device="cuda")
-        xg = torch.empty(world * xs.numel(), dtype=torch.float64, device="cuda")
-        ug = torch.empty(world * us.numel(), dtype=torch.float64, device="cuda")
-        gather = (xs, us, xg, ug)
+    if world > 1:  # RCCL all-gather of the converged trajectories, device-to-device
+        from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
+        gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
 
     def one_step():
         T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
         solver.solve()
         if gather is not None:
-            xs, us, xg, ug = gather
-            prob._call("get_states_device", C.c_void_p(xs.data_ptr()))
-            prob._call("get_controls_device", C.c_void_p(us.data_ptr()))
-            dist.all_gather_into_tensor(xg, xs)
-            dist.all_gather_into_tensor(ug, us)
+            gather()
         return solver.total_iterations, solver.batch_steps
 
     def barrier():

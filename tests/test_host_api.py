@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference interface: bookkeeping and error behaviour, CPU only.  The product library
+validates descriptors before it touches the device, so the reference's exception classes can be checked here
+without a GPU; with valid input and no GPU it must fail loudly (no CPU fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import trajopt_amd as T
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    lib = T.load_hip_library()
+    header = (ROOT / "include" / "trajopt_hip.h").read_text()
+    declared = set(re.findall(r"^(?:int|const char\*|void\*)\s+(to_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 45
+    dll = C.CDLL(lib.path)
+    missing = [s for s in sorted(declared) if not hasattr(dll, s)]
+    assert not missing, missing
+    bound = {"to_" + k for k in list(T.capi.SIGNATURES) + list(T.capi.HIP_ONLY)} | {"to_last_error", "to_stream"}
+    assert declared <= bound, sorted(declared - bound)
+    assert lib.abi_version() == T.capi.TO_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors vs the sizes the C compiler computes (guards against silent ABI drift)."""
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "trajopt_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(to_cost_desc), sizeof(to_constraint_desc), sizeof(to_problem_desc), sizeof(to_solver_opts), sizeof(to_solve_stats));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "s.c").write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", f"{d}/s", f"{d}/s.c"], check=True)
+        sizes = list(map(int, subprocess.run([f"{d}/s"], capture_output=True, text=True, check=True).stdout.split()))
+    assert sizes == [C.sizeof(T.capi.CostDesc), C.sizeof(T.capi.ConstraintDesc), C.sizeof(T.capi.ProblemDesc),
+                     C.sizeof(T.capi.SolverOpts), C.sizeof(T.capi.SolveStats)]
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = T.load_hip_library()
+    try:
+        ndev = lib.device_count()
+    except T.HipError:
+        ndev = 0
+    if ndev > 0:
+        pytest.skip("a GPU is visible")
+    model = T.Cartpole()
+    obj = T.LQRObjective(np.ones(4), np.ones(1), np.ones(4), np.zeros(4), 11)
+    with pytest.raises(T.HipError):
+        T.Problem(model, obj, np.zeros(4), 1.0)
+    with pytest.raises(T.HipError):
+        T.projection(T.SecondOrderCone(), np.array([1.0, 2, 3]))
+
+
+def test_constraint_list_bookkeeping():
+    """test/constraint_list.jl:35-76."""
+    n, m, N = 4, 1, 11
+    xf = np.array([0, np.pi, 0, 0.0])
+    cir = T.CircleConstraint(n, [1.0, 2], [1.0, 2], [0.1, 0.2])
+    goal = T.GoalConstraint(xf)
+    lin = T.LinearConstraint(n, m, np.ones((3, 5)), np.ones(3), T.Inequality())
+    bnd = T.BoundConstraint(n, m, x_min=-np.ones(n), x_max=np.ones(n), u_min=-1, u_max=1)
+    cons = T.ConstraintList(n, m, N)
+    T.add_constraint(cons, cir, range(1, N + 1))
+    assert cons[0] is cir and cons.inds[0] == (1, N) and cons.p == [2] * N
+    T.add_constraint(cons, goal, N)
+    assert cons[1] is goal and cons.inds[1] == (N, N) and cons.p[:-1] == [2] * (N - 1) and cons.p[-1] == 2 + 4
+    T.add_constraint(cons, lin, range(1, 5), 1)          # insert at the front (idx is 1-based like the reference)
+    assert cons[0] is lin and cons[1] is cir and cons[-1] is goal and cons.inds[0] == (1, 4)
+    assert cons.p[:4] == [5] * 4 and cons.p[4:N - 1] == [2] * (N - 5) and len(cons) == 3
+    cons2 = cons.copy()
+    T.add_constraint(cons, bnd, range(1, N))
+    assert len(cons) == 4 and len(cons2) == 3 and cons[-1] is bnd and bnd.p == 2 * (n + m)
+    lin2 = T.LinearConstraint(2, 1, np.ones((3, 2)), np.ones(3), T.Inequality(), [1, 2])
+    with pytest.raises(T.DimensionMismatch):
+        T.add_constraint(cons, lin2, range(1, 5))                                                     # :69-70
+    with pytest.raises(T.ArgumentError):
+        T.add_constraint(cons, goal, N, idx=9)
+    assert [c for c in cons] == [lin, cir, goal, bnd]
+    assert [T.sense(c) for c in cons] == [T.Inequality(), T.Inequality(), T.Equality(), T.Inequality()]
+
+
+def test_bound_constraint_constructor():
+    """test/constraint_tests.jl:209-266 and src/constraints.jl:660-719."""
+    n, m = 3, 2
+    bnd = T.BoundConstraint(n, m, x_max=[1, np.inf, 3], x_min=[-1, -2, -np.inf], u_max=4, u_min=[-np.inf, -5])
+    assert bnd.p == 2 + 2 + 2 + 1
+    assert bnd.inds == [1, 3, 4, 5, 6, 7, 10]   # finite entries of [-z_max; z_min], 1-based
+    with pytest.raises(T.ArgumentError):
+        T.BoundConstraint(n, m, x_max=0.0, x_min=1.0)
+    with pytest.raises(AssertionError):
+        T.NormConstraint(n, m, -1.0, T.Inequality())
+    assert T.NormConstraint(n, m, 5.0, T.SecondOrderCone(), "control").p == m + 1
+    assert T.NormConstraint(n, m, 5.0, T.Equality(), "state").inds == [1, 2, 3]
+
+
+def _create_rc(desc_mut):
+    """Call to_create on a mutated, otherwise valid, Cartpole descriptor; return (rc, message)."""
+    lib = T.load_hip_library()
+    model = T.Cartpole()
+    N = 11
+    obj = T.LQRObjective(np.ones(4), np.ones(1), np.ones(4), np.zeros(4), N)
+    uniq, index = obj._descs()
+    costs = (T.capi.CostDesc * len(uniq))(*[c._desc() for c in uniq])
+    cons = T.ConstraintList(4, 1, N)
+    T.add_constraint(cons, T.GoalConstraint(np.zeros(4)), N)
+    cdesc = cons._descs()
+    d = T.capi.ProblemDesc()
+    d.abi_version, d.model, d.integrator, d.n, d.m, d.N, d.B = 1, model.model_id, T.RK4, 4, 1, N, 2
+    d.model_params[:4] = model.params()
+    d.t0, d.tf = 0.0, 1.0
+    d.n_costs, d.costs, d.cost_index = len(uniq), costs, None
+    d.n_constraints, d.constraints = 1, cdesc
+    desc_mut(d, cdesc)
+    h = C.c_void_p()
+    rc = lib.raw("create")(C.byref(d), None, 0, C.byref(h))
+    if rc == 0:
+        lib.raw("destroy")(h)
+    return rc, lib.last_error()
+
+
+@pytest.mark.parametrize("mut,code", [
+    (lambda d, c: setattr(d, "n", 5), T.capi.TO_ERR_DIMENSION_MISMATCH),          # src/problem.jl:65-68
+    (lambda d, c: setattr(d, "tf", -1.0), T.capi.TO_ERR_ASSERTION),               # src/problem.jl:50  tf > t0
+    (lambda d, c: setattr(d, "N", 1), T.capi.TO_ERR_ASSERTION),
+    (lambda d, c: setattr(d, "B", 0), T.capi.TO_ERR_ARGUMENT),
+    (lambda d, c: setattr(d, "abi_version", 99), T.capi.TO_ERR_ARGUMENT),
+    (lambda d, c: setattr(d, "model", 17), T.capi.TO_ERR_UNSUPPORTED),
+    (lambda d, c: setattr(c[0], "k_last", 12), T.capi.TO_ERR_ASSERTION),           # src/constraint_list.jl:112
+    (lambda d, c: c[0].inds.__setitem__(0, 9), T.capi.TO_ERR_DIMENSION_MISMATCH),  # src/constraint_list.jl:109
+    (lambda d, c: setattr(c[0], "p", 3), T.capi.TO_ERR_DIMENSION_MISMATCH),
+    (lambda d, c: setattr(c[0], "kind", 77), T.capi.TO_ERR_UNSUPPORTED),
+    (lambda d, c: setattr(d, "n_costs", 1), T.capi.TO_ERR_ARGUMENT),
+])
+def test_descriptor_validation_error_classes(mut, code):
+    rc, msg = _create_rc(mut)
+    assert rc == code, (rc, msg)
+    assert msg
+
+
+def test_dt_vector_validation():
+    """test/problems_tests.jl:78-85,124-132: a dt vector must be positive and sum to tf."""
+    dt = np.full(10, 0.1)
+    keep = []
+
+    def good(d, c):
+        keep.append(dt.copy()); d.dt = keep[-1].ctypes.data_as(C.POINTER(C.c_double))
+
+    def bad(d, c):
+        keep.append(dt * 1.5); d.dt = keep[-1].ctypes.data_as(C.POINTER(C.c_double))
+
+    rc, _ = _create_rc(bad)
+    assert rc == T.capi.TO_ERR_ASSERTION
+    rc, _ = _create_rc(good)
+    assert rc in (0, T.capi.TO_ERR_HIP)  # valid descriptor: succeeds on a GPU box, HipError (no fallback) here
+
+
+def test_problem_constructor_errors():
+    model = T.Cartpole()
+    obj = T.LQRObjective(np.ones(4), np.ones(1), np.ones(4), np.zeros(4), 11)
+    with pytest.raises(T.ArgumentError):
+        T.Problem(model, obj, np.zeros(4), 1.0, x0=np.zeros(4))                               # src/problem.jl:87-91
+    with pytest.raises(T.DimensionMismatch):
+        T.Problem(model, obj, np.zeros(4), 1.0, constraints=T.ConstraintList(5, 1, 11))      # src/problem.jl:64
+    with pytest.raises(T.DimensionMismatch):
+        T.Problem(T.Quadrotor(), obj, np.zeros(13), 1.0)                                     # src/problem.jl:66-68
+    with pytest.raises(T.DimensionMismatch):
+        T.LQRCost(np.ones(4), np.ones(1), np.zeros(3))
+
+
+def test_lqr_objective_structure():
+    """src/objective.jl:159-183 / test/objective_tests.jl:100-120."""
+    n, m, N = 4, 2, 7
+    Q, R, Qf = np.arange(1, 5.0), np.array([0.1, 0.2]), np.arange(10, 14.0)
+    xf, uf = np.array([1.0, 2, 3, 4]), np.array([0.5, -0.5])
+    obj = T.LQRObjective(Q, R, Qf, xf, N, uf=uf)
+    assert len(obj) == N and obj[0] is obj[N - 2] and obj[-1] is not obj[0]
+    assert isinstance(obj[0], T.DiagonalCost) and obj[-1].terminal and not obj[0].terminal
+    np.testing.assert_allclose(obj[0].q, -Q * xf); np.testing.assert_allclose(obj[0].r, -R * uf)
+    assert obj[0].c == pytest.approx(0.5 * xf @ (Q * xf) + 0.5 * uf @ (R * uf))
+    np.testing.assert_allclose(obj[-1].Q, Qf); np.testing.assert_allclose(obj[-1].R, R)
+    assert obj[-1].c == pytest.approx(0.5 * xf @ (Qf * xf))
+    dense = T.LQRObjective(np.diag(Q) + 0.1, np.diag(R), np.diag(Qf), xf, N)
+    assert isinstance(dense[0], T.QuadraticCost) and dense[0].kind == T.capi.COST_QUADRATIC
+    uniq, index = obj._descs()
+    assert len(uniq) == 2 and index == [0] * (N - 1) + [1]
+    q = T.QuatLQRCost(np.ones(13), np.ones(4), np.arange(13.0), w=2.0)
+    assert q.kind == T.capi.COST_DIAGONAL_QUAT and q.w == 2.0 and list(q.q_ref) == [3, 4, 5, 6] and q.q_ind == (4, 5, 6, 7)
+    with pytest.raises(AssertionError):
+        T.QuatLQRCost(np.ones(13), np.ones(4), np.arange(13.0), quat_ind=(4, 5, 6))
+
+
+def test_host_layout_helpers(oracle):
+    """[B, knot, dim] numpy arrays are the C-ABI's column-major (dim, knot, B) memory."""
+    from trajectoryoptimization_jl_amd import configs
+    p = configs.cartpole_problem(batch=3, N=6, tf=0.5, lib=oracle)
+    U = np.arange(3 * 5 * 1, dtype=float).reshape(3, 5, 1)
+    T.initial_controls(p, U)
+    np.testing.assert_array_equal(T.controls(p), U)
+    T.initial_controls(p, np.array([0.25]))
+    assert np.all(T.controls(p) == 0.25)
+    X = np.random.default_rng(0).standard_normal((3, 6, 4))
+    T.initial_states(p, X)
+    np.testing.assert_array_equal(T.states(p), X)
+    T.initial_states(p, X[1].T)            # a single (n, N) Julia-layout trajectory is replicated
+    np.testing.assert_array_equal(T.states(p)[2], X[1])
+    with pytest.raises(T.DimensionMismatch):
+        T.initial_states(p, np.zeros((2, 6, 4)))
+    np.testing.assert_array_equal(T.get_initial_state(p), p.x0)
+    assert T.gettimes(p)[-1] == pytest.approx(0.5) and len(T.gettimes(p)) == 6
+    T.set_goal_state(p, np.array([0.1, 3.0, 0, 0]))
+    np.testing.assert_array_equal(T.get_final_state(p), [0.1, 3.0, 0, 0])

@@ -248,9 +248,11 @@ class Objective:
     """Vector of N cost functions (src/objective.jl:27-45)."""
 
     def __init__(self, costs, terminal_cost=None, N=None):
+        if isinstance(terminal_cost, (int, np.integer)):  # Objective(cost, N)
+            terminal_cost, N = None, int(terminal_cost)
         if terminal_cost is not None:  # Objective(cost, cost_terminal, N)  src/objective.jl:74-77
             self.cost = [costs] * (N - 1) + [terminal_cost]
-        elif isinstance(costs, QuadraticCostFunction):  # Objective(cost, N)
+        elif isinstance(costs, QuadraticCostFunction):  # Objective(cost, N)  src/objective.jl:66-72
             self.cost = [costs] * N
         else:
             self.cost = list(costs)
@@ -702,11 +704,14 @@ class Problem:
     ``device``.  ``x0`` may be [n] (replicated) or [n, B] / [B, n]-shaped via ``set_initial_state``.
     """
 
-    def __init__(self, model, obj, x0, tf, xf=None, constraints=None, t0=0.0, X0=None, U0=None, dt=None,
+    def __init__(self, model, obj, *args, xf=None, constraints=None, t0=0.0, X0=None, U0=None, dt=None,
                  integration=RK4, batch=1, device=0, options=None, lib=None, **kwargs):
-        if "x0" in kwargs:
+        if "x0" in kwargs:  # src/problem.jl:87-91
             raise ArgumentError("Cannot pass x0 as a keyword argument. It is now a positional argument, "
-                                "and xf is a keyword argument.")
+                                "and xf is a keyword argument.\n\tUse Problem(model, obj, x0, tf, xf=xf, kwargs...) instead.")
+        if len(args) != 2 or kwargs:
+            raise TypeError("Problem(model, obj, x0, tf; xf, constraints, t0, X0, U0, dt, integration, batch, device)")
+        x0, tf = args
         self._lib = lib or capi.load_hip_library()
         self.model, self.obj = model, obj
         n, m = model.dims()
