@@ -1,10 +1,13 @@
 // kernels.h — HIP kernels of the batched iLQR / AL hot path for gfx950 (MI355X).
 //
-// Data layout: batch-fastest structure-of-arrays.  Element (k, i) of a per-knot vector of
-// trajectory b lives at base[(k*dim + i)*Bp + b]; a wave's 64 lanes are 64 consecutive trajectories, so
-// every load/store below is one fully coalesced 512-byte transaction.  One lane == one trajectory for
-// the sequential recursions (rollout, backward Riccati, forward line search); the expansion kernel adds
-// two more grid axes (knot, direction) because it is embarrassingly parallel.
+// Data layout: array-of-structures-of-arrays with a 64-trajectory tile = one wavefront.
+// Element e (e.g. e = k*n + i) of trajectory b of an array with L elements per trajectory lives at
+//     base[((b/64)*L + e)*64 + (b%64)]
+// so (1) the 64 lanes of a wave read/write 512 contiguous bytes per access (fully coalesced), and (2) what one
+// wave touches as it walks the knots is ONE contiguous stream of L*512 bytes (sequential pages, prefetcher- and
+// TLB-friendly) instead of 32 KB-strided lines.  One lane == one trajectory for the sequential recursions
+// (rollout, backward Riccati, forward line search); the expansion kernel adds two more grid axes
+// (knot, direction) because it is embarrassingly parallel.  Workgroup = one wave = one tile.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -15,36 +18,42 @@ namespace to {
 
 struct KArgs {
   DevProblem P;
-  double* X[2];   // [N][n][Bp]   double-buffered; cur[b] selects the nominal trajectory
-  double* U[2];   // [N-1][m][Bp]
-  double* x0;     // [n][Bp]
-  int* cur;       // [Bp]
-  double *A, *Bm;                  // [N-1][ne][ne][Bp], [N-1][ne][m][Bp]
-  double *Qxx, *Quu, *Qux, *qx, *qu;  // [N][ne][ne], [N][m][m], [N][m][ne], [N][ne], [N][m]   (x Bp)
-  double *K, *d;                   // [N-1][m][ne][Bp], [N-1][m][Bp]
-  double *lam, *mu;                // [n_duals][Bp], [n_cons][Bp]
-  double *J, *dJ, *grad, *rho, *drho, *dV, *cmax, *Jout;  // [Bp] (dV: [2][Bp])
+  double* Xs;     // (T+1) slots of L = N*n: slot cur[b] holds the nominal trajectory, the other T hold line-search candidates
+  double* Us;     // (T+1) slots of L = (N-1)*m
+  size_t slotX, slotU;  // doubles per slot (L * Bp)
+  int T;          // line-search candidates evaluated concurrently per round (grid.y of k_forward)
+  double* x0;     // L = n
+  int* cur;       // [Bp] slot of the nominal trajectory
+  double *candJ, *candG;  // [T][Bp] cost and gradient metric of each candidate of the current round
+  int* candOk;            // [T][Bp] 1: rollout stayed within the state/control limits
+  int* ls_round;          // [Bp] next line-search round of this trajectory; -1: resolved for this iteration
+  double *Mc, *Hc, *gc;               // column layout (see "column layout" below): [Ā B̄], Q-function cost blocks, gradient
+  double *K, *d;                      // L = (N-1)*m*ne, (N-1)*m
+  double *lam, *mu;                   // L = n_duals, n_cons
+  double *J, *dJ, *grad, *rho, *drho, *dV, *cmax, *Jout;  // [Bp] plain (dV: [2][Bp])
   int *status, *iterations, *it_inner, *outer, *dJzero, *ls_index, *active, *budget, *bpfail;
   int* counter;   // [steps] number of trajectories still active after each batch step
+  int round;      // line-search round being launched
   int al_mode;    // 0: iLQR, 1: AL-iLQR
   int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
   int step;
 };
 
-#define TO_IDX(k, dim, i) (((size_t)(k) * (dim) + (i)) * Bp + b)
-
-template <class M>
-__device__ __forceinline__ void load_vec(const double* base, int k, int dim_total, int Bp, int b, double* out, int count) {
-  for (int i = 0; i < count; ++i) out[i] = base[TO_IDX(k, dim_total, i)];
-}
+// per-lane pointer to element 0 of this lane's trajectory in a tiled array with L elements per trajectory;
+// element e is then p[e*64] (e wave-uniform -> scalar address arithmetic, immediate offsets for small constants)
+#define TILE_PTR(base, L) ((base) + ((size_t)tile * (size_t)(L)) * 64 + lane)
+#define EL(p, e) (p)[(size_t)(e) * 64]
+#define TILE_LANE() const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane
+#define XSLOT(a, c) ((a).Xs + (size_t)(c) * (a).slotX)
+#define USLOT(a, c) ((a).Us + (size_t)(c) * (a).slotU)
 
 // objective (+AL) value of one knot.  u must be zeros at the terminal knot (the reference evaluates the
 // terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).
+// lam0 / mu0: this lane's pointers to dual row 0 / penalty 0 (tiled arrays).
 template <class M>
-__device__ __forceinline__ double knot_cost(const KArgs& a, int k, const double* x, const double* u, int b, bool with_al) {
+__device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
+                                            const double* mu0, bool with_al) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  const DevProblem& P = a.P;
-  const int Bp = P.Bp;
   double Jk = cost_eval<n, m>(P.costs[P.cost_index[k]], x, u);
   if (P.opts.cost_dt_scaling && k < P.N - 1) Jk *= P.dt[k];
   if (with_al && P.n_cons > 0) {
@@ -55,20 +64,38 @@ __device__ __forceinline__ double knot_cost(const KArgs& a, int k, const double*
     for (int i = 0; i < m; ++i) z[n + i] = u[i];
     double Ja = 0.0;
     for (int ci = 0; ci < P.n_cons; ++ci) {
-      const DevCon& K = P.cons[ci];
+      ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
-      const double* lam = a.lam + ((size_t)(K.dual_off + (long long)(k - K.k1) * K.p)) * Bp + b;
-      Ja += al_term<nz>(K, z, lam, (size_t)Bp, a.mu[(size_t)ci * Bp + b]);
+      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      Ja += al_term<nz>(K, z, lam, (size_t)64, EL(mu0, ci));
     }
     Jk += Ja;
   }
   return Jk;
 }
 
+// AL penalty terms of one knot only
 template <class M>
-__device__ __forceinline__ double knot_violation(const KArgs& a, int k, const double* x, const double* u) {
+__device__ __forceinline__ double knot_al(const DevProblem& P, int k, const double* x, const double* u, const double* lam0, const double* mu0) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  const DevProblem& P = a.P;
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = u[i];
+  double Ja = 0.0;
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    Ja += al_term<nz>(K, z, lam, (size_t)64, EL(mu0, ci));
+  }
+  return Ja;
+}
+
+template <class M>
+__device__ __forceinline__ double knot_violation(const DevProblem& P, int k, const double* x, const double* u) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
   double z[nz];
 #pragma unroll
   for (int i = 0; i < n; ++i) z[i] = x[i];
@@ -76,7 +103,7 @@ __device__ __forceinline__ double knot_violation(const KArgs& a, int k, const do
   for (int i = 0; i < m; ++i) z[n + i] = u[i];
   double vmax = 0.0;
   for (int ci = 0; ci < P.n_cons; ++ci) {
-    const DevCon& K = P.cons[ci];
+    ConC& K = P.cons[ci];
     if (k < K.k1 || k > K.k2) continue;
     const double v = con_violation<nz>(K, z);
     if (!(v <= vmax)) vmax = v;
@@ -86,20 +113,23 @@ __device__ __forceinline__ double knot_violation(const KArgs& a, int k, const do
 
 // whole-trajectory pass over the NOMINAL trajectory: cost (with or without AL), max violation, optional dual update
 template <class M>
-__device__ __forceinline__ void trajectory_pass(const KArgs& a, int b, bool with_al, bool do_dual_update, double* J_out, double* cmax_out) {
+__device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int lane, bool with_al, bool do_dual_update, double* J_out,
+                                                double* cmax_out) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   const DevProblem& P = a.P;
-  const int Bp = P.Bp, N = P.N;
+  const int N = P.N, b = tile * 64 + lane;
   const int c = a.cur[b];
-  const double* X = a.X[c];
-  const double* U = a.U[c];
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
   double J = 0.0, cmax = 0.0;
   for (int k = 0; k < N; ++k) {
     double x[n], u[m];
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = X[TO_IDX(k, n, i)];
+    for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
 #pragma unroll
-    for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? U[TO_IDX(k, m, i)] : 0.0;
+    for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
     if (do_dual_update) {
       double z[nz];
 #pragma unroll
@@ -107,14 +137,14 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int b, bool with
 #pragma unroll
       for (int i = 0; i < m; ++i) z[n + i] = u[i];
       for (int ci = 0; ci < P.n_cons; ++ci) {
-        const DevCon& K = P.cons[ci];
+        ConC& K = P.cons[ci];
         if (k < K.k1 || k > K.k2) continue;
-        double* lam = a.lam + ((size_t)(K.dual_off + (long long)(k - K.k1) * K.p)) * Bp + b;
-        con_dual_update<nz>(K, z, lam, (size_t)Bp, a.mu[(size_t)ci * Bp + b], P.opts.dual_max);
+        double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        con_dual_update<nz>(K, z, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
       }
     }
-    if (cmax_out && P.n_cons > 0) { const double v = knot_violation<M>(a, k, x, u); if (!(v <= cmax)) cmax = v; }
-    if (J_out) J += knot_cost<M>(a, k, x, u, b, with_al);
+    if (cmax_out && P.n_cons > 0) { const double v = knot_violation<M>(P, k, x, u); if (!(v <= cmax)) cmax = v; }
+    if (J_out) J += knot_cost<M>(P, k, x, u, lam0, mu0, with_al);
   }
   if (J_out) *J_out = J;
   if (cmax_out) *cmax_out = cmax;
@@ -124,105 +154,124 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int b, bool with
 template <class M>
 __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:334-340 — open-loop simulate from x0
   constexpr int n = M::n, m = M::m;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  const int Bp = P.Bp;
   const int c = a.cur[b];
-  double* X = a.X[c];
-  const double* U = a.U[c];
+  double* X = TILE_PTR(XSLOT(a, c), P.N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (P.N - 1) * m);
+  const double* x0 = TILE_PTR(a.x0, n);
   double x[n], u[m], xn[n];
 #pragma unroll
-  for (int i = 0; i < n; ++i) { x[i] = a.x0[(size_t)i * Bp + b]; X[TO_IDX(0, n, i)] = x[i]; }
+  for (int i = 0; i < n; ++i) { x[i] = EL(x0, i); EL(X, i) = x[i]; }
   for (int k = 0; k < P.N - 1; ++k) {
 #pragma unroll
-    for (int i = 0; i < m; ++i) u[i] = U[TO_IDX(k, m, i)];
+    for (int i = 0; i < m; ++i) u[i] = EL(U, k * m + i);
     rk_step<M, double>(P.mp, P.integrator, x, u, P.dt[k], xn);
 #pragma unroll
-    for (int i = 0; i < n; ++i) { x[i] = xn[i]; X[TO_IDX(k + 1, n, i)] = x[i]; }
+    for (int i = 0; i < n; ++i) { x[i] = xn[i]; EL(X, (k + 1) * n + i) = x[i]; }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ cost
-// mode bit0: include AL terms; bit1: write per-knot objective values to Jk[N][Bp] instead
+// out[b] = total (AL) cost, or — when Jk is given — per-knot objective values in a tiled array with L = N
 template <class M>
 __global__ void __launch_bounds__(64) k_cost(KArgs a, int with_al, double* out, double* Jk) {
   constexpr int n = M::n, m = M::m;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  const int Bp = P.Bp, N = P.N;
+  const int N = P.N;
   if (Jk) {
     const int c = a.cur[b];
+    const double* X = TILE_PTR(XSLOT(a, c), N * n);
+    const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+    double* o = TILE_PTR(Jk, N);
     for (int k = 0; k < N; ++k) {
       double x[n], u[m];
 #pragma unroll
-      for (int i = 0; i < n; ++i) x[i] = a.X[c][TO_IDX(k, n, i)];
+      for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
 #pragma unroll
-      for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? a.U[c][TO_IDX(k, m, i)] : 0.0;
-      Jk[(size_t)k * Bp + b] = knot_cost<M>(a, k, x, u, b, false);
+      for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+      EL(o, k) = knot_cost<M>(P, k, x, u, nullptr, nullptr, false);
     }
     return;
   }
   double J;
-  trajectory_pass<M>(a, b, with_al != 0, false, &J, nullptr);
+  trajectory_pass<M>(a, tile, lane, with_al != 0, false, &J, nullptr);
   out[b] = J;
 }
 
 template <class M>
 __global__ void __launch_bounds__(64) k_violation(KArgs a, double* out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   if (b >= a.P.B) return;
   double cm;
-  trajectory_pass<M>(a, b, false, false, nullptr, &cm);
+  trajectory_pass<M>(a, tile, lane, false, false, nullptr, &cm);
   out[b] = cm;
 }
 
 template <class M>
 __global__ void __launch_bounds__(64) k_dual_update(KArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  trajectory_pass<M>(a, b, false, true, nullptr, nullptr);
-  for (int ci = 0; ci < P.n_cons; ++ci) {
-    double* mu = &a.mu[(size_t)ci * P.Bp + b];
-    *mu = fmin(*mu * P.opts.penalty_scaling, P.opts.penalty_max);
-  }
+  trajectory_pass<M>(a, tile, lane, false, true, nullptr, nullptr);
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = fmin(EL(mu0, ci) * P.opts.penalty_scaling, P.opts.penalty_max);
 }
 
+// ------------------------------------------------------------------------------------------------ column layout
+// The expansion and the backward pass work on COLUMNS of the per-knot blocks: direction j of the error-state tangent
+// space [δx (ne); δu (m)] is owned by one lane.  R = ne+m rounded up to a power of two lanes form one trajectory's
+// group, G = 64/R trajectories share a wave.  Column arrays hold E entries per (trajectory, column):
+//     base[((b/G)*E + e)*64 + (b%G)*R + j]            (64 consecutive doubles = the G x R lanes of one wave)
+//   Mc: E = (N-1)*ne      Mc[k*ne + i]       = [Ā B̄]_k[i][j]
+//   Hc: E = N*(ne+m)      Hc[k*(ne+m) + i]   = Q-function cost block [Qxx Qxu; Qux Quu]_k[i][j]  (cost + AL, projected)
+//   gc: E = N             gc[k]              = [qx; qu]_k[j]
+template <class M>
+struct Coop {
+  static constexpr int ne = M::ne, m = M::m, nc = ne + m;
+  static constexpr int R = nc <= 4 ? 4 : nc <= 8 ? 8 : 16;
+  static constexpr int G = 64 / R;
+};
+#define COL_PTR(base, E) ((base) + ((size_t)gtile * (size_t)(E)) * 64 + lane)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 // ------------------------------------------------------------------------------------------------ expansion
-// One thread = one trajectory b (x), one knot k (y), one direction j (z) of the error-state tangent space
-// [δx (ne); δu (m)].  It produces column j of everything the backward pass needs:
-//   [Ā B̄][:,j]   = G(x_{k+1})ᵀ · ∂(RK step)/∂z · v_j          (forward-mode dual through all RK stages)
-//   [Qxx;Qux][:,j] or Quu[:,j-ne] = projected Hessian-vector product of (cost + AL) with v_j
-//   qx, qu (thread j==0 only)
+// grid (ceil(B/G), N): lane (g, j) of a wave = trajectory gtile*G+g, direction j.  It produces column j of everything
+// the backward pass needs at knot k:
+//   [Ā B̄][:,j] = G(x_{k+1})ᵀ · ∂(RK step)/∂z · v_j            (forward-mode dual through all RK stages)
+//   H[:,j]      = projected Hessian-vector product of (cost + AL) with v_j,   g[j] = projected gradient component
 // with v_j = [G(x_k) e_j; 0] (j<ne) or [0; e_{j-ne}].
 template <class M>
 __global__ void __launch_bounds__(64) k_expand(KArgs a) {
-  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  constexpr int R = Coop<M>::R, G = Coop<M>::G;
+  const int gtile = blockIdx.x, lane = threadIdx.x;
+  const int g = lane / R, j = lane % R;
+  const int b = gtile * G + g;
   const DevProblem& P = a.P;
-  if (b >= P.B) return;
+  if (b >= P.B || j >= nc) return;
   if (!a.active[b]) return;
-  const int Bp = P.Bp, N = P.N;
-  const int k = blockIdx.y, j = blockIdx.z;
+  const int N = P.N;
+  const int k = blockIdx.y;
   const bool terminal = (k == N - 1);
   if (terminal && j >= ne) return;
   const int c = a.cur[b];
-  const double* X = a.X[c];
-  const double* U = a.U[c];
+  const int tile = b >> 6, lane64 = b & 63;
+  const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
+  const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
   double x[n], u[m], v[nz];
 #pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = X[TO_IDX(k, n, i)];
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
 #pragma unroll
-  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : U[TO_IDX(k, m, i)];
-  if (j < ne) {
-    errstate_col<M>(x, j, v);
+  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(U, k * m + i);
+  {
+    double vx[n];
+    errstate_col<M>(x, j < ne ? j : 0, vx);
 #pragma unroll
-    for (int i = 0; i < m; ++i) v[n + i] = 0.0;
-  } else {
-#pragma unroll
-    for (int i = 0; i < n; ++i) v[i] = 0.0;
+    for (int i = 0; i < n; ++i) v[i] = (j < ne) ? vx[i] : 0.0;
 #pragma unroll
     for (int i = 0; i < m; ++i) v[n + i] = (i == j - ne) ? 1.0 : 0.0;
   }
@@ -236,23 +285,19 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
     rk_step<M, Dual>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
     double x1[n], t[n], col[ne];
 #pragma unroll
-    for (int i = 0; i < n; ++i) { x1[i] = X[TO_IDX(k + 1, n, i)]; t[i] = xn[i].d; }
+    for (int i = 0; i < n; ++i) { x1[i] = EL(X, (k + 1) * n + i); t[i] = xn[i].d; }
     errstate_tmul<M>(x1, t, col);
-    if (j < ne) {
+    double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
 #pragma unroll
-      for (int i = 0; i < ne; ++i) a.A[(((size_t)k * ne + i) * ne + j) * Bp + b] = col[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < ne; ++i) a.Bm[(((size_t)k * ne + i) * m + (j - ne)) * Bp + b] = col[i];
-    }
+    for (int i = 0; i < ne; ++i) EL(Mc, k * ne + i) = col[i];
   }
   // ---- cost (+AL) gradient and Hessian-vector product on the full state
-  double g[nz], y[nz];
-  cost_grad_hvp<n, m>(P.costs[P.cost_index[k]], x, u, terminal, v, g, y);
+  double gr[nz], y[nz];
+  cost_grad_hvp<n, m>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
   if (P.opts.cost_dt_scaling && !terminal) {
     const double h = P.dt[k];
 #pragma unroll
-    for (int i = 0; i < nz; ++i) { g[i] *= h; y[i] *= h; }
+    for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
   }
   if (P.n_cons > 0) {
     double z[nz];
@@ -260,43 +305,35 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
     for (int i = 0; i < n; ++i) z[i] = x[i];
 #pragma unroll
     for (int i = 0; i < m; ++i) z[n + i] = u[i];
+    const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
+    const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
     for (int ci = 0; ci < P.n_cons; ++ci) {
-      const DevCon& K = P.cons[ci];
+      ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
-      const double* lam = a.lam + ((size_t)(K.dual_off + (long long)(k - K.k1) * K.p)) * Bp + b;
-      al_grad_hvp<nz>(K, z, lam, (size_t)Bp, a.mu[(size_t)ci * Bp + b], v, g, y);
+      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      al_grad_hvp<nz>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
     }
   }
-  if (j < ne) {
-    double col[ne];
-    errstate_tmul<M>(x, y, col);
-    if constexpr (M::lie) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q)
-      const double b1 = x[3] * g[3] + x[4] * g[4] + x[5] * g[5] + x[6] * g[6];
-      if (j >= 3 && j < 6) {
+  double col[ne], qxe[ne];
+  errstate_tmul<M>(x, y, col);
+  errstate_tmul<M>(x, gr, qxe);
+  if constexpr (M::lie) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q) on the attitude diagonal
+    const double b1 = x[3] * gr[3] + x[4] * gr[4] + x[5] * gr[5] + x[6] * gr[6];
 #pragma unroll
-        for (int i = 3; i < 6; ++i) col[i] -= (i == j) ? b1 : 0.0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < ne; ++i) a.Qxx[(((size_t)k * ne + i) * ne + j) * Bp + b] = col[i];
-    if (!terminal) {
-#pragma unroll
-      for (int r = 0; r < m; ++r) a.Qux[(((size_t)k * m + r) * ne + j) * Bp + b] = y[n + r];
-    }
-    if (j == 0) {
-      double qxe[ne];
-      errstate_tmul<M>(x, g, qxe);
-#pragma unroll
-      for (int i = 0; i < ne; ++i) a.qx[TO_IDX(k, ne, i)] = qxe[i];
-      if (!terminal) {
-#pragma unroll
-        for (int r = 0; r < m; ++r) a.qu[TO_IDX(k, m, r)] = g[n + r];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < m; ++r) a.Quu[(((size_t)k * m + r) * m + (j - ne)) * Bp + b] = y[n + r];
+    for (int i = 3; i < 6; ++i) col[i] -= (i == j) ? b1 : 0.0;
   }
+  double* Hc = COL_PTR(a.Hc, N * nc);
+#pragma unroll
+  for (int i = 0; i < ne; ++i) EL(Hc, k * nc + i) = col[i];
+#pragma unroll
+  for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
+  double gj = 0.0;
+#pragma unroll
+  for (int i = 0; i < ne; ++i) gj = (i == j) ? qxe[i] : gj;
+#pragma unroll
+  for (int r = 0; r < m; ++r) gj = (ne + r == j) ? gr[n + r] : gj;
+  double* gc = COL_PTR(a.gc, N);
+  EL(gc, k) = gj;
 }
 
 // ------------------------------------------------------------------------------------------------ regularisation
@@ -313,289 +350,386 @@ __device__ __forceinline__ void reg_decrease(const to_solver_opts& o, double& rh
 }
 
 // ------------------------------------------------------------------------------------------------ backward pass
-// Riccati recursion, one lane per trajectory.  Control regularisation Quu + ρI with
-// restart on Cholesky failure.
+// Riccati recursion, cooperative: the R lanes of a trajectory each own one column of
+// [Ā B̄] / of the Q-function Hessian; the small dense products exchange operands through LDS (all lanes of a group
+// read the same word: broadcast, conflict-free; groups are padded onto different banks).  Control regularisation
+// Quu + ρI with a per-trajectory restart on Cholesky failure.  One wave per workgroup, G trajectories per wave.
+template <class M>
+struct BwdLds {
+  static constexpr int ne = M::ne, m = M::m, nc = ne + m, R = Coop<M>::R;
+  static constexpr int oS = 0;                 // S[i][r]          ne*ne
+  static constexpr int oM = oS + ne * ne;      // Mx[i][j]         ne*R   (also S_new staging)
+  static constexpr int oH = oM + ne * R;       // Hu[r][j]         m*R    rows ne.. of the Q-function Hessian = [Qux Quu]
+  static constexpr int oK = oH + m * R;        // Kf[r][j]         m*ne
+  static constexpr int oG = oK + m * ne;       // g[j]             R
+  static constexpr int os = oG + R;            // s[i]             ne
+  static constexpr int raw = os + ne;
+  static constexpr int stride = raw + ((34 - (raw % 32)) % 32);  // stride % 32 == 2 doubles: groups land on distinct banks
+};
+
 template <class M>
 __global__ void __launch_bounds__(64) k_backward(KArgs a) {
-  constexpr int m = M::m, ne = M::ne;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int m = M::m, ne = M::ne, nc = ne + m;
+  constexpr int R = Coop<M>::R, G = Coop<M>::G;
+  using L = BwdLds<M>;
+  __shared__ double lds[G * L::stride];
+  const int gtile = blockIdx.x, lane = threadIdx.x;
+  const int g = lane / R, j = lane % R;
+  const int b = gtile * G + g;
   const DevProblem& P = a.P;
-  if (b >= P.B) return;
-  if (!a.active[b]) return;
-  const int Bp = P.Bp, N = P.N;
+  const int N = P.N;
+  const bool live = (b < P.B) && (j < nc) && a.active[b < P.B ? b : 0];
+  if (!live) return;  // no hardware barrier below: dropping lanes is safe
+  double* S_ = lds + g * L::stride + L::oS;
+  double* Mx = lds + g * L::stride + L::oM;
+  double* Hu = lds + g * L::stride + L::oH;
+  double* Kf = lds + g * L::stride + L::oK;
+  double* gl = lds + g * L::stride + L::oG;
+  double* sl = lds + g * L::stride + L::os;
+  const double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
+  const double* Hc = COL_PTR(a.Hc, N * nc);
+  const double* gc = COL_PTR(a.gc, N);
+  const int tile = b >> 6, lane64 = b & 63;
+  double* pK = a.K + ((size_t)tile * ((N - 1) * m * ne)) * 64 + lane64;
+  double* pd = a.d + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
   double rho = a.rho[b], drho = a.drho[b];
-  double S[ne][ne], s[ne];
   double dV0 = 0.0, dV1 = 0.0;
   bool failed = false;
+  int k = N - 2;
+  bool init = true;
   while (true) {
-    bool restart = false;
-    dV0 = 0.0; dV1 = 0.0;
+    if (init) {  // (re)start: S = Qxx_N, s = qx_N
+      if (j < ne) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) S_[i * ne + j] = EL(Hc, (N - 1) * nc + i);
+        sl[j] = EL(gc, N - 1);
+      }
+      dV0 = 0.0; dV1 = 0.0; k = N - 2; init = false;
+      WAVE_SYNC();
+    }
+    if (k < 0) break;
+    // 1. own column of [Ā B̄] and of the cost blocks
+    double Mj[ne], Hj[nc];
+#pragma unroll
+    for (int i = 0; i < ne; ++i) Mj[i] = EL(Mc, k * ne + i);
+#pragma unroll
+    for (int i = 0; i < nc; ++i) Hj[i] = EL(Hc, k * nc + i);
+    double gj = EL(gc, k);
+#pragma unroll
+    for (int i = 0; i < ne; ++i) Mx[i * R + j] = Mj[i];
+    WAVE_SYNC();
+    // 2. T = S M[:,j];   H[:,j] += Mᵀ T;   g_j += M[:,j]·s
+    double Tj[ne];
 #pragma unroll
     for (int i = 0; i < ne; ++i) {
+      double t = 0.0;
 #pragma unroll
-      for (int j = 0; j < ne; ++j) S[i][j] = a.Qxx[(((size_t)(N - 1) * ne + i) * ne + j) * Bp + b];
-      s[i] = a.qx[TO_IDX(N - 1, ne, i)];
+      for (int r = 0; r < ne; ++r) t += S_[i * ne + r] * Mj[r];
+      Tj[i] = t;
     }
-    for (int k = N - 2; k >= 0; --k) {
-      double A[ne][ne], Bk[ne][m], SA[ne][ne], SB[ne][m];
 #pragma unroll
-      for (int i = 0; i < ne; ++i) {
+    for (int i = 0; i < nc; ++i) {
+      double t = Hj[i];
 #pragma unroll
-        for (int j = 0; j < ne; ++j) A[i][j] = a.A[(((size_t)k * ne + i) * ne + j) * Bp + b];
-#pragma unroll
-        for (int j = 0; j < m; ++j) Bk[i][j] = a.Bm[(((size_t)k * ne + i) * m + j) * Bp + b];
-      }
-#pragma unroll
-      for (int i = 0; i < ne; ++i) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) { double t = 0.0;
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += S[i][r] * A[r][j];
-          SA[i][j] = t; }
-#pragma unroll
-        for (int j = 0; j < m; ++j) { double t = 0.0;
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += S[i][r] * Bk[r][j];
-          SB[i][j] = t; }
-      }
-      double Qx[ne], Qu[m], Qxx[ne][ne], Quu[m][m], Qux[m][ne];
-#pragma unroll
-      for (int i = 0; i < ne; ++i) { double t = a.qx[TO_IDX(k, ne, i)];
-#pragma unroll
-        for (int r = 0; r < ne; ++r) t += A[r][i] * s[r];
-        Qx[i] = t; }
-#pragma unroll
-      for (int j = 0; j < m; ++j) { double t = a.qu[TO_IDX(k, m, j)];
-#pragma unroll
-        for (int r = 0; r < ne; ++r) t += Bk[r][j] * s[r];
-        Qu[j] = t; }
-#pragma unroll
-      for (int i = 0; i < ne; ++i)
-#pragma unroll
-        for (int j = 0; j < ne; ++j) { double t = a.Qxx[(((size_t)k * ne + i) * ne + j) * Bp + b];
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += A[r][i] * SA[r][j];
-          Qxx[i][j] = t; }
-#pragma unroll
-      for (int i = 0; i < m; ++i) {
-#pragma unroll
-        for (int j = 0; j < m; ++j) { double t = a.Quu[(((size_t)k * m + i) * m + j) * Bp + b];
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += Bk[r][i] * SB[r][j];
-          Quu[i][j] = t; }
-#pragma unroll
-        for (int j = 0; j < ne; ++j) { double t = a.Qux[(((size_t)k * m + i) * ne + j) * Bp + b];
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += Bk[r][i] * SA[r][j];
-          Qux[i][j] = t; }
-      }
-      // Cholesky of Quu + ρI (lower, in L)
-      double L[m][m];
-      bool pd = true;
-#pragma unroll
-      for (int i = 0; i < m; ++i)
-#pragma unroll
-        for (int j = 0; j < m; ++j) L[i][j] = Quu[i][j] + ((i == j) ? rho : 0.0);
-#pragma unroll
-      for (int j = 0; j < m; ++j) {
-        double sj = L[j][j];
-#pragma unroll
-        for (int r = 0; r < j; ++r) sj -= L[j][r] * L[j][r];
-        if (!(sj > 0.0)) pd = false;
-        const double l = sqrt(sj);
-        L[j][j] = l;
-#pragma unroll
-        for (int i = j + 1; i < m; ++i) {
-          double t = L[i][j];
-#pragma unroll
-          for (int r = 0; r < j; ++r) t -= L[i][r] * L[j][r];
-          L[i][j] = t / l;
-        }
-      }
-      if (!pd) {
-        reg_increase(P.opts, rho, drho);
-        if (rho > P.opts.bp_reg_max) failed = true;
-        restart = true;
-        break;
-      }
-      // gains: K = −(LLᵀ)⁻¹ Qux, d = −(LLᵀ)⁻¹ Qu
-      double Kk[m][ne], dk[m];
-#pragma unroll
-      for (int j = 0; j <= ne; ++j) {
-        double col[m];
-#pragma unroll
-        for (int i = 0; i < m; ++i) col[i] = (j < ne) ? Qux[i][j < ne ? j : 0] : Qu[i];
-#pragma unroll
-        for (int i = 0; i < m; ++i) { double t = col[i];
-#pragma unroll
-          for (int r = 0; r < i; ++r) t -= L[i][r] * col[r];
-          col[i] = t / L[i][i]; }
-#pragma unroll
-        for (int i = m - 1; i >= 0; --i) { double t = col[i];
-#pragma unroll
-          for (int r = i + 1; r < m; ++r) t -= L[r][i] * col[r];
-          col[i] = t / L[i][i]; }
-#pragma unroll
-        for (int i = 0; i < m; ++i) { if (j < ne) Kk[i][j < ne ? j : 0] = -col[i]; else dk[i] = -col[i]; }
-      }
-#pragma unroll
-      for (int i = 0; i < m; ++i) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) a.K[(((size_t)k * m + i) * ne + j) * Bp + b] = Kk[i][j];
-        a.d[TO_IDX(k, m, i)] = dk[i];
-      }
-      // cost-to-go with the un-regularised Quu
-      double KtQuu[ne][m];
-#pragma unroll
-      for (int i = 0; i < ne; ++i)
-#pragma unroll
-        for (int j = 0; j < m; ++j) { double t = 0.0;
-#pragma unroll
-          for (int r = 0; r < m; ++r) t += Kk[r][i] * Quu[r][j];
-          KtQuu[i][j] = t; }
-      double snew[ne];
-#pragma unroll
-      for (int i = 0; i < ne; ++i) {
-        double t = Qx[i];
-#pragma unroll
-        for (int j = 0; j < m; ++j) t += KtQuu[i][j] * dk[j];
-#pragma unroll
-        for (int j = 0; j < m; ++j) t += Kk[j][i] * Qu[j];
-#pragma unroll
-        for (int j = 0; j < m; ++j) t += Qux[j][i] * dk[j];
-        snew[i] = t;
-      }
-#pragma unroll
-      for (int i = 0; i < ne; ++i)
-#pragma unroll
-        for (int j = 0; j < ne; ++j) {
-          double t = Qxx[i][j];
-#pragma unroll
-          for (int r = 0; r < m; ++r) t += KtQuu[i][r] * Kk[r][j];
-#pragma unroll
-          for (int r = 0; r < m; ++r) t += Kk[r][i] * Qux[r][j];
-#pragma unroll
-          for (int r = 0; r < m; ++r) t += Qux[r][i] * Kk[r][j];
-          SA[i][j] = t;  // reuse SA as S_new
-        }
-#pragma unroll
-      for (int i = 0; i < ne; ++i) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) S[i][j] = 0.5 * (SA[i][j] + SA[j][i]);
-        s[i] = snew[i];
-      }
-      double dv1 = 0.0, dv2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < m; ++i) {
-        dv1 += dk[i] * Qu[i];
-        double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < m; ++j) t += Quu[i][j] * dk[j];
-        dv2 += dk[i] * t;
-      }
-      dV0 += dv1;
-      dV1 += 0.5 * dv2;
+      for (int r = 0; r < ne; ++r) t += Mx[r * R + i] * Tj[r];
+      Hj[i] = t;
     }
-    if (!restart || failed) break;
+#pragma unroll
+    for (int r = 0; r < ne; ++r) gj += Mj[r] * sl[r];
+    // 3. publish the control rows [Qux Quu] and the gradient
+#pragma unroll
+    for (int r = 0; r < m; ++r) Hu[r * R + j] = Hj[ne + r];
+    gl[j] = gj;
+    WAVE_SYNC();
+    // 4. every lane factors Quu + ρI (m x m) redundantly
+    double Quu[m][m], Lc[m][m], Qu[m];
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+#pragma unroll
+      for (int q = 0; q < m; ++q) Quu[r][q] = Hu[r * R + ne + q];
+      Qu[r] = gl[ne + r];
+    }
+    bool pd_ok = true;
+    double iL[m];  // reciprocals of the Cholesky diagonal: every later division becomes a product
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+#pragma unroll
+      for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
+#pragma unroll
+    for (int q = 0; q < m; ++q) {
+      double sj = Lc[q][q];
+#pragma unroll
+      for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
+      if (!(sj > 0.0)) pd_ok = false;
+      const double l = sqrt(sj);
+      Lc[q][q] = l;
+      iL[q] = rcp_fast(l);
+#pragma unroll
+      for (int i = q + 1; i < m; ++i) {
+        double t = Lc[i][q];
+#pragma unroll
+        for (int r = 0; r < q; ++r) t -= Lc[i][r] * Lc[q][r];
+        Lc[i][q] = t * iL[q];
+      }
+    }
+    if (!pd_ok) {  // same decision in every lane of the group
+      reg_increase(P.opts, rho, drho);
+      if (rho > P.opts.bp_reg_max) { failed = true; break; }
+      init = true;
+      continue;
+    }
+    // 5. gains: own column of K = −(LLᵀ)⁻¹ Qux, and d = −(LLᵀ)⁻¹ Qu (redundant)
+    double Kj[m], dk[m];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      double col[m];
+#pragma unroll
+      for (int i = 0; i < m; ++i) col[i] = pass ? Qu[i] : Hj[ne + i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) { double t = col[i];
+#pragma unroll
+        for (int r = 0; r < i; ++r) t -= Lc[i][r] * col[r];
+        col[i] = t * iL[i]; }
+#pragma unroll
+      for (int i = m - 1; i >= 0; --i) { double t = col[i];
+#pragma unroll
+        for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
+        col[i] = t * iL[i]; }
+#pragma unroll
+      for (int i = 0; i < m; ++i) { if (pass) dk[i] = -col[i]; else Kj[i] = -col[i]; }
+    }
+    if (j < ne) {
+#pragma unroll
+      for (int r = 0; r < m; ++r) { Kf[r * ne + j] = Kj[r]; EL(pK, (k * m + r) * ne + j) = Kj[r]; }
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < m; ++r) EL(pd, k * m + r) = dk[r];
+    }
+    WAVE_SYNC();
+    // 6. cost-to-go with the un-regularised Quu:  S' = Qxx + Kᵀ(Quu K + Qux) + Quxᵀ K,  s' = Qx + Kᵀ(Quu d + Qu) + Quxᵀ d
+    double Snew[ne], snew = 0.0;
+    if (j < ne) {
+      double Wj[m], qd[m];
+#pragma unroll
+      for (int r = 0; r < m; ++r) {
+        double t = Hj[ne + r], t2 = Qu[r];
+#pragma unroll
+        for (int q = 0; q < m; ++q) { t += Quu[r][q] * Kj[q]; t2 += Quu[r][q] * dk[q]; }
+        Wj[r] = t; qd[r] = t2;
+      }
+#pragma unroll
+      for (int i = 0; i < ne; ++i) {
+        double t = Hj[i];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Kf[r * ne + i] * Wj[r];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Hu[r * R + i] * Kj[r];
+        Snew[i] = t;
+      }
+      snew = gj;
+#pragma unroll
+      for (int r = 0; r < m; ++r) snew += Kj[r] * qd[r];
+#pragma unroll
+      for (int r = 0; r < m; ++r) snew += Hj[ne + r] * dk[r];
+#pragma unroll
+      for (int i = 0; i < ne; ++i) Mx[i * R + j] = Snew[i];  // stage S' for the symmetrisation
+    }
+    double dv1 = 0.0, dv2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+      dv1 += dk[r] * Qu[r];
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
+      dv2 += dk[r] * t;
+    }
+    dV0 += dv1;
+    dV1 += 0.5 * dv2;
+    WAVE_SYNC();
+    if (j < ne) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i) S_[i * ne + j] = 0.5 * (Snew[i] + Mx[j * R + i]);
+      sl[j] = snew;
+    }
+    WAVE_SYNC();
+    --k;
   }
   if (!failed) reg_decrease(P.opts, rho, drho);
-  a.rho[b] = rho;
-  a.drho[b] = drho;
-  a.dV[b] = dV0;
-  a.dV[(size_t)Bp + b] = dV1;
-  a.bpfail[b] = failed ? 1 : 0;
+  if (j == 0) {
+    a.rho[b] = rho;
+    a.drho[b] = drho;
+    a.dV[b] = dV0;
+    a.dV[(size_t)P.Bp + b] = dV1;
+    a.bpfail[b] = failed ? 1 : 0;
+    a.ls_round[b] = 0;  // arm the line search of this iteration
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward pass
-// Closed-loop rollout + backtracking line search, then — when a.control — the per-
-// trajectory solver state machine: convergence test (row S3) and the AL outer update (row S4).
 template <class M>
+struct FwdKnot {  // nominal state/control and gains of one knot, fetched one knot ahead of their use
+  static constexpr int n = M::n, m = M::m, ne = M::ne;
+  double x[n], u[m], K[m][ne], d[m];
+  __device__ __forceinline__ void load(const double* pX, const double* pU, const double* pK, const double* pd, int k) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = EL(pX, k * n + i);
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      u[j] = EL(pU, k * m + j);
+      d[j] = EL(pd, k * m + j);
+#pragma unroll
+      for (int i = 0; i < ne; ++i) K[j][i] = EL(pK, (k * m + j) * ne + i);
+    }
+  }
+};
+
+// Line-search candidate: closed-loop rollout with step alpha = decrease^(round*T + t) of trajectory b into slot
+// (cur + 1 + t) mod (T+1), its cost and gradient metric.  grid = (tiles, T): every step size of the round is evaluated
+// CONCURRENTLY by its own wave — a sequential backtracking search would cost (deepest search in the batch) x one
+// rollout per iteration, while the machine idles.
+// MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms).
+template <class M, int MODE>
 __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  if (!a.active[b] || a.bpfail[b] || a.ls_round[b] != a.round) return;
+  const int t = blockIdx.y;
+  const int idx = a.round * a.T + t;
+  const to_solver_opts& o = P.opts;
+  if (idx >= o.iterations_linesearch) return;
+  const int N = P.N;
+  const int c = a.cur[b];
+  const int cs = (c + 1 + t) % (a.T + 1);
+  const double* Xc = TILE_PTR(XSLOT(a, c), N * n);
+  const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  double* Xn = TILE_PTR(XSLOT(a, cs), N * n);
+  double* Un = TILE_PTR(USLOT(a, cs), (N - 1) * m);
+  const double* pK = TILE_PTR(a.K, (N - 1) * m * ne);
+  const double* pd = TILE_PTR(a.d, (N - 1) * m);
+  const double* px0 = TILE_PTR(a.x0, n);
+  const double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  double alpha = 1.0;
+  for (int i = 0; i < idx; ++i) alpha *= o.line_search_decrease_factor;  // same product the sequential search forms
+  // everything wave-uniform the loop needs is fetched ONCE: an in-order wave stalls on every scalar-load round trip
+  double mp[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mp[i] = in_vgpr(P.mp[i]);
+  const int integrator = P.integrator;
+  const bool dt_scaling = P.opts.cost_dt_scaling != 0;
+  const double max_x = o.max_state_value, max_u = o.max_control_value;
+  StageCostDiag<n, m> sc;
+  double h0 = 0.0;
+  if constexpr (SIMPLE) { sc.load(P.costs[P.cost_index[0]]); h0 = P.dt[0]; }
+  double xb[n], J = 0.0, gsum = 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < n; ++i) { xb[i] = EL(px0, i); EL(Xn, i) = xb[i]; }
+  FwdKnot<M> nxt;
+  nxt.load(Xc, Uc, pK, pd, 0);
+  for (int k = 0; k < N - 1; ++k) {
+    const FwdKnot<M> cur = nxt;
+    if (k + 1 < N - 1) nxt.load(Xc, Uc, pK, pd, k + 1);  // software prefetch of the next knot
+    double dx[ne], ub[m], xn[n];
+    state_diff<M>(xb, cur.x, dx);
+    double gk = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      double du = cur.d[j] * alpha;
+#pragma unroll
+      for (int i = 0; i < ne; ++i) du += cur.K[j][i] * dx[i];
+      ub[j] = cur.u[j] + du;
+      EL(Un, k * m + j) = ub[j];
+      gk = fmax(gk, fabs(cur.d[j]) * rcp_fast(fabs(ub[j]) + 1.0));
+    }
+    gsum += gk;
+    const double h = SIMPLE ? h0 : P.dt[k];
+    double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m>(P.costs[P.cost_index[k]], xb, ub);
+    if (dt_scaling) Jk *= h;
+    if constexpr (CONS) Jk += knot_al<M>(P, k, xb, ub, lam0, mu0);
+    J += Jk;
+    rk_step<M, double>(mp, integrator, xb, ub, h, xn);
+    double mx = 0.0, mu_ = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xb[i] = xn[i]; EL(Xn, (k + 1) * n + i) = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
+#pragma unroll
+    for (int j = 0; j < m; ++j) { const double v = fabs(ub[j]); if (!(v <= mu_)) mu_ = v; }
+    if (!(mx <= max_x) || !(mu_ <= max_u)) { ok = false; break; }
+  }
+  if (ok) {
+    double u0[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u0[j] = 0.0;
+    J += knot_cost<M>(P, N - 1, xb, u0, lam0, mu0, true);
+  }
+  const size_t ci = (size_t)t * P.Bp + b;
+  a.candJ[ci] = J;
+  a.candG[ci] = gsum / (N - 1);
+  a.candOk[ci] = ok ? 1 : 0;
+}
+
+// Picks the FIRST accepted step size of the round (identical to sequential backtracking), then — when
+// a.control — runs the per-trajectory solver state machine: convergence test (row S3) and the AL outer update (row S4).
+template <class M>
+__global__ void __launch_bounds__(64) k_select(KArgs a) {
+  constexpr int m = M::m;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
   if (!a.active[b]) return;
-  const int Bp = P.Bp, N = P.N;
+  const int N = P.N;
   const to_solver_opts& o = P.opts;
+  const bool bpfail = a.bpfail[b] != 0;
+  if (!bpfail && a.ls_round[b] != a.round) return;  // already resolved in an earlier round of this iteration
   const int c = a.cur[b];
-  const double* Xc = a.X[c];
-  const double* Uc = a.U[c];
-  double* Xn = a.X[1 - c];
-  double* Un = a.U[1 - c];
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
   const double Jprev = a.J[b];
   double rho = a.rho[b], drho = a.drho[b];
-  const bool bpfail = a.bpfail[b] != 0;
-  double Jnew = Jprev, grad = 0.0, grad_nominal = 0.0;
+  double Jnew = Jprev, grad = 0.0;
   int accepted = -1;
   if (!bpfail) {
-    const double dV0 = a.dV[b], dV1 = a.dV[(size_t)Bp + b];
+    const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
     double alpha = 1.0;
-    for (int it = 0; it < o.iterations_linesearch; ++it) {
-      double xb[n], J = 0.0, gsum = 0.0, gnom = 0.0;
-      bool ok = true;
-#pragma unroll
-      for (int i = 0; i < n; ++i) { xb[i] = a.x0[(size_t)i * Bp + b]; Xn[TO_IDX(0, n, i)] = xb[i]; }
-      for (int k = 0; k < N - 1; ++k) {
-        double xk[n], dx[ne], ub[m], xn[n];
-#pragma unroll
-        for (int i = 0; i < n; ++i) xk[i] = Xc[TO_IDX(k, n, i)];
-        state_diff<M>(xb, xk, dx);
-        double gk = 0.0, gk_nom = 0.0;
-#pragma unroll
-        for (int j = 0; j < m; ++j) {
-          const double dj = a.d[TO_IDX(k, m, j)];
-          double du = dj * alpha;
-#pragma unroll
-          for (int i = 0; i < ne; ++i) du += a.K[(((size_t)k * m + j) * ne + i) * Bp + b] * dx[i];
-          const double uk = Uc[TO_IDX(k, m, j)];
-          ub[j] = uk + du;
-          Un[TO_IDX(k, m, j)] = ub[j];
-          gk = fmax(gk, fabs(dj) / (fabs(ub[j]) + 1.0));
-          gk_nom = fmax(gk_nom, fabs(dj) / (fabs(uk) + 1.0));
-        }
-        gsum += gk; gnom += gk_nom;
-        J += knot_cost<M>(a, k, xb, ub, b, true);
-        rk_step<M, double>(P.mp, P.integrator, xb, ub, P.dt[k], xn);
-        double mx = 0.0, mu_ = 0.0;
-#pragma unroll
-        for (int i = 0; i < n; ++i) { xb[i] = xn[i]; Xn[TO_IDX(k + 1, n, i)] = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
-#pragma unroll
-        for (int j = 0; j < m; ++j) { const double v = fabs(ub[j]); if (!(v <= mu_)) mu_ = v; }
-        if (!(mx <= o.max_state_value) || !(mu_ <= o.max_control_value)) { ok = false; break; }
-      }
-      if (it == 0) grad_nominal = gnom / (N - 1);  // only complete (and only used) when the first rollout ran through; see below
-      if (ok) {
-        double u0[m];
-#pragma unroll
-        for (int j = 0; j < m; ++j) u0[j] = 0.0;
-        J += knot_cost<M>(a, N - 1, xb, u0, b, true);
+    for (int i = 0; i < a.round * a.T; ++i) alpha *= o.line_search_decrease_factor;
+    bool exhausted = false;
+    for (int t = 0; t < a.T; ++t) {
+      const int idx = a.round * a.T + t;
+      if (idx >= o.iterations_linesearch) { exhausted = true; break; }
+      const size_t ci = (size_t)t * P.Bp + b;
+      if (a.candOk[ci]) {
+        const double J = a.candJ[ci];
         const double expected = -alpha * (dV0 + alpha * dV1);
         const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
         if (z >= o.line_search_lower_bound && z <= o.line_search_upper_bound) {
-          accepted = it; Jnew = J; grad = gsum / (N - 1);
+          accepted = idx; Jnew = J; grad = a.candG[ci];
+          a.cur[b] = (c + 1 + t) % (a.T + 1);
           break;
         }
       }
       alpha *= o.line_search_decrease_factor;
     }
     if (accepted < 0) {
-      // gradient metric on the unchanged nominal controls (exact: recompute, the in-loop value may be partial)
+      if (!exhausted && (a.round + 1) * a.T < o.iterations_linesearch) { a.ls_round[b] = a.round + 1; return; }  // next round
+      // line search failed: gradient metric on the unchanged nominal controls, regularise harder
+      const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
+      const double* pd = TILE_PTR(a.d, (N - 1) * m);
       double gs = 0.0;
       for (int k = 0; k < N - 1; ++k) {
         double gk = 0.0;
 #pragma unroll
-        for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(a.d[TO_IDX(k, m, j)]) / (fabs(Uc[TO_IDX(k, m, j)]) + 1.0));
+        for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(EL(pd, k * m + j)) * rcp_fast(fabs(EL(Uc, k * m + j)) + 1.0));
         gs += gk;
       }
       grad = gs / (N - 1);
-      (void)grad_nominal;
       reg_increase(o, rho, drho);
       rho += o.bp_reg_fp;
-    } else {
-      a.cur[b] = 1 - c;
     }
   }
+  a.ls_round[b] = -1;
   a.ls_index[b] = accepted;
   if (!a.control) {  // phase API: report and leave the state machine alone
     a.Jout[b] = Jnew;
@@ -630,7 +764,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
       const int outer = a.outer[b] + 1;
       a.outer[b] = outer;
       double cm;
-      trajectory_pass<M>(a, b, false, false, nullptr, &cm);
+      trajectory_pass<M>(a, tile, lane, false, false, nullptr, &cm);
       a.cmax[b] = cm;
       const int its = a.iterations[b];
       if (st != TO_SOLVE_SUCCEEDED && st != TO_MAX_ITERATIONS && st != TO_NO_PROGRESS) { a.status[b] = st; still_active = false; }
@@ -639,13 +773,10 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
       else if (outer >= o.iterations_outer) { a.status[b] = TO_MAX_ITERATIONS_OUTER; still_active = false; }
       else {
         // dual + penalty update, then start the next inner solve on the same trajectory
-        trajectory_pass<M>(a, b, false, true, nullptr, nullptr);
-        for (int ci = 0; ci < P.n_cons; ++ci) {
-          double* mu = &a.mu[(size_t)ci * Bp + b];
-          *mu = fmin(*mu * o.penalty_scaling, o.penalty_max);
-        }
+        trajectory_pass<M>(a, tile, lane, false, true, nullptr, nullptr);
+        for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = fmin(EL(mu0, ci) * o.penalty_scaling, o.penalty_max);
         double Jal;
-        trajectory_pass<M>(a, b, true, false, &Jal, nullptr);
+        trajectory_pass<M>(a, tile, lane, true, false, &Jal, nullptr);
         a.J[b] = Jal;
         rho = o.bp_reg_initial; drho = 0.0;
         a.dJzero[b] = 0; a.it_inner[b] = 0;
@@ -662,84 +793,101 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
 
 // start of a solve: reset the per-trajectory solver state.  J must already hold the (AL) cost of the rollout.
 __global__ void k_solve_init(KArgs a, int reset_duals) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.Bp) return;
   const bool live = b < P.B;
   a.rho[b] = P.opts.bp_reg_initial; a.drho[b] = 0.0;
   a.dJzero[b] = 0; a.it_inner[b] = 0; a.iterations[b] = 0; a.outer[b] = 0;
-  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0;
+  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.ls_round[b] = -1;
   a.dJ[b] = 0.0; a.grad[b] = 0.0; a.cmax[b] = 0.0;
   const int tot = a.al_mode ? P.opts.iterations_total : P.opts.iterations;
   a.budget[b] = tot < P.opts.iterations ? tot : P.opts.iterations;
   a.active[b] = (live && a.budget[b] > 0) ? 1 : 0;
   if (live && a.budget[b] <= 0) a.status[b] = TO_MAX_ITERATIONS;
   if (reset_duals) {
-    for (long long r = 0; r < P.n_duals; ++r) a.lam[(size_t)r * P.Bp + b] = 0.0;
-    for (int ci = 0; ci < P.n_cons; ++ci) a.mu[(size_t)ci * P.Bp + b] = P.opts.penalty_initial;
+    double* lam0 = TILE_PTR(a.lam, P.n_duals);
+    double* mu0 = TILE_PTR(a.mu, P.n_cons);
+    for (long long r = 0; r < P.n_duals; ++r) EL(lam0, r) = 0.0;
+    for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = P.opts.penalty_initial;
   }
 }
 
-__global__ void k_set_active(KArgs a, int value) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_set_active(KArgs a, int value, int clear_bpfail) {
+  TILE_LANE();
   if (b >= a.P.Bp) return;
   a.active[b] = (b < a.P.B) ? value : 0;
-  a.bpfail[b] = 0;
+  if (clear_bpfail == 1) a.bpfail[b] = 0;
+  if (clear_bpfail) a.ls_round[b] = 0;  // 2: re-arm the line search only
 }
 
 __global__ void k_penalty_max(KArgs a, double* out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   if (b >= a.P.B) return;
+  const double* mu0 = TILE_PTR(a.mu, a.P.n_cons);
   double mx = 0.0;
-  for (int ci = 0; ci < a.P.n_cons; ++ci) mx = fmax(mx, a.mu[(size_t)ci * a.P.Bp + b]);
+  for (int ci = 0; ci < a.P.n_cons; ++ci) mx = fmax(mx, EL(mu0, ci));
   out[b] = mx;
 }
 
 // ------------------------------------------------------------------------------------------------ layout transposes
-// host layout  h[i + dim*(k + K*b)]   <->   device layout d[(k*dim + i)*Bp + b]
-__global__ void k_to_device(const double* __restrict__ h, double* __restrict__ d, int dim, int K, int B, int Bp) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ki = blockIdx.y;  // k*dim + i
+// host layout h[e + L*b] (e = i + dim*k, column-major (dim, K, B))  <->  tiled device layout, L elements per trajectory.
+// grid: (tiles, L).  Host-side access is strided, device-side coalesced; these are API-boundary copies, not hot.
+// (cnt host elements per trajectory map to device elements e0 .. e0+cnt-1 of an array with L per trajectory)
+__global__ void k_to_device(const double* __restrict__ h, double* __restrict__ d, int L, int e0, int cnt, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
   if (b >= B) return;
-  d[(size_t)ki * Bp + b] = h[(size_t)ki + (size_t)dim * K * b];
+  EL(TILE_PTR(d, L), e0 + e) = h[(size_t)e + (size_t)cnt * b];
 }
-__global__ void k_to_host(const double* __restrict__ d, double* __restrict__ h, int dim, int K, int B, int Bp) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ki = blockIdx.y;
+__global__ void k_to_host(const double* __restrict__ d, double* __restrict__ h, int L, int e0, int cnt, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
   if (b >= B) return;
-  h[(size_t)ki + (size_t)dim * K * b] = d[(size_t)ki * Bp + b];
+  h[(size_t)e + (size_t)cnt * b] = EL(TILE_PTR(d, L), e0 + e);
 }
 // same with the nominal buffer chosen per trajectory (X/U double buffering)
-__global__ void k_to_host_cur(const double* __restrict__ d0, const double* __restrict__ d1, const int* __restrict__ cur,
-                              double* __restrict__ h, int dim, int K, int B, int Bp) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ki = blockIdx.y;
+__global__ void k_to_host_cur(const double* __restrict__ ds, size_t slot, const int* __restrict__ cur, double* __restrict__ h, int L, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
   if (b >= B) return;
-  const double* d = cur[b] ? d1 : d0;
-  h[(size_t)ki + (size_t)dim * K * b] = d[(size_t)ki * Bp + b];
+  const double* d = ds + (size_t)cur[b] * slot;
+  h[(size_t)e + (size_t)L * b] = EL(TILE_PTR(d, L), e);
 }
-__global__ void k_to_device_cur(const double* __restrict__ h, double* __restrict__ d0, double* __restrict__ d1,
-                                const int* __restrict__ cur, int dim, int K, int B, int Bp) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ki = blockIdx.y;
+__global__ void k_to_device_cur(const double* __restrict__ h, double* __restrict__ ds, size_t slot, const int* __restrict__ cur, int L, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
   if (b >= B) return;
-  double* d = cur[b] ? d1 : d0;
-  d[(size_t)ki * Bp + b] = h[(size_t)ki + (size_t)dim * K * b];
+  double* d = ds + (size_t)cur[b] * slot;
+  EL(TILE_PTR(d, L), e) = h[(size_t)e + (size_t)L * b];
 }
-__global__ void k_fill_uniform(double* d0, double* d1, const int* cur, const double* u, int dim, int K, int B, int Bp) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ki = blockIdx.y;
+__global__ void k_fill_uniform(double* ds, size_t slot, const int* cur, const double* u, int dim, int L, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
   if (b >= B) return;
-  double* d = cur[b] ? d1 : d0;
-  d[(size_t)ki * Bp + b] = u[ki % dim];
+  double* d = ds + (size_t)cur[b] * slot;
+  EL(TILE_PTR(d, L), e) = u[e % dim];
 }
-// matrices: host h[r + R*(c + Cc*(k + K*b))] (column-major) <-> device d[((k*R + r)*Cc + c)*Bp + b]
-__global__ void k_mat_to_host(const double* __restrict__ d, double* __restrict__ h, int R, int Cc, int K, int B, int Bp) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// matrices: device blocks are row-major [k][r][c]; host wants column-major h[r + R*(c + Cc*(k + K*b))].  grid (tiles, K*R*Cc)
+__global__ void k_mat_to_host(const double* __restrict__ d, double* __restrict__ h, int R, int Cc, int K, int B) {
+  TILE_LANE();
   const int e = blockIdx.y;  // (k*R + r)*Cc + c
   if (b >= B) return;
   const int c = e % Cc, r = (e / Cc) % R, k = e / (Cc * R);
-  h[(size_t)r + (size_t)R * (c + (size_t)Cc * (k + (size_t)K * b))] = d[(size_t)e * Bp + b];
+  h[(size_t)r + (size_t)R * (c + (size_t)Cc * (k + (size_t)K * b))] = EL(TILE_PTR(d, R * Cc * K), e);
+}
+
+// column-layout arrays -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = col_array(b, column c0+c, entry k*rows_per_knot + r0 + r)
+// grid (ceil(B/64), K*Rr*Cc), one thread per trajectory.
+__global__ void k_col_to_host(const double* __restrict__ src, double* __restrict__ h, int E, int rows_per_knot, int r0, int Rr, int c0,
+                              int Cc, int K, int B, int R, int G) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int e = blockIdx.y;  // (k*Cc + c)*Rr + r
+  if (b >= B) return;
+  const int r = e % Rr, c = (e / Rr) % Cc, k = e / (Rr * Cc);
+  const int gtile = b / G, g = b % G;
+  const size_t idx = ((size_t)gtile * E + (size_t)k * rows_per_knot + r0 + r) * 64 + g * R + (c0 + c);
+  h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = src[idx];
 }
 
 // ------------------------------------------------------------------------------------------------ per-knot API kernels
@@ -748,17 +896,19 @@ __global__ void k_mat_to_host(const double* __restrict__ d, double* __restrict__
 template <class M>
 __global__ void __launch_bounds__(64) k_cost_derivs(KArgs a, double* grad, double* hess) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  const int Bp = P.Bp, N = P.N, k = blockIdx.y;
+  const int N = P.N, k = blockIdx.y;
   const bool terminal = (k == N - 1);
   const int c = a.cur[b];
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double x[n], u[m];
 #pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = a.X[c][TO_IDX(k, n, i)];
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
 #pragma unroll
-  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : a.U[c][TO_IDX(k, m, i)];
+  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(U, k * m + i);
   const size_t kb = (size_t)k + (size_t)N * b;
   for (int j = 0; j < nz; ++j) {
     double v[nz], g[nz], y[nz];
@@ -778,16 +928,18 @@ __global__ void __launch_bounds__(64) k_cost_derivs(KArgs a, double* grad, doubl
 template <class M>
 __global__ void __launch_bounds__(64) k_discrete_jacobian(KArgs a, double* F) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  const int Bp = P.Bp, N = P.N, k = blockIdx.y, j = blockIdx.z;
+  const int N = P.N, k = blockIdx.y, j = blockIdx.z;
   const int c = a.cur[b];
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   Dual xd[n], ud[m], xn[n];
 #pragma unroll
-  for (int i = 0; i < n; ++i) xd[i] = Dual(a.X[c][TO_IDX(k, n, i)], (i == j) ? 1.0 : 0.0);
+  for (int i = 0; i < n; ++i) xd[i] = Dual(EL(X, k * n + i), (i == j) ? 1.0 : 0.0);
 #pragma unroll
-  for (int i = 0; i < m; ++i) ud[i] = Dual(a.U[c][TO_IDX(k, m, i)], (n + i == j) ? 1.0 : 0.0);
+  for (int i = 0; i < m; ++i) ud[i] = Dual(EL(U, k * m + i), (n + i == j) ? 1.0 : 0.0);
   rk_step<M, Dual>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
   const size_t kb = (size_t)k + (size_t)(N - 1) * b;
 #pragma unroll
@@ -798,17 +950,19 @@ __global__ void __launch_bounds__(64) k_discrete_jacobian(KArgs a, double* F) {
 template <class M>
 __global__ void __launch_bounds__(64) k_constraint_eval(KArgs a, int ci, double* vals, double* jac) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  const DevCon& K = P.cons[ci];
-  const int Bp = P.Bp, N = P.N, kk = blockIdx.y, k = K.k1 + kk, nk = K.k2 - K.k1 + 1;
+  ConC& K = P.cons[ci];
+  const int N = P.N, kk = blockIdx.y, k = K.k1 + kk, nk = K.k2 - K.k1 + 1;
   const int c = a.cur[b];
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double z[nz];
 #pragma unroll
-  for (int i = 0; i < n; ++i) z[i] = a.X[c][TO_IDX(k, n, i)];
+  for (int i = 0; i < n; ++i) z[i] = EL(X, k * n + i);
 #pragma unroll
-  for (int i = 0; i < m; ++i) z[n + i] = (k < N - 1) ? a.U[c][TO_IDX(k, m, i)] : 0.0;
+  for (int i = 0; i < m; ++i) z[n + i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
   const size_t kb = (size_t)kk + (size_t)nk * b;
   const int p = K.p, w = K.width;
   double coef[nz];

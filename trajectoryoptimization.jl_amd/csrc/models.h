@@ -12,6 +12,15 @@
 
 namespace to {
 
+// 1/x to ~1 ulp: hardware reciprocal estimate + two Newton steps (5 VALU ops instead of the ~27 of an IEEE
+// double division — on gfx950 the division sequence was the single largest cost of every hot kernel).
+__device__ __forceinline__ double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 struct Dual {
   double v, d;
   __host__ __device__ Dual() : v(0.0), d(0.0) {}
@@ -23,8 +32,9 @@ __device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual(a.v - b.
 __device__ __forceinline__ Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
 __device__ __forceinline__ Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
 __device__ __forceinline__ Dual operator/(Dual a, Dual b) {
-  double q = a.v / b.v;
-  return Dual(q, (a.d - q * b.d) / b.v);
+  const double rb = rcp_fast(b.v);
+  const double q = a.v * rb;
+  return Dual(q, (a.d - q * b.d) * rb);
 }
 __device__ __forceinline__ Dual operator+(Dual a, double b) { return Dual(a.v + b, a.d); }
 __device__ __forceinline__ Dual operator+(double a, Dual b) { return Dual(a + b.v, b.d); }
@@ -32,12 +42,45 @@ __device__ __forceinline__ Dual operator-(Dual a, double b) { return Dual(a.v - 
 __device__ __forceinline__ Dual operator-(double a, Dual b) { return Dual(a - b.v, -b.d); }
 __device__ __forceinline__ Dual operator*(Dual a, double b) { return Dual(a.v * b, a.d * b); }
 __device__ __forceinline__ Dual operator*(double a, Dual b) { return Dual(a * b.v, a * b.d); }
-__device__ __forceinline__ Dual operator/(Dual a, double b) { return Dual(a.v / b, a.d / b); }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { const double rb = rcp_fast(b); return Dual(a.v * rb, a.d * rb); }
+__device__ __forceinline__ double recip_t(double x) { return rcp_fast(x); }
+__device__ __forceinline__ Dual recip_t(Dual x) { const double r = rcp_fast(x.v); return Dual(r, -(x.d * r) * r); }
 
-__device__ __forceinline__ void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
+// sin and cos together: 3-term Cody-Waite reduction by π/2 (exact products for |x| < 2^19·π/2, FMA-based) followed by
+// the classic minimax kernels on [-π/4, π/4] (< 1 ulp).  ~40 FP64 instructions instead of libm's ~150 with its
+// Payne-Hanek path; huge / non-finite arguments take the libm path so semantics are unchanged there.
+__device__ __forceinline__ void sincos_fast(double x, double* s, double* c) {
+#ifndef TRAJOPT_NO_SINCOS_FALLBACK
+  if (!(fabs(x) < 8.2e5)) { sincos(x, s, c); return; }
+#endif
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-fn, 1.57079632673412561417e+00, x);   // pio2_1  (33 bits)
+  r = fma(-fn, 6.07710050630396597660e-11, r);          // pio2_2  (33 bits)
+  r = fma(-fn, 2.02226624871116645580e-21, r);          // pio2_3  (33 bits)
+  r = fma(-fn, 8.47842766036889956997e-32, r);          // pio2_3t
+  const double z = r * r;
+  // sin(r) = r + r^3 (S1 + z (S2 + ...)),  cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)fn & 3;
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -s0 : s0;
+  *c = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ void sincos_t(double x, double* s, double* c) { sincos_fast(x, s, c); }
 __device__ __forceinline__ void sincos_t(Dual x, Dual* s, Dual* c) {
   double sv, cv;
-  sincos(x.v, &sv, &cv);
+  sincos_fast(x.v, &sv, &cv);
   *s = Dual(sv, cv * x.d);
   *c = Dual(cv, -sv * x.d);
 }
@@ -56,11 +99,11 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr bool lie = false;
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
-    const double mass = P[0];
+    const double inv_mass = rcp_fast(P[0]);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       xd[i] = x[D + i];
-      xd[D + i] = u[i] / mass;
+      xd[D + i] = u[i] * inv_mass;
     }
   }
 };
@@ -82,8 +125,9 @@ struct CartpoleModel {  // docs/src/model.md:34-50
     T b2 = ((mp * g) * l) * s;
     // 2x2 solve as StaticArrays does it: ((a22 b1 - a12 b2)/d, (a11 b2 - a21 b1)/d)
     T d = h11 * h22 - h12 * h12;
-    T s1 = (h22 * b1 - h12 * b2) / d;
-    T s2 = (h11 * b2 - h12 * b1) / d;
+    T rd = recip_t(d);  // one reciprocal, two products (the reference divides twice; a few ulp apart)
+    T s1 = (h22 * b1 - h12 * b2) * rd;
+    T s2 = (h11 * b2 - h12 * b1) * rd;
     xd[0] = qd1;
     xd[1] = qd2;
     xd[2] = -s1;
@@ -118,13 +162,14 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
     xd[4] = 0.5 * (qw * w1 + qy * w3 - qz * w2);
     xd[5] = 0.5 * (qw * w2 - qx * w3 + qz * w1);
     xd[6] = 0.5 * (qw * w3 + qx * w2 - qy * w1);
-    xd[7] = (mass * g1 + qF1) / mass;
-    xd[8] = (mass * g2 + qF2) / mass;
-    xd[9] = (mass * g3 + qF3) / mass;
+    const double inv_mass = rcp_fast(mass);
+    xd[7] = (mass * g1 + qF1) * inv_mass;
+    xd[8] = (mass * g2 + qF2) * inv_mass;
+    xd[9] = (mass * g3 + qF3) * inv_mass;
     T Jw1 = J1 * w1, Jw2 = J2 * w2, Jw3 = J3 * w3;
-    xd[10] = (1.0 / J1) * (t1 - (w2 * Jw3 - w3 * Jw2));
-    xd[11] = (1.0 / J2) * (t2 - (w3 * Jw1 - w1 * Jw3));
-    xd[12] = (1.0 / J3) * (t3 - (w1 * Jw2 - w2 * Jw1));
+    xd[10] = rcp_fast(J1) * (t1 - (w2 * Jw3 - w3 * Jw2));
+    xd[11] = rcp_fast(J2) * (t2 - (w3 * Jw1 - w1 * Jw3));
+    xd[12] = rcp_fast(J3) * (t3 - (w1 * Jw2 - w2 * Jw1));
   }
 };
 
@@ -135,33 +180,40 @@ enum { INTEG_RK4 = 0, INTEG_RK3 = 1, INTEG_EULER = 2 };
 
 template <class M, class T>
 __device__ __forceinline__ void rk_step(const double* P, int integrator, const T* x, const T* u, double h, T* xn) {
+  // Stage slopes are folded into a running sum as they are produced (same left-to-right order as
+  // x + (k1 + 2k2 + 2k3 + k4)/6), so only {x, xt, k, acc} are live instead of {x, xt, k1..k4}: for the Quadrotor in
+  // dual numbers that is the difference between fitting the register file and spilling.
   constexpr int n = M::n;
-  T k1[n], k2[n], k3[n], k4[n], xt[n];
-  M::f(P, x, u, k1);
+  T k[n], acc[n], xt[n];
+  M::f(P, x, u, k);
   if (integrator == INTEG_EULER) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) xn[i] = x[i] + k1[i] * h;
+    for (int i = 0; i < n; ++i) xn[i] = x[i] + k[i] * h;
     return;
   }
 #pragma unroll
-  for (int i = 0; i < n; ++i) { k1[i] = k1[i] * h; xt[i] = x[i] + k1[i] / 2.0; }
-  M::f(P, xt, u, k2);
+  for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = k[i]; xt[i] = x[i] + k[i] * 0.5; }
   if (integrator == INTEG_RK3) {
+    T k1[n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) { k2[i] = k2[i] * h; xt[i] = x[i] - k1[i] + 2.0 * k2[i]; }
-    M::f(P, xt, u, k3);
+    for (int i = 0; i < n; ++i) k1[i] = k[i];
+    M::f(P, xt, u, k);
 #pragma unroll
-    for (int i = 0; i < n; ++i) { k3[i] = k3[i] * h; xn[i] = x[i] + (k1[i] + 4.0 * k2[i] + k3[i]) / 6.0; }
+    for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + 4.0 * k[i]; xt[i] = x[i] - k1[i] + 2.0 * k[i]; }
+    M::f(P, xt, u, k);
+#pragma unroll
+    for (int i = 0; i < n; ++i) { k[i] = k[i] * h; xn[i] = x[i] + (acc[i] + k[i]) * (1.0 / 6.0); }
     return;
   }
+  M::f(P, xt, u, k);
 #pragma unroll
-  for (int i = 0; i < n; ++i) { k2[i] = k2[i] * h; xt[i] = x[i] + k2[i] / 2.0; }
-  M::f(P, xt, u, k3);
+  for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + 2.0 * k[i]; xt[i] = x[i] + k[i] * 0.5; }
+  M::f(P, xt, u, k);
 #pragma unroll
-  for (int i = 0; i < n; ++i) { k3[i] = k3[i] * h; xt[i] = x[i] + k3[i]; }
-  M::f(P, xt, u, k4);
+  for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + 2.0 * k[i]; xt[i] = x[i] + k[i]; }
+  M::f(P, xt, u, k);
 #pragma unroll
-  for (int i = 0; i < n; ++i) { k4[i] = k4[i] * h; xn[i] = x[i] + (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]) / 6.0; }
+  for (int i = 0; i < n; ++i) { k[i] = k[i] * h; xn[i] = x[i] + (acc[i] + k[i]) * (1.0 / 6.0); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -223,7 +275,8 @@ __device__ __forceinline__ void state_diff(const double* x, const double* x0, do
     const double v1 = w0 * a - a0 * w - (b0 * c - c0 * b);
     const double v2 = w0 * b - b0 * w - (c0 * a - a0 * c);
     const double v3 = w0 * c - c0 * w - (a0 * b - b0 * a);
-    dx[3] = v1 / s; dx[4] = v2 / s; dx[5] = v3 / s;
+    const double rs = rcp_fast(s);
+    dx[3] = v1 * rs; dx[4] = v2 * rs; dx[5] = v3 * rs;
 #pragma unroll
     for (int i = 0; i < 6; ++i) dx[6 + i] = x[7 + i] - x0[7 + i];
   }

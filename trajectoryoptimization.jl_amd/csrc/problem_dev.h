@@ -21,16 +21,31 @@ struct DevCon {
   double soff[TO_MAX_P];
 };
 
+// Read-only descriptor tables are addressed through the CONSTANT address space: with a wave-uniform address the
+// compiler then emits scalar loads (s_load, scalar cache) instead of per-lane vector loads that would sit on the
+// critical path of every knot (they may otherwise alias the kernels' double stores).
+#define TO_CONST_AS __attribute__((address_space(4)))
+typedef const to_cost_desc TO_CONST_AS CostC;
+typedef const DevCon TO_CONST_AS ConC;
+typedef const double TO_CONST_AS DoubleC;
+typedef const int TO_CONST_AS IntC;
+
 struct DevProblem {
   int n, m, ne, N, B, Bp, integrator, n_costs, n_cons;
+  int simple_stage;  // 1: every stage knot (k < N-1) uses the same diagonal-kind cost and the same dt (the common LQR-style objective)
   long long n_duals;
   double mp[16];
   to_solver_opts opts;
-  const double* dt;          // [N-1]
-  const int* cost_index;     // [N]
-  const to_cost_desc* costs; // [n_costs]
-  const DevCon* cons;        // [n_cons]
+  DoubleC* dt;         // [N-1]
+  IntC* cost_index;    // [N]
+  CostC* costs;        // [n_costs]
+  ConC* cons;          // [n_cons]
 };
+
+// Pin a wave-uniform value into a VGPR.  Loop-invariant uniform operands otherwise live in SGPRs; the hot loops
+// carry ~40 of them (model parameters, stage cost), which overflows the 102-SGPR file into spills and, with the
+// one-SGPR-per-VALU-instruction constant-bus limit, into extra moves.
+__device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
 
 // register-array helpers with a wave-uniform runtime index (no scratch: unrolled selects)
 template <int N_>
@@ -46,10 +61,24 @@ __device__ __forceinline__ void add_at(double* a, int idx, double v) {
   for (int i = 0; i < N_; ++i) a[i] += (i == idx) ? v : 0.0;
 }
 
+// q_ref' x[q_ind]: the quaternion sits at the default state indices 4:7 (src/lie_costs.jl:134) in every rigid-body
+// model; that case indexes registers directly, anything else falls back to the select chain.
+template <int n>
+__device__ __forceinline__ double quat_dot(const double* qref, const int* qind, const double* x) {
+  if constexpr (n >= 7) {
+    if (qind[0] == 4 && qind[1] == 5 && qind[2] == 6 && qind[3] == 7)
+      return qref[0] * x[3] + qref[1] * x[4] + qref[2] * x[5] + qref[3] * x[6];
+  }
+  double dq = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dq += qref[i] * pick<n>(x, qind[i] - 1);
+  return dq;
+}
+
 // ------------------------------------------------------------------------------------------------ costs
 // J = ½x'Qx + q'x + c (+ ½u'Ru + r'u whenever u is given) (+ u'Hx) (+ w·min(1±dq))
 template <int n, int m>
-__device__ __forceinline__ double cost_eval(const to_cost_desc& C, const double* x, const double* u) {
+__device__ __forceinline__ double cost_eval(CostC& C, const double* x, const double* u) {
   double J;
   if (C.kind == TO_COST_QUADRATIC) {
     double xQx = 0.0;
@@ -98,17 +127,55 @@ __device__ __forceinline__ double cost_eval(const to_cost_desc& C, const double*
     }
   }
   if (C.kind == TO_COST_DIAGONAL_QUAT) {
-    double dq = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dq += C.q_ref[i] * pick<n>(x, C.q_ind[i] - 1);
+    const double qr[4] = {C.q_ref[0], C.q_ref[1], C.q_ref[2], C.q_ref[3]};
+    const int qi[4] = {C.q_ind[0], C.q_ind[1], C.q_ind[2], C.q_ind[3]};
+    const double dq = quat_dot<n>(qr, qi, x);
     J += C.w * fmin(1 + dq, 1 - dq);
   }
   return J;
 }
 
+// Stage cost of a diagonal kind preloaded into registers once per kernel (hot rollout loops): identical arithmetic to
+// cost_eval's diagonal branch, without the per-knot descriptor fetches.
+template <int n, int m>
+struct StageCostDiag {
+  double Q[n], R[m], q[n], r[m], c, w, qref[4];
+  int qind[4], kind;
+  __device__ __forceinline__ void load(CostC& C) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) { Q[i] = in_vgpr(C.Q[i]); q[i] = in_vgpr(C.q[i]); }
+#pragma unroll
+    for (int i = 0; i < m; ++i) { R[i] = in_vgpr(C.R[i]); r[i] = in_vgpr(C.r[i]); }
+    c = in_vgpr(C.c); w = in_vgpr(C.w); kind = C.kind;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qref[i] = in_vgpr(C.q_ref[i]); qind[i] = C.q_ind[i]; }
+  }
+  __device__ __forceinline__ double eval(const double* x, const double* u) const {
+    double xQx = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) xQx += x[i] * Q[i] * x[i];
+    double J = 0.5 * xQx;
+    double qx = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) qx += q[i] * x[i];
+    J = J + qx + c;
+    double uRu = 0.0, ru = 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) uRu += u[i] * R[i] * u[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) ru += r[i] * u[i];
+    J += 0.5 * uRu + ru;
+    if (kind == TO_COST_DIAGONAL_QUAT) {
+      const double dq = quat_dot<n>(qref, qind, x);
+      J += w * fmin(1 + dq, 1 - dq);
+    }
+    return J;
+  }
+};
+
 // gradient g (n+m) and Hessian-vector product y = H v (n+m) of the cost at (x,u); u-parts zero if terminal
 template <int n, int m>
-__device__ __forceinline__ void cost_grad_hvp(const to_cost_desc& C, const double* x, const double* u, bool terminal,
+__device__ __forceinline__ void cost_grad_hvp(CostC& C, const double* x, const double* u, bool terminal,
                                               const double* v, double* g, double* y) {
   if (C.kind == TO_COST_QUADRATIC) {
 #pragma unroll
@@ -123,11 +190,20 @@ __device__ __forceinline__ void cost_grad_hvp(const to_cost_desc& C, const doubl
     for (int i = 0; i < n; ++i) { g[i] = C.Q[i] * x[i] + C.q[i]; y[i] = C.Q[i] * v[i]; }
   }
   if (C.kind == TO_COST_DIAGONAL_QUAT) {  // the intended gradient src/lie_costs.jl:82-90
-    double dq = 0.0;
+    const double qr[4] = {C.q_ref[0], C.q_ref[1], C.q_ref[2], C.q_ref[3]};
+    const int qi[4] = {C.q_ind[0], C.q_ind[1], C.q_ind[2], C.q_ind[3]};
+    const double dq = quat_dot<n>(qr, qi, x);
+    bool fast = false;
+    if constexpr (n >= 7) fast = (qi[0] == 4 && qi[1] == 5 && qi[2] == 6 && qi[3] == 7);
+    if (fast) {
+      if constexpr (n >= 7) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dq += C.q_ref[i] * pick<n>(x, C.q_ind[i] - 1);
+        for (int i = 0; i < 4; ++i) g[3 + i] += dq < 0 ? C.w * qr[i] : -(C.w * qr[i]);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) add_at<n>(g, C.q_ind[i] - 1, dq < 0 ? C.w * C.q_ref[i] : -(C.w * C.q_ref[i]));
+      for (int i = 0; i < 4; ++i) add_at<n>(g, qi[i] - 1, dq < 0 ? C.w * qr[i] : -(C.w * qr[i]));
+    }
   }
 #pragma unroll
   for (int i = 0; i < m; ++i) { g[n + i] = 0.0; y[n + i] = 0.0; }
@@ -158,8 +234,8 @@ __device__ __forceinline__ void cost_grad_hvp(const to_cost_desc& C, const doubl
 // ------------------------------------------------------------------------------------------------ constraints
 // One row of a non-selector constraint: value c and the gradient coefficients on z[inds[t]], t < n_inds.
 template <int nz>
-__device__ __forceinline__ double con_row(const DevCon& K, const double* z, int r, double* coef /* [nz] */) {
-  const to_constraint_desc& d = K.d;
+__device__ __forceinline__ double con_row(ConC& K, const double* z, int r, double* coef /* [nz] */) {
+  const to_constraint_desc TO_CONST_AS& d = K.d;
   double c = 0.0;
   switch (d.kind) {
     case TO_CON_NORM: {  // quadratic form: |z[inds]|² − val²
@@ -201,7 +277,7 @@ __device__ __forceinline__ double con_row(const DevCon& K, const double* z, int 
 
 // value of row r of a selector constraint
 template <int nz>
-__device__ __forceinline__ double sel_row(const DevCon& K, const double* z, int r) {
+__device__ __forceinline__ double sel_row(ConC& K, const double* z, int r) {
   const int j = K.sidx[r];
   return j < 0 ? K.soff[r] : K.ssgn[r] * (pick<nz>(z, j) - K.soff[r]);
 }
@@ -212,7 +288,7 @@ struct SocState { double a, s, coef; int branch; };  // Π(lb) = coef·[v; a] (b
 // AL penalty of one constraint at one knot.  lam: pointer to row 0 of this knot's duals
 // (batch-fastest: row r at lam[r*stride]).
 template <int nz>
-__device__ __forceinline__ double al_term(const DevCon& K, const double* z, const double* lam, size_t stride, double mu) {
+__device__ __forceinline__ double al_term(ConC& K, const double* z, const double* lam, size_t stride, double mu) {
   const int p = K.p;
   double J = 0.0;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
@@ -251,7 +327,7 @@ __device__ __forceinline__ double al_term(const DevCon& K, const double* z, cons
 // For the SOC the reference composes ∇Π'∇Π + ∇²Π[Π] (src/cones.jl); since ∇(½|Π(x)|²) = Π(x) this equals ∇Π(x), and
 // ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
 template <int nz>
-__device__ __forceinline__ void al_grad_hvp(const DevCon& K, const double* z, const double* lam, size_t stride, double mu,
+__device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const double* lam, size_t stride, double mu,
                                             const double* v, double* g, double* y) {
   const int p = K.p;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
@@ -301,7 +377,7 @@ __device__ __forceinline__ void al_grad_hvp(const DevCon& K, const double* z, co
 
 // max violation of one constraint at one knot
 template <int nz>
-__device__ __forceinline__ double con_violation(const DevCon& K, const double* z) {
+__device__ __forceinline__ double con_violation(ConC& K, const double* z) {
   const int p = K.p;
   double vmax = 0.0;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
@@ -332,7 +408,7 @@ __device__ __forceinline__ double con_violation(const DevCon& K, const double* z
 
 // dual update of one constraint at one knot (lam in place)
 template <int nz>
-__device__ __forceinline__ void con_dual_update(const DevCon& K, const double* z, double* lam, size_t stride, double mu, double dual_max) {
+__device__ __forceinline__ void con_dual_update(ConC& K, const double* z, double* lam, size_t stride, double mu, double dual_max) {
   const int p = K.p;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
     double a2 = 0.0, s = 0.0;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,7 @@ struct to_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
   int model_key = -1;
+  int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
   KArgs a;  // host copy of the kernel argument block (device pointers inside)
   std::vector<to_cost_desc> costs;
   std::vector<DevCon> cons;
@@ -200,25 +202,44 @@ int use_device(to_handle* h) { HIPCHECK(hipSetDevice(h->device)); return TO_OK; 
 
 dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 
-// host (dim, K, B) -> device [k][i][Bp] through the staging buffer
-int upload_vec(to_handle* h, const double* host, double* d0, double* d1, int dim, int K, bool use_cur) {
-  const size_t cnt = (size_t)dim * K * h->a.P.B;
-  TRY(ensure_stage(h, cnt * sizeof(double)));
-  HIPCHECK(hipMemcpyAsync(h->stage, host, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (use_cur) hipLaunchKernelGGL(k_to_device_cur, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, h->stage, d0, d1, h->a.cur, dim, K, h->a.P.B, h->a.P.Bp);
-  else hipLaunchKernelGGL(k_to_device, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, h->stage, d0, dim, K, h->a.P.B, h->a.P.Bp);
+// host (cnt per trajectory, column-major (dim, K, B)) -> tiled device array (elements e0..e0+cnt-1 of L) via the staging buffer
+int upload_vec(to_handle* h, const double* host, double* d, int cnt, int L = -1, int e0 = 0) {
+  if (L < 0) L = cnt;
+  const size_t total = (size_t)cnt * h->a.P.B;
+  TRY(ensure_stage(h, total * sizeof(double)));
+  HIPCHECK(hipMemcpyAsync(h->stage, host, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_to_device, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, h->stage, d, L, e0, cnt, h->a.P.B);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
-int download_vec(to_handle* h, double* host, const double* d0, const double* d1, int dim, int K, bool use_cur, void* dev_dst = nullptr) {
-  const size_t cnt = (size_t)dim * K * h->a.P.B;
-  double* dst = (double*)dev_dst;
-  if (!dst) { TRY(ensure_stage(h, cnt * sizeof(double))); dst = h->stage; }
-  if (use_cur) hipLaunchKernelGGL(k_to_host_cur, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, d0, d1, h->a.cur, dst, dim, K, h->a.P.B, h->a.P.Bp);
-  else hipLaunchKernelGGL(k_to_host, grid_b(h, dim * K), dim3(BLOCK), 0, h->stream, d0, dst, dim, K, h->a.P.B, h->a.P.Bp);
+int download_vec(to_handle* h, double* host, const double* d, int cnt, int L = -1, int e0 = 0) {
+  if (L < 0) L = cnt;
+  const size_t total = (size_t)cnt * h->a.P.B;
+  TRY(ensure_stage(h, total * sizeof(double)));
+  hipLaunchKernelGGL(k_to_host, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, d, h->stage, L, e0, cnt, h->a.P.B);
   HIPCHECK(hipGetLastError());
-  if (host) HIPCHECK(hipMemcpyAsync(host, dst, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(host, h->stage, total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+// the nominal trajectory (slot cur[b] of a slotted X/U array) <-> host layout
+int upload_nominal(to_handle* h, const double* host, double* slots, size_t slot, int cnt) {
+  const size_t total = (size_t)cnt * h->a.P.B;
+  TRY(ensure_stage(h, total * sizeof(double)));
+  HIPCHECK(hipMemcpyAsync(h->stage, host, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_to_device_cur, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, h->stage, slots, slot, h->a.cur, cnt, h->a.P.B);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+int download_nominal(to_handle* h, double* host, const double* slots, size_t slot, int cnt, void* dev_dst = nullptr) {
+  const size_t total = (size_t)cnt * h->a.P.B;
+  double* dst = (double*)dev_dst;
+  if (!dst) { TRY(ensure_stage(h, total * sizeof(double))); dst = h->stage; }
+  hipLaunchKernelGGL(k_to_host_cur, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, slots, slot, h->a.cur, dst, cnt, h->a.P.B);
+  HIPCHECK(hipGetLastError());
+  if (host) HIPCHECK(hipMemcpyAsync(host, dst, total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
@@ -226,7 +247,7 @@ int download_mat(to_handle* h, double* host, const double* d, int R, int Cc, int
   if (!host) return TO_OK;
   const size_t cnt = (size_t)R * Cc * K * h->a.P.B;
   TRY(ensure_stage(h, cnt * sizeof(double)));
-  hipLaunchKernelGGL(k_mat_to_host, grid_b(h, R * Cc * K), dim3(BLOCK), 0, h->stream, d, h->stage, R, Cc, K, h->a.P.B, h->a.P.Bp);
+  hipLaunchKernelGGL(k_mat_to_host, grid_b(h, R * Cc * K), dim3(BLOCK), 0, h->stream, d, h->stage, R, Cc, K, h->a.P.B);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -252,8 +273,8 @@ int upload_tables(to_handle* h) {
   return TO_OK;
 }
 
-int launch_set_active(to_handle* h, int v) {
-  hipLaunchKernelGGL(k_set_active, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, v);
+int launch_set_active(to_handle* h, int v, int clear_bpfail = 1) {
+  hipLaunchKernelGGL(k_set_active, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, v, clear_bpfail);
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
@@ -269,18 +290,33 @@ int launch_cost(to_handle* h, int with_al, double* out, double* Jk) {
 }
 int launch_expand(to_handle* h) {
   const DevProblem& P = h->a.P;
-  DISPATCH(h, hipLaunchKernelGGL(k_expand<M>, grid_b(h, P.N, P.ne + P.m), dim3(BLOCK), 0, h->stream, h->a));
+  DISPATCH(h, hipLaunchKernelGGL(k_expand<M>, dim3((P.B + h->G - 1) / h->G, P.N), dim3(BLOCK), 0, h->stream, h->a));
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
 int launch_backward(to_handle* h) {
-  DISPATCH(h, hipLaunchKernelGGL(k_backward<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  DISPATCH(h, hipLaunchKernelGGL(k_backward<M>, dim3((h->a.P.B + h->G - 1) / h->G), dim3(BLOCK), 0, h->stream, h->a));
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
+// forward pass = line-search rounds of (T concurrent candidates, select).  Rounds after the first only do work for
+// trajectories whose first T step sizes were all rejected.
 int launch_forward(to_handle* h) {
-  DISPATCH(h, hipLaunchKernelGGL(k_forward<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
-  HIPCHECK(hipGetLastError());
+  KArgs& a = h->a;
+  const int rounds = (a.P.opts.iterations_linesearch + a.T - 1) / a.T;
+  for (int r = 0; r < std::max(1, rounds); ++r) {
+    a.round = r;
+    const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0);
+    switch (mode) {
+      case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
+      default: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
+    }
+    HIPCHECK(hipGetLastError());
+    DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
+    HIPCHECK(hipGetLastError());
+  }
   return TO_OK;
 }
 int launch_violation(to_handle* h, double* out) {
@@ -318,19 +354,31 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   if (h->profile) {
     while ((int)h->ev.size() < 4 * max_steps) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); h->ev.push_back(e); }
   }
-  for (int step = 0; step < max_steps; ++step) {
-    a.step = step;
-    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 0], h->stream));
-    TRY(launch_expand(h));
-    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
-    TRY(launch_backward(h));
-    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
-    TRY(launch_forward(h));
-    if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
-    ++steps;
-    HIPCHECK(hipMemcpyAsync(&h->counter_host[step], &a.counter[step], sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  // The host only needs to know WHEN every trajectory has finished: it enqueues CHECK_EVERY batch steps back to back
+  // and reads the per-step "still active" counters once per chunk (kernels of finished trajectories exit at once).
+  constexpr int CHECK_EVERY = 4;
+  int launched = 0;
+  bool done = false;
+  while (launched < max_steps && !done) {
+    const int chunk = std::min(CHECK_EVERY, max_steps - launched);
+    for (int c = 0; c < chunk; ++c) {
+      const int step = launched + c;
+      a.step = step;
+      if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 0], h->stream));
+      TRY(launch_expand(h));
+      if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
+      TRY(launch_backward(h));
+      if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
+      TRY(launch_forward(h));
+      if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
+    }
+    HIPCHECK(hipMemcpyAsync(&h->counter_host[launched], &a.counter[launched], sizeof(int) * chunk, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
-    if (h->counter_host[step] == 0) break;
+    for (int c = 0; c < chunk; ++c) {
+      ++steps;
+      if (h->counter_host[launched + c] == 0) { done = true; break; }
+    }
+    launched += chunk;
   }
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
@@ -444,6 +492,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   to_handle* h = new to_handle();
   h->device = device;
   h->model_key = key;
+  h->R = (ne + m) <= 4 ? 4 : (ne + m) <= 8 ? 8 : 16;
+  h->G = 64 / h->R;
   h->costs.assign(desc->costs, desc->costs + desc->n_costs);
   h->cons = cons; h->dt = dt; h->cost_index = cost_index;
   auto bail = [&](int rc) { std::string e = g_err; to_destroy(h); g_err = e; return rc; };
@@ -458,6 +508,11 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   P.integrator = desc->integrator; P.n_costs = desc->n_costs; P.n_cons = (int)cons.size(); P.n_duals = n_duals;
   std::memcpy(P.mp, desc->model_params, sizeof(P.mp));
   if (opts) P.opts = *opts; else default_opts(&P.opts);
+  {  // simple_stage: one diagonal-kind cost on every stage knot and a uniform dt
+    bool simple = h->costs[cost_index[0]].kind != TO_COST_QUADRATIC;
+    for (int k = 1; k < N - 1; ++k) simple = simple && cost_index[k] == cost_index[0] && dt[k] == dt[0];
+    P.simple_stage = simple ? 1 : 0;
+  }
   const size_t Bp = P.Bp;
   TRYB(dev_alloc(h, &h->d_costs, h->costs.size()));
   TRYB(dev_alloc(h, &h->d_cons, cons.size()));
@@ -466,17 +521,25 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   HIPB(hipMemcpyAsync(h->d_dt, dt.data(), sizeof(double) * (N - 1), hipMemcpyHostToDevice, h->stream));
   HIPB(hipMemcpyAsync(h->d_cost_index, cost_index.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
   TRYB(upload_tables(h));
-  P.dt = h->d_dt; P.cost_index = h->d_cost_index; P.costs = h->d_costs; P.cons = h->d_cons;
-  for (int c = 0; c < 2; ++c) { TRYB(dev_alloc(h, &a.X[c], (size_t)N * n * Bp)); TRYB(dev_alloc(h, &a.U[c], (size_t)(N - 1) * m * Bp)); }
+  P.dt = (DoubleC*)h->d_dt; P.cost_index = (IntC*)h->d_cost_index; P.costs = (CostC*)h->d_costs; P.cons = (ConC*)h->d_cons;
+  // line-search candidates evaluated concurrently: enough waves to cover the chip, at most the default search depth
+  // (one candidate = one wave; the register-heavy rollout kernels are resident at one wave per SIMD, 1024 SIMDs per chip,
+  //  so T*tiles <= 1024 keeps a whole round in a single residency pass)
+  a.T = std::max(1, std::min(20, 1024 / (P.Bp / BLOCK)));
+  if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) a.T = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
+  a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
+  TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
+  TRYB(dev_alloc(h, &a.Us, a.slotU * (a.T + 1)));
+  TRYB(dev_alloc(h, &a.candJ, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.candG, (size_t)a.T * Bp));
+  TRYB(dev_alloc(h, &a.candOk, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.ls_round, Bp));
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.cur, Bp));
-  TRYB(dev_alloc(h, &a.A, (size_t)(N - 1) * ne * ne * Bp));
-  TRYB(dev_alloc(h, &a.Bm, (size_t)(N - 1) * ne * m * Bp));
-  TRYB(dev_alloc(h, &a.Qxx, (size_t)N * ne * ne * Bp));
-  TRYB(dev_alloc(h, &a.Quu, (size_t)N * m * m * Bp));
-  TRYB(dev_alloc(h, &a.Qux, (size_t)N * m * ne * Bp));
-  TRYB(dev_alloc(h, &a.qx, (size_t)N * ne * Bp));
-  TRYB(dev_alloc(h, &a.qu, (size_t)N * m * Bp));
+  {
+    const size_t gtiles = ((size_t)B + h->G - 1) / h->G;  // waves of the column-layout kernels
+    TRYB(dev_alloc(h, &a.Mc, gtiles * (size_t)(N - 1) * ne * 64));
+    TRYB(dev_alloc(h, &a.Hc, gtiles * (size_t)N * (ne + m) * 64));
+    TRYB(dev_alloc(h, &a.gc, gtiles * (size_t)N * 64));
+  }
   TRYB(dev_alloc(h, &a.K, (size_t)(N - 1) * m * ne * Bp));
   TRYB(dev_alloc(h, &a.d, (size_t)(N - 1) * m * Bp));
   TRYB(dev_alloc(h, &a.lam, (size_t)n_duals * Bp));
@@ -491,7 +554,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // reference defaults: X0 = NaN, U0 = 0 (src/problem.jl:83-84); duals 0, penalties penalty_initial
   {
     std::vector<double> nanv((size_t)N * n * Bp, std::nan(""));
-    HIPB(hipMemcpyAsync(a.X[0], nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPB(hipMemcpyAsync(a.Xs, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPB(hipStreamSynchronize(h->stream));
     if (!cons.empty()) {
       std::vector<double> mu(cons.size() * Bp, P.opts.penalty_initial);
@@ -551,45 +614,45 @@ int to_num_constraints(const to_handle* h, int32_t* p) {
 
 int to_set_initial_state(to_handle* h, const double* x0) {
   CHECK_H(h); CHECK_P(x0); TRY(use_device(h));
-  return upload_vec(h, x0, h->a.x0, nullptr, h->a.P.n, 1, false);
+  return upload_vec(h, x0, h->a.x0, h->a.P.n);
 }
 int to_get_initial_state(to_handle* h, double* x0) {
   CHECK_H(h); CHECK_P(x0); TRY(use_device(h));
-  return download_vec(h, x0, h->a.x0, nullptr, h->a.P.n, 1, false);
+  return download_vec(h, x0, h->a.x0, h->a.P.n);
 }
 int to_set_controls(to_handle* h, const double* U) {
   CHECK_H(h); CHECK_P(U); TRY(use_device(h));
-  return upload_vec(h, U, h->a.U[0], h->a.U[1], h->a.P.m, h->a.P.N - 1, true);
+  return upload_nominal(h, U, h->a.Us, h->a.slotU, h->a.P.m * (h->a.P.N - 1));
 }
 int to_set_states(to_handle* h, const double* X) {
   CHECK_H(h); CHECK_P(X); TRY(use_device(h));
-  return upload_vec(h, X, h->a.X[0], h->a.X[1], h->a.P.n, h->a.P.N, true);
+  return upload_nominal(h, X, h->a.Xs, h->a.slotX, h->a.P.n * h->a.P.N);
 }
 int to_set_controls_uniform(to_handle* h, const double* u) {
   CHECK_H(h); CHECK_P(u); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   TRY(ensure_stage(h, sizeof(double) * P.m));
   HIPCHECK(hipMemcpyAsync(h->stage, u, sizeof(double) * P.m, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_fill_uniform, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.U[0], h->a.U[1], h->a.cur, h->stage, P.m, P.N - 1, P.B, P.Bp);
+  hipLaunchKernelGGL(k_fill_uniform, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.Us, h->a.slotU, h->a.cur, h->stage, P.m, P.m * (P.N - 1), P.B);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
 int to_get_states(to_handle* h, double* X) {
   CHECK_H(h); CHECK_P(X); TRY(use_device(h));
-  return download_vec(h, X, h->a.X[0], h->a.X[1], h->a.P.n, h->a.P.N, true);
+  return download_nominal(h, X, h->a.Xs, h->a.slotX, h->a.P.n * h->a.P.N);
 }
 int to_get_controls(to_handle* h, double* U) {
   CHECK_H(h); CHECK_P(U); TRY(use_device(h));
-  return download_vec(h, U, h->a.U[0], h->a.U[1], h->a.P.m, h->a.P.N - 1, true);
+  return download_nominal(h, U, h->a.Us, h->a.slotU, h->a.P.m * (h->a.P.N - 1));
 }
 int to_get_states_device(to_handle* h, void* dX) {
   CHECK_H(h); CHECK_P(dX); TRY(use_device(h));
-  return download_vec(h, nullptr, h->a.X[0], h->a.X[1], h->a.P.n, h->a.P.N, true, dX);
+  return download_nominal(h, nullptr, h->a.Xs, h->a.slotX, h->a.P.n * h->a.P.N, dX);
 }
 int to_get_controls_device(to_handle* h, void* dU) {
   CHECK_H(h); CHECK_P(dU); TRY(use_device(h));
-  return download_vec(h, nullptr, h->a.U[0], h->a.U[1], h->a.P.m, h->a.P.N - 1, true, dU);
+  return download_nominal(h, nullptr, h->a.Us, h->a.slotU, h->a.P.m * (h->a.P.N - 1), dU);
 }
 int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
   CHECK_H(h); CHECK_P(c); TRY(use_device(h));
@@ -624,12 +687,12 @@ int to_al_cost(to_handle* h, double* J) {
 int to_stage_costs(to_handle* h, double* Jk) {
   CHECK_H(h); CHECK_P(Jk); TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  // per-knot values land in device layout [N][Bp] in the upper half of the staging buffer, then transpose to host (N,B)
+  // per-knot values land in a tiled array (L = N) in the upper half of the staging buffer, then transpose to host (N,B)
   const size_t cnt = (size_t)P.N * P.Bp;
   TRY(ensure_stage(h, 2 * cnt * sizeof(double)));
   double* dJk = h->stage + cnt;
   TRY(launch_cost(h, 0, nullptr, dJk));
-  hipLaunchKernelGGL(k_to_host, grid_b(h, P.N), dim3(BLOCK), 0, h->stream, dJk, h->stage, 1, P.N, P.B, P.Bp);
+  hipLaunchKernelGGL(k_to_host, grid_b(h, P.N), dim3(BLOCK), 0, h->stream, dJk, h->stage, P.N, 0, P.N, P.B);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(Jk, h->stage, sizeof(double) * P.N * P.B, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -652,12 +715,7 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
   h->a.control = 0;
   // keep bpfail from a preceding to_backward: set active without clearing it
   TRY(launch_cost(h, 1, h->a.J, nullptr));
-  {
-    std::vector<int> ones(h->a.P.Bp, 0);
-    for (int b = 0; b < h->a.P.B; ++b) ones[b] = 1;
-    HIPCHECK(hipMemcpyAsync(h->a.active, ones.data(), sizeof(int) * h->a.P.Bp, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-  }
+  TRY(launch_set_active(h, 1, 2));
   TRY(launch_forward(h));
   TRY(download_int(h, ls_index, h->a.ls_index));
   TRY(download_scalar(h, J_new, h->a.Jout));
@@ -667,29 +725,48 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
 int to_ilqr_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 0); }
 int to_al_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 1); }
 
+// column-layout array -> host column-major blocks (see k_col_to_host)
+static int download_cols(to_handle* h, double* host, const double* src, int E, int rows_per_knot, int r0, int Rr, int c0, int Cc, int K) {
+  if (!host) return TO_OK;
+  const DevProblem& P = h->a.P;
+  const size_t cnt = (size_t)Rr * Cc * K * P.B;
+  TRY(ensure_stage(h, cnt * sizeof(double)));
+  hipLaunchKernelGGL(k_col_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, src, h->stage, E, rows_per_knot, r0, Rr, c0, Cc, K, P.B, h->R, h->G);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
 int to_get_dynamics_jacobians(to_handle* h, double* A, double* Bm) {
   CHECK_H(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  TRY(download_mat(h, A, h->a.A, P.ne, P.ne, P.N - 1));
-  TRY(download_mat(h, Bm, h->a.Bm, P.ne, P.m, P.N - 1));
+  const int E = (P.N - 1) * P.ne;
+  TRY(download_cols(h, A, h->a.Mc, E, P.ne, 0, P.ne, 0, P.ne, P.N - 1));
+  TRY(download_cols(h, Bm, h->a.Mc, E, P.ne, 0, P.ne, P.ne, P.m, P.N - 1));
   return TO_OK;
 }
 int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, double* qx, double* qu) {
   CHECK_H(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  TRY(download_mat(h, Qxx, h->a.Qxx, P.ne, P.ne, P.N));
-  TRY(download_mat(h, Quu, h->a.Quu, P.m, P.m, P.N));
-  TRY(download_mat(h, Qux, h->a.Qux, P.m, P.ne, P.N));
-  if (qx) TRY(download_vec(h, qx, h->a.qx, nullptr, P.ne, P.N, false));
-  if (qu) TRY(download_vec(h, qu, h->a.qu, nullptr, P.m, P.N, false));
+  const int nc = P.ne + P.m, E = P.N * nc;
+  TRY(download_cols(h, Qxx, h->a.Hc, E, nc, 0, P.ne, 0, P.ne, P.N));
+  TRY(download_cols(h, Quu, h->a.Hc, E, nc, P.ne, P.m, P.ne, P.m, P.N));
+  TRY(download_cols(h, Qux, h->a.Hc, E, nc, P.ne, P.m, 0, P.ne, P.N));
+  TRY(download_cols(h, qx, h->a.gc, P.N, 1, 0, 1, 0, P.ne, P.N));
+  TRY(download_cols(h, qu, h->a.gc, P.N, 1, 0, 1, P.ne, P.m, P.N));
   return TO_OK;
 }
 int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
   CHECK_H(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   TRY(download_mat(h, K, h->a.K, P.m, P.ne, P.N - 1));
-  if (d) TRY(download_vec(h, d, h->a.d, nullptr, P.m, P.N - 1, false));
-  if (dV) TRY(download_vec(h, dV, h->a.dV, nullptr, 2, 1, false));
+  if (d) TRY(download_vec(h, d, h->a.d, P.m * (P.N - 1)));
+  if (dV) {  // plain [2][Bp] -> host (2, B)
+    std::vector<double> tmp(2 * (size_t)P.Bp);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), h->a.dV, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < P.B; ++b) { dV[2 * b] = tmp[b]; dV[2 * b + 1] = tmp[(size_t)P.Bp + b]; }
+  }
   TRY(download_scalar(h, rho, h->a.rho));
   return TO_OK;
 }
@@ -754,8 +831,8 @@ int to_get_duals(to_handle* h, int32_t id, double* lambda, double* mu) {
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   const DevCon& ci = h->cons[id];
   const DevProblem& P = h->a.P;
-  if (lambda) TRY(download_vec(h, lambda, h->a.lam + (size_t)ci.dual_off * P.Bp, nullptr, ci.p, ci.k2 - ci.k1 + 1, false));
-  if (mu) TRY(download_scalar(h, mu, h->a.mu + (size_t)id * P.Bp));
+  if (lambda) TRY(download_vec(h, lambda, h->a.lam, ci.p * (ci.k2 - ci.k1 + 1), (int)P.n_duals, (int)ci.dual_off));
+  if (mu) TRY(download_vec(h, mu, h->a.mu, 1, P.n_cons, id));
   return TO_OK;
 }
 int to_set_duals(to_handle* h, int32_t id, const double* lambda, const double* mu) {
@@ -763,8 +840,8 @@ int to_set_duals(to_handle* h, int32_t id, const double* lambda, const double* m
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   const DevCon& ci = h->cons[id];
   const DevProblem& P = h->a.P;
-  if (lambda) TRY(upload_vec(h, lambda, h->a.lam + (size_t)ci.dual_off * P.Bp, nullptr, ci.p, ci.k2 - ci.k1 + 1, false));
-  if (mu) { HIPCHECK(hipMemcpyAsync(h->a.mu + (size_t)id * P.Bp, mu, sizeof(double) * P.B, hipMemcpyHostToDevice, h->stream)); HIPCHECK(hipStreamSynchronize(h->stream)); }
+  if (lambda) TRY(upload_vec(h, lambda, h->a.lam, ci.p * (ci.k2 - ci.k1 + 1), (int)P.n_duals, (int)ci.dual_off));
+  if (mu) TRY(upload_vec(h, mu, h->a.mu, 1, P.n_cons, id));
   return TO_OK;
 }
 int to_reset_duals(to_handle* h) {
