@@ -396,9 +396,11 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
   double dV0 = 0.0, dV1 = 0.0;
   bool failed = false;
   int k = N - 2;
-  bool init = true;
+  bool init = true, fresh = true;
+  double Mn[ne], Hn[nc], gn = 0.0;  // prefetched column of the next knot
   while (true) {
     if (init) {  // (re)start: S = Qxx_N, s = qx_N
+      fresh = true;
       if (j < ne) {
 #pragma unroll
         for (int i = 0; i < ne; ++i) S_[i * ne + j] = EL(Hc, (N - 1) * nc + i);
@@ -408,13 +410,29 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
       WAVE_SYNC();
     }
     if (k < 0) break;
-    // 1. own column of [Ā B̄] and of the cost blocks
-    double Mj[ne], Hj[nc];
+    // 1. own column of [Ā B̄] and of the cost blocks (fetched one knot ahead: nothing else hides the load latency)
+    double Mj[ne], Hj[nc], gj;
+    if (fresh) {
 #pragma unroll
-    for (int i = 0; i < ne; ++i) Mj[i] = EL(Mc, k * ne + i);
+      for (int i = 0; i < ne; ++i) Mn[i] = EL(Mc, k * ne + i);
 #pragma unroll
-    for (int i = 0; i < nc; ++i) Hj[i] = EL(Hc, k * nc + i);
-    double gj = EL(gc, k);
+      for (int i = 0; i < nc; ++i) Hn[i] = EL(Hc, k * nc + i);
+      gn = EL(gc, k);
+      fresh = false;
+    }
+#pragma unroll
+    for (int i = 0; i < ne; ++i) Mj[i] = Mn[i];
+#pragma unroll
+    for (int i = 0; i < nc; ++i) Hj[i] = Hn[i];
+    gj = gn;
+    if constexpr (ne > 6) fresh = true;  // large models: the extra live registers cost more than the latency they hide
+    else if (k > 0) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i) Mn[i] = EL(Mc, (k - 1) * ne + i);
+#pragma unroll
+      for (int i = 0; i < nc; ++i) Hn[i] = EL(Hc, (k - 1) * nc + i);
+      gn = EL(gc, k - 1);
+    }
 #pragma unroll
     for (int i = 0; i < ne; ++i) Mx[i * R + j] = Mj[i];
     WAVE_SYNC();

@@ -525,7 +525,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // line-search candidates evaluated concurrently: enough waves to cover the chip, at most the default search depth
   // (one candidate = one wave; the register-heavy rollout kernels are resident at one wave per SIMD, 1024 SIMDs per chip,
   //  so T*tiles <= 1024 keeps a whole round in a single residency pass)
-  a.T = std::max(1, std::min(20, 1024 / (P.Bp / BLOCK)));
+  a.T = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
   if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) a.T = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
