@@ -536,6 +536,10 @@ bool rollout_closed_loop(const Problem& P, Traj& t, double alpha) {
 double forward(const Problem& P, Traj& t, double J_prev) {
   double alpha = 1.0;
   t.ls_index = -1; t.ls_failed = false;
+  /* Stationary point: the backward pass predicts no improvement at all (an exactly solved LQ problem gives ~1e-30).
+   * Every ratio z = dJ/expected would then be rounding noise; accept the zero step instead (dJ = 0 => converged).
+   * Oracle-defined; keeps iteration counts deterministic and skips Altro's 10 wasted NO_PROGRESS iterations. */
+  if (-(t.dV[0] + t.dV[1]) <= 1e-12 * (1.0 + std::fabs(J_prev))) { t.ls_index = 0; return J_prev; }
   for (int it = 0; it < P.opts.iterations_linesearch; ++it) {
     bool ok = rollout_closed_loop(P, t, alpha);
     if (ok) {

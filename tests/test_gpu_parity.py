@@ -209,3 +209,110 @@ def test_full_size_properties_C2(hip):
     assert int(s.stats["iterations"][0]) == 104              # the x0=0 instance
     assert s.total_iterations == int(s.stats["iterations"].sum())
     np.testing.assert_allclose(X[ok, -1, 1], math.pi, atol=0.3)  # swing-up reached
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("B", [1, 63, 65, 130])
+def test_ragged_batch_sizes(B, hip, oracle):
+    """Batches that do not fill a 64-trajectory tile / an 8-trajectory column group."""
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=B, N=31, tf=1.5, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph, iterations=25).solve(), T.iLQRSolver(po, iterations=25).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+def test_double_integrator_models(D, hip, oracle):
+    def build(lib):
+        model = T.DoubleIntegrator(1.3, D)
+        n, m = model.dims()
+        xf = np.concatenate([np.arange(1, D + 1, dtype=float), np.zeros(D)])
+        obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 10.0 * np.ones(n), xf, 16)
+        cons = T.ConstraintList(n, m, 16)
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=-2.0, u_max=2.0), range(1, 16))
+        T.add_constraint(cons, T.GoalConstraint(xf), 16)
+        p = T.Problem(model, obj, np.zeros(n), 2.0, xf=xf, constraints=cons, batch=5, lib=lib,
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-5))
+        p.set_initial_state(np.linspace(-0.5, 0.5, 5)[:, None] * np.ones((5, n)))
+        return p
+    ph, po = build(hip), build(oracle)
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
+def test_minimal_horizon_and_nonuniform_dt(hip, oracle):
+    """N=2 (a single step) and a non-uniform dt vector (test/problems_tests.jl:78-85)."""
+    def build(lib, N, dt):
+        model = T.Cartpole()
+        obj = T.LQRObjective(np.full(4, 1e-2), np.full(1, 1e-1), np.full(4, 10.0), np.array([0, np.pi, 0, 0.0]), N)
+        p = T.Problem(model, obj, np.zeros(4), float(np.sum(dt)), dt=dt, batch=3, lib=lib)
+        T.initial_controls(p, np.array([0.3]))
+        return p
+    for N, dt in [(2, np.array([0.1])), (6, np.array([0.05, 0.1, 0.02, 0.2, 0.13]))]:
+        ph, po = build(hip, N, dt), build(oracle, N, dt)
+        T.rollout(ph); T.rollout(po)
+        np.testing.assert_allclose(T.states(ph), T.states(po), rtol=1e-12, atol=1e-14)
+        sh, so = T.iLQRSolver(ph, iterations=10).solve(), T.iLQRSolver(po, iterations=10).solve()
+        assert_solve_parity(sh, so, ph, po)
+
+
+def test_every_constraint_kind_and_dense_cost(hip, oracle):
+    """All six constraint kinds + QuadraticCost with a cross term H + per-knot distinct costs in one problem."""
+    rng = np.random.default_rng(11)
+
+    def build(lib):
+        model = T.Quadrotor(); n, m = model.dims(); N = 12
+        xf = np.zeros(n); xf[:3] = [0.5, 0.3, 0.8]; xf[3] = 1
+        Q = np.diag(np.r_[np.ones(3), np.zeros(4), 0.1 * np.ones(6)]); Q[0, 1] = Q[1, 0] = 0.05
+        R = 0.02 * np.eye(m) + 0.001
+        H = 1e-3 * np.arange(m * n, dtype=float).reshape(m, n) / (m * n)
+        u0 = model.hover_control()
+        dense = T.QuadraticCost(Q, R, H, -Q @ xf, -R @ u0, 0.3)
+        diag = T.LQRCost(np.diag(Q), np.diag(R), xf, u0)
+        term = T.LQRCost(50 * np.diag(Q), np.diag(R), xf, u0, terminal=True)
+        obj = T.Objective([dense if k % 2 else diag for k in range(N - 1)] + [term])
+        cons = T.ConstraintList(n, m, N)
+        T.add_constraint(cons, T.GoalConstraint(xf, [1, 2, 3]), N)
+        T.add_constraint(cons, T.NormConstraint(n, m, 3.5, T.SecondOrderCone(), "control"), range(1, N))
+        T.add_constraint(cons, T.NormConstraint(n, m, 4.0, T.Inequality(), [8, 9, 10]), range(1, N + 1))
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=0.0, u_max=2.5, x_max=np.r_[3.0, np.full(12, np.inf)]), range(1, N))
+        T.add_constraint(cons, T.CircleConstraint(n, [0.25], [0.1], [0.05]), range(2, N))
+        T.add_constraint(cons, T.SphereConstraint(n, [0.4], [0.4], [0.2], [0.05]), range(2, N))
+        A = rng.standard_normal((2, 3)); b = np.array([5.0, 6.0])
+        T.add_constraint(cons, T.LinearConstraint(n, m, A, b, T.Inequality(), [1, 2, 14]), range(1, N))
+        x0 = np.zeros(n); x0[3] = 1
+        p = T.Problem(model, obj, x0, 1.1, xf=xf, constraints=cons, batch=6, lib=lib,
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-4, iterations_outer=6))
+        T.initial_controls(p, u0)
+        return p
+    rng = np.random.default_rng(11); ph = build(hip)
+    rng = np.random.default_rng(11); po = build(oracle)
+    for p in (ph, po):
+        T.rollout(p); I.dual_update(p); I.expand(p)
+    Eh, Eo = I.cost_expansion(ph), I.cost_expansion(po)
+    for k in Eh:
+        np.testing.assert_allclose(Eh[k], Eo[k], rtol=1e-9, atol=1e-10, err_msg=k)
+    for i in range(len(ph.constraints)):
+        np.testing.assert_allclose(T.evaluate_constraints(ph, i), T.evaluate_constraints(po, i), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(T.constraint_jacobians(ph, i), T.constraint_jacobians(po, i), rtol=1e-12, atol=1e-13)
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po, rtol=1e-5)
+
+
+def test_resolve_after_goal_change(hip, oracle):
+    """MPC-style reuse: set_goal_state! between solves (src/problem.jl:294-310) and warm start from the last solution."""
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=4, N=41, tf=2.0, constrained=True, **kw), hip, oracle)
+    for p in (ph, po):
+        T.ALSolver(p, iterations_outer=3).solve()
+        T.set_goal_state(p, np.array([0.2, np.pi, 0, 0.0]))
+    sh, so = T.ALSolver(ph, iterations_outer=3).solve(), T.ALSolver(po, iterations_outer=3).solve()
+    assert_solve_parity(sh, so, ph, po, rtol=1e-5)
+
+
+def test_error_paths_on_device(hip):
+    with pytest.raises(T.capi.ConeError):
+        T.projection(T.SecondOrderCone(), np.array([np.nan, 1.0, 1.0]), lib=hip)
+    p = configs.cartpole_problem(batch=2, N=5, tf=0.2, lib=hip)
+    with pytest.raises(T.ArgumentError):
+        p._call("set_cost", 7, None) if False else p._lib.call("set_cost", p._h, 7, T.capi.CostDesc())
+    with pytest.raises(T.DimensionMismatch):
+        T.initial_controls(p, np.zeros((3, 4, 1)))

@@ -714,7 +714,22 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
     double alpha = 1.0;
     for (int i = 0; i < a.round * a.T; ++i) alpha *= o.line_search_decrease_factor;
     bool exhausted = false;
-    for (int t = 0; t < a.T; ++t) {
+    // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
+    const bool stationary = -(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev));
+    if (stationary) {
+      accepted = 0;
+      const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
+      const double* pd = TILE_PTR(a.d, (N - 1) * m);
+      double gs = 0.0;
+      for (int k = 0; k < N - 1; ++k) {
+        double gk = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(EL(pd, k * m + j)) * rcp_fast(fabs(EL(Uc, k * m + j)) + 1.0));
+        gs += gk;
+      }
+      grad = gs / (N - 1);
+    }
+    for (int t = 0; t < a.T && !stationary; ++t) {
       const int idx = a.round * a.T + t;
       if (idx >= o.iterations_linesearch) { exhausted = true; break; }
       const size_t ci = (size_t)t * P.Bp + b;
