@@ -79,7 +79,7 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     solver.solve()
     dt = time.perf_counter() - t0
     return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port",
-            "sample": f"{WORKLOADS[name]['desc'].split(',')[0]}: first {sample} trajectories of the batch, 1 solve, "
+            "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve, "
                       f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
 
 
@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--workload", default="cartpole", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/scaling studies only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--throughput-probe", type=int, default=0, help="also solve a batch of this size once (reported separately, untimed region)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
     args = ap.parse_args()
 
@@ -105,13 +106,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path, RCCL on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
 
     lib = T.load_hip_library()
     if lib.device_count() < 1:
@@ -127,7 +127,7 @@ def main():
     duals = sum(prob.constraints.p)
 
     gather = None
-    if world > 1:  # RCCL all-gather of the converged trajectories, device-to-device
+    if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
         from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
         gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
 
@@ -202,9 +202,19 @@ def main():
             "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
                        "trajectory_iterations_per_step": iters_all / args.steps,
                        "batch_steps_per_solve": bsteps / args.steps,
-                       "collective": "RCCL all_gather of converged (X,U)" if world > 1 else "none"},
+                       "collective": "RCCL all_gather of converged (X,U), once per solve" if dist is not None else "none"},
             "roofline": roof,
         }
+        if args.throughput_probe > 0:  # outside the timed region: the same kernels on a batch large enough to fill the chip
+            pb = build_problem(T, configs, name, args.throughput_probe, 0, local_rank, lib)
+            ps = (T.ALSolver if W["solver"] == "al" else T.iLQRSolver)(pb)
+            ps.solve()
+            T.initial_controls(pb, u0)
+            t1 = time.perf_counter(); ps.solve(); d1 = time.perf_counter() - t1
+            out["throughput_probe"] = {"batch": args.throughput_probe, "value": ps.total_iterations / d1,
+                                       "unit": "trajectory-iterations/s", "ms": 1e3 * d1,
+                                       "whole_iteration_frac": bytes_it * ps.total_iterations / d1 / 1e9 / HBM_PEAK_GBS}
+            del ps, pb
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(T, configs, name, batch)

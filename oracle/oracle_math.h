@@ -228,8 +228,10 @@ inline void matmul(const double* A, const double* B, double* C, int r, int k, in
 inline void discrete_jacobian(const Model& M, int integrator, const double* x, const double* u, double h,
                               double* A, double* Bm) {
   const int n = M.n, m = M.m;
-  std::vector<double> fx(n * n), fu(n * m), T(n * n), Tu(n * m);
-  std::vector<double> D1x(n * n), D1u(n * m), D2x(n * n), D2u(n * m), D3x(n * n), D3u(n * m), D4x(n * n), D4u(n * m);
+  /* scratch lives in thread-local storage: the batched driver calls this ~1e7 times from many OpenMP threads */
+  static thread_local std::vector<double> fx, fu, T, Tu, D1x, D1u, D2x, D2u, D3x, D3u, D4x, D4u, Du;
+  for (auto* v : {&fx, &T, &D1x, &D2x, &D3x, &D4x}) v->resize(n * n);
+  for (auto* v : {&fu, &Tu, &D1u, &D2u, &D3u, &D4u, &Du}) v->resize(n * m);
   double k1[MAXN], k2[MAXN], k3[MAXN], xt[MAXN];
   auto eye_plus = [&](const double* D, double scale, double* out) { /* out = I + scale*D */
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = (i == j ? 1.0 : 0.0) + scale * D[i * n + j];
@@ -261,7 +263,6 @@ inline void discrete_jacobian(const Model& M, int integrator, const double* x, c
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
       T[i * n + j] = (i == j ? 1.0 : 0.0) - D1x[i * n + j] + 2.0 * D2x[i * n + j];
     matmul(fx.data(), T.data(), D3x.data(), n, n, n);
-    std::vector<double> Du(n * m);
     for (int i = 0; i < n * m; ++i) Du[i] = -D1u[i] + 2.0 * D2u[i];
     matmul(fx.data(), Du.data(), Tu.data(), n, n, m);
     for (int i = 0; i < n * n; ++i) D3x[i] *= h;

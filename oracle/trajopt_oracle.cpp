@@ -377,7 +377,8 @@ void knot_expansion_full(const Problem& P, const Traj& t, int k, double* grad, d
 
 void expand(const Problem& P, Traj& t) {
   const int n = P.n, m = P.m, ne = P.ne, nz = n + m, N = P.N;
-  std::vector<double> A(n * n), Bf(n * m), G0(n * ne), G1(n * ne), T1(n * ne), grad(nz), hess(nz * nz), T2(n * ne);
+  static thread_local std::vector<double> A, Bf, G0, G1, T1, grad, hess, T2;
+  A.resize(n * n); Bf.resize(n * m); G0.resize(n * ne); G1.resize(n * ne); T1.resize(n * ne); grad.resize(nz); hess.resize(nz * nz); T2.resize(n * ne);
   for (int k = 0; k < N - 1; ++k) {
     const double* x = &t.X[(size_t)k * n]; const double* u = &t.U[(size_t)k * m];
     discrete_jacobian(P.M, P.integrator, x, u, P.dt[k], A.data(), Bf.data());
@@ -444,8 +445,9 @@ void chol_solve(const double* L, int m, double* b) { /* solves (L L') x = b in p
 /* backward Riccati recursion.  Returns false when regularisation exceeded bp_reg_max. */
 bool backward(const Problem& P, Traj& t) {
   const int m = P.m, ne = P.ne, N = P.N;
-  std::vector<double> S(ne * ne), s(ne), SA(ne * ne), SB(ne * m), Qxx(ne * ne), Quu(m * m), Qux(m * ne), Qx(ne), Qu(m);
-  std::vector<double> L(m * m), col(m), KtQuu(ne * m), Snew(ne * ne), snew(ne);
+  static thread_local std::vector<double> S, s, SA, SB, Qxx, Quu, Qux, Qx, Qu, L, col, KtQuu, Snew, snew;
+  S.resize(ne * ne); s.resize(ne); SA.resize(ne * ne); SB.resize(ne * m); Qxx.resize(ne * ne); Quu.resize(m * m); Qux.resize(m * ne);
+  Qx.resize(ne); Qu.resize(m); L.resize(m * m); col.resize(m); KtQuu.resize(ne * m); Snew.resize(ne * ne); snew.resize(ne);
   while (true) {
     bool restart = false;
     t.dV[0] = t.dV[1] = 0.0;
