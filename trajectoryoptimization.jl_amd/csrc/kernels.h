@@ -67,7 +67,7 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-      Ja += al_term<nz>(K, z, lam, (size_t)64, EL(mu0, ci));
+      Ja += al_term<n, m>(K, z, lam, (size_t)64, EL(mu0, ci));
     }
     Jk += Ja;
   }
@@ -88,7 +88,7 @@ __device__ __forceinline__ double knot_al(const DevProblem& P, int k, const doub
     ConC& K = P.cons[ci];
     if (k < K.k1 || k > K.k2) continue;
     const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-    Ja += al_term<nz>(K, z, lam, (size_t)64, EL(mu0, ci));
+    Ja += al_term<n, m>(K, z, lam, (size_t)64, EL(mu0, ci));
   }
   return Ja;
 }
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-      al_grad_hvp<nz>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
+      al_grad_hvp<n, m>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
     }
   }
   double col[ne], qxe[ne];

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "../../include/trajopt_hip.h"
 
 namespace to {
@@ -16,6 +18,7 @@ struct DevCon {
   int p, width, k1, k2;     // k1,k2 0-based inclusive
   long long dual_off;       // row offset of this constraint's duals in the per-trajectory dual array
   int selector;             // 1: every row is s*(z[idx]-off) or a constant (GOAL, BOUND, NORM-SOC)
+  int fast;                 // selector rows r map to consecutive entries with sign +1: 1 = z[r] (state prefix), 2 = z[n+r] (controls)
   int sidx[TO_MAX_P];       // selector rows: 0-based index into z, or -1 for a constant row (value = soff)
   double ssgn[TO_MAX_P];
   double soff[TO_MAX_P];
@@ -275,6 +278,27 @@ __device__ __forceinline__ double con_row(ConC& K, const double* z, int r, doubl
   return c;
 }
 
+// ---- selector rows with compile-time register indices --------------------------------------------------------
+// The z-index of a selector row is wave-uniform but only known at run time; indexing registers with it costs an
+// nz-long select chain per access.  The two layouts every rigid-body problem uses (goal on a state prefix, norm / SOC
+// on the control block) are visited with compile-time indices instead; anything else takes the generic chain.
+template <int I> struct SIdx { static constexpr int value = I; };
+template <int N_, int I> __device__ __forceinline__ double zget(const double* a, SIdx<I>) { return a[I]; }
+template <int N_> __device__ __forceinline__ double zget(const double* a, int idx) { return pick<N_>(a, idx); }
+template <int N_, int I> __device__ __forceinline__ void zadd(double* a, SIdx<I>, double v) { a[I] += v; }
+template <int N_> __device__ __forceinline__ void zadd(double* a, int idx, double v) { add_at<N_>(a, idx, v); }
+template <int OFF, class F, int... Is>
+__device__ __forceinline__ void visit_static(int D, F&& f, std::integer_sequence<int, Is...>) {
+  ((Is < D ? (f(Is, SIdx<OFF + Is>{}), 0) : 0), ...);
+}
+// calls f(row, idx) for the first D selector rows of K; idx is an SIdx<> on the fast layouts, an int otherwise
+template <int n, int m, class F>
+__device__ __forceinline__ void visit_rows(ConC& K, int D, F&& f) {
+  if (K.fast == 1) visit_static<0>(D, f, std::make_integer_sequence<int, n>{});
+  else if (K.fast == 2) visit_static<n>(D, f, std::make_integer_sequence<int, m>{});
+  else for (int r = 0; r < D; ++r) f(r, (int)K.sidx[r]);
+}
+
 // value of row r of a selector constraint
 template <int nz>
 __device__ __forceinline__ double sel_row(ConC& K, const double* z, int r) {
@@ -287,19 +311,23 @@ struct SocState { double a, s, coef; int branch; };  // Π(lb) = coef·[v; a] (b
 
 // AL penalty of one constraint at one knot.  lam: pointer to row 0 of this knot's duals
 // (batch-fastest: row r at lam[r*stride]).
-template <int nz>
+template <int n, int m>
 __device__ __forceinline__ double al_term(ConC& K, const double* z, const double* lam, size_t stride, double mu) {
+  constexpr int nz = n + m;
   const int p = K.p;
   double J = 0.0;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
     // psi = (|Π(lb)|² − |lam|²)/(2mu);  |Π|² = 0 | |lb|² | 2·coef²·a²
-    double a2 = 0.0, l2 = 0.0, s = 0.0;
-    for (int r = 0; r < p; ++r) {
+    double a2 = 0.0, l2 = 0.0;
+    visit_rows<n, m>(K, p - 1, [&](int r, auto idx) {
       const double l = lam[r * stride];
-      const double lb = l - mu * sel_row<nz>(K, z, r);
+      const double lb = l - mu * (K.ssgn[r] * (zget<nz>(z, idx) - K.soff[r]));
       l2 += l * l;
-      if (r < p - 1) a2 += lb * lb; else s = lb;
-    }
+      a2 += lb * lb;
+    });
+    const double ls = lam[(p - 1) * stride];
+    const double s = ls - mu * K.soff[p - 1];
+    l2 += ls * ls;
     const double a = sqrt(a2);
     double pn;
     if (a <= -s) pn = 0.0;
@@ -307,11 +335,12 @@ __device__ __forceinline__ double al_term(ConC& K, const double* z, const double
     else { const double cf = 0.5 * (1 + s / a); pn = (cf * cf) * a2 + (a * cf) * (a * cf); }
     J = (pn - l2) / (2.0 * mu);
   } else if (K.selector) {
-    for (int r = 0; r < p; ++r) {
-      const double l = lam[r * stride], c = sel_row<nz>(K, z, r);
-      const bool active = (K.d.sense == TO_CONE_ZERO) || (c >= 0.0) || (l > 0.0);
+    const bool eq = (K.d.sense == TO_CONE_ZERO);
+    visit_rows<n, m>(K, p, [&](int r, auto idx) {
+      const double l = lam[r * stride], c = K.ssgn[r] * (zget<nz>(z, idx) - K.soff[r]);
+      const bool active = eq || (c >= 0.0) || (l > 0.0);
       J += l * c + (active ? 0.5 * mu * c * c : 0.0);
-    }
+    });
   } else {
     double coef[nz];
     for (int r = 0; r < p; ++r) {
@@ -326,38 +355,40 @@ __device__ __forceinline__ double al_term(ConC& K, const double* z, const double
 // adds the AL gradient (g += ∇c' y) and Gauss-Newton Hessian-vector product (y += ∇c' W ∇c v) of one constraint.
 // For the SOC the reference composes ∇Π'∇Π + ∇²Π[Π] (src/cones.jl); since ∇(½|Π(x)|²) = Π(x) this equals ∇Π(x), and
 // ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
-template <int nz>
+template <int n, int m>
 __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const double* lam, size_t stride, double mu,
                                             const double* v, double* g, double* y) {
+  constexpr int nz = n + m;
   const int p = K.p;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
-    double a2 = 0.0, s = 0.0, lw = 0.0;  // lw = lb_v · w_v with w = ∇c v
-    for (int r = 0; r < p; ++r) {
-      const double lb = lam[r * stride] - mu * sel_row<nz>(K, z, r);
-      if (r < p - 1) { a2 += lb * lb; lw += lb * (K.ssgn[r] * pick<nz>(v, K.sidx[r])); } else s = lb;
-    }
+    double a2 = 0.0, lw = 0.0;  // lw = lb_v · w_v with w = ∇c v
+    visit_rows<n, m>(K, p - 1, [&](int r, auto idx) {
+      const double lb = lam[r * stride] - mu * (K.ssgn[r] * (zget<nz>(z, idx) - K.soff[r]));
+      a2 += lb * lb;
+      lw += lb * (K.ssgn[r] * zget<nz>(v, idx));
+    });
+    const double s = lam[(p - 1) * stride] - mu * K.soff[p - 1];
     const double a = sqrt(a2);
     if (a <= -s) return;  // Π = 0, ∇Π = 0
     const bool inside = (a <= s);
     const double cf = inside ? 1.0 : 0.5 * (1 + s / a);
     const double k3 = inside ? 0.0 : 0.5 * s / (a * a * a);
-    for (int r = 0; r < p - 1; ++r) {
-      const int j = K.sidx[r];
+    visit_rows<n, m>(K, p - 1, [&](int r, auto idx) {
       const double sg = K.ssgn[r];
-      const double lb = lam[r * stride] - mu * sel_row<nz>(K, z, r);
-      add_at<nz>(g, j, -sg * (cf * lb));                       // −∇c'Π(lb)
-      const double w = sg * pick<nz>(v, j);
-      add_at<nz>(y, j, mu * sg * (cf * w - k3 * lb * lw));     // µ ∇c' ∇Π(lb) ∇c v  (the s-row of ∇c is zero)
-    }
+      const double lb = lam[r * stride] - mu * (sg * (zget<nz>(z, idx) - K.soff[r]));
+      zadd<nz>(g, idx, -sg * (cf * lb));                       // −∇c'Π(lb)
+      const double w = sg * zget<nz>(v, idx);
+      zadd<nz>(y, idx, mu * sg * (cf * w - k3 * lb * lw));     // µ ∇c' ∇Π(lb) ∇c v  (the s-row of ∇c is zero)
+    });
   } else if (K.selector) {
-    for (int r = 0; r < p; ++r) {
-      const int j = K.sidx[r];
-      const double l = lam[r * stride], c = sel_row<nz>(K, z, r);
-      const bool active = (K.d.sense == TO_CONE_ZERO) || (c >= 0.0) || (l > 0.0);
+    const bool eq = (K.d.sense == TO_CONE_ZERO);
+    visit_rows<n, m>(K, p, [&](int r, auto idx) {
       const double sg = K.ssgn[r];
-      add_at<nz>(g, j, sg * (l + (active ? mu * c : 0.0)));
-      add_at<nz>(y, j, active ? mu * pick<nz>(v, j) : 0.0);
-    }
+      const double l = lam[r * stride], c = sg * (zget<nz>(z, idx) - K.soff[r]);
+      const bool active = eq || (c >= 0.0) || (l > 0.0);
+      zadd<nz>(g, idx, sg * (l + (active ? mu * c : 0.0)));
+      zadd<nz>(y, idx, active ? mu * zget<nz>(v, idx) : 0.0);
+    });
   } else {
     double coef[nz];
     for (int r = 0; r < p; ++r) {

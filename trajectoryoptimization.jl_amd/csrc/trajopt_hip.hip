@@ -166,6 +166,13 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
     default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
   }
   if (p < 1 || p > TO_MAX_P) return fail(TO_ERR_UNSUPPORTED, "constraint output dimension outside 1..TO_MAX_P");
+  if (ci.selector && (d.kind == TO_CON_GOAL || (d.kind == TO_CON_NORM && d.sense == TO_CONE_SECOND_ORDER))) {
+    // fast layouts: rows map to a state prefix z[r] or to the control block z[n+r] with sign +1 (see problem_dev.h)
+    const int D = d.n_inds;
+    bool prefix = D <= n, ctrl = D <= m;
+    for (int r = 0; r < D; ++r) { prefix = prefix && d.inds[r] == r + 1; ctrl = ctrl && d.inds[r] == n + r + 1; }
+    ci.fast = prefix ? 1 : ctrl ? 2 : 0;
+  }
   if (d.p != 0 && d.p != p) return fail(TO_ERR_DIMENSION_MISMATCH, "constraint output dimension does not match its descriptor");
   ci.p = p; ci.k1 = d.k_first - 1; ci.k2 = d.k_last - 1;
   *out = ci;
