@@ -58,6 +58,25 @@ def initial_controls_value(T, prob, name):
     return np.full(prob.m, 0.01) if name == "cartpole" else prob.model.hover_control()
 
 
+def pmc_traffic(name, batch, phase):
+    """HBM bytes per launch of `phase` from the committed rocprofv3 PMC passes of this same command
+    (tools/run_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 note of
+    MI355X_MICROARCH.md).  PMC collection cannot run inside the timed bench, so the figure is read from profiles/;
+    returns (None, None) when no matching profile was committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_b%d_hbm_traffic_pmc.json" % (name, batch))))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        tab = json.load(f)
+    steps = sum(v["launches"] for k, v in tab.items() if "k_expand" in k)
+    total = sum(v["hbm_bytes_per_launch_fetch_x2"] * v["launches"] for k, v in tab.items()
+                if ("k_" + phase) in k or (phase == "forward" and "k_select" in k))
+    if steps == 0 or total == 0:
+        return None, None
+    return total / steps, os.path.relpath(files[-1], ROOT)
+
+
 def kernel_split_bytes(n, m, ne, N, duals):
     """Per trajectory-iteration algorithmic bytes attributed to each kernel (sums to SURVEY §8d's W)."""
     xu = 8 * (N * n + (N - 1) * m)
@@ -188,8 +207,9 @@ def main():
             # a launch processes, on average, (trajectory-iterations of this rank) / launches units
             units_per_launch = iters / kern[dom]["launches"]
             achieved = split[dom] * units_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            traffic, traffic_src = pmc_traffic(name, batch, dom)
             roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_unit": split[dom], "units_per_launch": units_per_launch,
                     "avg_launch_us": kern[dom]["avg_us"], "kernels": kern,
                     "whole_iteration": {"algorithmic_bytes_per_unit": bytes_it,

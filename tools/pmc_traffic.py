@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc counter_collection CSVs (one pass per counter) into per-kernel HBM bytes per launch.
+
+Usage: pmc_traffic.py OUT.json CSV [CSV ...]
+
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Following /opt/skills/guides/MI355X_MICROARCH.md (HBM
+section) FETCH_SIZE on gfx950 tallies 128-byte requests at 64 bytes, so the corrected figure doubles it; WRITE_SIZE is
+taken as reported.  Both raw and corrected numbers are kept.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def main(out, paths):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for p in paths:
+        with open(p, newline="") as f:
+            for row in csv.DictReader(f):
+                a = acc[short(row["Kernel_Name"])][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+    res = {}
+    for k, ctr in acc.items():
+        e = {}
+        fetch = write = 0.0
+        for c, (tot, n) in ctr.items():
+            e[c + "_KB_per_launch"] = tot / n
+            e["launches"] = n
+            if c == "FETCH_SIZE":
+                fetch = tot / n * 1024.0
+            if c == "WRITE_SIZE":
+                write = tot / n * 1024.0
+        e["hbm_bytes_per_launch_raw"] = fetch + write
+        e["hbm_bytes_per_launch_fetch_x2"] = 2.0 * fetch + write
+        res[k] = e
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2:])

@@ -18,12 +18,12 @@ namespace to {
 
 struct KArgs {
   DevProblem P;
-  double* Xs;     // (T+1) slots of L = N*n: slot cur[b] holds the nominal trajectory, the other T hold line-search candidates
+  double* Xs;     // (T+1) slots of L = N*n: slot 0 holds the nominal trajectory, slot t+1 line-search candidate t of the round
   double* Us;     // (T+1) slots of L = (N-1)*m
   size_t slotX, slotU;  // doubles per slot (L * Bp)
   int T;          // line-search candidates evaluated concurrently per round (grid.y of k_forward)
   double* x0;     // L = n
-  int* cur;       // [Bp] slot of the nominal trajectory
+  int* acc;       // [Bp] slot of the candidate accepted in the current round (0 = none): k_accept copies it to slot 0
   double *candJ, *candG;  // [T][Bp] cost and gradient metric of each candidate of the current round
   int* candOk;            // [T][Bp] 1: rollout stayed within the state/control limits
   int* ls_round;          // [Bp] next line-search round of this trajectory; -1: resolved for this iteration
@@ -114,11 +114,10 @@ __device__ __forceinline__ double knot_violation(const DevProblem& P, int k, con
 // whole-trajectory pass over the NOMINAL trajectory: cost (with or without AL), max violation, optional dual update
 template <class M>
 __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int lane, bool with_al, bool do_dual_update, double* J_out,
-                                                double* cmax_out) {
+                                                double* cmax_out, int c = 0) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   const DevProblem& P = a.P;
-  const int N = P.N, b = tile * 64 + lane;
-  const int c = a.cur[b];
+  const int N = P.N;
   const double* X = TILE_PTR(XSLOT(a, c), N * n);
   const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double* lam0 = TILE_PTR(a.lam, P.n_duals);
@@ -157,7 +156,7 @@ __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:33
   TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  const int c = a.cur[b];
+  constexpr int c = 0;  // nominal slot
   double* X = TILE_PTR(XSLOT(a, c), P.N * n);
   const double* U = TILE_PTR(USLOT(a, c), (P.N - 1) * m);
   const double* x0 = TILE_PTR(a.x0, n);
@@ -183,7 +182,7 @@ __global__ void __launch_bounds__(64) k_cost(KArgs a, int with_al, double* out, 
   if (b >= P.B) return;
   const int N = P.N;
   if (Jk) {
-    const int c = a.cur[b];
+    constexpr int c = 0;  // nominal slot
     const double* X = TILE_PTR(XSLOT(a, c), N * n);
     const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
     double* o = TILE_PTR(Jk, N);
@@ -252,13 +251,14 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   const int g = lane / R, j = lane % R;
   const int b = gtile * G + g;
   const DevProblem& P = a.P;
-  if (b >= P.B || j >= nc) return;
-  if (!a.active[b]) return;
   const int N = P.N;
   const int k = blockIdx.y;
   const bool terminal = (k == N - 1);
-  if (terminal && j >= ne) return;
-  const int c = a.cur[b];
+  // idle lanes (padding columns, finished trajectories) compute along with EXEC full — partially masked FP64 issues
+  // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
+  const bool valid = b < P.B && j < nc && a.active[b] && !(terminal && j >= ne);
+  if (__ballot(valid) == 0) return;
+  constexpr int c = 0;  // nominal slot
   const int tile = b >> 6, lane64 = b & 63;
   const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
   const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
@@ -288,8 +288,10 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
     for (int i = 0; i < n; ++i) { x1[i] = EL(X, (k + 1) * n + i); t[i] = xn[i].d; }
     errstate_tmul<M>(x1, t, col);
     double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
+    if (valid) {
 #pragma unroll
-    for (int i = 0; i < ne; ++i) EL(Mc, k * ne + i) = col[i];
+      for (int i = 0; i < ne; ++i) EL(Mc, k * ne + i) = col[i];
+    }
   }
   // ---- cost (+AL) gradient and Hessian-vector product on the full state
   double gr[nz], y[nz];
@@ -322,16 +324,17 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
 #pragma unroll
     for (int i = 3; i < 6; ++i) col[i] -= (i == j) ? b1 : 0.0;
   }
-  double* Hc = COL_PTR(a.Hc, N * nc);
-#pragma unroll
-  for (int i = 0; i < ne; ++i) EL(Hc, k * nc + i) = col[i];
-#pragma unroll
-  for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
   double gj = 0.0;
 #pragma unroll
   for (int i = 0; i < ne; ++i) gj = (i == j) ? qxe[i] : gj;
 #pragma unroll
   for (int r = 0; r < m; ++r) gj = (ne + r == j) ? gr[n + r] : gj;
+  if (!valid) return;
+  double* Hc = COL_PTR(a.Hc, N * nc);
+#pragma unroll
+  for (int i = 0; i < ne; ++i) EL(Hc, k * nc + i) = col[i];
+#pragma unroll
+  for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
   double* gc = COL_PTR(a.gc, N);
   EL(gc, k) = gj;
 }
@@ -378,8 +381,13 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
   const int b = gtile * G + g;
   const DevProblem& P = a.P;
   const int N = P.N;
-  const bool live = (b < P.B) && (j < nc) && a.active[b < P.B ? b : 0];
-  if (!live) return;  // no hardware barrier below: dropping lanes is safe
+  // gfx950 issues FP64 VALU ~1.3x slower when EXEC is not all ones (tools/fp64_issue_probe.hip): padding lanes
+  // (j >= nc) and finished trajectories run the arithmetic along with everybody else and only their stores are
+  // predicated.  glive: this group's trajectory takes part; live: this lane owns one of its columns.
+  const bool glive = (b < P.B) && a.active[b < P.B ? b : 0];
+  const bool live = glive && (j < nc);
+  if (__ballot(live) == 0) return;
+  const int jx = j < ne ? j : ne - 1;  // in-range state column for the lanes that own none
   double* S_ = lds + g * L::stride + L::oS;
   double* Mx = lds + g * L::stride + L::oM;
   double* Hu = lds + g * L::stride + L::oH;
@@ -401,10 +409,16 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
   while (true) {
     if (init) {  // (re)start: S = Qxx_N, s = qx_N
       fresh = true;
-      if (j < ne) {
+      {
+        double Sc[ne];
 #pragma unroll
-        for (int i = 0; i < ne; ++i) S_[i * ne + j] = EL(Hc, (N - 1) * nc + i);
-        sl[j] = EL(gc, N - 1);
+        for (int i = 0; i < ne; ++i) Sc[i] = EL(Hc, (N - 1) * nc + i);
+        const double s0 = EL(gc, N - 1);
+        if (j < ne) {
+#pragma unroll
+          for (int i = 0; i < ne; ++i) S_[i * ne + j] = Sc[i];
+          sl[j] = s0;
+        }
       }
       dV0 = 0.0; dV1 = 0.0; k = N - 2; init = false;
       WAVE_SYNC();
@@ -478,7 +492,7 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
       double sj = Lc[q][q];
 #pragma unroll
       for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
-      if (!(sj > 0.0)) pd_ok = false;
+      if (!(sj > 0.0) && glive) pd_ok = false;  // groups that only ride along never restart
       const double l = sqrt(sj);
       Lc[q][q] = l;
       iL[q] = rcp_fast(l);
@@ -518,16 +532,16 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     }
     if (j < ne) {
 #pragma unroll
-      for (int r = 0; r < m; ++r) { Kf[r * ne + j] = Kj[r]; EL(pK, (k * m + r) * ne + j) = Kj[r]; }
+      for (int r = 0; r < m; ++r) { Kf[r * ne + j] = Kj[r]; if (glive) EL(pK, (k * m + r) * ne + j) = Kj[r]; }
     }
-    if (j == 0) {
+    if (j == 0 && glive) {
 #pragma unroll
       for (int r = 0; r < m; ++r) EL(pd, k * m + r) = dk[r];
     }
     WAVE_SYNC();
     // 6. cost-to-go with the un-regularised Quu:  S' = Qxx + Kᵀ(Quu K + Qux) + Quxᵀ K,  s' = Qx + Kᵀ(Quu d + Qu) + Quxᵀ d
     double Snew[ne], snew = 0.0;
-    if (j < ne) {
+    {
       double Wj[m], qd[m];
 #pragma unroll
       for (int r = 0; r < m; ++r) {
@@ -565,16 +579,21 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     dV0 += dv1;
     dV1 += 0.5 * dv2;
     WAVE_SYNC();
-    if (j < ne) {
+    {
+      double Ss[ne];
 #pragma unroll
-      for (int i = 0; i < ne; ++i) S_[i * ne + j] = 0.5 * (Snew[i] + Mx[j * R + i]);
-      sl[j] = snew;
+      for (int i = 0; i < ne; ++i) Ss[i] = 0.5 * (Snew[i] + Mx[jx * R + i]);
+      if (j < ne) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) S_[i * ne + j] = Ss[i];
+        sl[j] = snew;
+      }
     }
     WAVE_SYNC();
     --k;
   }
   if (!failed) reg_decrease(P.opts, rho, drho);
-  if (j == 0) {
+  if (j == 0 && glive) {
     a.rho[b] = rho;
     a.drho[b] = drho;
     a.dV[b] = dV0;
@@ -602,8 +621,8 @@ struct FwdKnot {  // nominal state/control and gains of one knot, fetched one kn
   }
 };
 
-// Line-search candidate: closed-loop rollout with step alpha = decrease^(round*T + t) of trajectory b into slot
-// (cur + 1 + t) mod (T+1), its cost and gradient metric.  grid = (tiles, T): every step size of the round is evaluated
+// Line-search candidate: closed-loop rollout with step alpha = decrease^(round*T + t) of trajectory b into slot t+1,
+// its cost and gradient metric.  grid = (tiles, T): every step size of the round is evaluated
 // CONCURRENTLY by its own wave — a sequential backtracking search would cost (deepest search in the batch) x one
 // rollout per iteration, while the machine idles.
 // MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms).
@@ -613,15 +632,18 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0;
   TILE_LANE();
   const DevProblem& P = a.P;
-  if (b >= P.B) return;
-  if (!a.active[b] || a.bpfail[b] || a.ls_round[b] != a.round) return;
   const int t = blockIdx.y;
   const int idx = a.round * a.T + t;
   const to_solver_opts& o = P.opts;
   if (idx >= o.iterations_linesearch) return;
+  // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
+  // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
+  // predicated.  The wave leaves only when no lane needs the candidate.
+  const bool live = b < P.B && a.active[b] && !a.bpfail[b] && a.ls_round[b] == a.round;
+  if (__ballot(live) == 0) return;
   const int N = P.N;
-  const int c = a.cur[b];
-  const int cs = (c + 1 + t) % (a.T + 1);
+  constexpr int c = 0;  // nominal slot
+  const int cs = t + 1;
   const double* Xc = TILE_PTR(XSLOT(a, c), N * n);
   const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double* Xn = TILE_PTR(XSLOT(a, cs), N * n);
@@ -646,7 +668,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   double xb[n], J = 0.0, gsum = 0.0;
   bool ok = true;
 #pragma unroll
-  for (int i = 0; i < n; ++i) { xb[i] = EL(px0, i); EL(Xn, i) = xb[i]; }
+  for (int i = 0; i < n; ++i) { xb[i] = EL(px0, i); if (live) EL(Xn, i) = xb[i]; }
   FwdKnot<M> nxt;
   nxt.load(Xc, Uc, pK, pd, 0);
   for (int k = 0; k < N - 1; ++k) {
@@ -661,7 +683,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
 #pragma unroll
       for (int i = 0; i < ne; ++i) du += cur.K[j][i] * dx[i];
       ub[j] = cur.u[j] + du;
-      EL(Un, k * m + j) = ub[j];
+      if (live) EL(Un, k * m + j) = ub[j];
       gk = fmax(gk, fabs(cur.d[j]) * rcp_fast(fabs(ub[j]) + 1.0));
     }
     gsum += gk;
@@ -673,17 +695,21 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
     rk_step<M, double>(mp, integrator, xb, ub, h, xn);
     double mx = 0.0, mu_ = 0.0;
 #pragma unroll
-    for (int i = 0; i < n; ++i) { xb[i] = xn[i]; EL(Xn, (k + 1) * n + i) = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
+    for (int i = 0; i < n; ++i) { xb[i] = xn[i]; if (live) EL(Xn, (k + 1) * n + i) = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
 #pragma unroll
     for (int j = 0; j < m; ++j) { const double v = fabs(ub[j]); if (!(v <= mu_)) mu_ = v; }
-    if (!(mx <= max_x) || !(mu_ <= max_u)) { ok = false; break; }
+    // a rollout that left the admissible box is rejected; its lane keeps stepping (values are never used) so that the
+    // wave stays converged, and the wave stops once no live lane is inside the box any more
+    if (!(mx <= max_x) || !(mu_ <= max_u)) ok = false;
+    if (__ballot(live && ok) == 0) break;
   }
-  if (ok) {
+  {
     double u0[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
     J += knot_cost<M>(P, N - 1, xb, u0, lam0, mu0, true);
   }
+  if (!live) return;
   const size_t ci = (size_t)t * P.Bp + b;
   a.candJ[ci] = J;
   a.candG[ci] = gsum / (N - 1);
@@ -698,12 +724,14 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
+  a.acc[b] = 0;
   if (!a.active[b]) return;
   const int N = P.N;
   const to_solver_opts& o = P.opts;
   const bool bpfail = a.bpfail[b] != 0;
   if (!bpfail && a.ls_round[b] != a.round) return;  // already resolved in an earlier round of this iteration
-  const int c = a.cur[b];
+  constexpr int c = 0;  // nominal slot
+  int acc = 0;          // slot of the accepted candidate: the new nominal trajectory until k_accept has copied it to slot 0
   double* mu0 = TILE_PTR(a.mu, P.n_cons);
   const double Jprev = a.J[b];
   double rho = a.rho[b], drho = a.drho[b];
@@ -739,7 +767,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
         const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
         if (z >= o.line_search_lower_bound && z <= o.line_search_upper_bound) {
           accepted = idx; Jnew = J; grad = a.candG[ci];
-          a.cur[b] = (c + 1 + t) % (a.T + 1);
+          acc = t + 1;
           break;
         }
       }
@@ -764,6 +792,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   }
   a.ls_round[b] = -1;
   a.ls_index[b] = accepted;
+  a.acc[b] = acc;
   if (!a.control) {  // phase API: report and leave the state machine alone
     a.Jout[b] = Jnew;
     a.rho[b] = rho; a.drho[b] = drho;
@@ -797,7 +826,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
       const int outer = a.outer[b] + 1;
       a.outer[b] = outer;
       double cm;
-      trajectory_pass<M>(a, tile, lane, false, false, nullptr, &cm);
+      trajectory_pass<M>(a, tile, lane, false, false, nullptr, &cm, acc);
       a.cmax[b] = cm;
       const int its = a.iterations[b];
       if (st != TO_SOLVE_SUCCEEDED && st != TO_MAX_ITERATIONS && st != TO_NO_PROGRESS) { a.status[b] = st; still_active = false; }
@@ -806,10 +835,10 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
       else if (outer >= o.iterations_outer) { a.status[b] = TO_MAX_ITERATIONS_OUTER; still_active = false; }
       else {
         // dual + penalty update, then start the next inner solve on the same trajectory
-        trajectory_pass<M>(a, tile, lane, false, true, nullptr, nullptr);
+        trajectory_pass<M>(a, tile, lane, false, true, nullptr, nullptr, acc);
         for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = fmin(EL(mu0, ci) * o.penalty_scaling, o.penalty_max);
         double Jal;
-        trajectory_pass<M>(a, tile, lane, true, false, &Jal, nullptr);
+        trajectory_pass<M>(a, tile, lane, true, false, &Jal, nullptr, acc);
         a.J[b] = Jal;
         rho = o.bp_reg_initial; drho = 0.0;
         a.dJzero[b] = 0; a.it_inner[b] = 0;
@@ -824,6 +853,30 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   else atomicAdd(&a.counter[a.step], 1);
 }
 
+// Accepting a step = copying the accepted candidate's slot onto slot 0, so the nominal trajectory of every lane sits in
+// ONE slot and every kernel reads it with full-line coalesced loads (a per-trajectory slot index turned each nominal
+// load of a wave into up to 64 separate lines: measured 2x on the quadrotor forward pass).  grid (tiles, T, chunks):
+// wave (tile, t, z) copies chunk z for the lanes that accepted candidate t; waves nobody needs exit on a ballot.
+__global__ void __launch_bounds__(64) k_accept(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const int s = blockIdx.y + 1;
+  const bool want = b < P.B && a.acc[b] == s;
+  if (__ballot(want) == 0) return;
+  const int Lx = P.N * P.n, Lu = (P.N - 1) * P.m;
+  const int per = (Lx + Lu + gridDim.z - 1) / gridDim.z;
+  const int e0 = blockIdx.z * per, e1 = min(Lx + Lu, e0 + per);
+  if (!want) return;
+  const double* sx = TILE_PTR(XSLOT(a, s), Lx);
+  double* dx = TILE_PTR(XSLOT(a, 0), Lx);
+  const double* su = TILE_PTR(USLOT(a, s), Lu);
+  double* du = TILE_PTR(USLOT(a, 0), Lu);
+#pragma unroll 16
+  for (int e = e0; e < min(e1, Lx); ++e) EL(dx, e) = EL(sx, e);
+#pragma unroll 16
+  for (int e = max(e0, Lx) - Lx; e < e1 - Lx; ++e) EL(du, e) = EL(su, e);
+}
+
 // start of a solve: reset the per-trajectory solver state.  J must already hold the (AL) cost of the rollout.
 __global__ void k_solve_init(KArgs a, int reset_duals) {
   TILE_LANE();
@@ -832,7 +885,7 @@ __global__ void k_solve_init(KArgs a, int reset_duals) {
   const bool live = b < P.B;
   a.rho[b] = P.opts.bp_reg_initial; a.drho[b] = 0.0;
   a.dJzero[b] = 0; a.it_inner[b] = 0; a.iterations[b] = 0; a.outer[b] = 0;
-  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.ls_round[b] = -1;
+  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.ls_round[b] = -1; a.acc[b] = 0;
   a.dJ[b] = 0.0; a.grad[b] = 0.0; a.cmax[b] = 0.0;
   const int tot = a.al_mode ? P.opts.iterations_total : P.opts.iterations;
   a.budget[b] = tot < P.opts.iterations ? tot : P.opts.iterations;
@@ -879,26 +932,10 @@ __global__ void k_to_host(const double* __restrict__ d, double* __restrict__ h, 
   if (b >= B) return;
   h[(size_t)e + (size_t)cnt * b] = EL(TILE_PTR(d, L), e0 + e);
 }
-// same with the nominal buffer chosen per trajectory (X/U double buffering)
-__global__ void k_to_host_cur(const double* __restrict__ ds, size_t slot, const int* __restrict__ cur, double* __restrict__ h, int L, int B) {
+__global__ void k_fill_uniform(double* d, const double* u, int dim, int L, int B) {
   TILE_LANE();
   const int e = blockIdx.y;
   if (b >= B) return;
-  const double* d = ds + (size_t)cur[b] * slot;
-  h[(size_t)e + (size_t)L * b] = EL(TILE_PTR(d, L), e);
-}
-__global__ void k_to_device_cur(const double* __restrict__ h, double* __restrict__ ds, size_t slot, const int* __restrict__ cur, int L, int B) {
-  TILE_LANE();
-  const int e = blockIdx.y;
-  if (b >= B) return;
-  double* d = ds + (size_t)cur[b] * slot;
-  EL(TILE_PTR(d, L), e) = h[(size_t)e + (size_t)L * b];
-}
-__global__ void k_fill_uniform(double* ds, size_t slot, const int* cur, const double* u, int dim, int L, int B) {
-  TILE_LANE();
-  const int e = blockIdx.y;
-  if (b >= B) return;
-  double* d = ds + (size_t)cur[b] * slot;
   EL(TILE_PTR(d, L), e) = u[e % dim];
 }
 // matrices: device blocks are row-major [k][r][c]; host wants column-major h[r + R*(c + Cc*(k + K*b))].  grid (tiles, K*R*Cc)
@@ -934,7 +971,7 @@ __global__ void __launch_bounds__(64) k_cost_derivs(KArgs a, double* grad, doubl
   if (b >= P.B) return;
   const int N = P.N, k = blockIdx.y;
   const bool terminal = (k == N - 1);
-  const int c = a.cur[b];
+  constexpr int c = 0;  // nominal slot
   const double* X = TILE_PTR(XSLOT(a, c), N * n);
   const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double x[n], u[m];
@@ -965,7 +1002,7 @@ __global__ void __launch_bounds__(64) k_discrete_jacobian(KArgs a, double* F) {
   const DevProblem& P = a.P;
   if (b >= P.B) return;
   const int N = P.N, k = blockIdx.y, j = blockIdx.z;
-  const int c = a.cur[b];
+  constexpr int c = 0;  // nominal slot
   const double* X = TILE_PTR(XSLOT(a, c), N * n);
   const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   Dual xd[n], ud[m], xn[n];
@@ -988,7 +1025,7 @@ __global__ void __launch_bounds__(64) k_constraint_eval(KArgs a, int ci, double*
   if (b >= P.B) return;
   ConC& K = P.cons[ci];
   const int N = P.N, kk = blockIdx.y, k = K.k1 + kk, nk = K.k2 - K.k1 + 1;
-  const int c = a.cur[b];
+  constexpr int c = 0;  // nominal slot
   const double* X = TILE_PTR(XSLOT(a, c), N * n);
   const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double z[nz];

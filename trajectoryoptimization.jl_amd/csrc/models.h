@@ -90,8 +90,6 @@ __device__ __forceinline__ void sincos_t(Dual x, Dual* s, Dual* c) {
 // max(0, x): derivative is the indicator x > 0 (the rotor-force clamp of the Quadrotor)
 __device__ __forceinline__ double relu_t(double x) { return fmax(0.0, x); }
 __device__ __forceinline__ Dual relu_t(Dual x) { return x.v > 0.0 ? x : Dual(0.0, 0.0); }
-__device__ __forceinline__ double val(double x) { return x; }
-__device__ __forceinline__ double val(Dual x) { return x.v; }
 
 // ------------------------------------------------------------------------------------------------
 // Models.  P = model_params of the descriptor (wave-uniform, lives in SGPRs).

@@ -306,9 +306,6 @@ __device__ __forceinline__ double sel_row(ConC& K, const double* z, int r) {
   return j < 0 ? K.soff[r] : K.ssgn[r] * (pick<nz>(z, j) - K.soff[r]);
 }
 
-// SOC pieces for the vector lb = lam − mu·c of a NORM-SOC selector constraint (p = D+1, last row constant).
-struct SocState { double a, s, coef; int branch; };  // Π(lb) = coef·[v; a] (branch 2), lb (1), 0 (0)
-
 // AL penalty of one constraint at one knot.  lam: pointer to row 0 of this knot's duals
 // (batch-fastest: row r at lam[r*stride]).
 template <int n, int m>

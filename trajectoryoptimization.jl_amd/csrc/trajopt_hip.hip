@@ -63,6 +63,7 @@ struct to_handle_s {
   hipStream_t stream = nullptr;
   int model_key = -1;
   int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
+  int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 64 elements of [X; U]: the copy is latency-bound per wave)
   KArgs a;  // host copy of the kernel argument block (device pointers inside)
   std::vector<to_cost_desc> costs;
   std::vector<DevCon> cons;
@@ -230,21 +231,12 @@ int download_vec(to_handle* h, double* host, const double* d, int cnt, int L = -
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
-// the nominal trajectory (slot cur[b] of a slotted X/U array) <-> host layout
-int upload_nominal(to_handle* h, const double* host, double* slots, size_t slot, int cnt) {
-  const size_t total = (size_t)cnt * h->a.P.B;
-  TRY(ensure_stage(h, total * sizeof(double)));
-  HIPCHECK(hipMemcpyAsync(h->stage, host, total * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_to_device_cur, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, h->stage, slots, slot, h->a.cur, cnt, h->a.P.B);
-  HIPCHECK(hipGetLastError());
-  HIPCHECK(hipStreamSynchronize(h->stream));
-  return TO_OK;
-}
-int download_nominal(to_handle* h, double* host, const double* slots, size_t slot, int cnt, void* dev_dst = nullptr) {
+// the nominal trajectory (slot 0 of a slotted X/U array) -> host layout or a caller-owned device buffer
+int download_nominal(to_handle* h, double* host, const double* slot0, int cnt, void* dev_dst = nullptr) {
   const size_t total = (size_t)cnt * h->a.P.B;
   double* dst = (double*)dev_dst;
   if (!dst) { TRY(ensure_stage(h, total * sizeof(double))); dst = h->stage; }
-  hipLaunchKernelGGL(k_to_host_cur, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, slots, slot, h->a.cur, dst, cnt, h->a.P.B);
+  hipLaunchKernelGGL(k_to_host, grid_b(h, cnt), dim3(BLOCK), 0, h->stream, slot0, dst, cnt, 0, cnt, h->a.P.B);
   HIPCHECK(hipGetLastError());
   if (host) HIPCHECK(hipMemcpyAsync(host, dst, total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -314,14 +306,17 @@ int launch_forward(to_handle* h) {
   for (int r = 0; r < std::max(1, rounds); ++r) {
     a.round = r;
     const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0);
+    static const unsigned fwd_lds = std::getenv("TRAJOPT_FWD_LDS") ? (unsigned)std::atoi(std::getenv("TRAJOPT_FWD_LDS")) : 0u;
     switch (mode) {
-      case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
-      default: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.T), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
+      case 1: { DISPATCH(h, if (fwd_lds > 65536) hipFuncSetAttribute((const void*)k_forward<M, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds); hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
+      case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
+      default: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
     }
     HIPCHECK(hipGetLastError());
     DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_accept, grid_b(h, a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, a);
     HIPCHECK(hipGetLastError());
   }
   return TO_OK;
@@ -534,13 +529,14 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   //  so T*tiles <= 1024 keeps a whole round in a single residency pass)
   a.T = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
   if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) a.T = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
+  h->accept_chunks = std::max(1, std::min(64, (N * n + (N - 1) * P.m + 63) / 64));
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
   TRYB(dev_alloc(h, &a.Us, a.slotU * (a.T + 1)));
   TRYB(dev_alloc(h, &a.candJ, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.candG, (size_t)a.T * Bp));
   TRYB(dev_alloc(h, &a.candOk, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.ls_round, Bp));
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
-  TRYB(dev_alloc(h, &a.cur, Bp));
+  TRYB(dev_alloc(h, &a.acc, Bp));
   {
     const size_t gtiles = ((size_t)B + h->G - 1) / h->G;  // waves of the column-layout kernels
     TRYB(dev_alloc(h, &a.Mc, gtiles * (size_t)(N - 1) * ne * 64));
@@ -629,37 +625,37 @@ int to_get_initial_state(to_handle* h, double* x0) {
 }
 int to_set_controls(to_handle* h, const double* U) {
   CHECK_H(h); CHECK_P(U); TRY(use_device(h));
-  return upload_nominal(h, U, h->a.Us, h->a.slotU, h->a.P.m * (h->a.P.N - 1));
+  return upload_vec(h, U, h->a.Us, h->a.P.m * (h->a.P.N - 1));
 }
 int to_set_states(to_handle* h, const double* X) {
   CHECK_H(h); CHECK_P(X); TRY(use_device(h));
-  return upload_nominal(h, X, h->a.Xs, h->a.slotX, h->a.P.n * h->a.P.N);
+  return upload_vec(h, X, h->a.Xs, h->a.P.n * h->a.P.N);
 }
 int to_set_controls_uniform(to_handle* h, const double* u) {
   CHECK_H(h); CHECK_P(u); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   TRY(ensure_stage(h, sizeof(double) * P.m));
   HIPCHECK(hipMemcpyAsync(h->stage, u, sizeof(double) * P.m, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_fill_uniform, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.Us, h->a.slotU, h->a.cur, h->stage, P.m, P.m * (P.N - 1), P.B);
+  hipLaunchKernelGGL(k_fill_uniform, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.Us, h->stage, P.m, P.m * (P.N - 1), P.B);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
 int to_get_states(to_handle* h, double* X) {
   CHECK_H(h); CHECK_P(X); TRY(use_device(h));
-  return download_nominal(h, X, h->a.Xs, h->a.slotX, h->a.P.n * h->a.P.N);
+  return download_nominal(h, X, h->a.Xs, h->a.P.n * h->a.P.N);
 }
 int to_get_controls(to_handle* h, double* U) {
   CHECK_H(h); CHECK_P(U); TRY(use_device(h));
-  return download_nominal(h, U, h->a.Us, h->a.slotU, h->a.P.m * (h->a.P.N - 1));
+  return download_nominal(h, U, h->a.Us, h->a.P.m * (h->a.P.N - 1));
 }
 int to_get_states_device(to_handle* h, void* dX) {
   CHECK_H(h); CHECK_P(dX); TRY(use_device(h));
-  return download_nominal(h, nullptr, h->a.Xs, h->a.slotX, h->a.P.n * h->a.P.N, dX);
+  return download_nominal(h, nullptr, h->a.Xs, h->a.P.n * h->a.P.N, dX);
 }
 int to_get_controls_device(to_handle* h, void* dU) {
   CHECK_H(h); CHECK_P(dU); TRY(use_device(h));
-  return download_nominal(h, nullptr, h->a.Us, h->a.slotU, h->a.P.m * (h->a.P.N - 1), dU);
+  return download_nominal(h, nullptr, h->a.Us, h->a.P.m * (h->a.P.N - 1), dU);
 }
 int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
   CHECK_H(h); CHECK_P(c); TRY(use_device(h));
