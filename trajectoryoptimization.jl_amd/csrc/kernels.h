@@ -23,7 +23,7 @@ struct KArgs {
   size_t slotX, slotU;  // doubles per slot (L * Bp)
   int T;          // line-search candidates evaluated concurrently per round (grid.y of k_forward)
   double* x0;     // L = n
-  int* acc;       // [Bp] slot of the candidate accepted in the current round (0 = none): k_accept copies it to slot 0
+  int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): k_accept copies it to slot 0
   double *candJ, *candG;  // [T][Bp] cost and gradient metric of each candidate of the current round
   int* candOk;            // [T][Bp] 1: rollout stayed within the state/control limits
   int* ls_round;          // [Bp] next line-search round of this trajectory; -1: resolved for this iteration
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  a.acc[b] = 0;
+  if (a.round == 0) a.acc[b] = 0;  // accepted slots stay marked over the rounds: k_accept runs once, after the last one
   if (!a.active[b]) return;
   const int N = P.N;
   const to_solver_opts& o = P.opts;
@@ -855,7 +855,8 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
 
 // Accepting a step = copying the accepted candidate's slot onto slot 0, so the nominal trajectory of every lane sits in
 // ONE slot and every kernel reads it with full-line coalesced loads (a per-trajectory slot index turned each nominal
-// load of a wave into up to 64 separate lines: measured 2x on the quadrotor forward pass).  grid (tiles, T, chunks):
+// load of a wave into up to 64 separate lines: measured 2x on the quadrotor forward pass).  Runs once per forward pass:
+// later rounds only store into the slots of lanes that are still searching.  grid (tiles, T, chunks):
 // wave (tile, t, z) copies chunk z for the lanes that accepted candidate t; waves nobody needs exit on a ballot.
 __global__ void __launch_bounds__(64) k_accept(KArgs a) {
   TILE_LANE();

@@ -63,7 +63,7 @@ struct to_handle_s {
   hipStream_t stream = nullptr;
   int model_key = -1;
   int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
-  int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 64 elements of [X; U]: the copy is latency-bound per wave)
+  int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   KArgs a;  // host copy of the kernel argument block (device pointers inside)
   std::vector<to_cost_desc> costs;
   std::vector<DevCon> cons;
@@ -316,9 +316,9 @@ int launch_forward(to_handle* h) {
     HIPCHECK(hipGetLastError());
     DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_accept, grid_b(h, a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, a);
-    HIPCHECK(hipGetLastError());
   }
+  hipLaunchKernelGGL(k_accept, grid_b(h, a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, a);
+  HIPCHECK(hipGetLastError());
   return TO_OK;
 }
 int launch_violation(to_handle* h, double* out) {
@@ -357,11 +357,16 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
     while ((int)h->ev.size() < 4 * max_steps) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); h->ev.push_back(e); }
   }
   // The host only needs to know WHEN every trajectory has finished: it enqueues CHECK_EVERY batch steps back to back
-  // and reads the per-step "still active" counters once per chunk (kernels of finished trajectories exit at once).
+  // and reads the per-step "still active" counters once per chunk.  The read-back is pipelined: chunk g+1 is already
+  // enqueued when the host waits for the counters of chunk g, so the GPU never idles on the round trip; the price is at
+  // most one chunk of launches whose kernels find nothing to do (kernels of finished trajectories exit at once).
   constexpr int CHECK_EVERY = 4;
-  int launched = 0;
+  hipEvent_t cev[2];
+  HIPCHECK(hipEventCreateWithFlags(&cev[0], hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&cev[1], hipEventDisableTiming));
+  int launched = 0, checked = 0, nchunks = 0;
   bool done = false;
-  while (launched < max_steps && !done) {
+  auto enqueue_chunk = [&]() -> int {
     const int chunk = std::min(CHECK_EVERY, max_steps - launched);
     for (int c = 0; c < chunk; ++c) {
       const int step = launched + c;
@@ -375,13 +380,25 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
     }
     HIPCHECK(hipMemcpyAsync(&h->counter_host[launched], &a.counter[launched], sizeof(int) * chunk, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    for (int c = 0; c < chunk; ++c) {
-      ++steps;
-      if (h->counter_host[launched + c] == 0) { done = true; break; }
-    }
+    HIPCHECK(hipEventRecord(cev[nchunks & 1], h->stream));
     launched += chunk;
+    ++nchunks;
+    return TO_OK;
+  };
+  int waited = 0;  // chunks whose counters have been inspected
+  if (max_steps > 0) TRY(enqueue_chunk());
+  while (!done && waited < nchunks) {
+    if (launched < max_steps) TRY(enqueue_chunk());  // keep the queue one chunk ahead
+    HIPCHECK(hipEventSynchronize(cev[waited & 1]));
+    const int upto = std::min(launched, (waited + 1) * CHECK_EVERY);
+    for (; checked < upto; ++checked) {
+      ++steps;
+      if (h->counter_host[checked] == 0) { done = true; break; }
+    }
+    ++waited;
   }
+  HIPCHECK(hipEventDestroy(cev[0]));
+  HIPCHECK(hipEventDestroy(cev[1]));
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -529,7 +546,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   //  so T*tiles <= 1024 keeps a whole round in a single residency pass)
   a.T = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
   if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) a.T = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
-  h->accept_chunks = std::max(1, std::min(64, (N * n + (N - 1) * P.m + 63) / 64));
+  h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
   TRYB(dev_alloc(h, &a.Us, a.slotU * (a.T + 1)));
