@@ -21,7 +21,7 @@ struct KArgs {
   double* Xs;     // (T+1) slots of L = N*n: slot 0 holds the nominal trajectory, slot t+1 line-search candidate t of the round
   double* Us;     // (T+1) slots of L = (N-1)*m
   size_t slotX, slotU;  // doubles per slot (L * Bp)
-  int T;          // line-search candidates evaluated concurrently per round (grid.y of k_forward)
+  int T;          // candidate slots = most line-search candidates evaluated concurrently in one round
   double* x0;     // L = n
   int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): k_accept copies it to slot 0
   double *candJ, *candG;  // [T][Bp] cost and gradient metric of each candidate of the current round
@@ -33,7 +33,11 @@ struct KArgs {
   double *J, *dJ, *grad, *rho, *drho, *dV, *cmax, *Jout;  // [Bp] plain (dV: [2][Bp])
   int *status, *iterations, *it_inner, *outer, *dJzero, *ls_index, *active, *budget, *bpfail;
   int* counter;   // [steps] number of trajectories still active after each batch step
-  int round;      // line-search round being launched
+  int *oflag, *ost;   // [Bp] AL outer update pending (1: evaluate, 2: update duals) and the inner solve's status
+  double* knotbuf;    // tiled, L = N: per-knot scratch of the outer update (violations, then AL cost terms)
+  double* mu_next;    // tiled, L = n_cons: penalties after the pending outer update
+  int round;      // line-search round being launched: step sizes cand0 .. cand0+Tr-1 (grid.y of k_forward = Tr)
+  int cand0, Tr;
   int al_mode;    // 0: iLQR, 1: AL-iLQR
   int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
   int step;
@@ -633,7 +637,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   TILE_LANE();
   const DevProblem& P = a.P;
   const int t = blockIdx.y;
-  const int idx = a.round * a.T + t;
+  const int idx = a.cand0 + t;
   const to_solver_opts& o = P.opts;
   if (idx >= o.iterations_linesearch) return;
   // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
@@ -740,7 +744,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   if (!bpfail) {
     const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
     double alpha = 1.0;
-    for (int i = 0; i < a.round * a.T; ++i) alpha *= o.line_search_decrease_factor;
+    for (int i = 0; i < a.cand0; ++i) alpha *= o.line_search_decrease_factor;
     bool exhausted = false;
     // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
     const bool stationary = -(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev));
@@ -757,8 +761,8 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
       }
       grad = gs / (N - 1);
     }
-    for (int t = 0; t < a.T && !stationary; ++t) {
-      const int idx = a.round * a.T + t;
+    for (int t = 0; t < a.Tr && !stationary; ++t) {
+      const int idx = a.cand0 + t;
       if (idx >= o.iterations_linesearch) { exhausted = true; break; }
       const size_t ci = (size_t)t * P.Bp + b;
       if (a.candOk[ci]) {
@@ -774,7 +778,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
       alpha *= o.line_search_decrease_factor;
     }
     if (accepted < 0) {
-      if (!exhausted && (a.round + 1) * a.T < o.iterations_linesearch) { a.ls_round[b] = a.round + 1; return; }  // next round
+      if (!exhausted && a.cand0 + a.Tr < o.iterations_linesearch) { a.ls_round[b] = a.round + 1; return; }  // next round
       // line search failed: gradient metric on the unchanged nominal controls, regularise harder
       const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
       const double* pd = TILE_PTR(a.d, (N - 1) * m);
@@ -822,35 +826,118 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   bool still_active = true;
   if (inner_done) {
     if (!a.al_mode) { a.status[b] = st; still_active = false; }
-    else {
-      const int outer = a.outer[b] + 1;
-      a.outer[b] = outer;
-      double cm;
-      trajectory_pass<M>(a, tile, lane, false, false, nullptr, &cm, acc);
-      a.cmax[b] = cm;
-      const int its = a.iterations[b];
-      if (st != TO_SOLVE_SUCCEEDED && st != TO_MAX_ITERATIONS && st != TO_NO_PROGRESS) { a.status[b] = st; still_active = false; }
-      else if (cm < o.constraint_tolerance) { a.status[b] = TO_SOLVE_SUCCEEDED; still_active = false; }
-      else if (its >= o.iterations_total) { a.status[b] = TO_MAX_ITERATIONS; still_active = false; }
-      else if (outer >= o.iterations_outer) { a.status[b] = TO_MAX_ITERATIONS_OUTER; still_active = false; }
-      else {
-        // dual + penalty update, then start the next inner solve on the same trajectory
-        trajectory_pass<M>(a, tile, lane, false, true, nullptr, nullptr, acc);
-        for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = fmin(EL(mu0, ci) * o.penalty_scaling, o.penalty_max);
-        double Jal;
-        trajectory_pass<M>(a, tile, lane, true, false, &Jal, nullptr, acc);
-        a.J[b] = Jal;
-        rho = o.bp_reg_initial; drho = 0.0;
-        a.dJzero[b] = 0; a.it_inner[b] = 0;
-        const int rem = o.iterations_total - its;
-        a.budget[b] = rem < o.iterations ? rem : o.iterations;
-        a.status[b] = TO_UNSOLVED;
-      }
+    else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels after k_accept
+      a.ost[b] = st; a.oflag[b] = 1;
+      a.rho[b] = rho; a.drho[b] = drho;
+      return;
     }
   }
   a.rho[b] = rho; a.drho[b] = drho;
   if (!still_active) a.active[b] = 0;
   else atomicAdd(&a.counter[a.step], 1);
+}
+
+// ---- AL outer update of the trajectories whose inner solve just ended (oflag = 1), knot-parallel:
+//   k_outer_violation (tiles, N): constraint violation of every knot -> knotbuf
+//   k_outer_decide    (tiles)   : c_max, termination tests; trajectories that go on get oflag = 2 and their new penalties
+//   k_outer_update    (tiles, N): dual update with the OLD penalties, then the knot's AL cost with the new duals/penalties
+//   k_outer_finish    (tiles)   : J = sum of the knot terms in knot order (same sum as a sequential pass), restart the inner solve
+// One lane per trajectory walking all knots three times was the largest kernel of the constrained solves.
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_violation(KArgs a) {
+  constexpr int n = M::n, m = M::m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const bool want = b < P.B && a.oflag[b] == 1;
+  if (__ballot(want) == 0) return;
+  if (!want) return;
+  const int N = P.N, k = blockIdx.y;
+  const double* X = TILE_PTR(XSLOT(a, 0), N * n);
+  const double* U = TILE_PTR(USLOT(a, 0), (N - 1) * m);
+  double x[n], u[m];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+  EL(TILE_PTR(a.knotbuf, N), k) = (P.n_cons > 0) ? knot_violation<M>(P, k, x, u) : 0.0;
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_decide(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B || a.oflag[b] != 1) return;
+  const to_solver_opts& o = P.opts;
+  const int N = P.N, st = a.ost[b];
+  const int outer = a.outer[b] + 1;
+  a.outer[b] = outer;
+  const double* vb = TILE_PTR(a.knotbuf, N);
+  double cm = 0.0;
+  for (int k = 0; k < N; ++k) { const double v = EL(vb, k); if (!(v <= cm)) cm = v; }
+  a.cmax[b] = cm;
+  const int its = a.iterations[b];
+  bool go_on = false;
+  if (st != TO_SOLVE_SUCCEEDED && st != TO_MAX_ITERATIONS && st != TO_NO_PROGRESS) a.status[b] = st;
+  else if (cm < o.constraint_tolerance) a.status[b] = TO_SOLVE_SUCCEEDED;
+  else if (its >= o.iterations_total) a.status[b] = TO_MAX_ITERATIONS;
+  else if (outer >= o.iterations_outer) a.status[b] = TO_MAX_ITERATIONS_OUTER;
+  else go_on = true;
+  if (!go_on) { a.active[b] = 0; a.oflag[b] = 0; return; }
+  a.oflag[b] = 2;
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
+  for (int ci = 0; ci < P.n_cons; ++ci) EL(mn0, ci) = fmin(EL(mu0, ci) * o.penalty_scaling, o.penalty_max);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const bool want = b < P.B && a.oflag[b] == 2;
+  if (__ballot(want) == 0) return;
+  if (!want) return;
+  const int N = P.N, k = blockIdx.y;
+  const double* X = TILE_PTR(XSLOT(a, 0), N * n);
+  const double* U = TILE_PTR(USLOT(a, 0), (N - 1) * m);
+  double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  const double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
+  double x[n], u[m], z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { x[i] = EL(X, k * n + i); z[i] = x[i]; }
+#pragma unroll
+  for (int i = 0; i < m; ++i) { u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0; z[n + i] = u[i]; }
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    con_dual_update<nz>(K, z, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
+  }
+  EL(TILE_PTR(a.knotbuf, N), k) = knot_cost<M>(P, k, x, u, lam0, mn0, true);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_finish(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B || a.oflag[b] != 2) return;
+  const to_solver_opts& o = P.opts;
+  const int N = P.N;
+  const double* jb = TILE_PTR(a.knotbuf, N);
+  double J = 0.0;
+  for (int k = 0; k < N; ++k) J += EL(jb, k);
+  a.J[b] = J;
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  const double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
+  for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = EL(mn0, ci);
+  a.rho[b] = o.bp_reg_initial; a.drho[b] = 0.0;
+  a.dJzero[b] = 0; a.it_inner[b] = 0;
+  const int rem = o.iterations_total - a.iterations[b];
+  a.budget[b] = rem < o.iterations ? rem : o.iterations;
+  a.status[b] = TO_UNSOLVED;
+  a.oflag[b] = 0;
+  atomicAdd(&a.counter[a.step], 1);
 }
 
 // Accepting a step = copying the accepted candidate's slot onto slot 0, so the nominal trajectory of every lane sits in
@@ -886,7 +973,7 @@ __global__ void k_solve_init(KArgs a, int reset_duals) {
   const bool live = b < P.B;
   a.rho[b] = P.opts.bp_reg_initial; a.drho[b] = 0.0;
   a.dJzero[b] = 0; a.it_inner[b] = 0; a.iterations[b] = 0; a.outer[b] = 0;
-  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.ls_round[b] = -1; a.acc[b] = 0;
+  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.ls_round[b] = -1; a.acc[b] = 0; a.oflag[b] = 0;
   a.dJ[b] = 0.0; a.grad[b] = 0.0; a.cmax[b] = 0.0;
   const int tot = a.al_mode ? P.opts.iterations_total : P.opts.iterations;
   a.budget[b] = tot < P.opts.iterations ? tot : P.opts.iterations;

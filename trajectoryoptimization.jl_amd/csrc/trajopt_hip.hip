@@ -63,6 +63,7 @@ struct to_handle_s {
   hipStream_t stream = nullptr;
   int model_key = -1;
   int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
+  int T1 = 1;  // step sizes evaluated concurrently in the first line-search round (all trajectories take part)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   KArgs a;  // host copy of the kernel argument block (device pointers inside)
   std::vector<to_cost_desc> costs;
@@ -298,26 +299,40 @@ int launch_backward(to_handle* h) {
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
-// forward pass = line-search rounds of (T concurrent candidates, select).  Rounds after the first only do work for
-// trajectories whose first T step sizes were all rejected.
+// forward pass = line-search rounds of (concurrent candidates, select).  The first round evaluates the T1 largest step
+// sizes for every trajectory; the trajectories that rejected all of them are few, so the following rounds take up to T
+// step sizes at once (dead tiles leave immediately).
 int launch_forward(to_handle* h) {
   KArgs& a = h->a;
-  const int rounds = (a.P.opts.iterations_linesearch + a.T - 1) / a.T;
-  for (int r = 0; r < std::max(1, rounds); ++r) {
+  const int total = std::max(1, a.P.opts.iterations_linesearch);
+  const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0);
+  int r = 0;
+  for (int c0 = 0; c0 < total; ++r) {
     a.round = r;
-    const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0);
-    static const unsigned fwd_lds = std::getenv("TRAJOPT_FWD_LDS") ? (unsigned)std::atoi(std::getenv("TRAJOPT_FWD_LDS")) : 0u;
+    a.cand0 = c0;
+    a.Tr = std::min(total - c0, r == 0 ? h->T1 : a.T);
     switch (mode) {
-      case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
-      case 1: { DISPATCH(h, if (fwd_lds > 65536) hipFuncSetAttribute((const void*)k_forward<M, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, fwd_lds); hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
-      case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
-      default: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.T), dim3(BLOCK), fwd_lds, h->stream, a)); } break;
+      case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      default: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
     }
     HIPCHECK(hipGetLastError());
     DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
     HIPCHECK(hipGetLastError());
+    c0 += a.Tr;
   }
   hipLaunchKernelGGL(k_accept, grid_b(h, a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+// AL outer update of the trajectories whose inner solve ended in this batch step (kernels.h, k_outer_*)
+int launch_outer(to_handle* h) {
+  const int N = h->a.P.N;
+  DISPATCH(h, hipLaunchKernelGGL(k_outer_violation<M>, grid_b(h, N), dim3(BLOCK), 0, h->stream, h->a));
+  DISPATCH(h, hipLaunchKernelGGL(k_outer_decide<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  DISPATCH(h, hipLaunchKernelGGL(k_outer_update<M>, grid_b(h, N), dim3(BLOCK), 0, h->stream, h->a));
+  DISPATCH(h, hipLaunchKernelGGL(k_outer_finish<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
@@ -377,6 +392,7 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
       TRY(launch_backward(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
       TRY(launch_forward(h));
+      if (al_mode) TRY(launch_outer(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
     }
     HIPCHECK(hipMemcpyAsync(&h->counter_host[launched], &a.counter[launched], sizeof(int) * chunk, hipMemcpyDeviceToHost, h->stream));
@@ -544,8 +560,10 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // line-search candidates evaluated concurrently: enough waves to cover the chip, at most the default search depth
   // (one candidate = one wave; the register-heavy rollout kernels are resident at one wave per SIMD, 1024 SIMDs per chip,
   //  so T*tiles <= 1024 keeps a whole round in a single residency pass)
-  a.T = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
-  if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) a.T = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
+  h->T1 = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
+  if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) h->T1 = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
+  // later rounds: whatever remains of the default search depth, at once (only the few trajectories still searching take part)
+  a.T = std::max(h->T1, std::min(16, std::max(1, P.opts.iterations_linesearch - h->T1)));
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
@@ -554,6 +572,9 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.candOk, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.ls_round, Bp));
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
+  TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
+  TRYB(dev_alloc(h, &a.knotbuf, (size_t)N * Bp));
+  TRYB(dev_alloc(h, &a.mu_next, (size_t)std::max<size_t>(1, cons.size()) * Bp));
   {
     const size_t gtiles = ((size_t)B + h->G - 1) / h->G;  // waves of the column-layout kernels
     TRYB(dev_alloc(h, &a.Mc, gtiles * (size_t)(N - 1) * ne * 64));
