@@ -36,6 +36,9 @@ struct KArgs {
   int *oflag, *ost;   // [Bp] AL outer update pending (1: evaluate, 2: update duals) and the inner solve's status
   double* knotbuf;    // tiled, L = N: per-knot scratch of the outer update (violations, then AL cost terms)
   double* mu_next;    // tiled, L = n_cons: penalties after the pending outer update
+  int* list;          // [Bp] trajectories still searching, compacted by k_select for the next line-search round
+  int* nlist;         // [steps][lstride] length of that list per (batch step, round)
+  int lstride;
   int round;      // line-search round being launched: step sizes cand0 .. cand0+Tr-1 (grid.y of k_forward = Tr)
   int cand0, Tr;
   int al_mode;    // 0: iLQR, 1: AL-iLQR
@@ -634,16 +637,27 @@ template <class M, int MODE>
 __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne;
   constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0;
-  TILE_LANE();
   const DevProblem& P = a.P;
   const int t = blockIdx.y;
   const int idx = a.cand0 + t;
   const to_solver_opts& o = P.opts;
   if (idx >= o.iterations_linesearch) return;
+  // Round 0: lane = trajectory of tile blockIdx.x.  Later rounds: the few trajectories that rejected every step size so
+  // far were compacted into a list by k_select; wave v takes entries 64v..64v+63 (gathered loads, but a handful of
+  // waves instead of one per tile that still holds a searching trajectory).
+  int b = blockIdx.x * 64 + threadIdx.x;
+  bool listed = true;
+  if (a.round > 0) {
+    const int cnt = a.nlist[a.step * a.lstride + a.round];
+    if ((int)blockIdx.x * 64 >= cnt) return;
+    listed = b < cnt;
+    b = a.list[listed ? b : cnt - 1];
+  }
+  const int tile = b >> 6, lane = b & 63;
   // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
   // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
   // predicated.  The wave leaves only when no lane needs the candidate.
-  const bool live = b < P.B && a.active[b] && !a.bpfail[b] && a.ls_round[b] == a.round;
+  const bool live = listed && b < P.B && a.active[b] && !a.bpfail[b] && a.ls_round[b] == a.round;
   if (__ballot(live) == 0) return;
   const int N = P.N;
   constexpr int c = 0;  // nominal slot
@@ -778,7 +792,17 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
       alpha *= o.line_search_decrease_factor;
     }
     if (accepted < 0) {
-      if (!exhausted && a.cand0 + a.Tr < o.iterations_linesearch) { a.ls_round[b] = a.round + 1; return; }  // next round
+      if (!exhausted && a.cand0 + a.Tr < o.iterations_linesearch) {  // next round: join the compacted list
+        a.ls_round[b] = a.round + 1;
+        // one atomic per wave: the tile's entries stay adjacent, so the gathered loads of the next round still share lines
+        const unsigned long long grp = __ballot(1);
+        const int leader = __ffsll((long long)grp) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&a.nlist[a.step * a.lstride + a.round + 1], __popcll(grp));
+        base = __shfl(base, leader);
+        a.list[base + __popcll(grp & ((1ull << lane) - 1ull))] = b;
+        return;
+      }
       // line search failed: gradient metric on the unchanged nominal controls, regularise harder
       const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
       const double* pd = TILE_PTR(a.d, (N - 1) * m);

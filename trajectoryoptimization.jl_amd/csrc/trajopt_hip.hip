@@ -75,6 +75,7 @@ struct to_handle_s {
   size_t stage_bytes = 0;
   int* counter_host = nullptr;  // pinned
   int counter_len = 0;
+  size_t nlist_len = 0;
   // device copies of the descriptor tables
   to_cost_desc* d_costs = nullptr;
   DevCon* d_cons = nullptr;
@@ -299,6 +300,28 @@ int launch_backward(to_handle* h) {
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
+// number of line-search rounds launch_forward issues
+int ls_rounds(const to_handle* h) {
+  const int total = std::max(1, h->a.P.opts.iterations_linesearch);
+  int r = 0;
+  for (int c0 = 0; c0 < total; ++r) c0 += std::min(total - c0, r == 0 ? h->T1 : h->a.T);
+  return r;
+}
+// zeroed (batch step, round) counters of the compacted line-search lists
+int ensure_nlist(to_handle* h, int steps) {
+  KArgs& a = h->a;
+  a.lstride = ls_rounds(h) + 1;
+  const size_t need = (size_t)steps * a.lstride;
+  if (h->nlist_len < need) {
+    int* p = nullptr;
+    HIPCHECK(hipMalloc((void**)&p, sizeof(int) * need));
+    h->allocs.push_back(p);
+    a.nlist = p;
+    h->nlist_len = need;
+  }
+  HIPCHECK(hipMemsetAsync(a.nlist, 0, sizeof(int) * need, h->stream));
+  return TO_OK;
+}
 // forward pass = line-search rounds of (concurrent candidates, select).  The first round evaluates the T1 largest step
 // sizes for every trajectory; the trajectories that rejected all of them are few, so the following rounds take up to T
 // step sizes at once (dead tiles leave immediately).
@@ -359,6 +382,7 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
     h->counter_len = max_steps;
   }
   HIPCHECK(hipMemsetAsync(a.counter, 0, sizeof(int) * max_steps, h->stream));
+  TRY(ensure_nlist(h, max_steps));
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
@@ -563,7 +587,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->T1 = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
   if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) h->T1 = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
   // later rounds: whatever remains of the default search depth, at once (only the few trajectories still searching take part)
-  a.T = std::max(h->T1, std::min(16, std::max(1, P.opts.iterations_linesearch - h->T1)));
+  a.T = std::max(h->T1, std::min(20, std::max(1, P.opts.iterations_linesearch - h->T1)));
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
@@ -572,6 +596,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.candOk, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.ls_round, Bp));
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
+  TRYB(dev_alloc(h, &a.list, Bp));
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
   TRYB(dev_alloc(h, &a.knotbuf, (size_t)N * Bp));
   TRYB(dev_alloc(h, &a.mu_next, (size_t)std::max<size_t>(1, cons.size()) * Bp));
@@ -757,6 +782,8 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
   // keep bpfail from a preceding to_backward: set active without clearing it
   TRY(launch_cost(h, 1, h->a.J, nullptr));
   TRY(launch_set_active(h, 1, 2));
+  h->a.step = 0;
+  TRY(ensure_nlist(h, 1));
   TRY(launch_forward(h));
   TRY(download_int(h, ls_index, h->a.ls_index));
   TRY(download_scalar(h, J_new, h->a.Jout));
