@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (vector FP64; tools/fp64_issue_probe measures 65)
 
 WORKLOADS = {
     # name: (builder kwargs, description)
@@ -66,15 +67,17 @@ def pmc_traffic(name, batch, phase):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_b%d_hbm_traffic_pmc.json" % (name, batch))))
     if not files:
-        return None, None
+        return None, None, None
     with open(files[-1]) as f:
         tab = json.load(f)
     steps = sum(v["launches"] for k, v in tab.items() if "k_expand" in k)
-    total = sum(v["hbm_bytes_per_launch_fetch_x2"] * v["launches"] for k, v in tab.items()
-                if ("k_" + phase) in k or (phase == "forward" and "k_select" in k))
+    mine = [v for k, v in tab.items() if ("k_" + phase) in k
+            or (phase == "forward" and any(s in k for s in ("k_select", "k_accept", "k_outer")))]
+    total = sum(v["hbm_bytes_per_launch_fetch_x2"] * v["launches"] for v in mine)
     if steps == 0 or total == 0:
-        return None, None
-    return total / steps, os.path.relpath(files[-1], ROOT)
+        return None, None, None
+    flops = sum(v.get("fp64_flops_per_launch", 0.0) * v["launches"] for v in mine) / steps
+    return total / steps, os.path.relpath(files[-1], ROOT), (flops or None)
 
 
 def kernel_split_bytes(n, m, ne, N, duals):
@@ -207,11 +210,16 @@ def main():
             # a launch processes, on average, (trajectory-iterations of this rank) / launches units
             units_per_launch = iters / kern[dom]["launches"]
             achieved = split[dom] * units_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            traffic, traffic_src = pmc_traffic(name, batch, dom)
+            traffic, traffic_src, flops = pmc_traffic(name, batch, dom)
             roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_unit": split[dom], "units_per_launch": units_per_launch,
                     "avg_launch_us": kern[dom]["avg_us"], "kernels": kern,
+                    # what actually bounds these kernels: FP64 vector issue / dependency latency
+                    "fp64_valu": None if not flops else {
+                        "flops_per_launch": flops, "achieved_tflops": flops / (kern[dom]["avg_us"] * 1e-6) / 1e12,
+                        "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                        "frac": flops / (kern[dom]["avg_us"] * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS},
                     "whole_iteration": {"algorithmic_bytes_per_unit": bytes_it,
                                         "achieved": bytes_it * value / world / 1e9,
                                         "frac": bytes_it * value / world / 1e9 / HBM_PEAK_GBS}}

@@ -32,14 +32,20 @@ def main(out, paths):
         e = {}
         fetch = write = 0.0
         for c, (tot, n) in ctr.items():
-            e[c + "_KB_per_launch"] = tot / n
             e["launches"] = n
+            if c not in ("FETCH_SIZE", "WRITE_SIZE"):
+                e[c + "_per_launch"] = tot / n
+                continue
+            e[c + "_KB_per_launch"] = tot / n
             if c == "FETCH_SIZE":
                 fetch = tot / n * 1024.0
             if c == "WRITE_SIZE":
                 write = tot / n * 1024.0
         e["hbm_bytes_per_launch_raw"] = fetch + write
         e["hbm_bytes_per_launch_fetch_x2"] = 2.0 * fetch + write
+        if "SQ_INSTS_VALU_FMA_F64_per_launch" in e:  # wave-level FP64 instructions -> flops (64 lanes, FMA = 2)
+            e["fp64_flops_per_launch"] = 64.0 * (2.0 * e["SQ_INSTS_VALU_FMA_F64_per_launch"] + e.get("SQ_INSTS_VALU_ADD_F64_per_launch", 0.0)
+                                                 + e.get("SQ_INSTS_VALU_MUL_F64_per_launch", 0.0) + e.get("SQ_INSTS_VALU_TRANS_F64_per_launch", 0.0))
         res[k] = e
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
