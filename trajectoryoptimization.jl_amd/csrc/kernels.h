@@ -157,7 +157,7 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int la
 }
 
 // ------------------------------------------------------------------------------------------------ rollout!
-template <class M>
+template <class M, int FIXED_INTEG>
 __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:334-340 — open-loop simulate from x0
   constexpr int n = M::n, m = M::m;
   TILE_LANE();
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:33
   for (int k = 0; k < P.N - 1; ++k) {
 #pragma unroll
     for (int i = 0; i < m; ++i) u[i] = EL(U, k * m + i);
-    rk_step<M, double>(P.mp, P.integrator, x, u, P.dt[k], xn);
+    rk_step<M, double, FIXED_INTEG>(P.mp, P.integrator, x, u, P.dt[k], xn);
 #pragma unroll
     for (int i = 0; i < n; ++i) { x[i] = xn[i]; EL(X, (k + 1) * n + i) = x[i]; }
   }
@@ -250,7 +250,7 @@ struct Coop {
 //   [Ā B̄][:,j] = G(x_{k+1})ᵀ · ∂(RK step)/∂z · v_j            (forward-mode dual through all RK stages)
 //   H[:,j]      = projected Hessian-vector product of (cost + AL) with v_j,   g[j] = projected gradient component
 // with v_j = [G(x_k) e_j; 0] (j<ne) or [0; e_{j-ne}].
-template <class M>
+template <class M, int FIXED_INTEG>
 __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
   constexpr int R = Coop<M>::R, G = Coop<M>::G;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
     for (int i = 0; i < n; ++i) xd[i] = Dual(x[i], v[i]);
 #pragma unroll
     for (int i = 0; i < m; ++i) ud[i] = Dual(u[i], v[n + i]);
-    rk_step<M, Dual>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+    rk_step<M, Dual, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
     double x1[n], t[n], col[ne];
 #pragma unroll
     for (int i = 0; i < n; ++i) { x1[i] = EL(X, (k + 1) * n + i); t[i] = xn[i].d; }
@@ -632,7 +632,8 @@ struct FwdKnot {  // nominal state/control and gains of one knot, fetched one kn
 // its cost and gradient metric.  grid = (tiles, T): every step size of the round is evaluated
 // CONCURRENTLY by its own wave — a sequential backtracking search would cost (deepest search in the batch) x one
 // rollout per iteration, while the machine idles.
-// MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms).
+// MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms);
+// bit2: RK4 fixed at compile time.
 template <class M, int MODE>
 __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne;
@@ -710,7 +711,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
     if (dt_scaling) Jk *= h;
     if constexpr (CONS) Jk += knot_al<M>(P, k, xb, ub, lam0, mu0);
     J += Jk;
-    rk_step<M, double>(mp, integrator, xb, ub, h, xn);
+    rk_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, xb, ub, h, xn);
     double mx = 0.0, mu_ = 0.0;
 #pragma unroll
     for (int i = 0; i < n; ++i) { xb[i] = xn[i]; if (live) EL(Xn, (k + 1) * n + i) = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }

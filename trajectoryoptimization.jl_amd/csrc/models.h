@@ -98,6 +98,7 @@ template <int D>
 struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr int n = 2 * D, m = D, ne = 2 * D;
   static constexpr bool lie = false;
+  static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double inv_mass = rcp_fast(P[0]);
@@ -112,6 +113,7 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
 struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr int n = 4, m = 1, ne = 4;
   static constexpr bool lie = false;
+  static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mc = P[0], mp = P[1], l = P[2], g = P[3];
@@ -139,6 +141,7 @@ struct CartpoleModel {  // docs/src/model.md:34-50
 struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3) q(w,x,y,z) v(3) ω(3)]
   static constexpr int n = 13, m = 4, ne = 12;
   static constexpr bool lie = true;
+  static constexpr bool pin_rk4 = false;  // compile-time RK4 costs registers here: measured slower than the runtime switch
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mass = P[0], J1 = P[1], J2 = P[2], J3 = P[3];
@@ -179,8 +182,11 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
 // ------------------------------------------------------------------------------------------------
 enum { INTEG_RK4 = 0, INTEG_RK3 = 1, INTEG_EULER = 2 };
 
-template <class M, class T>
-__device__ __forceinline__ void rk_step(const double* P, int integrator, const T* x, const T* u, double h, T* xn) {
+// FIXED >= 0 pins the scheme at compile time: with a runtime switch the compiler merges the three schemes into one loop
+// full of selects (the Cartpole rollout loop was 857 instructions per knot, 300 of them FP64).
+template <class M, class T, int FIXED = -1>
+__device__ __forceinline__ void rk_step(const double* P, int integrator_rt, const T* x, const T* u, double h, T* xn) {
+  const int integrator = FIXED >= 0 ? FIXED : integrator_rt;
   // Stage slopes are folded into a running sum as they are produced (same left-to-right order as
   // x + (k1 + 2k2 + 2k3 + k4)/6), so only {x, xt, k, acc} are live instead of {x, xt, k1..k4}: for the Quadrotor in
   // dual numbers that is the difference between fitting the register file and spilling.

@@ -280,7 +280,8 @@ int launch_set_active(to_handle* h, int v, int clear_bpfail = 1) {
   return TO_OK;
 }
 int launch_rollout(to_handle* h) {
-  DISPATCH(h, hipLaunchKernelGGL(k_rollout<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
+  if (h->a.P.integrator == INTEG_RK4) { DISPATCH(h, hipLaunchKernelGGL((k_rollout<M, M::pin_rk4 ? INTEG_RK4 : -1>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a)); }
+  else { DISPATCH(h, hipLaunchKernelGGL((k_rollout<M, -1>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a)); }
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
@@ -291,7 +292,8 @@ int launch_cost(to_handle* h, int with_al, double* out, double* Jk) {
 }
 int launch_expand(to_handle* h) {
   const DevProblem& P = h->a.P;
-  DISPATCH(h, hipLaunchKernelGGL(k_expand<M>, dim3((P.B + h->G - 1) / h->G, P.N), dim3(BLOCK), 0, h->stream, h->a));
+  if (P.integrator == INTEG_RK4) { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, M::pin_rk4 ? INTEG_RK4 : -1>), dim3((P.B + h->G - 1) / h->G, P.N), dim3(BLOCK), 0, h->stream, h->a)); }
+  else { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, -1>), dim3((P.B + h->G - 1) / h->G, P.N), dim3(BLOCK), 0, h->stream, h->a)); }
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
@@ -328,7 +330,7 @@ int ensure_nlist(to_handle* h, int steps) {
 int launch_forward(to_handle* h) {
   KArgs& a = h->a;
   const int total = std::max(1, a.P.opts.iterations_linesearch);
-  const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0);
+  const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0);
   int r = 0;
   for (int c0 = 0; c0 < total; ++r) {
     a.round = r;
@@ -338,7 +340,11 @@ int launch_forward(to_handle* h) {
       case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      default: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 3: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 4: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 4 : 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 5: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 5 : 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 6: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 6 : 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 7: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 7 : 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
     }
     HIPCHECK(hipGetLastError());
     DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
