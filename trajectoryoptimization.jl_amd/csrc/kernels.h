@@ -250,7 +250,9 @@ struct Coop {
 //   [Ā B̄][:,j] = G(x_{k+1})ᵀ · ∂(RK step)/∂z · v_j            (forward-mode dual through all RK stages)
 //   H[:,j]      = projected Hessian-vector product of (cost + AL) with v_j,   g[j] = projected gradient component
 // with v_j = [G(x_k) e_j; 0] (j<ne) or [0; e_{j-ne}].
-template <class M, int FIXED_INTEG>
+// VAR bit0: dense QuadraticCost possible; bit1: constraints present; bit2: non-selector constraints possible.  Code the
+// problem cannot reach is compiled out: the all-purpose Quadrotor kernel needed 256 VGPRs + 140 AGPRs + 480 B of scratch.
+template <class M, int FIXED_INTEG, int VAR>
 __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
   constexpr int R = Coop<M>::R, G = Coop<M>::G;
@@ -302,13 +304,13 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   }
   // ---- cost (+AL) gradient and Hessian-vector product on the full state
   double gr[nz], y[nz];
-  cost_grad_hvp<n, m>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
+  cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
   if (P.opts.cost_dt_scaling && !terminal) {
     const double h = P.dt[k];
 #pragma unroll
     for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
   }
-  if (P.n_cons > 0) {
+  if ((VAR & 2) != 0 && P.n_cons > 0) {
     double z[nz];
 #pragma unroll
     for (int i = 0; i < n; ++i) z[i] = x[i];
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-      al_grad_hvp<n, m>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
+      al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
     }
   }
   double col[ne], qxe[ne];

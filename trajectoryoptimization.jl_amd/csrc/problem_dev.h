@@ -35,6 +35,7 @@ typedef const int TO_CONST_AS IntC;
 
 struct DevProblem {
   int n, m, ne, N, B, Bp, integrator, n_costs, n_cons;
+  int expand_variant;  // bit0: a dense QuadraticCost exists; bit1: constraints exist; bit2: a non-selector constraint exists
   int simple_stage;  // 1: every stage knot (k < N-1) uses the same diagonal-kind cost and the same dt (the common LQR-style objective)
   long long n_duals;
   double mp[16];
@@ -177,10 +178,11 @@ struct StageCostDiag {
 };
 
 // gradient g (n+m) and Hessian-vector product y = H v (n+m) of the cost at (x,u); u-parts zero if terminal
-template <int n, int m>
+// DENSE = false compiles the QuadraticCost (full Q, R, H) branches out.
+template <int n, int m, bool DENSE = true>
 __device__ __forceinline__ void cost_grad_hvp(CostC& C, const double* x, const double* u, bool terminal,
                                               const double* v, double* g, double* y) {
-  if (C.kind == TO_COST_QUADRATIC) {
+  if (DENSE && C.kind == TO_COST_QUADRATIC) {
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       double t = C.q[i], h = 0.0;
@@ -211,7 +213,7 @@ __device__ __forceinline__ void cost_grad_hvp(CostC& C, const double* x, const d
 #pragma unroll
   for (int i = 0; i < m; ++i) { g[n + i] = 0.0; y[n + i] = 0.0; }
   if (!terminal) {
-    if (C.kind == TO_COST_QUADRATIC) {
+    if (DENSE && C.kind == TO_COST_QUADRATIC) {
 #pragma unroll
       for (int i = 0; i < m; ++i) {
         double t = C.r[i], h = 0.0;
@@ -352,7 +354,8 @@ __device__ __forceinline__ double al_term(ConC& K, const double* z, const double
 // adds the AL gradient (g += ∇c' y) and Gauss-Newton Hessian-vector product (y += ∇c' W ∇c v) of one constraint.
 // For the SOC the reference composes ∇Π'∇Π + ∇²Π[Π] (src/cones.jl); since ∇(½|Π(x)|²) = Π(x) this equals ∇Π(x), and
 // ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
-template <int n, int m>
+// GENERIC = false compiles the non-selector constraint kinds (circle, sphere, linear, quadratic-form norm) out.
+template <int n, int m, bool GENERIC = true>
 __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const double* lam, size_t stride, double mu,
                                             const double* v, double* g, double* y) {
   constexpr int nz = n + m;
@@ -386,7 +389,7 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
       zadd<nz>(g, idx, sg * (l + (active ? mu * c : 0.0)));
       zadd<nz>(y, idx, active ? mu * zget<nz>(v, idx) : 0.0);
     });
-  } else {
+  } else if constexpr (GENERIC) {
     double coef[nz];
     for (int r = 0; r < p; ++r) {
       const double l = lam[r * stride], c = con_row<nz>(K, z, r, coef);

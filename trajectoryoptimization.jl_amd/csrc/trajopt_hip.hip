@@ -268,6 +268,18 @@ int download_int(to_handle* h, int32_t* host, const int* d) {
 }
 
 int upload_tables(to_handle* h) {
+  {  // kernel-variant flags derived from the tables (refreshed whenever a cost or constraint is replaced)
+    DevProblem& P = h->a.P;
+    const int N = P.N;
+    // simple_stage: one diagonal-kind cost on every stage knot and a uniform dt
+    bool simple = h->costs[h->cost_index[0]].kind != TO_COST_QUADRATIC;
+    for (int k = 1; k < N - 1; ++k) simple = simple && h->cost_index[k] == h->cost_index[0] && h->dt[k] == h->dt[0];
+    P.simple_stage = simple ? 1 : 0;
+    bool dense = false, generic = false;
+    for (const auto& c : h->costs) dense = dense || c.kind == TO_COST_QUADRATIC;
+    for (const auto& c : h->cons) generic = generic || !c.selector;
+    P.expand_variant = (dense ? 1 : 0) | (h->cons.empty() ? 0 : 2) | (generic ? 4 : 0);
+  }
   HIPCHECK(hipMemcpyAsync(h->d_costs, h->costs.data(), h->costs.size() * sizeof(to_cost_desc), hipMemcpyHostToDevice, h->stream));
   if (!h->cons.empty()) HIPCHECK(hipMemcpyAsync(h->d_cons, h->cons.data(), h->cons.size() * sizeof(DevCon), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -292,8 +304,18 @@ int launch_cost(to_handle* h, int with_al, double* out, double* Jk) {
 }
 int launch_expand(to_handle* h) {
   const DevProblem& P = h->a.P;
-  if (P.integrator == INTEG_RK4) { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, M::pin_rk4 ? INTEG_RK4 : -1>), dim3((P.B + h->G - 1) / h->G, P.N), dim3(BLOCK), 0, h->stream, h->a)); }
-  else { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, -1>), dim3((P.B + h->G - 1) / h->G, P.N), dim3(BLOCK), 0, h->stream, h->a)); }
+  const dim3 grid((P.B + h->G - 1) / h->G, P.N);
+  // variants compiled: 0 = diagonal-kind costs, no constraints; 2 = + selector / SOC-selector constraints; 7 = everything
+  const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
+#define EXPAND_LAUNCH(FI)                                                                                          \
+  switch (var) {                                                                                                   \
+    case 0: { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, FI, 0>), grid, dim3(BLOCK), 0, h->stream, h->a)); } break; \
+    case 2: { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, FI, 2>), grid, dim3(BLOCK), 0, h->stream, h->a)); } break; \
+    default: { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, FI, 7>), grid, dim3(BLOCK), 0, h->stream, h->a)); } break; \
+  }
+  if (P.integrator == INTEG_RK4) { EXPAND_LAUNCH((M::pin_rk4 ? INTEG_RK4 : -1)); }
+  else { EXPAND_LAUNCH(-1); }
+#undef EXPAND_LAUNCH
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
@@ -573,11 +595,6 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   P.integrator = desc->integrator; P.n_costs = desc->n_costs; P.n_cons = (int)cons.size(); P.n_duals = n_duals;
   std::memcpy(P.mp, desc->model_params, sizeof(P.mp));
   if (opts) P.opts = *opts; else default_opts(&P.opts);
-  {  // simple_stage: one diagonal-kind cost on every stage knot and a uniform dt
-    bool simple = h->costs[cost_index[0]].kind != TO_COST_QUADRATIC;
-    for (int k = 1; k < N - 1; ++k) simple = simple && cost_index[k] == cost_index[0] && dt[k] == dt[0];
-    P.simple_stage = simple ? 1 : 0;
-  }
   const size_t Bp = P.Bp;
   TRYB(dev_alloc(h, &h->d_costs, h->costs.size()));
   TRYB(dev_alloc(h, &h->d_cons, cons.size()));
