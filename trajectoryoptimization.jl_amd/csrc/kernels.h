@@ -57,11 +57,12 @@ struct KArgs {
 // objective (+AL) value of one knot.  u must be zeros at the terminal knot (the reference evaluates the
 // terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).
 // lam0 / mu0: this lane's pointers to dual row 0 / penalty 0 (tiled arrays).
-template <class M>
+// GEN = false: no dense QuadraticCost and no non-selector constraint in the tables (those branches are compiled out)
+template <class M, bool GEN = true>
 __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
                                             const double* mu0, bool with_al) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  double Jk = cost_eval<n, m>(P.costs[P.cost_index[k]], x, u);
+  double Jk = cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], x, u);
   if (P.opts.cost_dt_scaling && k < P.N - 1) Jk *= P.dt[k];
   if (with_al && P.n_cons > 0) {
     double z[nz];
@@ -74,7 +75,7 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-      Ja += al_term<n, m>(K, z, lam, (size_t)64, EL(mu0, ci));
+      Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
     }
     Jk += Ja;
   }
@@ -82,7 +83,7 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
 }
 
 // AL penalty terms of one knot only
-template <class M>
+template <class M, bool GEN = true>
 __device__ __forceinline__ double knot_al(const DevProblem& P, int k, const double* x, const double* u, const double* lam0, const double* mu0) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   double z[nz];
@@ -95,7 +96,7 @@ __device__ __forceinline__ double knot_al(const DevProblem& P, int k, const doub
     ConC& K = P.cons[ci];
     if (k < K.k1 || k > K.k2) continue;
     const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-    Ja += al_term<n, m>(K, z, lam, (size_t)64, EL(mu0, ci));
+    Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
   }
   return Ja;
 }
@@ -635,11 +636,11 @@ struct FwdKnot {  // nominal state/control and gains of one knot, fetched one kn
 // CONCURRENTLY by its own wave — a sequential backtracking search would cost (deepest search in the batch) x one
 // rollout per iteration, while the machine idles.
 // MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms);
-// bit2: RK4 fixed at compile time.
+// bit2: RK4 fixed at compile time; bit3: dense costs / non-selector constraints possible (else compiled out).
 template <class M, int MODE>
 __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne;
-  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0;
+  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0;
   const DevProblem& P = a.P;
   const int t = blockIdx.y;
   const int idx = a.cand0 + t;
@@ -709,9 +710,9 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
     }
     gsum += gk;
     const double h = SIMPLE ? h0 : P.dt[k];
-    double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m>(P.costs[P.cost_index[k]], xb, ub);
+    double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], xb, ub);
     if (dt_scaling) Jk *= h;
-    if constexpr (CONS) Jk += knot_al<M>(P, k, xb, ub, lam0, mu0);
+    if constexpr (CONS) Jk += knot_al<M, GEN>(P, k, xb, ub, lam0, mu0);
     J += Jk;
     rk_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, xb, ub, h, xn);
     double mx = 0.0, mu_ = 0.0;
@@ -728,7 +729,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
     double u0[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
-    J += knot_cost<M>(P, N - 1, xb, u0, lam0, mu0, true);
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true);
   }
   if (!live) return;
   const size_t ci = (size_t)t * P.Bp + b;

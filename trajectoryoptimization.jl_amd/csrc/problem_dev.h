@@ -81,10 +81,10 @@ __device__ __forceinline__ double quat_dot(const double* qref, const int* qind, 
 
 // ------------------------------------------------------------------------------------------------ costs
 // J = ½x'Qx + q'x + c (+ ½u'Ru + r'u whenever u is given) (+ u'Hx) (+ w·min(1±dq))
-template <int n, int m>
+template <int n, int m, bool DENSE = true>
 __device__ __forceinline__ double cost_eval(CostC& C, const double* x, const double* u) {
   double J;
-  if (C.kind == TO_COST_QUADRATIC) {
+  if (DENSE && C.kind == TO_COST_QUADRATIC) {
     double xQx = 0.0;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ double sel_row(ConC& K, const double* z, int r) {
 
 // AL penalty of one constraint at one knot.  lam: pointer to row 0 of this knot's duals
 // (batch-fastest: row r at lam[r*stride]).
-template <int n, int m>
+template <int n, int m, bool GENERIC = true>
 __device__ __forceinline__ double al_term(ConC& K, const double* z, const double* lam, size_t stride, double mu) {
   constexpr int nz = n + m;
   const int p = K.p;
@@ -340,7 +340,7 @@ __device__ __forceinline__ double al_term(ConC& K, const double* z, const double
       const bool active = eq || (c >= 0.0) || (l > 0.0);
       J += l * c + (active ? 0.5 * mu * c * c : 0.0);
     });
-  } else {
+  } else if constexpr (GENERIC) {
     double coef[nz];
     for (int r = 0; r < p; ++r) {
       const double l = lam[r * stride], c = con_row<nz>(K, z, r, coef);

@@ -352,7 +352,8 @@ int ensure_nlist(to_handle* h, int steps) {
 int launch_forward(to_handle* h) {
   KArgs& a = h->a;
   const int total = std::max(1, a.P.opts.iterations_linesearch);
-  const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0);
+  const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) |
+                   ((a.P.expand_variant & 5) ? 8 : 0);
   int r = 0;
   for (int c0 = 0; c0 < total; ++r) {
     a.round = r;
@@ -367,6 +368,14 @@ int launch_forward(to_handle* h) {
       case 5: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 5 : 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 6: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 6 : 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 7: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 7 : 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 8: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 8>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 9: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 9>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 10: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 10>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 11: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 11>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 12: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 12 : 8>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 13: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 13 : 9>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 14: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 14 : 10>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 15: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 15 : 11>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
     }
     HIPCHECK(hipGetLastError());
     DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
