@@ -324,11 +324,21 @@ int launch_backward(to_handle* h) {
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
+// Width of line-search round r starting at step size c0.  Round 0 takes T1 step sizes for every trajectory.  With a
+// wide first round (latency regime, few tiles) the rejecting trajectories are few and the next round takes everything
+// that is left; with a narrow one (throughput regime) many trajectories are still searching, so the widths grow
+// geometrically (T1, T1, 2 T1, ...) instead of spending 18 rollouts on trajectories that accept the third step size.
+int round_width(const to_handle* h, int r, int c0, int total) {
+  const int T1 = h->T1, Tmax = h->a.T;
+  if (r == 0) return std::min(total - c0, T1);
+  if (T1 >= 8) return std::min(total - c0, Tmax);
+  return std::min({total - c0, Tmax, T1 << std::min(r - 1, 8)});
+}
 // number of line-search rounds launch_forward issues
 int ls_rounds(const to_handle* h) {
   const int total = std::max(1, h->a.P.opts.iterations_linesearch);
   int r = 0;
-  for (int c0 = 0; c0 < total; ++r) c0 += std::min(total - c0, r == 0 ? h->T1 : h->a.T);
+  for (int c0 = 0; c0 < total; ++r) c0 += round_width(h, r, c0, total);
   return r;
 }
 // zeroed (batch step, round) counters of the compacted line-search lists
@@ -358,7 +368,7 @@ int launch_forward(to_handle* h) {
   for (int c0 = 0; c0 < total; ++r) {
     a.round = r;
     a.cand0 = c0;
-    a.Tr = std::min(total - c0, r == 0 ? h->T1 : a.T);
+    a.Tr = round_width(h, r, c0, total);
     switch (mode) {
       case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
