@@ -614,10 +614,10 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward pass
-template <class M>
+template <class M, bool WITHK>
 struct FwdKnot {  // nominal state/control and gains of one knot, fetched one knot ahead of their use
   static constexpr int n = M::n, m = M::m, ne = M::ne;
-  double x[n], u[m], K[m][ne], d[m];
+  double x[n], u[m], K[WITHK ? m : 1][WITHK ? ne : 1], d[m];
   __device__ __forceinline__ void load(const double* pX, const double* pU, const double* pK, const double* pd, int k) {
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = EL(pX, k * n + i);
@@ -625,11 +625,28 @@ struct FwdKnot {  // nominal state/control and gains of one knot, fetched one kn
     for (int j = 0; j < m; ++j) {
       u[j] = EL(pU, k * m + j);
       d[j] = EL(pd, k * m + j);
+      if constexpr (WITHK) {
 #pragma unroll
-      for (int i = 0; i < ne; ++i) K[j][i] = EL(pK, (k * m + j) * ne + i);
+        for (int i = 0; i < ne; ++i) K[j][i] = EL(pK, (k * m + j) * ne + i);
+      }
     }
   }
 };
+
+// Gains of one knot, global -> LDS by DMA (global_load_lds_dwordx4: no staging registers, the wave keeps computing).
+// The m*ne rows of a knot are contiguous in a tile (512 B each); one instruction moves two rows: lane L fetches 16 B at
+// rows + 16 L and the hardware writes them at kbuf + 16 L.  ktile = this tile's K base (wave-uniform).
+template <class M>
+__device__ __forceinline__ void stage_gains(const double* ktile, int k, double* kbuf, int lane) {
+  constexpr int rows = M::m * M::ne;
+  static_assert(rows % 2 == 0, "two 512-byte rows per DMA instruction");
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const char* src = (const char*)(ktile + (size_t)k * rows * 64) + lane * 16;
+#pragma unroll
+  for (int r2 = 0; r2 < rows / 2; ++r2)
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + r2 * 1024), (lptr_t)((char*)kbuf + r2 * 1024), 16, 0, 0);
+}
 
 // Line-search candidate: closed-loop rollout with step alpha = decrease^(round*T + t) of trajectory b into slot t+1,
 // its cost and gradient metric.  grid = (tiles, T): every step size of the round is evaluated
@@ -640,7 +657,9 @@ struct FwdKnot {  // nominal state/control and gains of one knot, fetched one kn
 template <class M, int MODE>
 __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne;
-  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0;
+  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0, LISTED = (MODE & 16) != 0;
+  constexpr bool KLDS = M::lds_gains && !LISTED;  // gains staged through LDS by DMA instead of prefetch registers
+  __shared__ double kbuf[KLDS ? m * ne * 64 : 1];
   const DevProblem& P = a.P;
   const int t = blockIdx.y;
   const int idx = a.cand0 + t;
@@ -651,7 +670,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   // waves instead of one per tile that still holds a searching trajectory).
   int b = blockIdx.x * 64 + threadIdx.x;
   bool listed = true;
-  if (a.round > 0) {
+  if constexpr (LISTED) {
     const int cnt = a.nlist[a.step * a.lstride + a.round];
     if ((int)blockIdx.x * 64 >= cnt) return;
     listed = b < cnt;
@@ -691,20 +710,30 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < n; ++i) { xb[i] = EL(px0, i); if (live) EL(Xn, i) = xb[i]; }
-  FwdKnot<M> nxt;
+  const double* ktile = a.K + ((size_t)tile * ((N - 1) * m * ne)) * 64;
+  if constexpr (KLDS) stage_gains<M>(ktile, 0, kbuf, lane);
+  FwdKnot<M, !KLDS> nxt;
   nxt.load(Xc, Uc, pK, pd, 0);
   for (int k = 0; k < N - 1; ++k) {
-    const FwdKnot<M> cur = nxt;
+    const FwdKnot<M, !KLDS> cur = nxt;
     if (k + 1 < N - 1) nxt.load(Xc, Uc, pK, pd, k + 1);  // software prefetch of the next knot
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
-    double gk = 0.0;
+    if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this knot's gains have landed in LDS
+    double gk = 0.0, du[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) {
-      double du = cur.d[j] * alpha;
+      du[j] = cur.d[j] * alpha;
 #pragma unroll
-      for (int i = 0; i < ne; ++i) du += cur.K[j][i] * dx[i];
-      ub[j] = cur.u[j] + du;
+      for (int i = 0; i < ne; ++i) du[j] += (KLDS ? kbuf[(j * ne + i) * 64 + lane] : cur.K[KLDS ? 0 : j][KLDS ? 0 : i]) * dx[i];
+    }
+    if constexpr (KLDS) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read the buffer before the DMA refills it
+      if (k + 1 < N - 1) stage_gains<M>(ktile, k + 1, kbuf, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      ub[j] = cur.u[j] + du[j];
       if (live) EL(Un, k * m + j) = ub[j];
       gk = fmax(gk, fabs(cur.d[j]) * rcp_fast(fabs(ub[j]) + 1.0));
     }

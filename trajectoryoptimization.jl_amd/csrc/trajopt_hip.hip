@@ -369,7 +369,8 @@ int launch_forward(to_handle* h) {
     a.round = r;
     a.cand0 = c0;
     a.Tr = round_width(h, r, c0, total);
-    switch (mode) {
+    // bit4: rounds after the first work on the compacted list (gathered lanes)
+    switch (mode | (r > 0 ? 16 : 0)) {
       case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
@@ -386,6 +387,22 @@ int launch_forward(to_handle* h) {
       case 13: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 13 : 9>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 14: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 14 : 10>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
       case 15: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 15 : 11>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 16: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 16>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 17: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 17>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 18: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 18>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 19: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 19>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 20: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 20 : 16>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 21: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 21 : 17>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 22: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 22 : 18>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 23: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 23 : 19>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 24: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 24>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 25: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 25>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 26: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 26>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 27: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 27>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 28: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 28 : 24>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 29: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 29 : 25>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 30: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 30 : 26>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
+      case 31: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 31 : 27>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
     }
     HIPCHECK(hipGetLastError());
     DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
