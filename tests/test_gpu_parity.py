@@ -311,6 +311,54 @@ def test_resolve_after_goal_change(hip, oracle):
     assert_solve_parity(sh, so, ph, po, rtol=1e-5)
 
 
+@pytest.mark.parametrize("t1", [1, 3])
+def test_line_search_round_schedule(t1, hip, oracle, monkeypatch):
+    """The concurrent line search must equal sequential backtracking for ANY round schedule: with a first round of 1
+    or 3 step sizes the later rounds run on the compacted list with geometrically growing widths (throughput regime)."""
+    monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", str(t1))
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=96, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=40, constrained=True, **kw), hip, oracle)
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
+@pytest.mark.parametrize("depth", [1, 7, 33])
+def test_line_search_depth_option(depth, hip, oracle):
+    """iterations_linesearch other than the default 20 (fewer than one round, more than the candidate slots)."""
+    def build(lib):
+        o = T.SolverOptions(lib=lib, iterations_linesearch=depth, iterations=60)
+        return configs.cartpole_problem(batch=48, lib=lib, options=o)
+    ph, po = build(hip), build(oracle)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
+def test_cost_kind_replaced_after_creation(hip, oracle):
+    """set_cost switching a diagonal cost to a dense QuadraticCost must re-select the kernel variants (the diagonal-only
+    expansion / forward kernels compile the dense branches out)."""
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=16, N=31, tf=1.5, **kw), hip, oracle)
+    rng = np.random.default_rng(5)
+    n, m = ph.n, ph.m
+    A = rng.standard_normal((n, n)); Q = A @ A.T + np.eye(n)
+    R = np.array([[0.3]]); H = 0.05 * rng.standard_normal((m, n))
+    dense = T.QuadraticCost(Q, R, H=H, q=rng.standard_normal(n) * 0.1, r=np.array([0.02]), c=0.5)
+    import ctypes as C
+    for p in (ph, po):
+        d = dense._desc()
+        p._call("set_cost", 0, C.byref(d))  # cost 0 = the stage cost of Objective(stage, terminal, N)
+    perturb_controls((ph, po), 0.05)
+    T.rollout(ph); T.rollout(po)
+    np.testing.assert_allclose(T.cost(ph), T.cost(po), rtol=1e-12)
+    I.expand(ph); I.expand(po)
+    Eh, Eo = I.cost_expansion(ph), I.cost_expansion(po)
+    for key in Eo:
+        np.testing.assert_allclose(Eh[key], Eo[key], rtol=1e-9, atol=1e-10, err_msg=key)
+    sh, so = T.iLQRSolver(ph, iterations=30).solve(), T.iLQRSolver(po, iterations=30).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
 def test_error_paths_on_device(hip):
     with pytest.raises(T.capi.ConeError):
         T.projection(T.SecondOrderCone(), np.array([np.nan, 1.0, 1.0]), lib=hip)
