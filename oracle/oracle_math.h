@@ -523,6 +523,7 @@ inline int constraint_output_dim(const to_constraint_desc& K, int n, int m) {
     case TO_CON_CIRCLE: return K.n_params / 3;
     case TO_CON_SPHERE: return K.n_params / 4;
     case TO_CON_LINEAR: return K.n_params / (K.n_inds + 1);
+    case TO_CON_COLLISION: return 1;
   }
   return -1;
 }
@@ -586,10 +587,23 @@ inline void constraint_evaluate(const to_constraint_desc& K, int n, int m, const
       }
       return;
     }
+    case TO_CON_COLLISION: { /* :362-387: r^2 - d'd with d = x[x1] - x[x2]; Jacobian entries are ASSIGNED (x1 first) */
+      const int D = K.n_inds / 2;
+      c[0] = K.params[0] * K.params[0];
+      for (int i = 0; i < D; ++i) {
+        const int j1 = K.inds[i] - 1, j2 = K.inds[D + i] - 1;
+        const double d = z[j1] - z[j2];
+        c[0] -= d * d;
+        if (jac) { jac[j1] = -2 * d; jac[j2] = 2 * d; }
+      }
+      return;
+    }
   }
 }
 
-inline bool constraint_is_state_only(int kind) { return kind == TO_CON_GOAL || kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE; }
+inline bool constraint_is_state_only(int kind) {
+  return kind == TO_CON_GOAL || kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE || kind == TO_CON_COLLISION;
+}
 
 }  // namespace oracle
 #endif

@@ -140,6 +140,12 @@ int validate_constraint(const Problem& P, const to_constraint_desc& d, ConInfo* 
       if (d.n_inds < 1 || d.n_params % (d.n_inds + 1) != 0 || d.n_params == 0) return fail(TO_ERR_ASSERTION, "size(A,1) == length(b)");
       for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > nz) return fail(TO_ERR_DIMENSION_MISMATCH, "LinearConstraint index outside [x;u]");
       ci.width = nz; break;
+    case TO_CON_COLLISION:
+      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "CollisionConstraint sense must be Inequality");
+      if (d.n_inds < 2 || d.n_inds % 2 != 0) return fail(TO_ERR_ASSERTION, "Position dimensions must be of equal length"); /* src/constraints.jl:349 */
+      if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "CollisionConstraint needs one parameter (radius)");
+      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "CollisionConstraint index outside state");
+      ci.width = n; break;
     default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
   }
   ci.p = constraint_output_dim(d, n, m);

@@ -15,7 +15,7 @@ Mirrored reference API (file:line in /root/reference):
   cones        Equality/ZeroCone, Inequality/NegativeOrthant, SecondOrderCone, projection, ∇projection,
                ∇²projection, cone_status                           src/cones.jl
   constraints  GoalConstraint, BoundConstraint, NormConstraint, CircleConstraint, SphereConstraint,
-               LinearConstraint, ConstraintList, add_constraint!   src/constraints.jl, src/constraint_list.jl
+               CollisionConstraint, LinearConstraint, ConstraintList, add_constraint!   src/constraints.jl, src/constraint_list.jl
   problem      Problem, rollout!, cost, states, controls, initial_controls!, initial_states!,
                set_initial_state!, set_goal_state!, get_* getters   src/problem.jl
   solvers      iLQRSolver, ALSolver (=Altro's AL-iLQR), SolverOptions, solve!, iterations, status,
@@ -38,7 +38,7 @@ __all__ = [
     "Objective", "LQRObjective", "TrackingObjective",
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
     "projection", "grad_projection", "hess_projection", "cone_status", "dualcone",
-    "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint",
+    "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint", "CollisionConstraint",
     "LinearConstraint", "ConstraintList", "add_constraint", "num_constraints",
     "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
     "set_initial_state", "set_goal_state", "get_constraints", "get_objective", "get_model",
@@ -560,6 +560,24 @@ class SphereConstraint(AbstractConstraint):
 
     def _fill(self):
         return [self.xi, self.yi, self.zi], list(self.x) + list(self.y) + list(self.z) + list(self.radius)
+
+
+class CollisionConstraint(AbstractConstraint):
+    """‖x[x1] − x[x2]‖² ≥ r²  (pairwise non-self-collision, src/constraints.jl:332-393); c = r² − dᵀd, p = 1."""
+    kind = capi.CON_COLLISION
+    state_only = True
+
+    def __init__(self, n, x1, x2, radius):
+        self.n = int(n)
+        self.x1, self.x2 = [int(i) for i in x1], [int(i) for i in x2]
+        if len(self.x1) != len(self.x2):
+            raise AssertionError(f"Position dimensions must be of equal length, got {len(self.x1)} and {len(self.x2)}")
+        self.radius = float(radius)
+        self.p = 1
+        self._sense = Inequality()
+
+    def _fill(self):
+        return self.x1 + self.x2, [self.radius]
 
 
 class LinearConstraint(AbstractConstraint):

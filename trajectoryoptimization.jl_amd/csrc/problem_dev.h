@@ -275,6 +275,20 @@ __device__ __forceinline__ double con_row(ConC& K, const double* z, int r, doubl
       c -= d.params[p * d.n_inds + r];
       break;
     }
+    case TO_CON_COLLISION: {  // r² − |x[x1] − x[x2]|²; inds = [x1; x2]
+      const int D = d.n_inds / 2;
+      c = d.params[0] * d.params[0];
+#pragma unroll
+      for (int t = 0; t < nz; ++t) coef[t] = 0.0;
+#pragma unroll
+      for (int t = 0; t < nz / 2; ++t)
+        if (t < D) {
+          const double dd = pick<nz>(z, d.inds[t] - 1) - pick<nz>(z, d.inds[D + t] - 1);
+          c -= dd * dd;
+          add_at<nz>(coef, t, -2 * dd); add_at<nz>(coef, D + t, 2 * dd);
+        }
+      break;
+    }
     default: break;
   }
   return c;

@@ -166,6 +166,12 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
       for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > nz) return dimerr("LinearConstraint index outside [x;u]");
       ci.width = nz; p = d.n_params / (d.n_inds + 1);
       break;
+    case TO_CON_COLLISION:
+      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "CollisionConstraint sense must be Inequality");
+      if (d.n_inds < 2 || d.n_inds % 2 != 0) return fail(TO_ERR_ASSERTION, "Position dimensions must be of equal length"); /* src/constraints.jl:349 */
+      if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "CollisionConstraint needs one parameter (radius)");
+      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "CollisionConstraint index outside state");
+      ci.width = n; p = 1; break;
     default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
   }
   if (p < 1 || p > TO_MAX_P) return fail(TO_ERR_UNSUPPORTED, "constraint output dimension outside 1..TO_MAX_P");
