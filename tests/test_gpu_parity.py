@@ -360,6 +360,25 @@ def test_cost_kind_replaced_after_creation(hip, oracle):
     assert_solve_parity(sh, so, ph, po)
 
 
+def test_tracking_mpc_resolves(hip, oracle):
+    """MPC-style tracking: TrackingObjective + update_trajectory! between solves (src/objective.jl:185-212)."""
+    model = T.Cartpole(); n, m = model.dims(); N = 31
+    t = np.linspace(0, 1, 60)
+    Xref = np.stack([0.3 * np.sin(2 * t), 0.2 * t, 0.6 * np.cos(2 * t), 0.2 + 0 * t]); Uref = 0.1 * np.cos(3 * t)[None, :-1]
+    def build(lib):
+        obj = T.TrackingObjective(np.array([5.0, 5.0, 0.1, 0.1]), np.array([0.05]), Xref[:, :N], Uref[:, :N], Qf=np.full(n, 20.0))
+        p = T.Problem(model, obj, np.zeros(n), 1.5, batch=5, lib=lib)
+        p.set_initial_state(np.tile(Xref[:, 0], (5, 1)) + 0.5 * np.arange(5)[:, None] * np.array([1.0, 1.0, 0.0, 0.0]))
+        T.initial_controls(p, np.array([0.01]))
+        return p
+    ph, po = build(hip), build(oracle)
+    for start in (1, 9, 20):
+        for p in (ph, po):
+            T.update_trajectory(p, Xref, Uref, start=start)
+        sh, so = T.iLQRSolver(ph, iterations=40).solve(), T.iLQRSolver(po, iterations=40).solve()
+        assert_solve_parity(sh, so, ph, po)
+
+
 def test_error_paths_on_device(hip):
     with pytest.raises(T.capi.ConeError):
         T.projection(T.SecondOrderCone(), np.array([np.nan, 1.0, 1.0]), lib=hip)

@@ -275,3 +275,35 @@ def test_ilqr_on_lqr_problem_is_exact(oracle):
     for K, d in zip(reversed(Ks), reversed(ds)):
         u = K @ x + d; Uopt.append(u); x = Ad @ x + Bd @ u
     np.testing.assert_allclose(T.controls(prob)[0], np.array(Uopt), rtol=1e-9, atol=1e-11)
+
+
+def test_tracking_objective_and_update_trajectory(oracle):
+    """TrackingObjective / update_trajectory! (src/objective.jl:185-212): per-knot LQR costs following a reference;
+    retargeting moves q and r only (set_LQR_goal!, src/cost_functions.jl:249-258)."""
+    model = T.DoubleIntegrator(1.0, 2); n, m = model.dims(); N = 8
+    Nref = 14
+    Xref = rng.uniform(-1, 1, (n, Nref)); Uref = rng.uniform(-1, 1, (m, Nref - 1))
+    Q, R, Qf = np.array([1.0, 2.0, 0.5, 0.1]), np.array([0.3, 0.2]), np.array([10.0, 10.0, 1.0, 1.0])
+    obj = T.TrackingObjective(Q, R, Xref[:, :N], Uref[:, :N], Qf=Qf)
+    prob = T.Problem(model, obj, np.zeros(n), 1.4, batch=3, lib=oracle)
+    U = rng.uniform(-1, 1, (prob.B, N - 1, m)); T.initial_controls(prob, U); T.rollout(prob)
+    X = T.states(prob)
+
+    def expected(start):
+        J = np.zeros(prob.B)
+        for b in range(prob.B):
+            for k in range(N):
+                xr = Xref[:, start - 1 + k]
+                Qk = Qf if k == N - 1 else Q
+                # constants c stay those of the ORIGINAL reference (set_LQR_goal! does not touch c)
+                xo = Xref[:, k]
+                J[b] += 0.5 * X[b, k] @ (Qk * X[b, k]) - (Qk * xr) @ X[b, k] + 0.5 * xo @ (Qk * xo)
+                if k < N - 1:
+                    ur, uo = Uref[:, start - 1 + k], Uref[:, k]
+                    J[b] += 0.5 * U[b, k] @ (R * U[b, k]) - (R * ur) @ U[b, k] + 0.5 * uo @ (R * uo)
+        return J
+    np.testing.assert_allclose(T.cost(prob), expected(1), rtol=1e-12)
+    T.update_trajectory(prob, Xref, Uref, start=5)
+    np.testing.assert_allclose(T.cost(prob), expected(5), rtol=1e-12)
+    with pytest.raises(IndexError):
+        T.update_trajectory(prob, Xref, Uref, start=Nref)

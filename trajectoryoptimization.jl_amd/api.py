@@ -41,7 +41,7 @@ __all__ = [
     "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint", "CollisionConstraint",
     "LinearConstraint", "ConstraintList", "add_constraint", "num_constraints",
     "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
-    "set_initial_state", "set_goal_state", "get_constraints", "get_objective", "get_model",
+    "set_initial_state", "set_goal_state", "update_trajectory", "get_constraints", "get_objective", "get_model",
     "get_initial_state", "get_final_state", "get_trajectory", "gettimes",
     "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "solve", "iterations", "status", "max_violation",
     "evaluate_constraints", "constraint_jacobians", "sense", "upper_bound", "lower_bound", "is_bound",
@@ -933,6 +933,29 @@ def set_goal_state(prob, xf, objective=True, constraint=True):
                 d = con._desc(a, b)
                 prob._call("set_constraint", i, C.byref(d))
     prob.xf = xf.copy()
+
+
+def update_trajectory(prob, X, U, start=1):
+    """update_trajectory!(obj, Z, start)  (src/objective.jl:198-212): retarget a tracking objective (one cost per knot,
+    see TrackingObjective) to knots start..start+N-1 of the reference (X [n, Nref], U [m, >=Nref-1]); like
+    set_LQR_goal! it changes only q and r, never the constant c (src/cost_functions.jl:249-258)."""
+    X = np.asarray(X, dtype=np.float64)
+    U = np.asarray(U, dtype=np.float64)
+    costs = prob.obj.cost
+    if len(set(map(id, costs))) != prob.N:
+        raise ValueError("update_trajectory! needs a tracking objective (a distinct cost per knot)")
+    if start < 1 or start - 1 + prob.N > X.shape[1]:
+        raise IndexError("reference trajectory too short for this start index")
+    for i, c in enumerate(costs):
+        k = start - 1 + i
+        xf = _vec(X[:, k], prob.n, "xf")
+        uf = _vec(U[:, k], prob.m, "uf") if k < U.shape[1] else np.zeros(prob.m)
+        if c.kind == capi.COST_QUADRATIC:
+            c.q, c.r = -c.Q @ xf, -c.R @ uf
+        else:
+            c.q, c.r = -c.Q * xf, -c.R * uf
+        d = c._desc()
+        prob._call("set_cost", prob._cost_objs.index(c), C.byref(d))
 
 
 def evaluate_constraints(prob, i):
