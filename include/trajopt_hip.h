@@ -130,8 +130,10 @@ typedef enum {
   TO_CON_CIRCLE = 3,  /* CircleConstraint :168-233 sense Inequality; inds[0]=xi, inds[1]=yi; params = x[P], y[P], r[P]; p=P  */
   TO_CON_SPHERE = 4,  /* SphereConstraint :249-326 inds = xi,yi,zi; params = x[P], y[P], z[P], r[P]                          */
   TO_CON_LINEAR = 5,  /* LinearConstraint :103-150 params = A (p x D col-major), then b[p]; inds[D] into z; sense Eq/Ineq    */
-  TO_CON_COLLISION = 6 /* CollisionConstraint :332-393 sense Inequality; inds = [x1(D); x2(D)] state indices, params[0] = radius;
+  TO_CON_COLLISION = 6, /* CollisionConstraint :332-393 sense Inequality; inds = [x1(D); x2(D)] state indices, params[0] = radius;
                           c = r^2 - |x[x1] - x[x2]|^2, p = 1                                                                 */
+  TO_CON_QUATVEC = 7   /* QuatVecEq :938-965 sense Equality; inds[4] = quaternion indices (w,x,y,z), params[0..4) = qf (unit);
+                          c = vec(q/|q|) - sign(qf'q) vec(qf), p = 3; Jacobian = d/dq of the normalisation (ForwardDiff there) */
 } to_con_kind;
 
 typedef struct {

@@ -524,6 +524,7 @@ inline int constraint_output_dim(const to_constraint_desc& K, int n, int m) {
     case TO_CON_SPHERE: return K.n_params / 4;
     case TO_CON_LINEAR: return K.n_params / (K.n_inds + 1);
     case TO_CON_COLLISION: return 1;
+    case TO_CON_QUATVEC: return 3;
   }
   return -1;
 }
@@ -587,6 +588,19 @@ inline void constraint_evaluate(const to_constraint_desc& K, int n, int m, const
       }
       return;
     }
+    case TO_CON_QUATVEC: { /* :947-955: q = normalize(x[qind]); qf flipped onto q's hemisphere; c = vec(q) - vec(qf).
+                              Jacobian (ForwardDiff in the reference) = rows 2..4 of (I - q q')/|x[qind]| */
+      double q[4], nrm = 0.0, dq = 0.0;
+      for (int t = 0; t < 4; ++t) { q[t] = z[K.inds[t] - 1]; nrm += q[t] * q[t]; }
+      nrm = std::sqrt(nrm);
+      for (int t = 0; t < 4; ++t) { q[t] /= nrm; dq += K.params[t] * q[t]; }
+      const double sg = dq < 0 ? -1.0 : 1.0;
+      for (int r = 0; r < 3; ++r) {
+        c[r] = -(sg * K.params[r + 1] - q[r + 1]);
+        if (jac) for (int t = 0; t < 4; ++t) jac[r * nz + K.inds[t] - 1] = ((t == r + 1 ? 1.0 : 0.0) - q[r + 1] * q[t]) / nrm;
+      }
+      return;
+    }
     case TO_CON_COLLISION: { /* :362-387: r^2 - d'd with d = x[x1] - x[x2]; Jacobian entries are ASSIGNED (x1 first) */
       const int D = K.n_inds / 2;
       c[0] = K.params[0] * K.params[0];
@@ -602,7 +616,7 @@ inline void constraint_evaluate(const to_constraint_desc& K, int n, int m, const
 }
 
 inline bool constraint_is_state_only(int kind) {
-  return kind == TO_CON_GOAL || kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE || kind == TO_CON_COLLISION;
+  return kind == TO_CON_GOAL || kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE || kind == TO_CON_COLLISION || kind == TO_CON_QUATVEC;
 }
 
 }  // namespace oracle

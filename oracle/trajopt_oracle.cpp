@@ -146,6 +146,11 @@ int validate_constraint(const Problem& P, const to_constraint_desc& d, ConInfo* 
       if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "CollisionConstraint needs one parameter (radius)");
       for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "CollisionConstraint index outside state");
       ci.width = n; break;
+    case TO_CON_QUATVEC:
+      if (d.sense != TO_CONE_ZERO) return fail(TO_ERR_ARGUMENT, "QuatVecEq sense must be Equality");
+      if (d.n_inds != 4 || d.n_params != 4) return fail(TO_ERR_ARGUMENT, "QuatVecEq needs 4 quaternion indices and a 4-vector qf");
+      for (int i = 0; i < 4; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "QuatVecEq index outside state");
+      ci.width = n; break;
     default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
   }
   ci.p = constraint_output_dim(d, n, m);

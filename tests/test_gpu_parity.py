@@ -283,6 +283,7 @@ def test_every_constraint_kind_and_dense_cost(hip, oracle):
         A = rng.standard_normal((2, 3)); b = np.array([5.0, 6.0])
         T.add_constraint(cons, T.LinearConstraint(n, m, A, b, T.Inequality(), [1, 2, 14]), range(1, N))
         T.add_constraint(cons, T.CollisionConstraint(n, [1, 2, 3], [8, 9, 10], 0.02), range(2, N + 1))
+        T.add_constraint(cons, T.QuatVecEq(n, m, xf[3:7]), N)
         x0 = np.zeros(n); x0[3] = 1
         p = T.Problem(model, obj, x0, 1.1, xf=xf, constraints=cons, batch=6, lib=lib,
                       options=T.SolverOptions(lib=lib, constraint_tolerance=1e-4, iterations_outer=6))

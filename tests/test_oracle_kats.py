@@ -117,7 +117,9 @@ def test_constraints_closed_forms(oracle):
     T.add_constraint(cons, T.SphereConstraint(n, [0.1], [0.3], [0.2], [0.5]), range(1, N + 1))
     T.add_constraint(cons, T.LinearConstraint(n, m, A, bl, T.Equality(), [1, 2, 3, 14, 15]), range(1, N))
     T.add_constraint(cons, T.CollisionConstraint(n, [1, 2], [3, 4], 2.0), range(1, N + 1))   # test/constraint_tests.jl:155-168
-    assert T.num_constraints(cons) == [1 + 4 + 10 + 1 + 3 + 1, *[1 + 4 + 10 + 2 + 1 + 3 + 1] * (N - 2), 4 + 4 + 2 + 1 + 1]
+    qf = np.array([math.cos(math.pi / 8), math.sin(math.pi / 8), 0.0, 0.0])                  # expm([1,0,0]·45°), :412-442
+    T.add_constraint(cons, T.QuatVecEq(n, m, qf), range(1, N + 1))
+    assert T.num_constraints(cons) == [1 + 4 + 10 + 1 + 3 + 1 + 3, *[1 + 4 + 10 + 2 + 1 + 3 + 1 + 3] * (N - 2), 4 + 4 + 2 + 1 + 1 + 3]
     obj = T.LQRObjective(np.ones(n), np.ones(m), np.ones(n), xf, N)
     prob, X, U = random_problem(oracle, model, obj, cons)
     Z = np.concatenate([X, np.concatenate([U, np.zeros((prob.B, 1, m))], axis=1)], axis=2)
@@ -133,6 +135,7 @@ def test_constraints_closed_forms(oracle):
             lambda: np.array([-(x[0] - 0.1) ** 2 - (x[1] - 0.3) ** 2 - (x[2] - 0.2) ** 2 + 0.25]),
             lambda: A @ z[[0, 1, 2, 13, 14]] - bl,
             lambda: np.array([4.0 - (x[[0, 1]] - x[[2, 3]]) @ (x[[0, 1]] - x[[2, 3]])]),
+            lambda: -(np.sign(qf @ x[3:7]) * qf[1:] - x[4:7] / np.linalg.norm(x[3:7])),   # -(sign(dq) vec(qf) - vec(q)), q normalised
         ][i]()
 
     for i, con in enumerate(cons):
@@ -148,7 +151,7 @@ def test_constraints_closed_forms(oracle):
     assert np.all(T.upper_bound(cons[0]) == 0) and np.all(T.lower_bound(cons[0]) == 0)
     assert np.all(T.upper_bound(cons[1]) == 0) and np.all(T.lower_bound(cons[1]) == -np.inf)
     assert np.all(T.upper_bound(cons[2]) == np.inf) and np.all(T.lower_bound(cons[2]) == -np.inf)
-    assert [T.is_bound(c) for c in cons] == [True, False, False, True, False, False, False, False]
+    assert [T.is_bound(c) for c in cons] == [True, False, False, True, False, False, False, False, False]
     # the reference's own checks: ∇c = [-2d' 2d'], p = 1, equal-length assertion (test/constraint_tests.jl:163-173)
     jac = T.constraint_jacobians(prob, 7)[2, 0, 0]
     d = Z[2, 0, [0, 1]] - Z[2, 0, [2, 3]]

@@ -15,7 +15,7 @@ Mirrored reference API (file:line in /root/reference):
   cones        Equality/ZeroCone, Inequality/NegativeOrthant, SecondOrderCone, projection, ∇projection,
                ∇²projection, cone_status                           src/cones.jl
   constraints  GoalConstraint, BoundConstraint, NormConstraint, CircleConstraint, SphereConstraint,
-               CollisionConstraint, LinearConstraint, ConstraintList, add_constraint!   src/constraints.jl, src/constraint_list.jl
+               CollisionConstraint, QuatVecEq, LinearConstraint, ConstraintList, add_constraint!   src/constraints.jl, src/constraint_list.jl
   problem      Problem, rollout!, cost, states, controls, initial_controls!, initial_states!,
                set_initial_state!, set_goal_state!, get_* getters   src/problem.jl
   solvers      iLQRSolver, ALSolver (=Altro's AL-iLQR), SolverOptions, solve!, iterations, status,
@@ -38,7 +38,7 @@ __all__ = [
     "Objective", "LQRObjective", "TrackingObjective",
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
     "projection", "grad_projection", "hess_projection", "cone_status", "dualcone",
-    "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint", "CollisionConstraint",
+    "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint", "CollisionConstraint", "QuatVecEq",
     "LinearConstraint", "ConstraintList", "add_constraint", "num_constraints",
     "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
     "set_initial_state", "set_goal_state", "update_trajectory", "get_constraints", "get_objective", "get_model",
@@ -578,6 +578,26 @@ class CollisionConstraint(AbstractConstraint):
 
     def _fill(self):
         return self.x1 + self.x2, [self.radius]
+
+
+class QuatVecEq(AbstractConstraint):
+    """vec(normalize(x[qind])) = ±vec(qf)  (src/constraints.jl:938-965): the vector part of the attitude matches the goal
+    quaternion on the nearer hemisphere; p = 3, Equality.  qf = (w, x, y, z), normalised like QuatRotation(qf)."""
+    kind = capi.CON_QUATVEC
+    state_only = True
+
+    def __init__(self, n, m, qf, qind=(4, 5, 6, 7)):
+        self.n, self.m = int(n), int(m)
+        qf = _vec(qf, 4, "qf")
+        self.qf = qf / np.linalg.norm(qf)
+        self.qind = [int(i) for i in qind]
+        if len(self.qind) != 4:
+            raise ValueError("qind must hold 4 indices")
+        self.p = 3
+        self._sense = Equality()
+
+    def _fill(self):
+        return self.qind, list(self.qf)
 
 
 class LinearConstraint(AbstractConstraint):

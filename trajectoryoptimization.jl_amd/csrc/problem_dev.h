@@ -275,6 +275,22 @@ __device__ __forceinline__ double con_row(ConC& K, const double* z, int r, doubl
       c -= d.params[p * d.n_inds + r];
       break;
     }
+    case TO_CON_QUATVEC: {  // row r of vec(q/|q|) − sign(qf'q) vec(qf); coefficients = row r+1 of (I − q̂q̂ᵀ)/|q|
+      double q[4], n2 = 0.0, dq = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { q[t] = pick<nz>(z, d.inds[t] - 1); n2 += q[t] * q[t]; }
+      const double inv = rcp_fast(sqrt(n2));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { q[t] *= inv; dq += d.params[t] * q[t]; }
+      const double qr = (r == 0) ? q[1] : (r == 1) ? q[2] : q[3];
+      const double qfr = (r == 0) ? d.params[1] : (r == 1) ? d.params[2] : d.params[3];
+      c = -((dq < 0 ? -qfr : qfr) - qr);
+      if constexpr (nz >= 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) coef[t] = (((t == r + 1) ? 1.0 : 0.0) - qr * q[t]) * inv;
+      }
+      break;
+    }
     case TO_CON_COLLISION: {  // r² − |x[x1] − x[x2]|²; inds = [x1; x2]
       const int D = d.n_inds / 2;
       c = d.params[0] * d.params[0];

@@ -172,6 +172,11 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
       if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "CollisionConstraint needs one parameter (radius)");
       for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "CollisionConstraint index outside state");
       ci.width = n; p = 1; break;
+    case TO_CON_QUATVEC:
+      if (d.sense != TO_CONE_ZERO) return fail(TO_ERR_ARGUMENT, "QuatVecEq sense must be Equality");
+      if (d.n_inds != 4 || d.n_params != 4) return fail(TO_ERR_ARGUMENT, "QuatVecEq needs 4 quaternion indices and a 4-vector qf");
+      for (int i = 0; i < 4; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "QuatVecEq index outside state");
+      ci.width = n; p = 3; break;
     default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
   }
   if (p < 1 || p > TO_MAX_P) return fail(TO_ERR_UNSUPPORTED, "constraint output dimension outside 1..TO_MAX_P");
