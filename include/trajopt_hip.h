@@ -94,7 +94,11 @@ typedef enum { TO_RK4 = 0, TO_RK3 = 1, TO_EULER = 2 } to_integrator; /* default 
 typedef enum {
   TO_COST_DIAGONAL = 0,      /* DiagonalCost      src/cost_functions.jl:326-346: Q,R hold diagonals     */
   TO_COST_QUADRATIC = 1,     /* QuadraticCost     src/cost_functions.jl:422-453: dense Q (n x n), R (m x m), H (m x n), column-major */
-  TO_COST_DIAGONAL_QUAT = 2  /* DiagonalQuatCost  src/lie_costs.jl:34-55: diagonal + w*min(1 +/- q_ref'q) */
+  TO_COST_DIAGONAL_QUAT = 2, /* DiagonalQuatCost  src/lie_costs.jl:34-55: diagonal + w*min(1 +/- q_ref'q) */
+  TO_COST_ERROR_QUADRATIC = 3 /* ErrorQuadratic  src/lie_costs.jl:178-241 (rigid bodies, n = 13): 0.5 dx'Q dx + c + 0.5 u'Ru + r'u with
+                                 dx = state_diff(x, x_ref, CayleyMap) in R^12; Q[0..12) = error-state diagonal, R/r diagonal/linear
+                                 control terms, q[0..13) = x_ref, q_ind = quaternion indices (4,5,6,7).  Gradient and Hessian are
+                                 exact (ForwardDiff in the reference). */
 } to_cost_kind;
 
 typedef struct {

@@ -431,11 +431,46 @@ inline int cone_projection_hessian(int cone, const double* x, const double* b, d
   return -1;
 }
 
+/* ---------------------------------------------------------------- ErrorQuadratic (src/lie_costs.jl:178-241) */
+/* dx = x (-) x_ref on the 13-state rigid body: dphi = vec(dq)/scalar(dq), dq = conj(q_ref) (x) q = [q0'q; V q]. */
+struct ErrQuadGeom {
+  double s, phi[3], V[3][4], q0[4];
+};
+inline void errquad_geom(const double* x, const double* xr, ErrQuadGeom& G) {
+  const double w0 = xr[3], a0 = xr[4], b0 = xr[5], c0 = xr[6];
+  const double V[3][4] = {{-a0, w0, c0, -b0}, {-b0, -c0, w0, a0}, {-c0, b0, -a0, w0}};
+  G.q0[0] = w0; G.q0[1] = a0; G.q0[2] = b0; G.q0[3] = c0;
+  G.s = 0.0;
+  for (int t = 0; t < 4; ++t) G.s += G.q0[t] * x[3 + t];
+  for (int i = 0; i < 3; ++i) {
+    double v = 0.0;
+    for (int t = 0; t < 4; ++t) { G.V[i][t] = V[i][t]; v += V[i][t] * x[3 + t]; }
+    G.phi[i] = v / G.s;
+  }
+}
+inline void errquad_dx(const double* x, const double* xr, double* dx) {
+  ErrQuadGeom G; errquad_geom(x, xr, G);
+  for (int i = 0; i < 3; ++i) { dx[i] = x[i] - xr[i]; dx[3 + i] = G.phi[i]; }
+  for (int i = 0; i < 6; ++i) dx[6 + i] = x[7 + i] - xr[7 + i];
+}
+
 /* ---------------------------------------------------------------- costs */
 /* J = 0.5 x'Qx + q'x + c (+ 0.5 u'Ru + r'u) (+ u'Hx) (+ w min(1+dq,1-dq)); src/cost_functions.jl:89-104, src/lie_costs.jl:68-76.
  * `with_u`: the reference adds the control terms whenever u is non-empty. */
 inline double cost_evaluate(const to_cost_desc& C, int n, int m, const double* x, const double* u) {
   double J = 0.0;
+  if (C.kind == TO_COST_ERROR_QUADRATIC) { /* src/lie_costs.jl:237-240 */
+    double dx[12], e = 0.0;
+    errquad_dx(x, C.q, dx);
+    for (int i = 0; i < 12; ++i) e += dx[i] * C.Q[i] * dx[i];
+    J = 0.5 * e + C.c;
+    if (u) {
+      double uRu = 0.0, ru = 0.0;
+      for (int i = 0; i < m; ++i) { uRu += u[i] * C.R[i] * u[i]; ru += C.r[i] * u[i]; }
+      J += 0.5 * uRu + ru;
+    }
+    return J;
+  }
   if (C.kind == TO_COST_QUADRATIC) {
     double xQx = 0.0;
     for (int j = 0; j < n; ++j) { double t = 0.0; for (int i = 0; i < n; ++i) t += x[i] * C.Q[i + n * j]; xQx += t * x[j]; }
@@ -477,6 +512,23 @@ inline void cost_expansion(const to_cost_desc& C, int n, int m, const double* x,
   const int nz = n + m;
   std::memset(grad, 0, sizeof(double) * nz);
   std::memset(hess, 0, sizeof(double) * nz * nz);
+  if (C.kind == TO_COST_ERROR_QUADRATIC) {
+    /* exact derivatives of 0.5 dx'Q dx (the reference takes them with ForwardDiff): with D_i = (V_i - phi_i q0')/s,
+     * grad_q = sum_i Q_i phi_i D_i',  H_qq = sum_i Q_i [D_i'D_i - phi_i (V_i'q0' + q0 V_i)/s^2 + 2 phi_i^2 q0 q0'/s^2] */
+    ErrQuadGeom G; errquad_geom(x, C.q, G);
+    for (int i = 0; i < 3; ++i) { grad[i] = C.Q[i] * (x[i] - C.q[i]); hess[i * nz + i] = C.Q[i]; }
+    for (int i = 0; i < 6; ++i) { grad[7 + i] = C.Q[6 + i] * (x[7 + i] - C.q[7 + i]); hess[(7 + i) * nz + 7 + i] = C.Q[6 + i]; }
+    for (int i = 0; i < 3; ++i) {
+      const double Qi = C.Q[3 + i], ph = G.phi[i];
+      double D[4];
+      for (int t = 0; t < 4; ++t) { D[t] = (G.V[i][t] - ph * G.q0[t]) / G.s; grad[3 + t] += Qi * ph * D[t]; }
+      for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r)
+        hess[(3 + t) * nz + 3 + r] += Qi * (D[t] * D[r] - ph * (G.V[i][t] * G.q0[r] + G.q0[t] * G.V[i][r]) / (G.s * G.s)
+                                            + 2 * ph * ph * G.q0[t] * G.q0[r] / (G.s * G.s));
+    }
+    if (!terminal) for (int i = 0; i < m; ++i) { grad[n + i] = C.R[i] * u[i] + C.r[i]; hess[(n + i) * nz + n + i] = C.R[i]; }
+    return;
+  }
   if (C.kind == TO_COST_QUADRATIC) {
     for (int i = 0; i < n; ++i) { double t = C.q[i]; for (int j = 0; j < n; ++j) t += C.Q[i + n * j] * x[j]; grad[i] = t; }
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) hess[i * nz + j] = C.Q[i + n * j];

@@ -162,8 +162,12 @@ int validate_constraint(const Problem& P, const to_constraint_desc& d, ConInfo* 
 }
 
 int validate_cost(const Problem& P, const to_cost_desc& c) {
-  if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT)
+  if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT && c.kind != TO_COST_ERROR_QUADRATIC)
     return fail(TO_ERR_UNSUPPORTED, "unknown cost kind");
+  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; q(4:7); v; w]
+    if (P.n != 13) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model (n = 13)");
+    for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
+  }
   if (c.kind == TO_COST_DIAGONAL_QUAT)
     for (int i = 0; i < 4; ++i) if (c.q_ind[i] < 1 || c.q_ind[i] > P.n) return fail(TO_ERR_DIMENSION_MISMATCH, "quat_ind outside state");
   return TO_OK;

@@ -310,3 +310,55 @@ def test_tracking_objective_and_update_trajectory(oracle):
     np.testing.assert_allclose(T.cost(prob), expected(5), rtol=1e-12)
     with pytest.raises(IndexError):
         T.update_trajectory(prob, Xref, Uref, start=Nref)
+
+
+def _errstate(x, xr):
+    """x ⊖ xr with the Cayley map (RD.state_diff): δφ = vec(δq)/scalar(δq), δq = conj(q_ref) ⊗ q."""
+    w0, v0 = xr[3], xr[4:7]; w, v = x[3], x[4:7]
+    s = w0 * w + v0 @ v
+    dv = w0 * v - w * v0 - np.cross(v0, v)
+    return np.concatenate([x[:3] - xr[:3], dv / s, x[7:] - xr[7:]])
+
+
+def test_error_quadratic_cost(oracle):
+    """ErrorQuadratic (src/lie_costs.jl:178-241): value against the definition; the exact gradient / Hessian (ForwardDiff
+    in the reference) against central differences of the value; constructor bookkeeping (:226-231)."""
+    model = T.Quadrotor(); n, m = model.dims(); N = 5
+    xr = rng.uniform(-1, 1, n); xr[3:7] /= np.linalg.norm(xr[3:7])
+    Q13 = rng.uniform(0.5, 2.0, 13); R = rng.uniform(0.1, 0.5, m); uref = rng.uniform(0, 1, m)
+    cost = T.ErrorQuadratic(model, Q13, R, xr, uref, c=0.25)
+    assert cost.Q.size == 12 and np.all(cost.Q == np.delete(Q13, 3))                 # 4th weight dropped
+    np.testing.assert_allclose(cost.r, -R * uref); assert cost.c == pytest.approx(0.25 + 0.5 * uref @ (R * uref))
+    term = T.ErrorQuadratic(model, 10 * Q13, R, xr, uref, terminal=True)
+    obj = T.Objective(cost, term, N)
+    prob, X, U = random_problem(oracle, model, obj, T.ConstraintList(n, m, N))
+
+    def value(x, u, c):
+        dx = _errstate(x, xr)
+        return 0.5 * dx @ (c.Q * dx) + c.c + 0.5 * u @ (R * u) + c.r @ u
+    J = T.stage_costs(prob)
+    for b in range(prob.B):
+        for k in range(N):
+            u = U[b, k] if k < N - 1 else np.zeros(m)
+            assert J[b, k] == pytest.approx(value(X[b, k], u, cost if k < N - 1 else term), rel=1e-12)
+    g, H = I.cost_gradient_hessian(prob)
+    eps = 1e-5
+    for k in (0, N - 1):
+        c = cost if k < N - 1 else term
+        u = U[1, k] if k < N - 1 else np.zeros(m)
+        z0 = np.concatenate([X[1, k], u])
+        f = lambda z: value(z[:n], z[n:], c)
+        gfd = np.array([(f(z0 + eps * e) - f(z0 - eps * e)) / (2 * eps) for e in np.eye(n + m)])
+        if k == N - 1:
+            gfd[n:] = 0.0   # control parts are skipped at the terminal knot
+        np.testing.assert_allclose(g[1, k], gfd, rtol=1e-7, atol=1e-8)
+        Hfd = np.array([[(f(z0 + eps * (ei + ej)) - f(z0 + eps * (ei - ej)) - f(z0 - eps * (ei - ej)) + f(z0 - eps * (ei + ej))) / (4 * eps * eps)
+                         for ej in np.eye(n + m)] for ei in np.eye(n + m)])
+        if k == N - 1:
+            Hfd[n:, :] = 0.0; Hfd[:, n:] = 0.0
+        np.testing.assert_allclose(H[1, k], Hfd, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(H[1, k], H[1, k].T, atol=1e-13)
+    with pytest.raises(TypeError):
+        T.set_goal_state(prob, xr)
+    with pytest.raises(T.capi.DimensionMismatch):
+        T.Problem(T.Cartpole(), T.Objective(cost, term, N), np.zeros(4), 1.0, lib=oracle)

@@ -28,7 +28,7 @@ TO_ERR_HIP, TO_ERR_UNSUPPORTED, TO_ERR_NULL, TO_ERR_CONE = -4, -5, -6, -7
 
 MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR = 0, 1, 2
 RK4, RK3, EULER = 0, 1, 2
-COST_DIAGONAL, COST_QUADRATIC, COST_DIAGONAL_QUAT = 0, 1, 2
+COST_DIAGONAL, COST_QUADRATIC, COST_DIAGONAL_QUAT, COST_ERROR_QUADRATIC = 0, 1, 2, 3
 CONE_ZERO, CONE_NEGATIVE_ORTHANT, CONE_SECOND_ORDER, CONE_POSITIVE_ORTHANT, CONE_IDENTITY = range(5)
 CON_GOAL, CON_BOUND, CON_NORM, CON_CIRCLE, CON_SPHERE, CON_LINEAR, CON_COLLISION, CON_QUATVEC = range(8)
 

@@ -34,7 +34,7 @@ from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, 
 
 __all__ = [
     "DoubleIntegrator", "Cartpole", "Quadrotor", "RK4", "RK3", "Euler",
-    "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "QuatLQRCost",
+    "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
     "projection", "grad_projection", "hess_projection", "cone_status", "dualcone",
@@ -229,6 +229,54 @@ class DiagonalQuatCost(DiagonalCost):
         if len(q_ind) != 4:
             raise AssertionError("quat_ind argument must be of length 4")
         self.q_ind = tuple(int(i) for i in q_ind)
+
+
+class ErrorQuadratic(QuadraticCostFunction):
+    """½ (x ⊖ x_ref)ᵀ Q (x ⊖ x_ref) + c + ½uᵀRu + rᵀu with the Cayley-map error state of a rigid body
+    (src/lie_costs.jl:178-241).  ``Q`` is the 12-vector of error-state weights, or a 13-vector / 13x13 diagonal whose
+    4th entry is dropped like the reference constructor does (:226-229); ``u_ref`` folds into r and c (:230-231)."""
+    kind = capi.COST_ERROR_QUADRATIC
+
+    def __init__(self, model, Q, R, x_ref, u_ref=None, r=None, c=0.0, q_ind=(4, 5, 6, 7), terminal=False):
+        n, m = model.dims()
+        if n != 13:
+            raise ArgumentError("ErrorQuadratic needs a rigid-body model (13 states)")
+        dq, Qd = _diag_or_vec(Q)
+        dr, Rd = _diag_or_vec(R)
+        if not (dq and dr):
+            raise ArgumentError("ErrorQuadratic needs diagonal Q and R")
+        if Qd.size == 13:
+            Qd = np.delete(Qd, 3)
+        if Qd.size != 12 or Rd.size != m:
+            raise DimensionMismatch("ErrorQuadratic: Q must have 12 (or 13) entries, R m entries")
+        self.n, self.m = n, m
+        self.Q, self.R = Qd, Rd
+        self.H = np.zeros((m, n))
+        self.x_ref = _vec(x_ref, n, "x_ref")
+        u_ref = np.zeros(m) if u_ref is None else _vec(u_ref, m, "u_ref")
+        self.r = (np.zeros(m) if r is None else _vec(r, m, "r")) - Rd * u_ref
+        self.c = float(c) + 0.5 * u_ref @ (Rd * u_ref)
+        if tuple(int(i) for i in q_ind) != (4, 5, 6, 7):
+            raise ArgumentError("ErrorQuadratic: q_ind must be 4:7 (the rigid-body state layout)")
+        self.q_ind = (4, 5, 6, 7)
+        self.terminal = bool(terminal)
+
+    @property
+    def q(self):  # the descriptor's q slot carries x_ref for this kind (include/trajopt_hip.h)
+        return self.x_ref
+
+    def _desc(self):
+        d = CostDesc()
+        d.kind, d.terminal = self.kind, int(self.terminal)
+        d.Q[:12] = list(self.Q)
+        d.R[: self.m] = list(self.R)
+        d.q[: self.n] = list(self.x_ref)
+        d.r[: self.m] = list(self.r)
+        d.c = self.c
+        d.w = 0.0
+        d.q_ref[:] = [1.0, 0.0, 0.0, 0.0]
+        d.q_ind[:] = list(self.q_ind)
+        return d
 
 
 def QuatLQRCost(Q, R, xf, uf=None, w=1.0, quat_ind=(4, 5, 6, 7), terminal=False):
@@ -940,6 +988,8 @@ def set_goal_state(prob, xf, objective=True, constraint=True):
     xf = _vec(xf, prob.n, "xf")
     if objective:
         for i, c in enumerate(prob._cost_objs):
+            if c.kind == capi.COST_ERROR_QUADRATIC:
+                raise TypeError("set_LQR_goal! is only defined for QuadraticCostFunction (src/cost_functions.jl:249)")
             if c.kind == capi.COST_QUADRATIC:
                 c.q = -c.Q @ xf  # set_LQR_goal!: only q changes (src/cost_functions.jl:249-252)
             else:
@@ -970,6 +1020,8 @@ def update_trajectory(prob, X, U, start=1):
         k = start - 1 + i
         xf = _vec(X[:, k], prob.n, "xf")
         uf = _vec(U[:, k], prob.m, "uf") if k < U.shape[1] else np.zeros(prob.m)
+        if c.kind == capi.COST_ERROR_QUADRATIC:
+            raise TypeError("update_trajectory! needs QuadraticCostFunction costs (src/objective.jl:207)")
         if c.kind == capi.COST_QUADRATIC:
             c.q, c.r = -c.Q @ xf, -c.R @ uf
         else:

@@ -35,7 +35,7 @@ typedef const int TO_CONST_AS IntC;
 
 struct DevProblem {
   int n, m, ne, N, B, Bp, integrator, n_costs, n_cons;
-  int expand_variant;  // bit0: a dense QuadraticCost exists; bit1: constraints exist; bit2: a non-selector constraint exists
+  int expand_variant;  // bit0: a QuadraticCost / ErrorQuadratic exists; bit1: constraints exist; bit2: a non-selector constraint exists
   int simple_stage;  // 1: every stage knot (k < N-1) uses the same diagonal-kind cost and the same dt (the common LQR-style objective)
   long long n_duals;
   double mp[16];
@@ -79,11 +79,66 @@ __device__ __forceinline__ double quat_dot(const double* qref, const int* qind, 
   return dq;
 }
 
+// ------------------------------------------------------------------------------------------------ ErrorQuadratic
+// ½ dx'Q dx with dx = x ⊖ x_ref on the 13-state rigid body (src/lie_costs.jl:178-241).  Templated on the scalar: the value
+// path runs it in double, the expansion evaluates the GRADIENT in dual numbers to get exact Hessian-vector products
+// (the reference differentiates the value twice with ForwardDiff).  xr = x_ref (13), Qe = 12 error-state weights.
+template <class T>
+__device__ __forceinline__ void errquad_phi(CostC& C, const T* x, T* phi /*3*/, T* rs_out) {
+  const double w0 = C.q[3], a0 = C.q[4], b0 = C.q[5], c0 = C.q[6];
+  const T w = x[3], a = x[4], b = x[5], c = x[6];
+  const T s = w0 * w + a0 * a + b0 * b + c0 * c;
+  const T rs = recip_t(s);
+  phi[0] = (w0 * a - a0 * w + c0 * b - b0 * c) * rs;
+  phi[1] = (w0 * b - b0 * w - c0 * a + a0 * c) * rs;
+  phi[2] = (w0 * c - c0 * w + b0 * a - a0 * b) * rs;
+  *rs_out = rs;
+}
+template <class T>
+__device__ __forceinline__ T errquad_value(CostC& C, const T* x) {
+  T phi[3], rs;
+  errquad_phi<T>(C, x, phi, &rs);
+  T e = T(0.0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const T d = x[i] - C.q[i]; e = e + d * C.Q[i] * d; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e = e + phi[i] * C.Q[3 + i] * phi[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const T d = x[7 + i] - C.q[7 + i]; e = e + d * C.Q[6 + i] * d; }
+  return 0.5 * e;
+}
+template <class T>
+__device__ __forceinline__ void errquad_grad(CostC& C, const T* x, T* g /*13*/) {
+  const double q0[4] = {C.q[3], C.q[4], C.q[5], C.q[6]};
+  const double V[3][4] = {{-q0[1], q0[0], q0[3], -q0[2]}, {-q0[2], -q0[3], q0[0], q0[1]}, {-q0[3], q0[2], -q0[1], q0[0]}};
+  T phi[3], rs;
+  errquad_phi<T>(C, x, phi, &rs);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g[i] = C.Q[i] * (x[i] - C.q[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[7 + i] = C.Q[6 + i] * (x[7 + i] - C.q[7 + i]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    T acc = T(0.0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc = acc + (C.Q[3 + i] * phi[i]) * (V[i][t] - phi[i] * q0[t]);
+    g[3 + t] = acc * rs;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ costs
 // J = ½x'Qx + q'x + c (+ ½u'Ru + r'u whenever u is given) (+ u'Hx) (+ w·min(1±dq))
 template <int n, int m, bool DENSE = true>
 __device__ __forceinline__ double cost_eval(CostC& C, const double* x, const double* u) {
   double J;
+  if constexpr (DENSE && n == 13) {
+    if (C.kind == TO_COST_ERROR_QUADRATIC) {
+      double uRu = 0.0, ru = 0.0;
+#pragma unroll
+      for (int i = 0; i < m; ++i) { uRu += u[i] * C.R[i] * u[i]; ru += C.r[i] * u[i]; }
+      return errquad_value<double>(C, x) + C.c + (0.5 * uRu + ru);
+    }
+  }
   if (DENSE && C.kind == TO_COST_QUADRATIC) {
     double xQx = 0.0;
 #pragma unroll
@@ -182,6 +237,22 @@ struct StageCostDiag {
 template <int n, int m, bool DENSE = true>
 __device__ __forceinline__ void cost_grad_hvp(CostC& C, const double* x, const double* u, bool terminal,
                                               const double* v, double* g, double* y) {
+  if constexpr (DENSE && n == 13) {
+    if (C.kind == TO_COST_ERROR_QUADRATIC) {
+      Dual xd[n], gd[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) xd[i] = Dual(x[i], v[i]);
+      errquad_grad<Dual>(C, xd, gd);
+#pragma unroll
+      for (int i = 0; i < n; ++i) { g[i] = gd[i].v; y[i] = gd[i].d; }
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        g[n + i] = terminal ? 0.0 : C.R[i] * u[i] + C.r[i];
+        y[n + i] = terminal ? 0.0 : C.R[i] * v[n + i];
+      }
+      return;
+    }
+  }
   if (DENSE && C.kind == TO_COST_QUADRATIC) {
 #pragma unroll
     for (int i = 0; i < n; ++i) {

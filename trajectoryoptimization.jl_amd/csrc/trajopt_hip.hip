@@ -194,8 +194,12 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
 }
 
 int validate_cost(int n, const to_cost_desc& c) {
-  if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT)
+  if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT && c.kind != TO_COST_ERROR_QUADRATIC)
     return fail(TO_ERR_UNSUPPORTED, "unknown cost kind");
+  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; q(4:7); v; w]
+    if (n != 13) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model (n = 13)");
+    for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
+  }
   if (c.kind == TO_COST_DIAGONAL_QUAT)
     for (int i = 0; i < 4; ++i) if (c.q_ind[i] < 1 || c.q_ind[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "quat_ind outside the state");
   return TO_OK;
@@ -283,11 +287,12 @@ int upload_tables(to_handle* h) {
     DevProblem& P = h->a.P;
     const int N = P.N;
     // simple_stage: one diagonal-kind cost on every stage knot and a uniform dt
-    bool simple = h->costs[h->cost_index[0]].kind != TO_COST_QUADRATIC;
+    const int k0 = h->costs[h->cost_index[0]].kind;
+    bool simple = k0 != TO_COST_QUADRATIC && k0 != TO_COST_ERROR_QUADRATIC;
     for (int k = 1; k < N - 1; ++k) simple = simple && h->cost_index[k] == h->cost_index[0] && h->dt[k] == h->dt[0];
     P.simple_stage = simple ? 1 : 0;
     bool dense = false, generic = false;
-    for (const auto& c : h->costs) dense = dense || c.kind == TO_COST_QUADRATIC;
+    for (const auto& c : h->costs) dense = dense || c.kind == TO_COST_QUADRATIC || c.kind == TO_COST_ERROR_QUADRATIC;
     for (const auto& c : h->cons) generic = generic || !c.selector;
     P.expand_variant = (dense ? 1 : 0) | (h->cons.empty() ? 0 : 2) | (generic ? 4 : 0);
   }
