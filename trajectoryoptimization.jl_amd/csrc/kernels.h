@@ -268,7 +268,11 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
   const bool valid = b < P.B && j < nc && a.active[b] && !(terminal && j >= ne);
   if (__ballot(valid) == 0) return;
-  constexpr int c = 0;  // nominal slot
+  // Inside a solve the step accepted by the previous forward pass still sits in its candidate slot (acc != 0): the
+  // expansion reads it there and writes it through to slot 0, so the separate k_accept copy (and its re-read of every
+  // candidate line that any lane of a tile accepted) disappears from the iteration.  Outside a solve acc is 0.
+  // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
+  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
   const int tile = b >> 6, lane64 = b & 63;
   const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
   const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
@@ -277,6 +281,16 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
 #pragma unroll
   for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(U, k * m + i);
+  if (M::accept_write_through && c != 0 && j == 0 && valid) {
+    double* X0 = XSLOT(a, 0) + ((size_t)tile * (N * n)) * 64 + lane64;
+    double* U0 = USLOT(a, 0) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+#pragma unroll
+    for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
+    if (!terminal) {
+#pragma unroll
+      for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
+    }
+  }
   {
     double vx[n];
     errstate_col<M>(x, j < ne ? j : 0, vx);
@@ -775,8 +789,8 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.B) return;
-  if (a.round == 0) a.acc[b] = 0;  // accepted slots stay marked over the rounds: k_accept runs once, after the last one
-  if (!a.active[b]) return;
+  if (!a.active[b]) return;        // a finished trajectory keeps its last accepted slot marked until the final k_accept
+  if (a.round == 0) a.acc[b] = 0;  // (the previous step's slot was written through to slot 0 by this step's expansion)
   const int N = P.N;
   const to_solver_opts& o = P.opts;
   const bool bpfail = a.bpfail[b] != 0;
@@ -909,8 +923,9 @@ __global__ void __launch_bounds__(64) k_outer_violation(KArgs a) {
   if (__ballot(want) == 0) return;
   if (!want) return;
   const int N = P.N, k = blockIdx.y;
-  const double* X = TILE_PTR(XSLOT(a, 0), N * n);
-  const double* U = TILE_PTR(USLOT(a, 0), (N - 1) * m);
+  const int sl = a.acc[b];  // the step accepted in this iteration (0: none, nominal unchanged)
+  const double* X = TILE_PTR(XSLOT(a, sl), N * n);
+  const double* U = TILE_PTR(USLOT(a, sl), (N - 1) * m);
   double x[n], u[m];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
@@ -955,8 +970,9 @@ __global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
   if (__ballot(want) == 0) return;
   if (!want) return;
   const int N = P.N, k = blockIdx.y;
-  const double* X = TILE_PTR(XSLOT(a, 0), N * n);
-  const double* U = TILE_PTR(USLOT(a, 0), (N - 1) * m);
+  const int sl = a.acc[b];
+  const double* X = TILE_PTR(XSLOT(a, sl), N * n);
+  const double* U = TILE_PTR(USLOT(a, sl), (N - 1) * m);
   double* lam0 = TILE_PTR(a.lam, P.n_duals);
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
   const double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
@@ -1020,6 +1036,11 @@ __global__ void __launch_bounds__(64) k_accept(KArgs a) {
   for (int e = e0; e < min(e1, Lx); ++e) EL(dx, e) = EL(sx, e);
 #pragma unroll 16
   for (int e = max(e0, Lx) - Lx; e < e1 - Lx; ++e) EL(du, e) = EL(su, e);
+}
+
+__global__ void k_clear_acc(KArgs a) {
+  TILE_LANE();
+  if (b < a.P.Bp) a.acc[b] = 0;
 }
 
 // start of a solve: reset the per-trajectory solver state.  J must already hold the (AL) cost of the rollout.

@@ -63,6 +63,7 @@ struct to_handle_s {
   hipStream_t stream = nullptr;
   int model_key = -1;
   int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
+  bool write_through = false;  // model trait accept_write_through (models.h)
   int T1 = 1;  // step sizes evaluated concurrently in the first line-search round (all trajectories take part)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   KArgs a;  // host copy of the kernel argument block (device pointers inside)
@@ -375,7 +376,13 @@ int ensure_nlist(to_handle* h, int steps) {
 // forward pass = line-search rounds of (concurrent candidates, select).  The first round evaluates the T1 largest step
 // sizes for every trajectory; the trajectories that rejected all of them are few, so the following rounds take up to T
 // step sizes at once (dead tiles leave immediately).
-int launch_forward(to_handle* h) {
+int launch_accept(to_handle* h) {  // materialise accepted candidate slots on slot 0, then forget them
+  hipLaunchKernelGGL(k_accept, grid_b(h, h->a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
+  hipLaunchKernelGGL(k_clear_acc, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+int launch_forward(to_handle* h, bool accept = true) {
   KArgs& a = h->a;
   const int total = std::max(1, a.P.opts.iterations_linesearch);
   const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) |
@@ -425,8 +432,7 @@ int launch_forward(to_handle* h) {
     HIPCHECK(hipGetLastError());
     c0 += a.Tr;
   }
-  hipLaunchKernelGGL(k_accept, grid_b(h, a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, a);
-  HIPCHECK(hipGetLastError());
+  if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
   return TO_OK;
 }
 // AL outer update of the trajectories whose inner solve ended in this batch step (kernels.h, k_outer_*)
@@ -495,7 +501,7 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
       TRY(launch_backward(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
-      TRY(launch_forward(h));
+      TRY(launch_forward(h, !h->write_through));
       if (al_mode) TRY(launch_outer(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
     }
@@ -519,6 +525,7 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   }
   HIPCHECK(hipEventDestroy(cev[0]));
   HIPCHECK(hipEventDestroy(cev[1]));
+  TRY(launch_accept(h));  // trajectories keep the slot of their last accepted step until here
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -633,6 +640,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->model_key = key;
   h->R = (ne + m) <= 4 ? 4 : (ne + m) <= 8 ? 8 : 16;
   h->G = 64 / h->R;
+  DISPATCH(h, h->write_through = M::accept_write_through);
   h->costs.assign(desc->costs, desc->costs + desc->n_costs);
   h->cons = cons; h->dt = dt; h->cost_index = cost_index;
   auto bail = [&](int rc) { std::string e = g_err; to_destroy(h); g_err = e; return rc; };
