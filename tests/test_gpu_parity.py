@@ -418,6 +418,99 @@ def test_error_quadratic_cost_on_gpu(hip, oracle):
     np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-3)
 
 
+def _random_config(seed):
+    """A random problem from the supported space: model, horizon, batch, integrator, dt pattern, cost kinds, a random
+    subset of constraints, a few solver options."""
+    r = np.random.default_rng(seed)
+    kind = r.choice(["di1", "di2", "di3", "cartpole", "quadrotor"])
+    model = {"di1": T.DoubleIntegrator(1.0, 1), "di2": T.DoubleIntegrator(1.3, 2), "di3": T.DoubleIntegrator(0.7, 3),
+             "cartpole": T.Cartpole(), "quadrotor": T.Quadrotor()}[kind]
+    n, m = model.dims()
+    N = int(r.integers(3, 34)); B = int(r.integers(1, 75)); tf = float(r.uniform(0.4, 2.0))
+    integ = [T.RK4, T.RK3, T.Euler][int(r.integers(0, 3))]
+    quad = kind == "quadrotor"
+    xf = r.uniform(-0.5, 0.5, n)
+    if quad:
+        xf[3:7] = r.standard_normal(4); xf[3:7] /= np.linalg.norm(xf[3:7])
+    u0 = model.hover_control() if quad else np.zeros(m)
+    Qd, Rd = r.uniform(0.1, 2.0, n), r.uniform(0.05, 0.5, m)
+    style = int(r.integers(0, 3))
+    if quad and style == 0:
+        stage, term = T.QuatLQRCost(Qd, Rd, xf, u0, w=float(r.uniform(0.2, 2))), T.QuatLQRCost(20 * Qd, Rd, xf, u0, terminal=True)
+    elif style == 1:
+        A = 0.1 * r.standard_normal((n, n)); Qm = np.diag(Qd) + A @ A.T
+        Hm = 0.02 * r.standard_normal((m, n))
+        stage = T.QuadraticCost(Qm, np.diag(Rd), Hm, -Qm @ xf, -Rd * u0, 0.1)
+        term = T.LQRCost(20 * Qd, Rd, xf, u0, terminal=True)
+    else:
+        stage, term = T.LQRCost(Qd, Rd, xf, u0), T.LQRCost(20 * Qd, Rd, xf, u0, terminal=True)
+    obj = T.Objective(stage, term, N)
+    cons = T.ConstraintList(n, m, N)
+    npos = 3 if quad else {"di1": 1, "di2": 2, "di3": 3, "cartpole": 1}[kind]
+    with_cons = r.random() < 0.7
+    if with_cons and r.random() < 0.5:
+        T.add_constraint(cons, T.GoalConstraint(xf, list(range(1, npos + 1))), N)
+    if not with_cons:
+        pass
+    elif r.random() < 0.5 and N > 2:
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=u0 - 3.0, u_max=u0 + 3.0), range(1, N))
+    if with_cons and r.random() < 0.4 and N > 2:
+        T.add_constraint(cons, T.NormConstraint(n, m, float(np.linalg.norm(u0) + 4.0), T.SecondOrderCone(), "control"), range(1, N))
+    if with_cons and r.random() < 0.3 and n >= 2 and N > 3:
+        T.add_constraint(cons, T.CircleConstraint(n, [0.9], [0.8], [0.2]), range(2, N))
+    if with_cons and r.random() < 0.3 and N > 2:
+        T.add_constraint(cons, T.LinearConstraint(n, m, r.standard_normal((1, 2)), np.array([4.0]), T.Inequality(), [1, n + 1]), range(1, N))
+    dt = None
+    if r.random() < 0.3:
+        w = r.uniform(0.5, 1.5, N - 1); dt = tf * w / w.sum()
+    opts = dict(cost_dt_scaling=int(r.random() < 0.3), iterations=int(r.integers(3, 25)), iterations_outer=int(r.integers(1, 4)),
+                iterations_linesearch=int(r.integers(1, 24)), constraint_tolerance=1e-3)
+    x0 = r.uniform(-0.3, 0.3, (B, n))
+    if quad:
+        x0[:, 3:7] = [1.0, 0, 0, 0]
+    Uinit = np.tile(u0, (B, N - 1, 1)) + 0.05 * r.standard_normal((B, N - 1, m))
+
+    def build(lib):
+        p = T.Problem(model, obj, np.zeros(n), tf, xf=xf, constraints=cons, batch=B, integration=integ, dt=dt, lib=lib,
+                      options=T.SolverOptions(lib=lib, **opts))
+        p.set_initial_state(x0)
+        T.initial_controls(p, Uinit)
+        return p
+    return build, len(cons) > 0, f"{kind} N={N} B={B} integ={integ} style={style} ncons={len(cons)} opts={opts}"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations(seed, hip, oracle):
+    """Randomised drop-in check: any supported problem must give the oracle's phases and (short) solves."""
+    build, constrained, desc = _random_config(1000 + seed)
+    ph, po = build(hip), build(oracle)
+    for p in (ph, po):
+        T.rollout(p)
+    np.testing.assert_allclose(T.states(ph), T.states(po), rtol=1e-10, atol=1e-12, err_msg=desc)
+    np.testing.assert_allclose(T.cost(ph), T.cost(po), rtol=1e-11, err_msg=desc)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    Eh, Eo = I.cost_expansion(ph), I.cost_expansion(po)
+    for key in Eo:
+        np.testing.assert_allclose(Eh[key], Eo[key], rtol=1e-8, atol=1e-9 * (1 + np.abs(Eo[key]).max()), err_msg=desc + " " + key)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_array_equal(gh["rho"], go["rho"], err_msg=desc)
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-6, atol=1e-8 * (1 + np.abs(go["K"]).max()), err_msg=desc)
+    solver = T.ALSolver if constrained else T.iLQRSolver
+    sh, so = solver(ph).solve(), solver(po).solve()
+    for k in ("iterations", "iterations_outer", "status"):
+        np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=desc + " " + k)
+    np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6, err_msg=desc)
+    # converged trajectories: the north-star tolerance; solves cut off by an iteration limit (or driven to the
+    # regularisation limit) stop on an ill-conditioned iterate, where rounding differences are amplified: 1e-4
+    done = so.stats["status"] == T.capi.SOLVE_SUCCEEDED
+    Xh, Xo, Uh, Uo = T.states(ph), T.states(po), T.controls(ph), T.controls(po)
+    np.testing.assert_allclose(Xh[done], Xo[done], rtol=1e-6, atol=1e-7, err_msg=desc)
+    np.testing.assert_allclose(Uh[done], Uo[done], rtol=1e-6, atol=1e-7, err_msg=desc)
+    np.testing.assert_allclose(Xh[~done], Xo[~done], rtol=1e-4, atol=1e-5, err_msg=desc)
+    np.testing.assert_allclose(Uh[~done], Uo[~done], rtol=1e-4, atol=1e-5, err_msg=desc)
+
+
 def test_error_paths_on_device(hip):
     with pytest.raises(T.capi.ConeError):
         T.projection(T.SecondOrderCone(), np.array([np.nan, 1.0, 1.0]), lib=hip)
