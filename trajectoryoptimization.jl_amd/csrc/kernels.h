@@ -668,37 +668,19 @@ __device__ __forceinline__ void stage_gains(const double* ktile, int k, double* 
 // rollout per iteration, while the machine idles.
 // MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms);
 // bit2: RK4 fixed at compile time; bit3: dense costs / non-selector constraints possible (else compiled out).
+// One line-search candidate for the 64 trajectories (tile, lane) of a wave: closed-loop rollout with step size alpha
+// into slot cs, its (AL) cost J, gradient metric gsum/(N-1) and admissibility ok.  Lanes with live == false roll out as
+// well (see below) but store nothing.  kbuf: the wave's LDS buffer for DMA-staged gains (KLDS models).
 template <class M, int MODE>
-__global__ void __launch_bounds__(64) k_forward(KArgs a) {
+__device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int lane, bool live, double alpha, int cs, double* kbuf,
+                                                  double& J_out, double& g_out, bool& ok_out) {
   constexpr int n = M::n, m = M::m, ne = M::ne;
   constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0, LISTED = (MODE & 16) != 0;
-  constexpr bool KLDS = M::lds_gains && !LISTED;  // gains staged through LDS by DMA instead of prefetch registers
-  __shared__ double kbuf[KLDS ? m * ne * 64 : 1];
+  constexpr bool KLDS = M::lds_gains && !LISTED;
   const DevProblem& P = a.P;
-  const int t = blockIdx.y;
-  const int idx = a.cand0 + t;
   const to_solver_opts& o = P.opts;
-  if (idx >= o.iterations_linesearch) return;
-  // Round 0: lane = trajectory of tile blockIdx.x.  Later rounds: the few trajectories that rejected every step size so
-  // far were compacted into a list by k_select; wave v takes entries 64v..64v+63 (gathered loads, but a handful of
-  // waves instead of one per tile that still holds a searching trajectory).
-  int b = blockIdx.x * 64 + threadIdx.x;
-  bool listed = true;
-  if constexpr (LISTED) {
-    const int cnt = a.nlist[a.step * a.lstride + a.round];
-    if ((int)blockIdx.x * 64 >= cnt) return;
-    listed = b < cnt;
-    b = a.list[listed ? b : cnt - 1];
-  }
-  const int tile = b >> 6, lane = b & 63;
-  // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
-  // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
-  // predicated.  The wave leaves only when no lane needs the candidate.
-  const bool live = listed && b < P.B && a.active[b] && !a.bpfail[b] && a.ls_round[b] == a.round;
-  if (__ballot(live) == 0) return;
   const int N = P.N;
   constexpr int c = 0;  // nominal slot
-  const int cs = t + 1;
   const double* Xc = TILE_PTR(XSLOT(a, c), N * n);
   const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
   double* Xn = TILE_PTR(XSLOT(a, cs), N * n);
@@ -708,8 +690,6 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   const double* px0 = TILE_PTR(a.x0, n);
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
-  double alpha = 1.0;
-  for (int i = 0; i < idx; ++i) alpha *= o.line_search_decrease_factor;  // same product the sequential search forms
   // everything wave-uniform the loop needs is fetched ONCE: an in-order wave stalls on every scalar-load round trip
   double mp[16];
 #pragma unroll
@@ -774,16 +754,55 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
     J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true);
   }
+  J_out = J; g_out = gsum / (N - 1); ok_out = ok;
+}
+
+template <class M, int MODE>
+__global__ void __launch_bounds__(64) k_forward(KArgs a) {
+  constexpr int m = M::m, ne = M::ne;
+  constexpr bool LISTED = (MODE & 16) != 0;
+  constexpr bool KLDS = M::lds_gains && !LISTED;  // gains staged through LDS by DMA instead of prefetch registers
+  __shared__ double kbuf[KLDS ? m * ne * 64 : 1];
+  const DevProblem& P = a.P;
+  const int t = blockIdx.y;
+  const int idx = a.cand0 + t;
+  const to_solver_opts& o = P.opts;
+  if (idx >= o.iterations_linesearch) return;
+  // Round 0: lane = trajectory of tile blockIdx.x.  Later rounds: the few trajectories that rejected every step size so
+  // far were compacted into a list by k_select; wave v takes entries 64v..64v+63 (gathered loads, but a handful of
+  // waves instead of one per tile that still holds a searching trajectory).
+  int b = blockIdx.x * 64 + threadIdx.x;
+  bool listed = true;
+  if constexpr (LISTED) {
+    const int cnt = a.nlist[a.step * a.lstride + a.round];
+    if ((int)blockIdx.x * 64 >= cnt) return;
+    listed = b < cnt;
+    b = a.list[listed ? b : cnt - 1];
+  }
+  const int tile = b >> 6, lane = b & 63;
+  // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
+  // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
+  // predicated.  The wave leaves only when no lane needs the candidate.
+  const bool live = listed && b < P.B && a.active[b] && !a.bpfail[b] && a.ls_round[b] == a.round;
+  if (__ballot(live) == 0) return;
+  double alpha = 1.0;
+  for (int i = 0; i < idx; ++i) alpha *= o.line_search_decrease_factor;  // same product the sequential search forms
+  double J, gm;
+  bool ok;
+  forward_candidate<M, MODE>(a, tile, lane, live, alpha, t + 1, kbuf, J, gm, ok);
   if (!live) return;
   const size_t ci = (size_t)t * P.Bp + b;
   a.candJ[ci] = J;
-  a.candG[ci] = gsum / (N - 1);
+  a.candG[ci] = gm;
   a.candOk[ci] = ok ? 1 : 0;
 }
 
 // Picks the FIRST accepted step size of the round (identical to sequential backtracking), then — when
 // a.control — runs the per-trajectory solver state machine: convergence test (row S3) and the AL outer update (row S4).
-template <class M>
+// Small models (M::tail_in_select): the step sizes beyond the first round are not given launches of their own (for the
+// Cartpole workload they never had any work) — the rare trajectory that rejects the whole first round finishes its
+// search right here, sequentially, with the same rollout code (MODE as in k_forward; 0 for the other models).
+template <class M, int MODE>
 __global__ void __launch_bounds__(64) k_select(KArgs a) {
   constexpr int m = M::m;
   TILE_LANE();
@@ -837,6 +856,25 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
         }
       }
       alpha *= o.line_search_decrease_factor;
+    }
+    if constexpr (M::tail_in_select) {
+      // sequential tail of the search (exactly what backtracking does); candidates go to slot 1: all of this
+      // trajectory's first-round slots hold rejected steps
+      bool need = accepted < 0 && !exhausted;
+      for (int idx = a.cand0 + a.Tr; idx < o.iterations_linesearch && __ballot(need) != 0; ++idx) {
+        double J, gm, kdummy[1];
+        bool ok;
+        forward_candidate<M, MODE>(a, tile, lane, need, alpha, 1, kdummy, J, gm, ok);
+        if (need && ok) {
+          const double expected = -alpha * (dV0 + alpha * dV1);
+          const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+          if (z >= o.line_search_lower_bound && z <= o.line_search_upper_bound) {
+            accepted = idx; Jnew = J; grad = gm; acc = 1; need = false;
+          }
+        }
+        alpha *= o.line_search_decrease_factor;
+      }
+      exhausted = true;
     }
     if (accepted < 0) {
       if (!exhausted && a.cand0 + a.Tr < o.iterations_linesearch) {  // next round: join the compacted list

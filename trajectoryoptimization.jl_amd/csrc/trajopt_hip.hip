@@ -64,6 +64,7 @@ struct to_handle_s {
   int model_key = -1;
   int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
   bool write_through = false;  // model trait accept_write_through (models.h)
+  bool tail = false;           // model trait tail_in_select: only the first line-search round is launched
   int T1 = 1;  // step sizes evaluated concurrently in the first line-search round (all trajectories take part)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   KArgs a;  // host copy of the kernel argument block (device pointers inside)
@@ -341,6 +342,14 @@ int launch_backward(to_handle* h) {
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
+// compile-time dispatch of a small runtime integer: f(std::integral_constant<int, value>)
+template <int COUNT, int I = 0, class F>
+inline void mode_switch(int value, F&& f) {
+  if constexpr (I < COUNT) {
+    if (value == I) f(std::integral_constant<int, I>{});
+    else mode_switch<COUNT, I + 1>(value, f);
+  }
+}
 // Width of line-search round r starting at step size c0.  Round 0 takes T1 step sizes for every trajectory.  With a
 // wide first round (latency regime, few tiles) the rejecting trajectories are few and the next round takes everything
 // that is left; with a narrow one (throughput regime) many trajectories are still searching, so the widths grow
@@ -354,6 +363,7 @@ int round_width(const to_handle* h, int r, int c0, int total) {
 // number of line-search rounds launch_forward issues
 int ls_rounds(const to_handle* h) {
   const int total = std::max(1, h->a.P.opts.iterations_linesearch);
+  if (h->tail) return 1;
   int r = 0;
   for (int c0 = 0; c0 < total; ++r) c0 += round_width(h, r, c0, total);
   return r;
@@ -373,15 +383,15 @@ int ensure_nlist(to_handle* h, int steps) {
   HIPCHECK(hipMemsetAsync(a.nlist, 0, sizeof(int) * need, h->stream));
   return TO_OK;
 }
-// forward pass = line-search rounds of (concurrent candidates, select).  The first round evaluates the T1 largest step
-// sizes for every trajectory; the trajectories that rejected all of them are few, so the following rounds take up to T
-// step sizes at once (dead tiles leave immediately).
 int launch_accept(to_handle* h) {  // materialise accepted candidate slots on slot 0, then forget them
   hipLaunchKernelGGL(k_accept, grid_b(h, h->a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
   hipLaunchKernelGGL(k_clear_acc, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
+// forward pass = line-search rounds of (concurrent candidates, select).  The first round evaluates the T1 largest step
+// sizes for every trajectory; the trajectories that rejected all of them are few: large models give them further rounds
+// on a compacted list (round_width), small models finish the search sequentially inside the first k_select.
 int launch_forward(to_handle* h, bool accept = true) {
   KArgs& a = h->a;
   const int total = std::max(1, a.P.opts.iterations_linesearch);
@@ -392,44 +402,20 @@ int launch_forward(to_handle* h, bool accept = true) {
     a.round = r;
     a.cand0 = c0;
     a.Tr = round_width(h, r, c0, total);
-    // bit4: rounds after the first work on the compacted list (gathered lanes)
-    switch (mode | (r > 0 ? 16 : 0)) {
-      case 0: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 1: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 2: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 3: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 4: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 4 : 0>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 5: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 5 : 1>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 6: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 6 : 2>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 7: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 7 : 3>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 8: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 8>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 9: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 9>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 10: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 10>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 11: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 11>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 12: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 12 : 8>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 13: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 13 : 9>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 14: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 14 : 10>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 15: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 15 : 11>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 16: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 16>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 17: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 17>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 18: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 18>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 19: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 19>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 20: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 20 : 16>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 21: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 21 : 17>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 22: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 22 : 18>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 23: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 23 : 19>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 24: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 24>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 25: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 25>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 26: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 26>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 27: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, 27>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 28: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 28 : 24>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 29: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 29 : 25>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 30: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 30 : 26>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-      case 31: { DISPATCH(h, hipLaunchKernelGGL((k_forward<M, M::pin_rk4 ? 31 : 27>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a)); } break;
-    }
+    // kernel variants (kernels.h, k_forward): bit0 simple stage cost, bit1 constraints, bit2 compile-time RK4 (models that
+    // pin it), bit3 dense costs / generic constraints, bit4 compacted list (rounds after the first)
+    DISPATCH(h, mode_switch<32>(mode | (r > 0 ? 16 : 0), [&](auto I) {
+      constexpr int MD = M::pin_rk4 ? I.value : (I.value & ~4);
+      hipLaunchKernelGGL((k_forward<M, MD>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a);
+    }));
     HIPCHECK(hipGetLastError());
-    DISPATCH(h, hipLaunchKernelGGL(k_select<M>, grid_b(h), dim3(BLOCK), 0, h->stream, a));
+    // k_select only depends on the variant for the models that finish the search inside it (tail_in_select)
+    DISPATCH(h, mode_switch<16>(h->tail ? mode : 0, [&](auto I) {
+      constexpr int MD = M::tail_in_select ? (M::pin_rk4 ? I.value : (I.value & ~4)) : 0;
+      hipLaunchKernelGGL((k_select<M, MD>), grid_b(h), dim3(BLOCK), 0, h->stream, a);
+    }));
     HIPCHECK(hipGetLastError());
+    if (h->tail) break;  // the rest of the search runs inside k_select
     c0 += a.Tr;
   }
   if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
@@ -640,7 +626,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->model_key = key;
   h->R = (ne + m) <= 4 ? 4 : (ne + m) <= 8 ? 8 : 16;
   h->G = 64 / h->R;
-  DISPATCH(h, h->write_through = M::accept_write_through);
+  DISPATCH(h, h->write_through = M::accept_write_through; h->tail = M::tail_in_select);
   h->costs.assign(desc->costs, desc->costs + desc->n_costs);
   h->cons = cons; h->dt = dt; h->cost_index = cost_index;
   auto bail = [&](int rc) { std::string e = g_err; to_destroy(h); g_err = e; return rc; };
@@ -670,7 +656,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->T1 = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
   if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) h->T1 = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
   // later rounds: whatever remains of the default search depth, at once (only the few trajectories still searching take part)
-  a.T = std::max(h->T1, std::min(20, std::max(1, P.opts.iterations_linesearch - h->T1)));
+  a.T = h->tail ? h->T1 : std::max(h->T1, std::min(20, std::max(1, P.opts.iterations_linesearch - h->T1)));
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
