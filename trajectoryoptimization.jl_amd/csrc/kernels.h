@@ -556,13 +556,15 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     }
     if (j < ne) {
 #pragma unroll
-      for (int r = 0; r < m; ++r) { Kf[r * ne + j] = Kj[r]; if (glive) EL(pK, (k * m + r) * ne + j) = Kj[r]; }
+      for (int r = 0; r < m; ++r) { if constexpr (m > 1) Kf[r * ne + j] = Kj[r]; if (glive) EL(pK, (k * m + r) * ne + j) = Kj[r]; }
     }
     if (j == 0 && glive) {
 #pragma unroll
       for (int r = 0; r < m; ++r) EL(pd, k * m + r) = dk[r];
     }
-    WAVE_SYNC();
+    // single-input models: every lane rebuilds the other columns' gains from the published Qux row (same two products
+    // as the owner lane, bit for bit) instead of exchanging K through LDS — one barrier round less per knot
+    if constexpr (m > 1) WAVE_SYNC();
     // 6. cost-to-go with the un-regularised Quu:  S' = Qxx + Kᵀ(Quu K + Qux) + Quxᵀ K,  s' = Qx + Kᵀ(Quu d + Qu) + Quxᵀ d
     double Snew[ne], snew = 0.0;
     {
@@ -578,7 +580,7 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
       for (int i = 0; i < ne; ++i) {
         double t = Hj[i];
 #pragma unroll
-        for (int r = 0; r < m; ++r) t += Kf[r * ne + i] * Wj[r];
+        for (int r = 0; r < m; ++r) t += ((m > 1) ? Kf[r * ne + i] : -((Hu[i] * iL[0]) * iL[0])) * Wj[r];
 #pragma unroll
         for (int r = 0; r < m; ++r) t += Hu[r * R + i] * Kj[r];
         Snew[i] = t;
