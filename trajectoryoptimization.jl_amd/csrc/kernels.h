@@ -430,6 +430,8 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
   int k = N - 2;
   bool init = true, fresh = true;
   double Mn[ne], Hn[nc], gn = 0.0;  // prefetched column of the next knot
+  const double *pMk = Mc, *pHk = Hc, *pgk = gc;
+  double *pKk = pK, *pdk = pd;
   while (true) {
     if (init) {  // (re)start: S = Qxx_N, s = qx_N
       fresh = true;
@@ -445,6 +447,9 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
         }
       }
       dV0 = 0.0; dV1 = 0.0; k = N - 2; init = false;
+      // per-knot pointers walk backwards with the recursion: constant offsets instead of 64-bit address arithmetic per load
+      pMk = Mc + (size_t)(N - 2) * ne * 64; pHk = Hc + (size_t)(N - 2) * nc * 64; pgk = gc + (size_t)(N - 2) * 64;
+      pKk = pK + (size_t)(N - 2) * m * ne * 64; pdk = pd + (size_t)(N - 2) * m * 64;
       WAVE_SYNC();
     }
     if (k < 0) break;
@@ -452,10 +457,10 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     double Mj[ne], Hj[nc], gj;
     if (fresh) {
 #pragma unroll
-      for (int i = 0; i < ne; ++i) Mn[i] = EL(Mc, k * ne + i);
+      for (int i = 0; i < ne; ++i) Mn[i] = EL(pMk, i);
 #pragma unroll
-      for (int i = 0; i < nc; ++i) Hn[i] = EL(Hc, k * nc + i);
-      gn = EL(gc, k);
+      for (int i = 0; i < nc; ++i) Hn[i] = EL(pHk, i);
+      gn = EL(pgk, 0);
       fresh = false;
     }
 #pragma unroll
@@ -466,10 +471,10 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     if constexpr (ne > 6) fresh = true;  // large models: the extra live registers cost more than the latency they hide
     else if (k > 0) {
 #pragma unroll
-      for (int i = 0; i < ne; ++i) Mn[i] = EL(Mc, (k - 1) * ne + i);
+      for (int i = 0; i < ne; ++i) Mn[i] = (pMk - ne * 64)[(size_t)i * 64];
 #pragma unroll
-      for (int i = 0; i < nc; ++i) Hn[i] = EL(Hc, (k - 1) * nc + i);
-      gn = EL(gc, k - 1);
+      for (int i = 0; i < nc; ++i) Hn[i] = (pHk - nc * 64)[(size_t)i * 64];
+      gn = (pgk - 64)[0];
     }
 #pragma unroll
     for (int i = 0; i < ne; ++i) Mx[i * R + j] = Mj[i];
@@ -556,11 +561,11 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     }
     if (j < ne) {
 #pragma unroll
-      for (int r = 0; r < m; ++r) { if constexpr (m > 1) Kf[r * ne + j] = Kj[r]; if (glive) EL(pK, (k * m + r) * ne + j) = Kj[r]; }
+      for (int r = 0; r < m; ++r) { if constexpr (m > 1) Kf[r * ne + j] = Kj[r]; if (glive) EL(pKk, r * ne + j) = Kj[r]; }
     }
     if (j == 0 && glive) {
 #pragma unroll
-      for (int r = 0; r < m; ++r) EL(pd, k * m + r) = dk[r];
+      for (int r = 0; r < m; ++r) EL(pdk, r) = dk[r];
     }
     // single-input models: every lane rebuilds the other columns' gains from the published Qux row (same two products
     // as the owner lane, bit for bit) instead of exchanging K through LDS — one barrier round less per knot
@@ -617,6 +622,7 @@ __global__ void __launch_bounds__(64) k_backward(KArgs a) {
     }
     WAVE_SYNC();
     --k;
+    pMk -= ne * 64; pHk -= nc * 64; pgk -= 64; pKk -= m * ne * 64; pdk -= m * 64;
   }
   if (!failed) reg_decrease(P.opts, rho, drho);
   if (j == 0 && glive) {
