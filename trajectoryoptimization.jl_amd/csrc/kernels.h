@@ -640,16 +640,17 @@ template <class M, bool WITHK>
 struct FwdKnot {  // nominal state/control and gains of one knot, fetched one knot ahead of their use
   static constexpr int n = M::n, m = M::m, ne = M::ne;
   double x[n], u[m], K[WITHK ? m : 1][WITHK ? ne : 1], d[m];
-  __device__ __forceinline__ void load(const double* pX, const double* pU, const double* pK, const double* pd, int k) {
+  // pointers are already at this knot (the caller walks them): constant offsets, no address arithmetic per load
+  __device__ __forceinline__ void load(const double* pXk, const double* pUk, const double* pKk, const double* pdk) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = EL(pX, k * n + i);
+    for (int i = 0; i < n; ++i) x[i] = EL(pXk, i);
 #pragma unroll
     for (int j = 0; j < m; ++j) {
-      u[j] = EL(pU, k * m + j);
-      d[j] = EL(pd, k * m + j);
+      u[j] = EL(pUk, j);
+      d[j] = EL(pdk, j);
       if constexpr (WITHK) {
 #pragma unroll
-        for (int i = 0; i < ne; ++i) K[j][i] = EL(pK, (k * m + j) * ne + i);
+        for (int i = 0; i < ne; ++i) K[j][i] = EL(pKk, j * ne + i);
       }
     }
   }
@@ -715,10 +716,13 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const double* ktile = a.K + ((size_t)tile * ((N - 1) * m * ne)) * 64;
   if constexpr (KLDS) stage_gains<M>(ktile, 0, kbuf, lane);
   FwdKnot<M, !KLDS> nxt;
-  nxt.load(Xc, Uc, pK, pd, 0);
+  nxt.load(Xc, Uc, pK, pd);
+  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + m * ne * 64, *pdn = pd + m * 64;  // knot k+1 of the nominal
+  double *pXo = Xn + n * 64, *pUo = Un;                                                              // where knot k's results go
   for (int k = 0; k < N - 1; ++k) {
     const FwdKnot<M, !KLDS> cur = nxt;
-    if (k + 1 < N - 1) nxt.load(Xc, Uc, pK, pd, k + 1);  // software prefetch of the next knot
+    if (k + 1 < N - 1) nxt.load(pXn, pUn, pKn, pdn);  // software prefetch of the next knot
+    pXn += n * 64; pUn += m * 64; pKn += m * ne * 64; pdn += m * 64;
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
     if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this knot's gains have landed in LDS
@@ -736,7 +740,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
 #pragma unroll
     for (int j = 0; j < m; ++j) {
       ub[j] = cur.u[j] + du[j];
-      if (live) EL(Un, k * m + j) = ub[j];
+      if (live) EL(pUo, j) = ub[j];
       gk = fmax(gk, fabs(cur.d[j]) * rcp_fast(fabs(ub[j]) + 1.0));
     }
     gsum += gk;
@@ -748,7 +752,8 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     rk_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, xb, ub, h, xn);
     double mx = 0.0, mu_ = 0.0;
 #pragma unroll
-    for (int i = 0; i < n; ++i) { xb[i] = xn[i]; if (live) EL(Xn, (k + 1) * n + i) = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
+    for (int i = 0; i < n; ++i) { xb[i] = xn[i]; if (live) EL(pXo, i) = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
+    pXo += n * 64; pUo += m * 64;
 #pragma unroll
     for (int j = 0; j < m; ++j) { const double v = fabs(ub[j]); if (!(v <= mu_)) mu_ = v; }
     // a rollout that left the admissible box is rejected; its lane keeps stepping (values are never used) so that the
