@@ -284,8 +284,11 @@ int to_cost_expansion(to_handle* h, double* grad, double* hess);
 int to_discrete_jacobian(to_handle* h, double* F);
 
 /* ---- measurement: per-kernel device time of the solve loop, from hipEvents recorded on the handle's stream ----
- * slots: 0 expansion, 1 backward pass, 2 forward pass (+ state machine), 3 fused whole-solve kernel (when used).
- * Accumulates over solves until reset.  Enabling it adds two event records per launch. */
+ * slots: 0 expansion, 1 backward pass, 2 forward pass (line-search rounds, selection / state machine, accept copy, AL
+ * outer update), 3 unused.  A "launch" is one batch step.  Accumulates over solves until reset.  Enabling it adds four
+ * event records per batch step.
+ * Tuning knob (environment, read at to_create): TRAJOPT_LS_CANDIDATES = step sizes evaluated concurrently in the first
+ * line-search round (default min(16, 1024 / tiles)); results do not depend on it. */
 #define TO_PROFILE_SLOTS 4
 int to_set_profiling(to_handle* h, int enable);
 int to_get_profile(to_handle* h, double* kernel_ms /* [TO_PROFILE_SLOTS] */, int64_t* launches /* [TO_PROFILE_SLOTS] */);
@@ -293,7 +296,7 @@ int to_reset_profile(to_handle* h);
 
 /* ---- constraints --------------------------------------------------------------------------- */
 /* evaluate_constraints! / constraint_jacobians! for constraint `con_id` over its knot range.
- * vals[p, nk, B], jac[p, w, nk, B] with w = n (state constraints: GOAL, CIRCLE, SPHERE) or n+m (stage constraints),
+ * vals[p, nk, B], jac[p, w, nk, B] with w = n (state constraints: GOAL, CIRCLE, SPHERE, COLLISION, QUATVEC) or n+m (stage constraints),
  * nk = k_last-k_first+1.  jac is fully written (zeros included). */
 int to_evaluate_constraints(to_handle* h, int32_t con_id, double* vals);
 int to_constraint_jacobians(to_handle* h, int32_t con_id, double* jac);
