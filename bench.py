@@ -100,7 +100,15 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     t0 = time.perf_counter()
     solver.solve()
     dt = time.perf_counter() - t0
-    return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port",
+    # one trajectory on one core: the figure comparable to published single-core solver timings
+    p1 = build_problem(T, configs, name, 1, 0, 0, o)
+    set_threads(p1, 1)
+    s1 = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(p1)
+    t1 = time.perf_counter()
+    s1.solve()
+    d1 = time.perf_counter() - t1
+    single = {"value": s1.total_iterations / d1, "cores": 1, "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms"}
+    return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "single_thread": single,
             "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve, "
                       f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
 
