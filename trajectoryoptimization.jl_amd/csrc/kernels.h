@@ -83,6 +83,30 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
 }
 
 // AL penalty terms of one knot only
+// AL terms of one stage knot with up to two register-cached control-block constraints (ConStage); the others take the
+// descriptor-table path.  Terms are summed in constraint order, like knot_al.
+template <class M, bool GEN>
+__device__ __forceinline__ double knot_al_cached(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
+                                                 const double* mu0, int ncs, const ConStage<M::n, M::m>& c0,
+                                                 const ConStage<M::n, M::m>& c1) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  double Ja = 0.0;
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    if (ncs > 0 && ci == c0.ci) { Ja += c0.term(u); continue; }
+    if (ncs > 1 && ci == c1.ci) { Ja += c1.term(u); continue; }
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    double z[nz];
+#pragma unroll
+    for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) z[n + i] = u[i];
+    const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
+  }
+  return Ja;
+}
+
 template <class M, bool GEN = true>
 __device__ __forceinline__ double knot_al(const DevProblem& P, int k, const double* x, const double* u, const double* lam0, const double* mu0) {
   constexpr int n = M::n, m = M::m, nz = n + m;
@@ -709,6 +733,19 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   StageCostDiag<n, m> sc;
   double h0 = 0.0;
   if constexpr (SIMPLE) { sc.load(P.costs[P.cost_index[0]]); h0 = P.dt[0]; }
+  // stage constraints on the control block (norm / SOC / one-sided bounds on u) are cached in registers once
+  ConStage<n, m> cs0, cs1;
+  int ncs = 0, uncached = 0;
+  cs0.ci = -1; cs1.ci = -1;
+  if constexpr (CONS) {
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (K.fast == 2 && K.k1 == 0 && K.k2 >= N - 2 && K.p <= m + 1 && ncs < 2) {
+        if (ncs == 0) cs0.load(K, ci, lam0, mu0); else cs1.load(K, ci, lam0, mu0);
+        ++ncs;
+      } else if (K.k1 <= N - 2) ++uncached;  // applies to some stage knot: needs the descriptor-table path
+    }
+  }
   double xb[n], J = 0.0, gsum = 0.0;
   bool ok = true;
 #pragma unroll
@@ -719,9 +756,18 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   nxt.load(Xc, Uc, pK, pd);
   const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + m * ne * 64, *pdn = pd + m * 64;  // knot k+1 of the nominal
   double *pXo = Xn + n * 64, *pUo = Un;                                                              // where knot k's results go
+  const bool all_cached = CONS && uncached == 0;  // wave-uniform: the loop then never touches the descriptor table
+  if (ncs > 0) cs0.prefetch(0);
+  if (ncs > 1) cs1.prefetch(0);
   for (int k = 0; k < N - 1; ++k) {
     const FwdKnot<M, !KLDS> cur = nxt;
-    if (k + 1 < N - 1) nxt.load(pXn, pUn, pKn, pdn);  // software prefetch of the next knot
+    if (ncs > 0) cs0.advance();
+    if (ncs > 1) cs1.advance();
+    if (k + 1 < N - 1) {  // software prefetch of the next knot
+      nxt.load(pXn, pUn, pKn, pdn);
+      if (ncs > 0) cs0.prefetch(k + 1);
+      if (ncs > 1) cs1.prefetch(k + 1);
+    }
     pXn += n * 64; pUn += m * 64; pKn += m * ne * 64; pdn += m * 64;
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
@@ -747,7 +793,14 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     const double h = SIMPLE ? h0 : P.dt[k];
     double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], xb, ub);
     if (dt_scaling) Jk *= h;
-    if constexpr (CONS) Jk += knot_al<M, GEN>(P, k, xb, ub, lam0, mu0);
+    if constexpr (CONS) {
+      if (all_cached) {
+        double Ja = 0.0;
+        if (ncs > 0) Ja += cs0.term(ub);
+        if (ncs > 1) Ja += cs1.term(ub);
+        Jk += Ja;
+      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1);
+    }
     J += Jk;
     rk_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, xb, ub, h, xn);
     double mx = 0.0, mu_ = 0.0;

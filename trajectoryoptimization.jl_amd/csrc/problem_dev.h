@@ -452,6 +452,70 @@ __device__ __forceinline__ double al_term(ConC& K, const double* z, const double
   return J;
 }
 
+// A constraint whose selector rows are the control block (fast == 2) and that applies to every stage knot, cached in
+// registers for the rollout loops: al_term re-reads k1/k2/p/sense/ssgn/soff from the descriptor table on every knot —
+// ~80 dependent scalar loads per Quadrotor knot with the C5 constraint set.  Same expressions as al_term.
+template <int n, int m>
+struct ConStage {
+  int ci, p, sense;
+  double ssgn[m + 1], soff[m + 1], mu;
+  double lcur[m + 1], lnxt[m + 1];  // duals of the current knot / fetched one knot ahead (a load at the point of use
+                                    // costs a full memory round trip per knot: measured 2.2x the waits of the unconstrained loop)
+  const double* lam;  // this lane's dual row 0 at knot 0; row r of knot k at lam[(k*p + r)*64]
+  __device__ __forceinline__ void prefetch(int k) {
+    const double* lk = lam + (size_t)k * p * 64;
+#pragma unroll
+    for (int r = 0; r < m + 1; ++r) lnxt[r] = (r < p) ? lk[r * 64] : 0.0;
+  }
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int r = 0; r < m + 1; ++r) lcur[r] = lnxt[r];
+  }
+  __device__ __forceinline__ void load(ConC& K, int ci_, const double* lam0, const double* mu0) {
+    ci = ci_; p = K.p; sense = K.d.sense;
+#pragma unroll
+    for (int r = 0; r < m + 1; ++r) { ssgn[r] = (r < p) ? K.ssgn[r] : 0.0; soff[r] = (r < p) ? K.soff[r] : 0.0; }
+    mu = mu0[(size_t)ci_ * 64];
+    lam = lam0 + (size_t)K.dual_off * 64;
+  }
+  // uses the duals in lcur (prefetch(k) + advance() by the caller)
+  __device__ __forceinline__ double term(const double* u) const {
+    double J = 0.0;
+    if (sense == TO_CONE_SECOND_ORDER) {
+      double a2 = 0.0, l2 = 0.0, ls = 0.0, so = 0.0;
+#pragma unroll
+      for (int r = 0; r < m; ++r)
+        if (r < p - 1) {
+          const double l = lcur[r];
+          const double lb = l - mu * (ssgn[r] * (u[r] - soff[r]));
+          l2 += l * l;
+          a2 += lb * lb;
+        }
+#pragma unroll
+      for (int r = 0; r < m + 1; ++r)
+        if (r == p - 1) { ls = lcur[r]; so = soff[r]; }
+      const double s = ls - mu * so;
+      l2 += ls * ls;
+      const double a = sqrt(a2);
+      double pn;
+      if (a <= -s) pn = 0.0;
+      else if (a <= s) pn = a2 + s * s;
+      else { const double cf = 0.5 * (1 + s / a); pn = (cf * cf) * a2 + (a * cf) * (a * cf); }
+      J = (pn - l2) / (2.0 * mu);
+    } else {
+      const bool eq = (sense == TO_CONE_ZERO);
+#pragma unroll
+      for (int r = 0; r < m; ++r)
+        if (r < p) {
+          const double l = lcur[r], c = ssgn[r] * (u[r] - soff[r]);
+          const bool active = eq || (c >= 0.0) || (l > 0.0);
+          J += l * c + (active ? 0.5 * mu * c * c : 0.0);
+        }
+    }
+    return J;
+  }
+};
+
 // adds the AL gradient (g += ∇c' y) and Gauss-Newton Hessian-vector product (y += ∇c' W ∇c v) of one constraint.
 // For the SOC the reference composes ∇Π'∇Π + ∇²Π[Π] (src/cones.jl); since ∇(½|Π(x)|²) = Π(x) this equals ∇Π(x), and
 // ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
