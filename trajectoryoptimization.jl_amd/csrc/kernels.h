@@ -277,44 +277,15 @@ struct Coop {
 // with v_j = [G(x_k) e_j; 0] (j<ne) or [0; e_{j-ne}].
 // VAR bit0: dense QuadraticCost possible; bit1: constraints present; bit2: non-selector constraints possible.  Code the
 // problem cannot reach is compiled out: the all-purpose Quadrotor kernel needed 256 VGPRs + 140 AGPRs + 480 B of scratch.
+// one knot of the expansion for lane (g, j): x = x_k, u = u_k (zeros at the terminal knot), x1 = x_{k+1}
 template <class M, int FIXED_INTEG, int VAR>
-__global__ void __launch_bounds__(64) k_expand(KArgs a) {
+__device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane, int tile, int lane64, int j, int k, bool valid,
+                                            const double* x, const double* u, const double* x1) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
-  constexpr int R = Coop<M>::R, G = Coop<M>::G;
-  const int gtile = blockIdx.x, lane = threadIdx.x;
-  const int g = lane / R, j = lane % R;
-  const int b = gtile * G + g;
   const DevProblem& P = a.P;
   const int N = P.N;
-  const int k = blockIdx.y;
   const bool terminal = (k == N - 1);
-  // idle lanes (padding columns, finished trajectories) compute along with EXEC full — partially masked FP64 issues
-  // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
-  const bool valid = b < P.B && j < nc && a.active[b] && !(terminal && j >= ne);
-  if (__ballot(valid) == 0) return;
-  // Inside a solve the step accepted by the previous forward pass still sits in its candidate slot (acc != 0): the
-  // expansion reads it there and writes it through to slot 0, so the separate k_accept copy (and its re-read of every
-  // candidate line that any lane of a tile accepted) disappears from the iteration.  Outside a solve acc is 0.
-  // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
-  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
-  const int tile = b >> 6, lane64 = b & 63;
-  const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
-  const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
-  double x[n], u[m], v[nz];
-#pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
-#pragma unroll
-  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(U, k * m + i);
-  if (M::accept_write_through && c != 0 && j == 0 && valid) {
-    double* X0 = XSLOT(a, 0) + ((size_t)tile * (N * n)) * 64 + lane64;
-    double* U0 = USLOT(a, 0) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
-#pragma unroll
-    for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
-    if (!terminal) {
-#pragma unroll
-      for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
-    }
-  }
+  double v[nz];
   {
     double vx[n];
     errstate_col<M>(x, j < ne ? j : 0, vx);
@@ -331,9 +302,9 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
 #pragma unroll
     for (int i = 0; i < m; ++i) ud[i] = Dual(u[i], v[n + i]);
     rk_step<M, Dual, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
-    double x1[n], t[n], col[ne];
+    double t[n], col[ne];
 #pragma unroll
-    for (int i = 0; i < n; ++i) { x1[i] = EL(X, (k + 1) * n + i); t[i] = xn[i].d; }
+    for (int i = 0; i < n; ++i) t[i] = xn[i].d;
     errstate_tmul<M>(x1, t, col);
     double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
     if (valid) {
@@ -385,6 +356,68 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
   double* gc = COL_PTR(a.gc, N);
   EL(gc, k) = gj;
+}
+
+// A wave walks M::expand_knots consecutive knots and fetches the next knot's state/control while it works on the
+// current one: with one wave per SIMD (Quadrotor) nothing else hides the load round trip, which was half of the wave's
+// life (rocprof: SQ_WAIT_ANY 49 % of SQ_WAVE_CYCLES, 60 % with AL terms).  x_{k+1} is shared between neighbours.
+template <class M, int FIXED_INTEG, int VAR>
+__global__ void __launch_bounds__(64) k_expand(KArgs a) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, KC = M::expand_knots;
+  constexpr int R = Coop<M>::R, G = Coop<M>::G;
+  const int gtile = blockIdx.x, lane = threadIdx.x;
+  const int g = lane / R, j = lane % R;
+  const int b = gtile * G + g;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const int k0 = blockIdx.y * KC;
+  // idle lanes (padding columns, finished trajectories) compute along with EXEC full — partially masked FP64 issues
+  // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
+  const bool lane_ok = b < P.B && j < nc && a.active[b];
+  if (__ballot(lane_ok) == 0) return;
+  // Inside a solve the step accepted by the previous forward pass still sits in its candidate slot (acc != 0): the
+  // expansion reads it there and writes it through to slot 0, so the separate k_accept copy (and its re-read of every
+  // candidate line that any lane of a tile accepted) disappears from the iteration.  Outside a solve acc is 0.
+  // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
+  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
+  const int tile = b >> 6, lane64 = b & 63;
+  const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
+  const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+  double x[n], u[m], x1[n], x2[n], un[m];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { x[i] = EL(X, k0 * n + i); x1[i] = (k0 + 1 < N) ? EL(X, (k0 + 1) * n + i) : 0.0; }
+#pragma unroll
+  for (int i = 0; i < m; ++i) u[i] = (k0 < N - 1) ? EL(U, k0 * m + i) : 0.0;
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+    const int k = k0 + kk;
+    if (k >= N) break;
+    const bool terminal = (k == N - 1);
+    if (KC > 1 && kk + 1 < KC && k + 1 < N) {  // next knot's operands (x_{k+1} is already here)
+#pragma unroll
+      for (int i = 0; i < n; ++i) x2[i] = (k + 2 < N) ? EL(X, (k + 2) * n + i) : 0.0;
+#pragma unroll
+      for (int i = 0; i < m; ++i) un[i] = (k + 1 < N - 1) ? EL(U, (k + 1) * m + i) : 0.0;
+    }
+    const bool valid = lane_ok && !(terminal && j >= ne);
+    if (M::accept_write_through && c != 0 && j == 0 && valid) {
+      double* X0 = XSLOT(a, 0) + ((size_t)tile * (N * n)) * 64 + lane64;
+      double* U0 = USLOT(a, 0) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+#pragma unroll
+      for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
+      if (!terminal) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
+      }
+    }
+    expand_knot<M, FIXED_INTEG, VAR>(a, gtile, lane, tile, lane64, j, k, valid, x, u, x1);
+    if (KC > 1) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { x[i] = x1[i]; x1[i] = x2[i]; }
+#pragma unroll
+      for (int i = 0; i < m; ++i) u[i] = un[i];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ regularisation

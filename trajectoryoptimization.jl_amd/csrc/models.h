@@ -99,6 +99,7 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr int n = 2 * D, m = D, ne = 2 * D;
   static constexpr bool lie = false;
   static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
+  static constexpr int expand_knots = 1;
   static constexpr bool tail_in_select = true;         // ... are finished sequentially inside k_select (kernels.h)
   static constexpr bool accept_write_through = true;   // ... by the next expansion instead (kernels.h, k_expand)
   static constexpr bool lds_gains = false;
@@ -117,6 +118,7 @@ struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr int n = 4, m = 1, ne = 4;
   static constexpr bool lie = false;
   static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
+  static constexpr int expand_knots = 1;
   static constexpr bool tail_in_select = true;         // ... are finished sequentially inside k_select (kernels.h)
   static constexpr bool accept_write_through = true;   // ... by the next expansion instead (kernels.h, k_expand)
   static constexpr bool lds_gains = false;
@@ -148,6 +150,7 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr int n = 13, m = 4, ne = 12;
   static constexpr bool lie = true;
   static constexpr bool pin_rk4 = false;  // compile-time RK4 costs registers here: measured slower than the runtime switch
+  static constexpr int expand_knots = 4;               // knots one expansion wave walks (software-pipelined loads)
   static constexpr bool tail_in_select = false;        // later line-search rounds get their own launches (compacted list)
   static constexpr bool accept_write_through = false;  // accepted steps are copied onto slot 0 by k_accept after every forward pass
   static constexpr bool lds_gains = true;  // forward pass: the 48 gain rows of a knot come through LDS (DMA), not 96 prefetch VGPRs

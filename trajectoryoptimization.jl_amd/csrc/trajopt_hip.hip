@@ -322,7 +322,9 @@ int launch_cost(to_handle* h, int with_al, double* out, double* Jk) {
 }
 int launch_expand(to_handle* h) {
   const DevProblem& P = h->a.P;
-  const dim3 grid((P.B + h->G - 1) / h->G, P.N);
+  int kc = 1;
+  DISPATCH(h, kc = M::expand_knots);
+  const dim3 grid((P.B + h->G - 1) / h->G, (P.N + kc - 1) / kc);
   // variants compiled: 0 = diagonal-kind costs, no constraints; 2 = + selector / SOC-selector constraints; 7 = everything
   const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
 #define EXPAND_LAUNCH(FI)                                                                                          \
