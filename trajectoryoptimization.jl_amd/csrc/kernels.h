@@ -294,6 +294,29 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
 #pragma unroll
     for (int i = 0; i < m; ++i) v[n + i] = (i == j - ne) ? 1.0 : 0.0;
   }
+  // duals of (up to two) control-block constraints of this knot are fetched NOW, ahead of the dynamics column: the AL
+  // terms below would otherwise pay a memory round trip of their own (the stores in between pin their loads in place)
+  constexpr int LR = m + 1;
+  double l0[LR], l1[LR], mu0r = 0.0, mu1r = 0.0;
+  int lci0 = -1, lci1 = -1;
+  if ((VAR & 2) != 0 && P.n_cons > 0) {
+    const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
+    const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (k < K.k1 || k > K.k2 || K.fast != 2 || K.p > LR) continue;
+      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      if (lci0 < 0) {
+        lci0 = ci; mu0r = EL(mu0, ci);
+#pragma unroll
+        for (int r = 0; r < LR; ++r) l0[r] = (r < K.p) ? lam[r * 64] : 0.0;
+      } else if (lci1 < 0) {
+        lci1 = ci; mu1r = EL(mu0, ci);
+#pragma unroll
+        for (int r = 0; r < LR; ++r) l1[r] = (r < K.p) ? lam[r * 64] : 0.0;
+      }
+    }
+  }
   // ---- dynamics column
   if (!terminal) {
     Dual xd[n], ud[m], xn[n];
@@ -331,6 +354,8 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
     for (int ci = 0; ci < P.n_cons; ++ci) {
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
+      if (ci == lci0) { al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, l0, 1, mu0r, v, gr, y); continue; }
+      if (ci == lci1) { al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, l1, 1, mu1r, v, gr, y); continue; }
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
       al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
     }

@@ -520,10 +520,12 @@ struct ConStage {
 // For the SOC the reference composes ∇Π'∇Π + ∇²Π[Π] (src/cones.jl); since ∇(½|Π(x)|²) = Π(x) this equals ∇Π(x), and
 // ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
 // GENERIC = false compiles the non-selector constraint kinds (circle, sphere, linear, quadratic-form norm) out.
-template <int n, int m, bool GENERIC = true>
-__device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const double* lam, size_t stride, double mu,
+// REGROWS > 0: lam points to a register copy of the first REGROWS dual rows (stride 1, fetched early by the caller).
+template <int n, int m, bool GENERIC = true, int REGROWS = 0>
+__device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const double* lam, size_t stride_rt, double mu,
                                             const double* v, double* g, double* y) {
   constexpr int nz = n + m;
+  const size_t stride = REGROWS > 0 ? (size_t)1 : stride_rt;
   const int p = K.p;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
     double a2 = 0.0, lw = 0.0;  // lw = lb_v · w_v with w = ∇c v
@@ -532,7 +534,8 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
       a2 += lb * lb;
       lw += lb * (K.ssgn[r] * zget<nz>(v, idx));
     });
-    const double s = lam[(p - 1) * stride] - mu * K.soff[p - 1];
+    const double llast = REGROWS > 0 ? pick<(REGROWS > 0 ? REGROWS : 1)>(lam, p - 1) : lam[(p - 1) * stride];
+    const double s = llast - mu * K.soff[p - 1];
     const double a = sqrt(a2);
     if (a <= -s) return;  // Π = 0, ∇Π = 0
     const bool inside = (a <= s);
