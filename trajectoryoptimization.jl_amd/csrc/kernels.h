@@ -821,12 +821,16 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     const FwdKnot<M, !KLDS> cur = nxt;
     if (ncs > 0) cs0.advance();
     if (ncs > 1) cs1.advance();
-    if (k + 1 < N - 1) {  // software prefetch of the next knot
-      nxt.load(pXn, pUn, pKn, pdn);
-      if (ncs > 0) cs0.prefetch(k + 1);
-      if (ncs > 1) cs1.prefetch(k + 1);
+    // software prefetch of the next knot.  With DMA-staged gains the wave waits for vmcnt(0) below, which would also
+    // wait for loads issued here: those models issue the whole next knot AFTER that wait (one knot of compute to land).
+    if constexpr (!KLDS) {
+      if (k + 1 < N - 1) {
+        nxt.load(pXn, pUn, pKn, pdn);
+        if (ncs > 0) cs0.prefetch(k + 1);
+        if (ncs > 1) cs1.prefetch(k + 1);
+      }
+      pXn += n * 64; pUn += m * 64; pKn += m * ne * 64; pdn += m * 64;
     }
-    pXn += n * 64; pUn += m * 64; pKn += m * ne * 64; pdn += m * 64;
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
     if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this knot's gains have landed in LDS
@@ -839,7 +843,13 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     }
     if constexpr (KLDS) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read the buffer before the DMA refills it
-      if (k + 1 < N - 1) stage_gains<M>(ktile, k + 1, kbuf, lane);
+      if (k + 1 < N - 1) {
+        stage_gains<M>(ktile, k + 1, kbuf, lane);
+        nxt.load(pXn, pUn, pKn, pdn);
+        if (ncs > 0) cs0.prefetch(k + 1);
+        if (ncs > 1) cs1.prefetch(k + 1);
+      }
+      pXn += n * 64; pUn += m * 64; pKn += m * ne * 64; pdn += m * 64;
     }
 #pragma unroll
     for (int j = 0; j < m; ++j) {
