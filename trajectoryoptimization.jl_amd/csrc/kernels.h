@@ -8,6 +8,9 @@
 // TLB-friendly) instead of 32 KB-strided lines.  One lane == one trajectory for the sequential recursions
 // (rollout, backward Riccati, forward line search); the expansion kernel adds two more grid axes
 // (knot, direction) because it is embarrassingly parallel.  Workgroup = one wave = one tile.
+//
+// One batch step of a solve = k_expand -> k_backward -> [k_forward (all step sizes of a round concurrently) -> k_select]
+// per line-search round -> k_accept (large models) -> k_outer_* (AL).  Per-model choices live in models.h (traits).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,7 +26,8 @@ struct KArgs {
   size_t slotX, slotU;  // doubles per slot (L * Bp)
   int T;          // candidate slots = most line-search candidates evaluated concurrently in one round
   double* x0;     // L = n
-  int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): k_accept copies it to slot 0
+  int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): copied onto slot 0 by k_accept, or
+                  //      written through by the next k_expand (M::accept_write_through)
   double *candJ, *candG;  // [T][Bp] cost and gradient metric of each candidate of the current round
   int* candOk;            // [T][Bp] 1: rollout stayed within the state/control limits
   int* ls_round;          // [Bp] next line-search round of this trajectory; -1: resolved for this iteration
