@@ -1192,18 +1192,18 @@ __global__ void __launch_bounds__(64) k_outer_finish(KArgs a) {
 // Accepting a step = copying the accepted candidate's slot onto slot 0, so the nominal trajectory of every lane sits in
 // ONE slot and every kernel reads it with full-line coalesced loads (a per-trajectory slot index turned each nominal
 // load of a wave into up to 64 separate lines: measured 2x on the quadrotor forward pass).  Runs once per forward pass:
-// later rounds only store into the slots of lanes that are still searching.  grid (tiles, T, chunks):
-// wave (tile, t, z) copies chunk z for the lanes that accepted candidate t; waves nobody needs exit on a ballot.
+// later rounds only store into the slots of lanes that are still searching.  grid (tiles, 1, chunks): wave (tile, z)
+// copies chunk z; every lane reads ITS accepted slot (a gather: as many lines as a per-slot pass would touch) and the
+// stores to slot 0 are whole 512-byte rows.
 __global__ void __launch_bounds__(64) k_accept(KArgs a) {
   TILE_LANE();
   const DevProblem& P = a.P;
-  const int s = blockIdx.y + 1;
-  const bool want = b < P.B && a.acc[b] == s;
-  if (__ballot(want) == 0) return;
+  const int s = b < P.B ? a.acc[b] : 0;
+  if (__ballot(s != 0) == 0) return;
   const int Lx = P.N * P.n, Lu = (P.N - 1) * P.m;
   const int per = (Lx + Lu + gridDim.z - 1) / gridDim.z;
   const int e0 = blockIdx.z * per, e1 = min(Lx + Lu, e0 + per);
-  if (!want) return;
+  if (s == 0) return;
   const double* sx = TILE_PTR(XSLOT(a, s), Lx);
   double* dx = TILE_PTR(XSLOT(a, 0), Lx);
   const double* su = TILE_PTR(USLOT(a, s), Lu);

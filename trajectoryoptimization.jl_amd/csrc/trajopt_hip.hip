@@ -386,7 +386,7 @@ int ensure_nlist(to_handle* h, int steps) {
   return TO_OK;
 }
 int launch_accept(to_handle* h) {  // materialise accepted candidate slots on slot 0, then forget them
-  hipLaunchKernelGGL(k_accept, grid_b(h, h->a.T, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
+  hipLaunchKernelGGL(k_accept, grid_b(h, 1, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
   hipLaunchKernelGGL(k_clear_acc, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
   HIPCHECK(hipGetLastError());
   return TO_OK;
