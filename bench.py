@@ -51,7 +51,8 @@ def build_problem(T, configs, name, batch, b_offset, device, lib):
     if name == "quadrotor":
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
     if name == "quadrotor_al":
-        return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib, constrained=True)
+        return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib, constrained=True,
+                                         goal_inds=configs.C5_GOAL_INDS)
     raise ValueError(name)
 
 
@@ -94,23 +95,131 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     o = load_oracle()
     threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
     sample = min(batch, 1024 if name == "cartpole" else 256 if name == "quadrotor" else 128)
+    Solver = T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver
     prob = build_problem(T, configs, name, sample, 0, 0, o)
     set_threads(prob, threads)
-    solver = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(prob)
+    u0 = initial_controls_value(T, prob, name)
+    solver = Solver(prob)
+    solver.solve()                            # warm call: OpenMP team start-up, page faults
+    T.initial_controls(prob, u0)
     t0 = time.perf_counter()
     solver.solve()
     dt = time.perf_counter() - t0
-    # one trajectory on one core: the figure comparable to published single-core solver timings
+    # one trajectory on one core: the figure comparable to published single-core solver timings;
+    # best of 5 after a warm call (a single cold sample was 10x off in round 1)
     p1 = build_problem(T, configs, name, 1, 0, 0, o)
     set_threads(p1, 1)
-    s1 = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(p1)
-    t1 = time.perf_counter()
+    s1 = Solver(p1)
     s1.solve()
-    d1 = time.perf_counter() - t1
-    single = {"value": s1.total_iterations / d1, "cores": 1, "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms"}
+    d1 = float("inf")
+    for _ in range(5):
+        T.initial_controls(p1, u0)
+        t1 = time.perf_counter()
+        s1.solve()
+        d1 = min(d1, time.perf_counter() - t1)
+    single = {"value": s1.total_iterations / d1, "cores": 1,
+              "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms (best of 5 after a warm call)"}
     return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "single_thread": single,
-            "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve, "
+            "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve after a warm call, "
                       f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
+
+
+def roofline_block(configs, name, batch, dims, iters, value_per_gpu, kms, kln):
+    """roofline object from the hipEvent phase timings of the PROFILED pass (same workload, run right after the timed one)."""
+    n, m, ne, N, duals = dims
+    bytes_it = configs.algorithmic_bytes_per_iteration(n, m, ne, N, duals)
+    split = kernel_split_bytes(n, m, ne, N, duals)
+    kern = {}
+    for i, kn in enumerate(["expand", "backward", "forward"]):
+        if kln[i] > 0:
+            kern[kn] = {"ms_total": kms[i], "launches": int(kln[i]), "avg_us": 1e3 * kms[i] / kln[i]}
+    if not kern:
+        return None
+    dom = max(kern, key=lambda k: kern[k]["ms_total"])
+    # a launch processes, on average, (trajectory-iterations of this rank) / launches units
+    units_per_launch = iters / kern[dom]["launches"]
+    achieved = split[dom] * units_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
+    traffic, traffic_src, flops = pmc_traffic(name, batch, dom)
+    return {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_unit": split[dom], "units_per_launch": units_per_launch,
+            "avg_launch_us": kern[dom]["avg_us"], "kernels": kern,
+            "timing": "hipEvents on the library stream around each phase, in a separate profiled pass of the same "
+                      "steps (the timed pass records no events)",
+            # what actually bounds these kernels (DESIGN.md §4): FP64 vector issue / dependency latency
+            "fp64_valu": None if not flops else {
+                "flops_per_launch": flops, "achieved_tflops": flops / (kern[dom]["avg_us"] * 1e-6) / 1e12,
+                "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                "frac": flops / (kern[dom]["avg_us"] * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS},
+            "whole_iteration": {"algorithmic_bytes_per_unit": bytes_it,
+                                "achieved": bytes_it * value_per_gpu / 1e9,
+                                "frac": bytes_it * value_per_gpu / 1e9 / HBM_PEAK_GBS}}
+
+
+def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True):
+    """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings."""
+    W = WORKLOADS[name]
+    prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
+    solver = (T.ALSolver if W["solver"] == "al" else T.iLQRSolver)(prob)
+    u0 = initial_controls_value(T, prob, name)
+    n, m, N = prob.dims()
+    dims = (n, m, prob.errstate_dim, N, sum(prob.constraints.p))
+    gather = None
+    if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
+        from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
+        gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
+
+    def one_step():
+        T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
+        solver.solve()
+        if gather is not None:
+            gather()
+        return solver.total_iterations, solver.batch_steps
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        one_step()
+    prob._call("set_profiling", 0)
+    barrier()
+    t0 = time.perf_counter()
+    iters = bsteps = 0
+    for _ in range(steps):
+        it, bs = one_step()
+        iters += it
+        bsteps += bs
+    barrier()
+    dt = time.perf_counter() - t0
+    status = solver.stats["status"].copy()
+    kms, kln = (C.c_double * 4)(), (C.c_int64 * 4)()
+    if profile:
+        prob._call("reset_profile")
+        prob._call("set_profiling", 1)
+        for _ in range(steps):
+            one_step()
+        prob._call("set_profiling", 0)
+        prob._call("get_profile", kms, kln)
+    if dist is not None:
+        t = torch.tensor([dt, float(iters)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, iters_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, iters_all = dt, float(iters)
+    value = iters_all / dt_max
+    res = {"value": value, "unit": "trajectory-iterations/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt_max / steps,
+           "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
+                      "trajectory_iterations_per_step": iters_all / steps, "batch_steps_per_solve": bsteps / steps,
+                      "converged_fraction": float(np.mean(status == T.capi.SOLVE_SUCCEEDED)),
+                      "collective": "RCCL all_gather of converged (X,U), once per solve" if dist is not None else "none"},
+           "roofline": roofline_block(configs, name, batch, dims, iters, value / world, kms, kln) if profile else None}
+    return res, prob, u0
 
 
 def main():
@@ -121,8 +230,10 @@ def main():
     ap.add_argument("--workload", default="cartpole", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/scaling studies only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--throughput-probe", type=int, default=0, help="also solve a batch of this size once (reported separately, untimed region)")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents in the timed region")
+    ap.add_argument("--throughput-probe", type=int, default=-1,
+                    help="also solve a batch of this size once (reported separately; default 32768 for the cartpole workload at N=1, 0 = off)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the separate hipEvent-profiled pass (no roofline object)")
+    ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     args = ap.parse_args()
 
     import torch
@@ -147,107 +258,27 @@ def main():
     if lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libtrajopt_hip.so has no CPU fallback")
     name = args.workload
-    W = WORKLOADS[name]
-    batch = args.batch or W["batch"]
-    prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
-    solver = (T.ALSolver if W["solver"] == "al" else T.iLQRSolver)(prob)
-    u0 = initial_controls_value(T, prob, name)
-    n, m, N = prob.dims()
-    ne = prob.errstate_dim
-    duals = sum(prob.constraints.p)
-
-    gather = None
-    if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
-        from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
-        gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
-
-    def one_step():
-        T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
-        solver.solve()
-        if gather is not None:
-            gather()
-        return solver.total_iterations, solver.batch_steps
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    profile = not args.no_profile
-    prob._call("reset_profile")
-    prob._call("set_profiling", 1 if profile else 0)
-    barrier()
-    t0 = time.perf_counter()
-    iters = 0
-    bsteps = 0
-    for _ in range(args.steps):
-        it, bs = one_step()
-        iters += it
-        bsteps += bs
-    barrier()
-    dt = time.perf_counter() - t0
-    prob._call("set_profiling", 0)
-    kms = (C.c_double * 4)()
-    kln = (C.c_int64 * 4)()
-    prob._call("get_profile", kms, kln)
-
-    if dist is not None:
-        t = torch.tensor([dt, float(iters)], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, iters_all = float(tmax[0]), float(tsum[1])
-    else:
-        dt_max, iters_all = dt, float(iters)
+    batch = args.batch or WORKLOADS[name]["batch"]
+    res, prob, u0 = run_workload(T, configs, lib, name, batch, args.steps, args.warmup, rank, local_rank, world, dist, torch,
+                                 profile=not args.no_profile)
 
     if rank == 0:
-        value = iters_all / dt_max
-        bytes_it = configs.algorithmic_bytes_per_iteration(n, m, ne, N, duals)
-        split = kernel_split_bytes(n, m, ne, N, duals)
-        names = ["expand", "backward", "forward"]
-        kern = {}
-        for i, kn in enumerate(names):
-            if kln[i] > 0:
-                kern[kn] = {"ms_total": kms[i], "launches": int(kln[i]), "avg_us": 1e3 * kms[i] / kln[i]}
-        roof = None
-        if kern:
-            dom = max(kern, key=lambda k: kern[k]["ms_total"])
-            # a launch processes, on average, (trajectory-iterations of this rank) / launches units
-            units_per_launch = iters / kern[dom]["launches"]
-            achieved = split[dom] * units_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            traffic, traffic_src, flops = pmc_traffic(name, batch, dom)
-            roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_unit": split[dom], "units_per_launch": units_per_launch,
-                    "avg_launch_us": kern[dom]["avg_us"], "kernels": kern,
-                    # what actually bounds these kernels: FP64 vector issue / dependency latency
-                    "fp64_valu": None if not flops else {
-                        "flops_per_launch": flops, "achieved_tflops": flops / (kern[dom]["avg_us"] * 1e-6) / 1e12,
-                        "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                        "frac": flops / (kern[dom]["avg_us"] * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS},
-                    "whole_iteration": {"algorithmic_bytes_per_unit": bytes_it,
-                                        "achieved": bytes_it * value / world / 1e9,
-                                        "frac": bytes_it * value / world / 1e9 / HBM_PEAK_GBS}}
-        out = {
-            "metric": "iLQR iterations/sec (batched trajectories)", "value": value, "unit": "trajectory-iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
-                       "trajectory_iterations_per_step": iters_all / args.steps,
-                       "batch_steps_per_solve": bsteps / args.steps,
-                       "collective": "RCCL all_gather of converged (X,U), once per solve" if dist is not None else "none"},
-            "roofline": roof,
-        }
-        if args.throughput_probe > 0:  # outside the timed region: the same kernels on a batch large enough to fill the chip
-            pb = build_problem(T, configs, name, args.throughput_probe, 0, local_rank, lib)
-            ps = (T.ALSolver if W["solver"] == "al" else T.iLQRSolver)(pb)
+        out = {"metric": "iLQR iterations/sec (batched trajectories)", "value": res["value"], "unit": res["unit"],
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": res["config"], "roofline": res["roofline"], "build_id": lib.build_id()}
+        probe = args.throughput_probe
+        if probe < 0:
+            probe = 32768 if (name == "cartpole" and world == 1) else 0
+        if probe > 0:  # outside the timed region: the same kernels on a batch large enough to fill the chip
+            n, m, N = prob.dims()
+            bytes_it = configs.algorithmic_bytes_per_iteration(n, m, prob.errstate_dim, N, sum(prob.constraints.p))
+            pb = build_problem(T, configs, name, probe, 0, local_rank, lib)
+            ps = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(pb)
             ps.solve()
             T.initial_controls(pb, u0)
             t1 = time.perf_counter(); ps.solve(); d1 = time.perf_counter() - t1
-            out["throughput_probe"] = {"batch": args.throughput_probe, "value": ps.total_iterations / d1,
+            out["throughput_probe"] = {"batch": probe, "value": ps.total_iterations / d1,
                                        "unit": "trajectory-iterations/s", "ms": 1e3 * d1,
                                        "whole_iteration_frac": bytes_it * ps.total_iterations / d1 / 1e9 / HBM_PEAK_GBS}
             del ps, pb
@@ -256,6 +287,22 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(T, configs, name, batch)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+    del prob
+    # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
+    if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:
+        extra = {}
+        for key, wname in (("C3", "quadrotor"), ("C5", "quadrotor_al")):
+            try:
+                r, p2, _ = run_workload(T, configs, lib, wname, WORKLOADS[wname]["batch"], 2, 1, 0, local_rank, 1, None, torch,
+                                        profile=not args.no_profile)
+                del p2
+                if not args.no_cpu_baseline:
+                    r["cpu_baseline"] = cpu_baseline(T, configs, wname, WORKLOADS[wname]["batch"])
+                extra[key] = r
+            except Exception as e:
+                extra[key] = {"error": repr(e)}
+        out["extra_workloads"] = extra
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -73,8 +73,8 @@ typedef enum {
   TO_MAX_ITERATIONS = 3,
   TO_MAX_ITERATIONS_OUTER = 4,
   TO_MAXIMUM_COST = 5,
-  TO_STATE_LIMIT = 6,
-  TO_CONTROL_LIMIT = 7,
+  TO_STATE_LIMIT = 6,   /* reserved (Altro order); never emitted: a rollout that leaves |x| <= max_state_value /  */
+  TO_CONTROL_LIMIT = 7, /* |u| <= max_control_value is rejected as a line-search candidate, not reported as a status */
   TO_NO_PROGRESS = 8,
   TO_COST_INCREASE = 9,
   TO_REGULARIZATION_MAX = 10
@@ -225,6 +225,8 @@ typedef struct to_handle_s to_handle;
 
 /* ---- library ------------------------------------------------------------------------------ */
 int to_abi_version(void);
+const char* to_build_id(void);             /* hash of the sources this binary was compiled from (build.py stamps it; tests and
+                                              bench.py print it, build() recompiles when it differs from the tree) */
 const char* to_last_error(void);
 int to_device_count(int* count);           /* number of usable HIP devices */
 int to_default_options(to_solver_opts* o); /* fill with the defaults documented above */
@@ -236,6 +238,9 @@ int to_default_options(to_solver_opts* o); /* fill with the defaults documented 
  * `device` (HIP ordinal).  opts may be NULL (defaults). */
 int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int device, to_handle** out);
 int to_destroy(to_handle* h);
+/* Options are validated (TO_ERR_ARGUMENT for out-of-range values, here and in to_create).  The number of line-search
+ * candidate slots is fixed at to_create from iterations_linesearch: raising it later works, with less concurrency than
+ * a fresh handle would have. */
 int to_set_options(to_handle* h, const to_solver_opts* opts);
 int to_get_options(const to_handle* h, to_solver_opts* opts);
 int to_sync(to_handle* h);                 /* block until the handle's stream is idle */
@@ -266,6 +271,9 @@ int to_cost(to_handle* h, double* J /* [B] */);                  /* cost      sr
 int to_stage_costs(to_handle* h, double* Jk /* [N*B], Objective.J */);
 int to_expand(to_handle* h);     /* dynamics Jacobians (error-state) + cost expansion (+AL terms) at the current (X,U) */
 int to_backward(to_handle* h);   /* Riccati recursion -> K, d, dV; regularises per trajectory */
+/* ls_index: index of the accepted step size alpha = decrease^index; -1 = line search failed (nominal kept, regularisation
+ * raised).  At a stationary point (predicted decrease <= 1e-12 (1+|J|)) the ZERO step is taken: ls_index = 0 with
+ * J_new == J and an unchanged trajectory; inside a solve such a step counts towards dJ_counter_limit. */
 int to_forward(to_handle* h, int32_t* ls_index /* [B], -1 = failed */, double* J_new /* [B] */);
 int to_ilqr_solve(to_handle* h, to_solve_stats* stats);
 int to_al_solve(to_handle* h, to_solve_stats* stats);

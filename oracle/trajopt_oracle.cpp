@@ -72,7 +72,7 @@ struct Traj {
   double J = 0, dJ = 0, grad = 0, c_max = 0;
   int iterations = 0, iterations_outer = 0, status = TO_UNSOLVED, ls_index = -1;
   int dJ_zero_counter = 0;
-  bool ls_failed = false;
+  bool ls_failed = false, zero_step = false;
 };
 
 }  // namespace
@@ -98,6 +98,22 @@ void default_opts(to_solver_opts* o) {
 }
 
 /* ------------------------------------------------------------------ descriptor validation */
+int validate_opts(const to_solver_opts& o) {
+  auto bad = [](const char* what) { return fail(TO_ERR_ARGUMENT, std::string("solver option out of range: ") + what); };
+  if (!(o.cost_tolerance >= 0) || !(o.cost_tolerance_intermediate >= 0) || !(o.gradient_tolerance >= 0) || !(o.constraint_tolerance >= 0))
+    return bad("tolerances must be >= 0");
+  if (o.iterations < 0 || o.iterations_outer < 0 || o.iterations_total < 0 || o.dJ_counter_limit < 0) return bad("iteration counts must be >= 0");
+  if (o.iterations_linesearch < 1 || o.iterations_linesearch > 64) return bad("iterations_linesearch must be in 1..64");
+  if (!(o.line_search_decrease_factor > 0.0 && o.line_search_decrease_factor < 1.0)) return bad("line_search_decrease_factor must be in (0,1)");
+  if (!(o.line_search_lower_bound >= 0.0) || !(o.line_search_upper_bound > o.line_search_lower_bound)) return bad("line-search bounds must satisfy 0 <= lower < upper");
+  if (!(o.bp_reg_increase_factor > 1.0)) return bad("bp_reg_increase_factor must be > 1");
+  if (!(o.bp_reg_initial >= 0.0) || !(o.bp_reg_min >= 0.0) || !(o.bp_reg_max > o.bp_reg_min) || !(o.bp_reg_fp >= 0.0)) return bad("regularisation bounds");
+  if (!(o.penalty_initial > 0.0) || !(o.penalty_scaling >= 1.0) || !(o.penalty_max >= o.penalty_initial) || !(o.dual_max > 0.0)) return bad("penalty parameters");
+  if (!(o.max_cost_value > 0.0) || !(o.max_state_value > 0.0) || !(o.max_control_value > 0.0)) return bad("max_*_value must be > 0");
+  if (o.cost_dt_scaling != 0 && o.cost_dt_scaling != 1) return bad("cost_dt_scaling must be 0 or 1");
+  return TO_OK;
+}
+
 int validate_constraint(const Problem& P, const to_constraint_desc& d, ConInfo* out) {
   const int n = P.n, m = P.m, nz = n + m;
   ConInfo ci; ci.d = d;
@@ -105,6 +121,9 @@ int validate_constraint(const Problem& P, const to_constraint_desc& d, ConInfo* 
     return fail(TO_ERR_ASSERTION, "constraint knot range outside 1:N");
   if (d.n_inds < 0 || d.n_inds > TO_MAX_CON_INDS || d.n_params < 0 || d.n_params > TO_MAX_CON_PARAMS)
     return fail(TO_ERR_ARGUMENT, "constraint inds/params count out of range");
+  for (int i = 0; i < d.n_inds; ++i)
+    for (int j = i + 1; j < d.n_inds; ++j)
+      if (d.inds[i] == d.inds[j]) return fail(TO_ERR_ARGUMENT, "constraint indices must be distinct");
   switch (d.kind) {
     case TO_CON_GOAL:
       if (d.sense != TO_CONE_ZERO) return fail(TO_ERR_ARGUMENT, "GoalConstraint sense must be Equality");
@@ -179,6 +198,7 @@ int build_problem(const to_problem_desc* desc, const to_solver_opts* opts, Probl
   int n, m, ne;
   if (model_dims(desc->model, desc->model_params, &n, &m, &ne) != 0) return fail(TO_ERR_UNSUPPORTED, "unknown model");
   if (desc->n != n || desc->m != m) return fail(TO_ERR_DIMENSION_MISMATCH, "Model and problem dimensions are inconsistent");
+  if (opts) { int r = validate_opts(*opts); if (r) return r; }
   if (desc->N < 2) return fail(TO_ERR_ASSERTION, "N must be at least 2");
   if (desc->B < 1) return fail(TO_ERR_ARGUMENT, "batch must be positive");
   if (!(desc->tf > desc->t0)) return fail(TO_ERR_ASSERTION, "Final time must be greater than initial time"); /* src/problem.jl:50 */
@@ -552,11 +572,11 @@ bool rollout_closed_loop(const Problem& P, Traj& t, double alpha) {
 /* forward pass with backtracking line search.  On success (Xb,Ub) are copied into (X,U). Returns new J. */
 double forward(const Problem& P, Traj& t, double J_prev) {
   double alpha = 1.0;
-  t.ls_index = -1; t.ls_failed = false;
+  t.ls_index = -1; t.ls_failed = false; t.zero_step = false;
   /* Stationary point: the backward pass predicts no improvement at all (an exactly solved LQ problem gives ~1e-30).
    * Every ratio z = dJ/expected would then be rounding noise; accept the zero step instead (dJ = 0 => converged).
    * Oracle-defined; keeps iteration counts deterministic and skips Altro's 10 wasted NO_PROGRESS iterations. */
-  if (-(t.dV[0] + t.dV[1]) <= 1e-12 * (1.0 + std::fabs(J_prev))) { t.ls_index = 0; return J_prev; }
+  if (-(t.dV[0] + t.dV[1]) <= 1e-12 * (1.0 + std::fabs(J_prev))) { t.ls_index = 0; t.zero_step = true; return J_prev; }
   for (int it = 0; it < P.opts.iterations_linesearch; ++it) {
     bool ok = rollout_closed_loop(P, t, alpha);
     if (ok) {
@@ -593,7 +613,9 @@ bool ilqr_step(const Problem& P, Traj& t, double cost_tol, int max_iters, double
   if (!backward(P, t)) { t.status = TO_REGULARIZATION_MAX; return true; }
   double J = forward(P, t, J_prev);
   t.dJ = J_prev - J;
-  if (t.ls_failed) t.dJ_zero_counter++; else t.dJ_zero_counter = 0;
+  /* a zero step (stationary point) makes no progress either: with a gradient tolerance it cannot meet, the solve ends
+   * NO_PROGRESS after dJ_counter_limit repeats instead of spinning to MAX_ITERATIONS */
+  if (t.ls_failed || t.zero_step) t.dJ_zero_counter++; else t.dJ_zero_counter = 0;
   t.grad = gradient_metric(P, t);
   J_prev = J; t.J = J;
   t.iterations++;
@@ -696,7 +718,7 @@ int oracle_create(const to_problem_desc* desc, const to_solver_opts* opts, int /
 }
 int oracle_destroy(oracle_handle* h) { delete h; return TO_OK; }
 int oracle_set_threads(oracle_handle* h, int threads) { CHECK_H(h); h->threads = threads < 1 ? 1 : threads; return TO_OK; }
-int oracle_set_options(oracle_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_P(o); h->P.opts = *o; return TO_OK; }
+int oracle_set_options(oracle_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_P(o); { int r = validate_opts(*o); if (r) return r; } h->P.opts = *o; return TO_OK; }
 int oracle_get_options(const oracle_handle* h, to_solver_opts* o) { CHECK_H(h); CHECK_P(o); *o = h->P.opts; return TO_OK; }
 int oracle_dims(const oracle_handle* h, int32_t* n, int32_t* m, int32_t* ne, int32_t* N, int32_t* B) {
   CHECK_H(h);

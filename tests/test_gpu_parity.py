@@ -191,12 +191,15 @@ def test_cones(cone, hip, oracle):
         assert T.cone_status(cone, np.array([2, 3, 1, 10.0]), lib=hip) == "in"          # :62-66
 
 
-def test_full_size_properties_C2(hip):
-    """BASELINE config C2 at full size: size-independent properties instead of an oracle run."""
+def test_full_size_C2_vs_oracle(hip, oracle):
+    """BASELINE config C2 at full size (Cartpole, N=101, B=1024): EVERY trajectory against the oracle, plus the
+    size-independent properties (monotone improvement, dynamic consistency, idempotent rollout)."""
     p = configs.cartpole_problem(batch=1024, lib=hip)
+    po = configs.cartpole_problem(batch=1024, lib=oracle)
     T.rollout(p)
     J0 = T.cost(p)
-    s = T.iLQRSolver(p).solve()
+    s, so = T.iLQRSolver(p).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(s, so, p, po)                         # iterations / status bit-exact, X, U, J at 1e-6
     ok = s.stats["status"] == T.capi.SOLVE_SUCCEEDED
     assert ok.sum() >= 0.99 * ok.size                         # the oracle leaves 4 of 1024 at MAX_ITERATIONS too
     assert set(np.unique(s.stats["status"])) <= {T.capi.SOLVE_SUCCEEDED, T.capi.MAX_ITERATIONS}
@@ -212,6 +215,64 @@ def test_full_size_properties_C2(hip):
     assert int(s.stats["iterations"][0]) == 104              # the x0=0 instance
     assert s.total_iterations == int(s.stats["iterations"].sum())
     np.testing.assert_allclose(X[ok, -1, 1], math.pi, atol=0.3)  # swing-up reached
+
+
+def _subsample_vs_oracle(build, B, oracle, solver):
+    """Solve the FULL batch (global trajectories 0..B-1) on the GPU and a deterministic sub-sample — the first two
+    tiles and the last tile; inputs are indexed by the global trajectory number, so the oracle can solve just those —
+    on the CPU oracle.  Returns (GPU solver, GPU problem, [(index array, oracle solver, oracle problem)])."""
+    ph = build(batch=B, b_offset=0)
+    sh = solver(ph).solve()
+    blocks = []
+    for b0, cnt in ((0, 128), (B - 64, 64)):
+        po = build(batch=cnt, b_offset=b0, lib=oracle)
+        blocks.append((np.arange(b0, b0 + cnt), solver(po).solve(), po))
+    return sh, ph, blocks
+
+
+def test_full_size_C3_vs_oracle_subsample(hip, oracle):
+    """BASELINE config C3 at its own shape (Quadrotor, N=201, B=4096 = 64 tiles, multi-round residency): trajectories
+    0..127 and the last tile against the oracle — integers bit-exact, X / U / J at the north-star 1e-6."""
+    build = lambda **kw: configs.quadrotor_problem(N=201, **{"lib": hip, **kw})
+    sh, ph, blocks = _subsample_vs_oracle(build, 4096, oracle, T.iLQRSolver)
+    Xh, Uh = T.states(ph), T.controls(ph)
+    for idx, so, po in blocks:
+        for k in ("iterations", "status"):
+            np.testing.assert_array_equal(sh.stats[k][idx], so.stats[k], err_msg=k)
+        np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=1e-6)
+        np.testing.assert_allclose(Xh[idx], T.states(po), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(Uh[idx], T.controls(po), rtol=1e-6, atol=1e-7)
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+    assert sh.total_iterations == int(sh.stats["iterations"].sum())
+
+
+def test_full_size_C5_vs_oracle_subsample(hip, oracle):
+    """BASELINE config C5 at its own shape (Quadrotor + GoalConstraint@N + SOC norm cone@1..N-1, N=201, B=8192 =
+    128 tiles, first line-search round of 8 step sizes) with the feasible goal (position + velocities) and the default
+    constraint_tolerance 1e-6: the sub-sample against the oracle.  AL-iLQR without the projected-Newton polish creeps
+    towards 1e-6 over hundreds of iterations at penalty 1e8 (the oracle itself leaves part of the batch at
+    MAX_ITERATIONS_OUTER); over such tails a last-bit difference eventually flips one line-search decision, so the
+    test pins (a) exact integer agreement on the overwhelming majority, (b) 1e-6 on X / U / J wherever the iteration
+    paths coincide, (c) the same outcome class and final violation scale everywhere."""
+    build = lambda **kw: configs.quadrotor_problem(N=201, constrained=True, goal_inds=configs.C5_GOAL_INDS, **{"lib": hip, **kw})
+    sh, ph, blocks = _subsample_vs_oracle(build, 8192, oracle, T.ALSolver)
+    Xh, Uh = T.states(ph), T.controls(ph)
+    same_total, total = 0, 0
+    for idx, so, po in blocks:
+        same = (sh.stats["iterations"][idx] == so.stats["iterations"]) & (sh.stats["status"][idx] == so.stats["status"]) \
+            & (sh.stats["iterations_outer"][idx] == so.stats["iterations_outer"])
+        same_total += int(same.sum()); total += same.size
+        np.testing.assert_allclose(sh.stats["cost"][idx][same], so.stats["cost"][same], rtol=1e-6)
+        np.testing.assert_allclose(Xh[idx][same], T.states(po)[same], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(Uh[idx][same], T.controls(po)[same], rtol=1e-6, atol=1e-7)
+        # where the paths separated: same problem, same optimum to the accuracy the outer loop reached
+        np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=2e-3)
+        assert np.all(sh.stats["c_max"][idx] < 1e-3) and np.all(so.stats["c_max"] < 1e-3)
+    print(f"C5 sub-sample: {same_total}/{total} trajectories with identical iterations/outer/status")
+    assert same_total >= 0.9 * total
+    ok = sh.stats["status"] == T.capi.SOLVE_SUCCEEDED
+    assert np.all(sh.stats["c_max"][ok] < 1e-6)
+    assert set(np.unique(sh.stats["status"])) <= {T.capi.SOLVE_SUCCEEDED, T.capi.MAX_ITERATIONS, T.capi.MAX_ITERATIONS_OUTER}
 
 
 # ---------------------------------------------------------------------------------------------- edge cases

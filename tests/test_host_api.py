@@ -21,9 +21,19 @@ def test_library_exports_every_declared_symbol():
     dll = C.CDLL(lib.path)
     missing = [s for s in sorted(declared) if not hasattr(dll, s)]
     assert not missing, missing
-    bound = {"to_" + k for k in list(T.capi.SIGNATURES) + list(T.capi.HIP_ONLY)} | {"to_last_error", "to_stream"}
+    bound = {"to_" + k for k in list(T.capi.SIGNATURES) + list(T.capi.HIP_ONLY)} | {"to_last_error", "to_stream", "to_build_id"}
     assert declared <= bound, sorted(declared - bound)
     assert lib.abi_version() == T.capi.TO_ABI_VERSION
+
+
+def test_binary_matches_the_sources_in_the_tree():
+    """The shipped libtrajopt_hip.so carries a hash of the sources it was compiled from (to_build_id); a stale binary —
+    it is git-ignored and travels with snapshots — fails here instead of silently testing old kernels."""
+    from trajectoryoptimization_jl_amd import build as B
+    lib = T.load_hip_library()
+    assert re.fullmatch(r"[0-9a-f]{16}", lib.build_id())
+    assert lib.build_id() == B.binary_id(lib.path)
+    assert lib.build_id() == B.source_id(), "rebuild: python -c 'import __graft_entry__ as g; g.build()'"
 
 
 def test_struct_layouts_match_header():
@@ -212,3 +222,54 @@ def test_host_layout_helpers(oracle):
     assert T.gettimes(p)[-1] == pytest.approx(0.5) and len(T.gettimes(p)) == 6
     T.set_goal_state(p, np.array([0.1, 3.0, 0, 0]))
     np.testing.assert_array_equal(T.get_final_state(p), [0.1, 3.0, 0, 0])
+
+
+def test_solver_option_validation():
+    """Out-of-range options are ArgumentErrors at to_create / to_set_options, not silent MAX_ITERATIONS runs."""
+    lib = T.load_hip_library()
+    for field, value in [("line_search_decrease_factor", 0.0), ("line_search_decrease_factor", 1.0), ("penalty_scaling", 0.5),
+                         ("bp_reg_increase_factor", 1.0), ("iterations", -1), ("iterations_linesearch", 0),
+                         ("iterations_linesearch", 65), ("cost_tolerance", -1e-3), ("penalty_initial", 0.0)]:
+        o = lib.default_options()
+        setattr(o, field, value)
+        keep = []
+
+        def mut(d, c):
+            keep.append(o)
+        # options travel as the second argument of to_create
+        model = T.Cartpole()
+        obj = T.LQRObjective(np.ones(4), np.ones(1), np.ones(4), np.zeros(4), 11)
+        with pytest.raises(T.ArgumentError):
+            T.Problem(model, obj, np.zeros(4), 1.0, options=T.SolverOptions(lib=lib, **{field: value}))
+    o = lib.default_options()  # defaults are valid: only the missing GPU may stop the constructor here
+    try:
+        T.Problem(T.Cartpole(), T.LQRObjective(np.ones(4), np.ones(1), np.ones(4), np.zeros(4), 11), np.zeros(4), 1.0)
+    except T.HipError:
+        pass
+
+
+def test_duplicate_constraint_indices_rejected():
+    def dup(d, c):
+        c[0].inds[1] = c[0].inds[0]
+    rc, msg = _create_rc(dup)
+    assert rc == T.capi.TO_ERR_ARGUMENT and "distinct" in msg
+
+
+def test_set_duals_shape_checks(oracle):
+    from trajectoryoptimization_jl_amd import configs
+    from trajopt_amd import internal as I
+    p = configs.cartpole_problem(batch=3, N=6, tf=0.5, constrained=True, lib=oracle)
+    lam = np.arange(3 * 5 * 2, dtype=float).reshape(3, 5, 2)
+    I.set_duals(p, 0, lam=lam, mu=np.array([1.0, 2.0, 3.0]))
+    l2, m2 = I.get_duals(p, 0)
+    np.testing.assert_array_equal(l2, lam); np.testing.assert_array_equal(m2, [1.0, 2.0, 3.0])
+    I.set_duals(p, 0, lam=lam[1], mu=7.0)              # one trajectory / a scalar: explicit broadcast
+    l2, m2 = I.get_duals(p, 0)
+    np.testing.assert_array_equal(l2[2], lam[1]); np.testing.assert_array_equal(m2, [7.0] * 3)
+    with pytest.raises(T.DimensionMismatch):
+        I.set_duals(p, 0, lam=np.zeros((5, 3)))
+    with pytest.raises(T.DimensionMismatch):
+        I.set_duals(p, 0, mu=np.zeros(2))
+    with pytest.raises(T.ArgumentError):                # n == N: (n, N) could be either layout
+        q = configs.cartpole_problem(batch=2, N=4, tf=0.3, lib=oracle)
+        T.initial_states(q, np.zeros((4, 4)))

@@ -209,6 +209,11 @@ class Library:
         le.argtypes = []
         le.restype = C.c_char_p
         self._last_error = le
+        bid = getattr(self.dll, prefix + "build_id", None)  # the CPU oracle (tests only) has none
+        if bid is not None:
+            bid.argtypes = []
+            bid.restype = C.c_char_p
+        self._build_id = bid
         if hip:
             st = getattr(self.dll, prefix + "stream")
             st.argtypes = [_H]
@@ -227,6 +232,9 @@ class Library:
         if rc < 0:
             raise _ERRORS.get(rc, RuntimeError)(f"{self.prefix}{name}: {self.last_error()} (code {rc})")
         return rc
+
+    def build_id(self):
+        return self._build_id().decode() if self._build_id is not None else None
 
     def abi_version(self):
         return self._fn["abi_version"]()

@@ -911,7 +911,11 @@ def initial_controls(prob, U0):
 
 
 def initial_states(prob, X0):
-    a = prob._batch(X0, (prob.n, prob.N), "X0")
+    """initial_states!(prob, X0) (src/problem.jl:242-253): X0 is [n, N] / [N, n] (one trajectory, replicated) or [B, N, n]."""
+    a = np.asarray(X0, dtype=np.float64)
+    if a.ndim == 2 and prob.n == prob.N and a.shape == (prob.n, prob.N):
+        raise ArgumentError("ambiguous X0 shape (n == N); pass [B, N, n]")
+    a = prob._batch(a, (prob.n, prob.N), "X0")
     prob._call("set_states", prob._pd(a))
 
 

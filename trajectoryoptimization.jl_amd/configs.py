@@ -67,6 +67,11 @@ def quadrotor_x0(batch, b_offset=0, seed=2):
     return x0
 
 
+# C5's GoalConstraint acts on position and both velocities (SURVEY.md §8d "optionally inds=[1,2,3,8..13]"): the full
+# 13-state goal also pins the quaternion, which RK4 does not keep on the unit sphere, so it is infeasible at 1e-6.
+C5_GOAL_INDS = [1, 2, 3, 8, 9, 10, 11, 12, 13]
+
+
 def quadrotor_problem(batch=4096, N=201, tf=5.0, b_offset=0, constrained=False, goal_inds=None, u_norm_max=6.0,
                       integration=T.RK4, device=0, lib=None, options=None):
     """C3/C4 (shape from test/quatcosts.jl:152-168 + src/lie_costs.jl:133-142): point-to-point with QuatLQRCost,

@@ -959,6 +959,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
   double rho = a.rho[b], drho = a.drho[b];
   double Jnew = Jprev, grad = 0.0;
   int accepted = -1;
+  bool zero_step = false;  // stationary point: the zero step was "accepted" (ls_index 0, J unchanged)
   if (!bpfail) {
     const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
     double alpha = 1.0;
@@ -967,7 +968,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
     // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
     const bool stationary = -(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev));
     if (stationary) {
-      accepted = 0;
+      accepted = 0; zero_step = true;
       const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
       const double* pd = TILE_PTR(a.d, (N - 1) * m);
       double gs = 0.0;
@@ -1059,7 +1060,7 @@ __global__ void __launch_bounds__(64) k_select(KArgs a) {
     const bool ls_failed = accepted < 0;
     const double dJ = Jprev - Jnew;
     int dz = a.dJzero[b];
-    dz = ls_failed ? dz + 1 : 0;
+    dz = (ls_failed || zero_step) ? dz + 1 : 0;  // a zero step makes no progress either
     a.dJzero[b] = dz;
     a.dJ[b] = dJ; a.grad[b] = grad; a.J[b] = Jnew;
     const int its = a.iterations[b] + 1, iti = a.it_inner[b] + 1;

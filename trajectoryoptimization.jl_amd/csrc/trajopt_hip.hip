@@ -43,6 +43,23 @@ void default_opts(to_solver_opts* o) {
   o->iterations_total = 1000;
 }
 
+// Nonsense options used to give silent non-termination-style behaviour (every trajectory runs to MAX_ITERATIONS).
+int validate_opts(const to_solver_opts& o) {
+  auto bad = [](const char* what) { return fail(TO_ERR_ARGUMENT, std::string("solver option out of range: ") + what); };
+  if (!(o.cost_tolerance >= 0) || !(o.cost_tolerance_intermediate >= 0) || !(o.gradient_tolerance >= 0) || !(o.constraint_tolerance >= 0))
+    return bad("tolerances must be >= 0");
+  if (o.iterations < 0 || o.iterations_outer < 0 || o.iterations_total < 0 || o.dJ_counter_limit < 0) return bad("iteration counts must be >= 0");
+  if (o.iterations_linesearch < 1 || o.iterations_linesearch > 64) return bad("iterations_linesearch must be in 1..64");
+  if (!(o.line_search_decrease_factor > 0.0 && o.line_search_decrease_factor < 1.0)) return bad("line_search_decrease_factor must be in (0,1)");
+  if (!(o.line_search_lower_bound >= 0.0) || !(o.line_search_upper_bound > o.line_search_lower_bound)) return bad("line-search bounds must satisfy 0 <= lower < upper");
+  if (!(o.bp_reg_increase_factor > 1.0)) return bad("bp_reg_increase_factor must be > 1");
+  if (!(o.bp_reg_initial >= 0.0) || !(o.bp_reg_min >= 0.0) || !(o.bp_reg_max > o.bp_reg_min) || !(o.bp_reg_fp >= 0.0)) return bad("regularisation bounds");
+  if (!(o.penalty_initial > 0.0) || !(o.penalty_scaling >= 1.0) || !(o.penalty_max >= o.penalty_initial) || !(o.dual_max > 0.0)) return bad("penalty parameters");
+  if (!(o.max_cost_value > 0.0) || !(o.max_state_value > 0.0) || !(o.max_control_value > 0.0)) return bad("max_*_value must be > 0");
+  if (o.cost_dt_scaling != 0 && o.cost_dt_scaling != 1) return bad("cost_dt_scaling must be 0 or 1");
+  return TO_OK;
+}
+
 int model_dims(int id, const double* params, int* n, int* m, int* ne, int* key) {
   switch (id) {
     case TO_MODEL_DOUBLE_INTEGRATOR: {
@@ -88,6 +105,7 @@ struct to_handle_s {
   // measurement
   bool profile = false;
   std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
+  hipEvent_t sev[4] = {nullptr, nullptr, nullptr, nullptr};  // solve(): start, stop, two chunk read-back events (created once)
   double prof_ms[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
   int64_t prof_launches[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
 };
@@ -117,6 +135,11 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
     return fail(TO_ERR_DIMENSION_MISMATCH, std::string("New constraint not consistent with n=") + std::to_string(n) +
                                                " and m=" + std::to_string(m) + ": " + what);  // src/constraint_list.jl:109
   };
+  // index lists address [x;u] positions one-to-one: a duplicate would make the reported Jacobian (last duplicate wins)
+  // disagree with the one the solver accumulates
+  for (int i = 0; i < d.n_inds; ++i)
+    for (int j = i + 1; j < d.n_inds; ++j)
+      if (d.inds[i] == d.inds[j]) return fail(TO_ERR_ARGUMENT, "constraint indices must be distinct");
   int p = 0;
   switch (d.kind) {
     case TO_CON_GOAL:
@@ -171,6 +194,7 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
     case TO_CON_COLLISION:
       if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "CollisionConstraint sense must be Inequality");
       if (d.n_inds < 2 || d.n_inds % 2 != 0) return fail(TO_ERR_ASSERTION, "Position dimensions must be of equal length"); /* src/constraints.jl:349 */
+      if (d.n_inds > n) return dimerr("CollisionConstraint has more position indices than states");
       if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "CollisionConstraint needs one parameter (radius)");
       for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "CollisionConstraint index outside state");
       ci.width = n; p = 1; break;
@@ -439,7 +463,13 @@ int launch_violation(to_handle* h, double* out) {
   return TO_OK;
 }
 
+int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
+  const int rc = solve_impl(h, st, al_mode);
+  h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
+  return rc;
+}
+int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   TRY(use_device(h));
   KArgs& a = h->a;
   const DevProblem& P = a.P;
@@ -457,9 +487,13 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   }
   HIPCHECK(hipMemsetAsync(a.counter, 0, sizeof(int) * max_steps, h->stream));
   TRY(ensure_nlist(h, max_steps));
-  hipEvent_t e0, e1;
-  HIPCHECK(hipEventCreate(&e0));
-  HIPCHECK(hipEventCreate(&e1));
+  if (!h->sev[0]) {
+    HIPCHECK(hipEventCreate(&h->sev[0]));
+    HIPCHECK(hipEventCreate(&h->sev[1]));
+    HIPCHECK(hipEventCreateWithFlags(&h->sev[2], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->sev[3], hipEventDisableTiming));
+  }
+  const hipEvent_t e0 = h->sev[0], e1 = h->sev[1];
   HIPCHECK(hipEventRecord(e0, h->stream));
   hipLaunchKernelGGL(k_solve_init, grid_b(h), dim3(BLOCK), 0, h->stream, a, al_mode);
   HIPCHECK(hipGetLastError());
@@ -474,9 +508,7 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   // enqueued when the host waits for the counters of chunk g, so the GPU never idles on the round trip; the price is at
   // most one chunk of launches whose kernels find nothing to do (kernels of finished trajectories exit at once).
   constexpr int CHECK_EVERY = 4;
-  hipEvent_t cev[2];
-  HIPCHECK(hipEventCreateWithFlags(&cev[0], hipEventDisableTiming));
-  HIPCHECK(hipEventCreateWithFlags(&cev[1], hipEventDisableTiming));
+  const hipEvent_t cev[2] = {h->sev[2], h->sev[3]};
   int launched = 0, checked = 0, nchunks = 0;
   bool done = false;
   auto enqueue_chunk = [&]() -> int {
@@ -511,15 +543,11 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
     }
     ++waited;
   }
-  HIPCHECK(hipEventDestroy(cev[0]));
-  HIPCHECK(hipEventDestroy(cev[1]));
   TRY(launch_accept(h));  // trajectories keep the slot of their last accepted step until here
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;
   HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-  HIPCHECK(hipEventDestroy(e0));
-  HIPCHECK(hipEventDestroy(e1));
   if (h->profile) {
     for (int step = 0; step < steps; ++step)
       for (int s = 0; s < 3; ++s) {
@@ -529,7 +557,6 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
         h->prof_launches[s] += 1;
       }
   }
-  a.control = 0;
   if (st) {
     const int B = P.B;
     std::vector<int32_t> its(B);
@@ -563,6 +590,11 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
 extern "C" {
 
 int to_abi_version(void) { return TO_ABI_VERSION; }
+#ifndef TO_BUILD_ID
+#define TO_BUILD_ID "unstamped"
+#endif
+static const char g_build_stamp[] = "TO_BUILD_ID=" TO_BUILD_ID;  // also found by scanning the file (build.py)
+const char* to_build_id(void) { return g_build_stamp + 12; }
 const char* to_last_error(void) { return g_err.c_str(); }
 int to_device_count(int* count) {
   CHECK_P(count);
@@ -578,6 +610,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   CHECK_P(out);
   if (!desc) return fail(TO_ERR_NULL, "null descriptor");
   if (desc->abi_version != TO_ABI_VERSION) return fail(TO_ERR_ARGUMENT, "ABI version mismatch");
+  if (opts) TRY(validate_opts(*opts));
   int n, m, ne, key;
   if (model_dims(desc->model, desc->model_params, &n, &m, &ne, &key)) return fail(TO_ERR_UNSUPPORTED, "unknown model");
   if (desc->n != n || desc->m != m) return fail(TO_ERR_DIMENSION_MISMATCH, "Objective state/control dimensions don't match model.");  // src/problem.jl:65-68
@@ -714,12 +747,13 @@ int to_destroy(to_handle* h) {
   if (h->stage) hipFree(h->stage);
   if (h->counter_host) hipHostFree(h->counter_host);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  for (hipEvent_t e : h->sev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return TO_OK;
 }
 
-int to_set_options(to_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_P(o); h->a.P.opts = *o; return TO_OK; }
+int to_set_options(to_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_P(o); TRY(validate_opts(*o)); h->a.P.opts = *o; return TO_OK; }
 int to_get_options(const to_handle* h, to_solver_opts* o) { CHECK_H(h); CHECK_P(o); *o = h->a.P.opts; return TO_OK; }
 int to_sync(to_handle* h) { CHECK_H(h); TRY(use_device(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
 void* to_stream(to_handle* h) { return h ? (void*)h->stream : nullptr; }
@@ -1010,13 +1044,17 @@ static int cone_op(int device, int which, int32_t cone, int32_t dim, int64_t cou
   if (count <= 0) return TO_OK;
   HIPCHECK(hipSetDevice(device));
   const size_t nx = (size_t)dim * count, no = which == 0 ? nx : nx * dim;
-  double *dx = nullptr, *db = nullptr, *dout = nullptr;
-  int* dst = nullptr;
-  HIPCHECK(hipMalloc((void**)&dx, nx * sizeof(double)));
-  HIPCHECK(hipMalloc((void**)&dout, no * sizeof(double)));
-  HIPCHECK(hipMalloc((void**)&dst, count * sizeof(int)));
+  struct DevBuf {  // freed on every exit path
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+  } bx, bb, bo, bs;
+  HIPCHECK(hipMalloc(&bx.p, nx * sizeof(double)));
+  HIPCHECK(hipMalloc(&bo.p, no * sizeof(double)));
+  HIPCHECK(hipMalloc(&bs.p, count * sizeof(int)));
+  double *dx = (double*)bx.p, *dout = (double*)bo.p, *db = nullptr;
+  int* dst = (int*)bs.p;
   HIPCHECK(hipMemcpy(dx, x, nx * sizeof(double), hipMemcpyHostToDevice));
-  if (which == 2) { HIPCHECK(hipMalloc((void**)&db, nx * sizeof(double))); HIPCHECK(hipMemcpy(db, b, nx * sizeof(double), hipMemcpyHostToDevice)); }
+  if (which == 2) { HIPCHECK(hipMalloc(&bb.p, nx * sizeof(double))); db = (double*)bb.p; HIPCHECK(hipMemcpy(db, b, nx * sizeof(double), hipMemcpyHostToDevice)); }
   const unsigned blocks = (unsigned)((count + 255) / 256);
   if (which == 0) hipLaunchKernelGGL(k_cone_projection, dim3(blocks), dim3(256), 0, 0, cone, dim, (long long)count, dx, dout, dst);
   else if (which == 1) hipLaunchKernelGGL(k_cone_jacobian, dim3(blocks), dim3(256), 0, 0, cone, dim, (long long)count, dx, dout, dst);
@@ -1025,7 +1063,6 @@ static int cone_op(int device, int which, int32_t cone, int32_t dim, int64_t cou
   HIPCHECK(hipMemcpy(out, dout, no * sizeof(double), hipMemcpyDeviceToHost));
   std::vector<int> st(count);
   HIPCHECK(hipMemcpy(st.data(), dst, count * sizeof(int), hipMemcpyDeviceToHost));
-  hipFree(dx); hipFree(dout); hipFree(dst); if (db) hipFree(db);
   for (int64_t i = 0; i < count; ++i) {
     if (st[i] < 0) return fail(TO_ERR_CONE, "Invalid second-order cone projection");
     if (status) status[i] = st[i];

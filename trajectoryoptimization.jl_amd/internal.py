@@ -87,8 +87,27 @@ def get_duals(prob, i):
 
 
 def set_duals(prob, i, lam=None, mu=None):
-    lam = None if lam is None else np.ascontiguousarray(lam, dtype=np.float64)
-    mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+    """Overwrite the duals [B, nk, p] and/or the penalty [B] of constraint ``i``.  One trajectory's worth ([nk, p] / a
+    scalar) is broadcast over the batch explicitly; anything else raises DimensionMismatch (the C-ABI copies p*nk*B
+    and B doubles from the pointers it is given)."""
+    from .api import DimensionMismatch
+    con = prob.constraints[i]
+    a, b = prob.constraints.inds[i]
+    nk = b - a + 1
+    if lam is not None:
+        lam = np.asarray(lam, dtype=np.float64)
+        if lam.shape == (nk, con.p):
+            lam = np.broadcast_to(lam, (prob.B, nk, con.p))
+        elif lam.shape != (prob.B, nk, con.p):
+            raise DimensionMismatch(f"lam must be [B={prob.B}, nk={nk}, p={con.p}] or [nk, p]; got {lam.shape}")
+        lam = np.ascontiguousarray(lam)
+    if mu is not None:
+        mu = np.asarray(mu, dtype=np.float64)
+        if mu.ndim == 0:
+            mu = np.full(prob.B, float(mu))
+        elif mu.shape != (prob.B,):
+            raise DimensionMismatch(f"mu must be a scalar or [B={prob.B}]; got {mu.shape}")
+        mu = np.ascontiguousarray(mu)
     prob._call("set_duals", i, _pd(lam) if lam is not None else None, _pd(mu) if mu is not None else None)
 
 
