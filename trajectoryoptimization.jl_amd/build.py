@@ -15,8 +15,8 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 TARGET = CSRC / "libtrajopt_hip.so"
-SOURCES = ["trajopt_hip.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+OBJDIR = CSRC / "build"
 
 
 def hipcc_path():
@@ -54,16 +54,41 @@ def is_stale(extra_flags=()):
     return binary_id() != source_id(extra_flags)
 
 
-def build_hip(force=False, verbose=False, extra_flags=(), target=TARGET):
-    """Compile the HIP kernels + C-ABI into csrc/libtrajopt_hip.so.  Returns the path."""
+def _compile(args):
+    cmd, src = args
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC))
+    return src, res.returncode, res.stderr
+
+
+def build_hip(force=False, verbose=False, extra_flags=(), target=TARGET, jobs=None):
+    """Compile every csrc/*.hip (one translation unit per model / phase group, in parallel) for gfx950 and link
+    csrc/libtrajopt_hip.so.  Returns the path.  Objects are cached per (source, stamp) under csrc/build/."""
+    from concurrent.futures import ThreadPoolExecutor
     target = Path(target)
     sid = source_id(extra_flags)
     if not force and binary_id(target) == sid:
         return target
-    cmd = [hipcc_path(), *FLAGS, *extra_flags, f'-DTO_BUILD_ID="{sid}"', "-o", str(target), *[str(CSRC / s) for s in SOURCES]]
-    res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC))
+    hipcc = hipcc_path()
+    OBJDIR.mkdir(exist_ok=True)
+    sources = sorted(CSRC.glob("*.hip"))
+    work, objs = [], []
+    for src in sources:
+        obj = OBJDIR / f"{src.stem}.{sid}.o"
+        objs.append(obj)
+        if force or not obj.exists():
+            flags = [*FLAGS, *extra_flags] + ([f'-DTO_BUILD_ID="{sid}"'] if src.name == "trajopt_hip.hip" else [])
+            work.append(([hipcc, *flags, "-c", "-o", str(obj), str(src)], src))
+    with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
+        for src, rc, err in ex.map(_compile, work):
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {src.name}:\n" + err[-6000:])
+            if verbose:
+                print(src.name, err)
+    for old in OBJDIR.glob("*.o"):  # objects of earlier stamps
+        if old not in objs:
+            old.unlink()
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(target), *map(str, objs)],
+                         capture_output=True, text=True, cwd=str(CSRC))
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stderr[-4000:])
-    if verbose:
-        print(res.stderr)
+        raise RuntimeError("link failed:\n" + res.stderr[-4000:])
     return target

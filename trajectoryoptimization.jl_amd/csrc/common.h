@@ -1,0 +1,212 @@
+// common.h — kernel argument block, layout macros and per-knot helpers shared by the kernels of the batched
+// iLQR / AL hot path for gfx950 (MI355X).  See DESIGN.md §3 for the layouts.
+//
+// Tiled arrays (X, U, duals): array-of-structures-of-arrays with a 64-trajectory tile.  Element e (e.g. e = k*n + i) of
+// trajectory b of an array with L elements per trajectory lives at
+//     base[((b/64)*L + e)*64 + (b%64)]
+// so the lanes of a wave that hold neighbouring trajectories read/write contiguous bytes and what a wave touches as it
+// walks the knots is ONE contiguous stream.  Gains (K, d) and the expansion blocks are TRAJECTORY-major (below).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "models.h"
+#include "problem_dev.h"
+
+namespace to {
+
+struct KArgs {
+  DevProblem P;
+  double* Xs;     // (T+1) slots of L = N*n: slot 0 holds the nominal trajectory, slot t+1 line-search candidate t of the round
+  double* Us;     // (T+1) slots of L = (N-1)*m
+  size_t slotX, slotU;  // doubles per slot (L * Bp)
+  int T;          // candidate slots = CW = line-search candidates a wave evaluates concurrently (power of two <= 16)
+  int cw_log;     // log2(CW); a forward wave holds CW candidates x TW = 64/CW trajectories
+  double* x0;     // L = n
+  int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): copied onto slot 0 by k_accept, or
+                  //      written through by the next k_expand (M::accept_write_through)
+  double *Mc, *Hc, *gc;               // column layout (see "column layout" below): [Ā B̄], Q-function cost blocks, gradient
+  double* Kt;                         // gains, trajectory-major rows: Kt[(b*(N-1) + k)*RSK + r*(ne+1) + i] = K_k[r][i], i = ne: d_k[r]
+  double *Mt, *Ht, *gt;               // tangent-matrix layout of the expansion for the MFMA backward pass (k_backward.h)
+  int bwd_mfma;                       // 1: expansion writes Mt/Ht/gt and the MFMA backward pass runs; 0: column layout + cooperative pass
+  int h_compact;                      // Ht holds one row per knot (block-diagonal Qxx, Quu, no Qux): see k_expand.h
+  double *lam, *mu;                   // L = n_duals, n_cons
+  double *J, *dJ, *grad, *rho, *drho, *dV, *cmax, *Jout;  // [Bp] plain (dV: [2][Bp])
+  int *status, *iterations, *it_inner, *outer, *dJzero, *ls_index, *active, *budget, *bpfail;
+  int* counter;   // [steps] number of trajectories still active after each batch step
+  int *oflag, *ost;   // [Bp] AL outer update pending (1: evaluate, 2: update duals) and the inner solve's status
+  double* knotbuf;    // tiled, L = N: per-knot scratch of the outer update (violations, then AL cost terms)
+  double* mu_next;    // tiled, L = n_cons: penalties after the pending outer update
+  int al_mode;    // 0: iLQR, 1: AL-iLQR
+  int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
+  int step;
+};
+
+// gains row of one knot of one trajectory: m rows of (ne gains + 1 feed-forward) doubles
+template <class M> struct Gains { static constexpr int RSK = M::m * (M::ne + 1); };
+
+// per-lane pointer to element 0 of this lane's trajectory in a tiled array with L elements per trajectory;
+// element e is then p[e*64] (e wave-uniform -> scalar address arithmetic, immediate offsets for small constants)
+#define TILE_PTR(base, L) ((base) + ((size_t)tile * (size_t)(L)) * 64 + lane)
+#define EL(p, e) (p)[(size_t)(e) * 64]
+#define TILE_LANE() const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane
+#define XSLOT(a, c) ((a).Xs + (size_t)(c) * (a).slotX)
+#define USLOT(a, c) ((a).Us + (size_t)(c) * (a).slotU)
+
+// objective (+AL) value of one knot.  u must be zeros at the terminal knot (the reference evaluates the
+// terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).
+// lam0 / mu0: this lane's pointers to dual row 0 / penalty 0 (tiled arrays).
+// GEN = false: no dense QuadraticCost and no non-selector constraint in the tables (those branches are compiled out)
+template <class M, bool GEN = true>
+__device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
+                                            const double* mu0, bool with_al) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  double Jk = cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], x, u);
+  if (P.opts.cost_dt_scaling && k < P.N - 1) Jk *= P.dt[k];
+  if (with_al && P.n_cons > 0) {
+    double z[nz];
+#pragma unroll
+    for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) z[n + i] = u[i];
+    double Ja = 0.0;
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (k < K.k1 || k > K.k2) continue;
+      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
+    }
+    Jk += Ja;
+  }
+  return Jk;
+}
+
+// AL penalty terms of one knot only
+// AL terms of one stage knot with up to two register-cached control-block constraints (ConStage); the others take the
+// descriptor-table path.  Terms are summed in constraint order, like knot_al.
+template <class M, bool GEN>
+__device__ __forceinline__ double knot_al_cached(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
+                                                 const double* mu0, int ncs, const ConStage<M::n, M::m>& c0,
+                                                 const ConStage<M::n, M::m>& c1) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  double Ja = 0.0;
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    if (ncs > 0 && ci == c0.ci) { Ja += c0.term(u); continue; }
+    if (ncs > 1 && ci == c1.ci) { Ja += c1.term(u); continue; }
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    double z[nz];
+#pragma unroll
+    for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) z[n + i] = u[i];
+    const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
+  }
+  return Ja;
+}
+
+template <class M, bool GEN = true>
+__device__ __forceinline__ double knot_al(const DevProblem& P, int k, const double* x, const double* u, const double* lam0, const double* mu0) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = u[i];
+  double Ja = 0.0;
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
+  }
+  return Ja;
+}
+
+template <class M>
+__device__ __forceinline__ double knot_violation(const DevProblem& P, int k, const double* x, const double* u) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = u[i];
+  double vmax = 0.0;
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    const double v = con_violation<nz>(K, z);
+    if (!(v <= vmax)) vmax = v;
+  }
+  return vmax;
+}
+
+// whole-trajectory pass over the NOMINAL trajectory: cost (with or without AL), max violation, optional dual update
+template <class M>
+__device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int lane, bool with_al, bool do_dual_update, double* J_out,
+                                                double* cmax_out, int c = 0) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  double J = 0.0, cmax = 0.0;
+  for (int k = 0; k < N; ++k) {
+    double x[n], u[m];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+    for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+    if (do_dual_update) {
+      double z[nz];
+#pragma unroll
+      for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) z[n + i] = u[i];
+      for (int ci = 0; ci < P.n_cons; ++ci) {
+        ConC& K = P.cons[ci];
+        if (k < K.k1 || k > K.k2) continue;
+        double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        con_dual_update<nz>(K, z, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
+      }
+    }
+    if (cmax_out && P.n_cons > 0) { const double v = knot_violation<M>(P, k, x, u); if (!(v <= cmax)) cmax = v; }
+    if (J_out) J += knot_cost<M>(P, k, x, u, lam0, mu0, with_al);
+  }
+  if (J_out) *J_out = J;
+  if (cmax_out) *cmax_out = cmax;
+}
+
+// ------------------------------------------------------------------------------------------------ column layout
+// The expansion and the backward pass work on COLUMNS of the per-knot blocks: direction j of the error-state tangent
+// space [δx (ne); δu (m)] is owned by one lane.  R = ne+m rounded up to a power of two lanes form one trajectory's
+// group, G = 64/R trajectories share a wave.  Column arrays hold E entries per (trajectory, column):
+//     base[((b/G)*E + e)*64 + (b%G)*R + j]            (64 consecutive doubles = the G x R lanes of one wave)
+//   Mc: E = (N-1)*ne      Mc[k*ne + i]       = [Ā B̄]_k[i][j]
+//   Hc: E = N*(ne+m)      Hc[k*(ne+m) + i]   = Q-function cost block [Qxx Qxu; Qux Quu]_k[i][j]  (cost + AL, projected)
+//   gc: E = N             gc[k]              = [qx; qu]_k[j]
+template <class M>
+struct Coop {
+  static constexpr int ne = M::ne, m = M::m, nc = ne + m;
+  static constexpr int R = nc <= 4 ? 4 : nc <= 8 ? 8 : 16;
+  static constexpr int G = 64 / R;
+};
+#define COL_PTR(base, E) ((base) + ((size_t)gtile * (size_t)(E)) * 64 + lane)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// ------------------------------------------------------------------------------------------------ regularisation
+__device__ __forceinline__ void reg_increase(const to_solver_opts& o, double& rho, double& drho) {
+  const double f = o.bp_reg_increase_factor;
+  drho = fmax(drho * f, f);
+  rho = fmax(rho * drho, o.bp_reg_min);
+}
+__device__ __forceinline__ void reg_decrease(const to_solver_opts& o, double& rho, double& drho) {
+  const double f = o.bp_reg_increase_factor;
+  drho = fmin(drho / f, 1.0 / f);
+  const double r = rho * drho;
+  rho = (r > o.bp_reg_min) ? r : 0.0;
+}
+
+}  // namespace to

@@ -1,0 +1,101 @@
+// handle.h — host-side state behind a to_handle and the per-model launch table.  The kernels of one model are
+// instantiated in their own translation units (ops_*.hip: the Quadrotor forward pass alone is a minute of compile
+// time); trajopt_hip.hip holds the C-ABI and the model-independent kernels and reaches the rest through ModelOps.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace to {
+
+int fail(int code, const std::string& msg);  // records the message for to_last_error(), returns code
+
+#define HIPCHECK(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return ::to::fail(TO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+#define TRY(expr) do { int r_ = (expr); if (r_ != TO_OK) return r_; } while (0)
+
+constexpr int BLOCK = 64;  // one wave per workgroup: a small batch is spread over as many CUs as possible
+
+struct ModelOps;
+
+}  // namespace to
+
+struct to_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int model_key = -1;
+  const to::ModelOps* ops = nullptr;
+  int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
+  to::KArgs a;       // host copy of the kernel argument block (device pointers inside)
+  std::vector<to_cost_desc> costs;
+  std::vector<to::DevCon> cons;
+  std::vector<double> dt;
+  std::vector<int> cost_index;
+  std::vector<void*> allocs;
+  double* stage = nullptr;  // device staging buffer in host layout
+  size_t stage_bytes = 0;
+  int* counter_host = nullptr;  // pinned
+  int counter_len = 0;
+  int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
+  // device copies of the descriptor tables
+  to_cost_desc* d_costs = nullptr;
+  to::DevCon* d_cons = nullptr;
+  double* d_dt = nullptr;
+  int* d_cost_index = nullptr;
+  int* d_crow = nullptr;    // [64] compact_row table of the model (tangent-matrix getters)
+  double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
+  double* d_tmp2 = nullptr;
+  // measurement
+  bool profile = false;
+  std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
+  hipEvent_t sev[4] = {nullptr, nullptr, nullptr, nullptr};  // solve(): start, stop, two chunk read-back events (created once)
+  double prof_ms[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
+  int64_t prof_launches[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
+};
+
+namespace to {
+
+// Launchers of the model-templated kernels (all enqueue on h->stream and return TO_OK / TO_ERR_HIP).
+struct ModelOps {
+  // model traits the host logic needs
+  bool write_through = false;  // M::accept_write_through
+  bool mfma_backward = false;  // M::mfma_backward: tangent-matrix expansion + one-wave-per-trajectory Riccati
+  bool lds_gains = false;      // forward pass stages gains through LDS
+  int expand_knots = 1;
+  int gains_lds_pieces = 0;    // 16-byte pieces of one gains row (LDS sizing of the forward pass)
+  int crow[64];                // compact_row(g, c) of the tangent-matrix layout
+  int nep = 0, rs = 0;         // Tm<M>::NEP, Tm<M>::RS
+  int (*rollout)(to_handle*) = nullptr;
+  int (*cost)(to_handle*, int with_al, double* out, double* Jk) = nullptr;
+  int (*violation)(to_handle*, double* out) = nullptr;
+  int (*dual_update)(to_handle*) = nullptr;
+  int (*outer)(to_handle*) = nullptr;
+  int (*cost_derivs)(to_handle*, double* grad, double* hess) = nullptr;
+  int (*discrete_jacobian)(to_handle*, double* F) = nullptr;
+  int (*constraint_eval)(to_handle*, int ci, double* vals, double* jac) = nullptr;
+  int (*expand)(to_handle*) = nullptr;
+  int (*backward)(to_handle*) = nullptr;
+  int (*forward[16])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
+};
+
+// each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole, 4 Quadrotor)
+constexpr int N_MODEL_KEYS = 5;
+void fill_ops_small(ModelOps* table);
+void fill_ops_small_forward(ModelOps* table);
+void fill_ops_quad_misc(ModelOps* table);
+void fill_ops_quad_expand(ModelOps* table);
+void fill_ops_quad_backward(ModelOps* table);
+void fill_ops_quad_forward_a(ModelOps* table);
+void fill_ops_quad_forward_b(ModelOps* table);
+
+inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
+
+}  // namespace to

@@ -1,0 +1,217 @@
+// k_expand.h — dynamics / cost / constraint expansion.
+#pragma once
+#include "common.h"
+#include "k_backward.h"  // Tm<M>, compact_row: the layouts the backward pass reads
+
+namespace to {
+
+// ------------------------------------------------------------------------------------------------ expansion
+// grid (ceil(B/G), N): lane (g, j) of a wave = trajectory gtile*G+g, direction j.  It produces column j of everything
+// the backward pass needs at knot k:
+//   [Ā B̄][:,j] = G(x_{k+1})ᵀ · ∂(RK step)/∂z · v_j            (forward-mode dual through all RK stages)
+//   H[:,j]      = projected Hessian-vector product of (cost + AL) with v_j,   g[j] = projected gradient component
+// with v_j = [G(x_k) e_j; 0] (j<ne) or [0; e_{j-ne}].
+// VAR bit0: dense QuadraticCost possible; bit1: constraints present; bit2: non-selector constraints possible.  Code the
+// problem cannot reach is compiled out: the all-purpose Quadrotor kernel needed 256 VGPRs + 140 AGPRs + 480 B of scratch.
+// one knot of the expansion for lane (g, j): x = x_k, u = u_k (zeros at the terminal knot), x1 = x_{k+1}
+// LAY: where the columns go.  0: column layout (cooperative backward pass); 1: tangent-matrix layout, full cost block;
+// 2: tangent-matrix layout, compact cost block (k_backward.h).
+template <class M, int FIXED_INTEG, int VAR, int LAY>
+__device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane, int tile, int lane64, int b, int j, int k, bool valid,
+                                            const double* x, const double* u, const double* x1) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  constexpr int NEP = Tm<M>::NEP, RS = Tm<M>::RS, NR = Tm<M>::NR;
+  const int ct = j < ne ? j : NEP + (j - ne);  // tangent index of this lane's column
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const bool terminal = (k == N - 1);
+  double v[nz];
+  {
+    double vx[n];
+    errstate_col<M>(x, j < ne ? j : 0, vx);
+#pragma unroll
+    for (int i = 0; i < n; ++i) v[i] = (j < ne) ? vx[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) v[n + i] = (i == j - ne) ? 1.0 : 0.0;
+  }
+  // duals of (up to two) control-block constraints of this knot are fetched NOW, ahead of the dynamics column: the AL
+  // terms below would otherwise pay a memory round trip of their own (the stores in between pin their loads in place)
+  constexpr int LR = m + 1;
+  double l0[LR], l1[LR], mu0r = 0.0, mu1r = 0.0;
+  int lci0 = -1, lci1 = -1;
+  if ((VAR & 2) != 0 && P.n_cons > 0) {
+    const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
+    const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (k < K.k1 || k > K.k2 || K.fast != 2 || K.p > LR) continue;
+      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      if (lci0 < 0) {
+        lci0 = ci; mu0r = EL(mu0, ci);
+#pragma unroll
+        for (int r = 0; r < LR; ++r) l0[r] = (r < K.p) ? lam[r * 64] : 0.0;
+      } else if (lci1 < 0) {
+        lci1 = ci; mu1r = EL(mu0, ci);
+#pragma unroll
+        for (int r = 0; r < LR; ++r) l1[r] = (r < K.p) ? lam[r * 64] : 0.0;
+      }
+    }
+  }
+  // ---- dynamics column
+  if (!terminal) {
+    Dual xd[n], ud[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xd[i] = Dual(x[i], v[i]);
+#pragma unroll
+    for (int i = 0; i < m; ++i) ud[i] = Dual(u[i], v[n + i]);
+    rk_step<M, Dual, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+    double t[n], col[ne];
+#pragma unroll
+    for (int i = 0; i < n; ++i) t[i] = xn[i].d;
+    errstate_tmul<M>(x1, t, col);
+    if constexpr (LAY == 0) {
+      double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) EL(Mc, k * ne + i) = col[i];
+      }
+    } else {
+      double* Mt = a.Mt + (((size_t)b * (N - 1) + k) * RS) * 64 + ct;
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) Mt[(i / 4) * 64 + (i % 4) * 16] = col[i];
+      }
+    }
+  }
+  // ---- cost (+AL) gradient and Hessian-vector product on the full state
+  double gr[nz], y[nz];
+  cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
+  if (P.opts.cost_dt_scaling && !terminal) {
+    const double h = P.dt[k];
+#pragma unroll
+    for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
+  }
+  if ((VAR & 2) != 0 && P.n_cons > 0) {
+    double z[nz];
+#pragma unroll
+    for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) z[n + i] = u[i];
+    const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
+    const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (k < K.k1 || k > K.k2) continue;
+      if (ci == lci0) { al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, l0, 1, mu0r, v, gr, y); continue; }
+      if (ci == lci1) { al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, l1, 1, mu1r, v, gr, y); continue; }
+      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
+    }
+  }
+  double col[ne], qxe[ne];
+  errstate_tmul<M>(x, y, col);
+  errstate_tmul<M>(x, gr, qxe);
+  if constexpr (M::lie) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q) on the attitude diagonal
+    const double b1 = x[3] * gr[3] + x[4] * gr[4] + x[5] * gr[5] + x[6] * gr[6];
+#pragma unroll
+    for (int i = 3; i < 6; ++i) col[i] -= (i == j) ? b1 : 0.0;
+  }
+  double gj = 0.0;
+#pragma unroll
+  for (int i = 0; i < ne; ++i) gj = (i == j) ? qxe[i] : gj;
+#pragma unroll
+  for (int r = 0; r < m; ++r) gj = (ne + r == j) ? gr[n + r] : gj;
+  if (!valid) return;
+  if constexpr (LAY == 0) {
+    double* Hc = COL_PTR(a.Hc, N * nc);
+#pragma unroll
+    for (int i = 0; i < ne; ++i) EL(Hc, k * nc + i) = col[i];
+#pragma unroll
+    for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
+    double* gc = COL_PTR(a.gc, N);
+    EL(gc, k) = gj;
+  } else {
+    if constexpr (LAY == 1) {
+      double* Ht = a.Ht + (((size_t)b * N + k) * NR) * 64 + ct;
+#pragma unroll
+      for (int i = 0; i < ne; ++i) Ht[(i / 4) * 64 + (i % 4) * 16] = col[i];
+#pragma unroll
+      for (int r = 0; r < m; ++r) Ht[((NEP + r) / 4) * 64 + ((NEP + r) % 4) * 16] = terminal ? 0.0 : y[n + r];
+    } else {  // one entry per lane group: the row compact_row(g, column) of this column
+      double* Ht = a.Ht + ((size_t)b * N + k) * 64 + ct;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = compact_row<M>(g, ct);
+        if (i < 0) continue;
+        double v = 0.0;
+        if (i >= NEP) v = terminal ? 0.0 : pick<m>(y + n, i - NEP); else v = pick<ne>(col, i);
+        Ht[g * 16] = v;
+      }
+    }
+    a.gt[((size_t)b * N + k) * 16 + ct] = gj;
+  }
+}
+
+// A wave walks M::expand_knots consecutive knots and fetches the next knot's state/control while it works on the
+// current one: with one wave per SIMD (Quadrotor) nothing else hides the load round trip, which was half of the wave's
+// life (rocprof: SQ_WAIT_ANY 49 % of SQ_WAVE_CYCLES, 60 % with AL terms).  x_{k+1} is shared between neighbours.
+template <class M, int FIXED_INTEG, int VAR, int LAY>
+__global__ void __launch_bounds__(64) k_expand(KArgs a) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, KC = M::expand_knots;
+  constexpr int R = Coop<M>::R, G = Coop<M>::G;
+  const int gtile = blockIdx.x, lane = threadIdx.x;
+  const int g = lane / R, j = lane % R;
+  const int b = gtile * G + g;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const int k0 = blockIdx.y * KC;
+  // idle lanes (padding columns, finished trajectories) compute along with EXEC full — partially masked FP64 issues
+  // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
+  const bool lane_ok = b < P.B && j < nc && a.active[b];
+  if (__ballot(lane_ok) == 0) return;
+  // Inside a solve the step accepted by the previous forward pass still sits in its candidate slot (acc != 0): the
+  // expansion reads it there and writes it through to slot 0, so the separate k_accept copy (and its re-read of every
+  // candidate line that any lane of a tile accepted) disappears from the iteration.  Outside a solve acc is 0.
+  // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
+  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
+  const int tile = b >> 6, lane64 = b & 63;
+  const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
+  const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+  double x[n], u[m], x1[n], x2[n], un[m];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { x[i] = EL(X, k0 * n + i); x1[i] = (k0 + 1 < N) ? EL(X, (k0 + 1) * n + i) : 0.0; }
+#pragma unroll
+  for (int i = 0; i < m; ++i) u[i] = (k0 < N - 1) ? EL(U, k0 * m + i) : 0.0;
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) {
+    const int k = k0 + kk;
+    if (k >= N) break;
+    const bool terminal = (k == N - 1);
+    if (KC > 1 && kk + 1 < KC && k + 1 < N) {  // next knot's operands (x_{k+1} is already here)
+#pragma unroll
+      for (int i = 0; i < n; ++i) x2[i] = (k + 2 < N) ? EL(X, (k + 2) * n + i) : 0.0;
+#pragma unroll
+      for (int i = 0; i < m; ++i) un[i] = (k + 1 < N - 1) ? EL(U, (k + 1) * m + i) : 0.0;
+    }
+    const bool valid = lane_ok && !(terminal && j >= ne);
+    if (M::accept_write_through && c != 0 && j == 0 && valid) {
+      double* X0 = XSLOT(a, 0) + ((size_t)tile * (N * n)) * 64 + lane64;
+      double* U0 = USLOT(a, 0) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+#pragma unroll
+      for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
+      if (!terminal) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
+      }
+    }
+    expand_knot<M, FIXED_INTEG, VAR, LAY>(a, gtile, lane, tile, lane64, b, j, k, valid, x, u, x1);
+    if (KC > 1) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { x[i] = x1[i]; x1[i] = x2[i]; }
+#pragma unroll
+      for (int i = 0; i < m; ++i) u[i] = un[i];
+    }
+  }
+}
+
+}  // namespace to

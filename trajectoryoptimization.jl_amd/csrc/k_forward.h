@@ -1,0 +1,315 @@
+// k_forward.h — forward pass: concurrent line search + per-trajectory solver state machine.
+//
+// One wave holds CW line-search candidates x TW = 64/CW trajectories: hardware lane h = q*TW + t evaluates step size
+// alpha = decrease^(c0 + q) for trajectory b0 + t.  The CW candidates of a trajectory therefore sit in ONE wave:
+//   * they share the trajectory's gains: a knot's K,d row (trajectory-major, Kt) is brought into LDS once per wave by
+//     DMA and read with CW-way broadcasts — the first version gave every candidate its own wave, which re-read the
+//     gains 16 times through L2 (5 GB per Quadrotor round) and issued 24 DMA instructions per knot per wave;
+//   * the first accepted step size (identical to sequential backtracking) is found with a ballot at the end of the
+//     rollout, and the convergence / AL state machine runs right there: no candidate cost arrays, no k_select launch;
+//   * a trajectory that rejected all CW step sizes continues with the next CW inside the same kernel (only the waves
+//     that still hold a searching trajectory keep running): no compacted lists, no further launches.
+#pragma once
+#include "common.h"
+
+namespace to {
+
+template <class M, bool WITHK>
+struct FwdKnot {  // nominal state/control of one knot (+ its gains row for models that do not stage gains through LDS)
+  static constexpr int n = M::n, m = M::m, RSK = Gains<M>::RSK;
+  double x[n], u[m], kd[WITHK ? RSK : 1];
+  // pointers are already at this knot (the caller walks them): constant offsets, no address arithmetic per load
+  __device__ __forceinline__ void load(const double* pXk, const double* pUk, const double* pKk) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = EL(pXk, i);
+#pragma unroll
+    for (int j = 0; j < m; ++j) u[j] = EL(pUk, j);
+    if constexpr (WITHK) {
+#pragma unroll
+      for (int i = 0; i < RSK; ++i) kd[i] = pKk[i];
+    }
+  }
+};
+
+// Gains rows of knot k of the wave's TW trajectories, global -> LDS by DMA (global_load_lds_dwordx4: no staging
+// registers, the wave keeps computing).  A row is RSK doubles = PCS 16-byte pieces; piece GL = i*64 + lane of
+// instruction i belongs to trajectory GL / PCS and lands at kbuf + 16 GL, i.e. the rows sit back to back in LDS
+// (row stride RSK doubles: 416 B for the Quadrotor, so the TW rows read together fall on distinct banks).
+template <class M>
+__device__ __forceinline__ void stage_gains(const double* Kt, int b0, int TW, int k, int N, double* kbuf, int hw) {
+  constexpr int RSK = Gains<M>::RSK;
+  static_assert(RSK % 2 == 0, "gains rows must be whole 16-byte pieces");
+  constexpr int PCS = RSK / 2;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int pieces = TW * PCS;
+  for (int i0 = 0; i0 < pieces; i0 += 64) {
+    const int gl = i0 + hw;
+    int t = gl / PCS;
+    const int off = gl - t * PCS;
+    t = t < TW ? t : TW - 1;  // lanes past the last row re-fetch it (their LDS pieces are never read)
+    const char* src = (const char*)(Kt + ((size_t)(b0 + t) * (N - 1) + k) * RSK) + off * 16;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)((char*)kbuf + (size_t)i0 * 16), 16, 0, 0);
+  }
+}
+template <class M>
+__host__ __device__ inline int gains_lds_doubles(int TW) {  // per buffer, whole DMA instructions
+  constexpr int PCS = Gains<M>::RSK / 2;
+  return ((TW * PCS + 63) / 64) * 64 * 2;
+}
+
+// One line-search candidate per lane: closed-loop rollout of trajectory (tile, lane) with step size alpha into slot cs,
+// its (AL) cost J, gradient metric gsum/(N-1) and admissibility ok.  Lanes with live == false roll out as well (a
+// partially masked wave issues FP64 ~1.3x slower on gfx950) but store nothing.
+// MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms);
+// bit2: RK4 fixed at compile time; bit3: dense costs / non-selector constraints possible (else compiled out).
+// kbuf: the wave's two LDS buffers for DMA-staged gains (M::lds_gains); krow: this lane's row offset in a buffer.
+template <class M, int MODE>
+__device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int lane, int b, bool live, double alpha, int cs, double* kbuf,
+                                                  int kbuf_len, int krow, int b0, int TW, int hw, double& J_out, double& g_out, bool& ok_out) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
+  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0;
+  constexpr bool KLDS = M::lds_gains;
+  const DevProblem& P = a.P;
+  const to_solver_opts& o = P.opts;
+  const int N = P.N;
+  constexpr int c = 0;  // nominal slot
+  const double* Xc = TILE_PTR(XSLOT(a, c), N * n);
+  const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  double* Xn = TILE_PTR(XSLOT(a, cs), N * n);
+  double* Un = TILE_PTR(USLOT(a, cs), (N - 1) * m);
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
+  const double* px0 = TILE_PTR(a.x0, n);
+  const double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  // everything wave-uniform the loop needs is fetched ONCE: an in-order wave stalls on every scalar-load round trip
+  double mp[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mp[i] = in_vgpr(P.mp[i]);
+  const int integrator = P.integrator;
+  const bool dt_scaling = P.opts.cost_dt_scaling != 0;
+  const double max_x = o.max_state_value, max_u = o.max_control_value;
+  StageCostDiag<n, m> sc;
+  double h0 = 0.0;
+  if constexpr (SIMPLE) { sc.load(P.costs[P.cost_index[0]]); h0 = P.dt[0]; }
+  // stage constraints on the control block (norm / SOC / one-sided bounds on u) are cached in registers once
+  ConStage<n, m> cs0, cs1;
+  int ncs = 0, uncached = 0;
+  cs0.ci = -1; cs1.ci = -1;
+  if constexpr (CONS) {
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (K.fast == 2 && K.k1 == 0 && K.k2 >= N - 2 && K.p <= m + 1 && ncs < 2) {
+        if (ncs == 0) cs0.load(K, ci, lam0, mu0); else cs1.load(K, ci, lam0, mu0);
+        ++ncs;
+      } else if (K.k1 <= N - 2) ++uncached;  // applies to some stage knot: needs the descriptor-table path
+    }
+  }
+  double xb[n], J = 0.0, gsum = 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
+  if constexpr (KLDS) stage_gains<M>(a.Kt, b0, TW, 0, N, kbuf, hw);
+  FwdKnot<M, !KLDS> nxt;
+  nxt.load(Xc, Uc, pK);
+  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + RSK;  // knot k+1 of the nominal
+  double *pXo = Xn, *pUo = Un;                                          // where knot k's candidate state / control go
+  const bool all_cached = CONS && uncached == 0;  // wave-uniform: the loop then never touches the descriptor table
+  if (ncs > 0) cs0.prefetch(0);
+  if (ncs > 1) cs1.prefetch(0);
+  for (int k = 0; k < N - 1; ++k) {
+    // this knot's gains have landed in LDS, its nominal is in registers; the stores of the previous knot were issued a
+    // whole knot ago, so waiting for everything costs nothing extra
+    if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const FwdKnot<M, !KLDS> cur = nxt;
+    if (ncs > 0) cs0.advance();
+    if (ncs > 1) cs1.advance();
+    // x̄_k goes out FIRST, then the next knot's loads / DMA: nothing issued from here on is needed before the next wait
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
+    }
+    pXo += n * 64;
+    const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
+    if (k + 1 < N - 1) {
+      if constexpr (KLDS) stage_gains<M>(a.Kt, b0, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
+      nxt.load(pXn, pUn, pKn);
+      if (ncs > 0) cs0.prefetch(k + 1);
+      if (ncs > 1) cs1.prefetch(k + 1);
+    }
+    pXn += n * 64; pUn += m * 64; pKn += RSK;
+    double dx[ne], ub[m], xn[n];
+    state_diff<M>(xb, cur.x, dx);
+    double gk = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      const double dj = KLDS ? kcur[j * (ne + 1) + ne] : cur.kd[KLDS ? 0 : j * (ne + 1) + ne];
+      double du = dj * alpha;
+#pragma unroll
+      for (int i = 0; i < ne; ++i) du += (KLDS ? kcur[j * (ne + 1) + i] : cur.kd[KLDS ? 0 : j * (ne + 1) + i]) * dx[i];
+      ub[j] = cur.u[j] + du;
+      if (live) EL(pUo, j) = ub[j];
+      gk = fmax(gk, fabs(dj) * rcp_fast(fabs(ub[j]) + 1.0));
+    }
+    pUo += m * 64;
+    gsum += gk;
+    const double h = SIMPLE ? h0 : P.dt[k];
+    double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], xb, ub);
+    if (dt_scaling) Jk *= h;
+    if constexpr (CONS) {
+      if (all_cached) {
+        double Ja = 0.0;
+        if (ncs > 0) Ja += cs0.term(ub);
+        if (ncs > 1) Ja += cs1.term(ub);
+        Jk += Ja;
+      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1);
+    }
+    J += Jk;
+    rk_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, xb, ub, h, xn);
+    double mx = 0.0, mu_ = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xb[i] = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
+#pragma unroll
+    for (int j = 0; j < m; ++j) { const double v = fabs(ub[j]); if (!(v <= mu_)) mu_ = v; }
+    // a rollout that left the admissible box is rejected; its lane keeps stepping (values are never used) so that the
+    // wave stays converged, and the wave stops once no live lane is inside the box any more
+    if (!(mx <= max_x) || !(mu_ <= max_u)) ok = false;
+    if (__ballot(live && ok) == 0) break;
+  }
+  if (live && ok) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];  // x̄_N (pXo has walked to the terminal knot when the loop ran to its end)
+  }
+  {
+    double u0[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u0[j] = 0.0;
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true);
+  }
+  if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be in flight when the next pass refills the buffers
+  J_out = J; g_out = gsum / (N - 1); ok_out = ok;
+}
+
+// gradient metric of the UNCHANGED nominal controls (zero step / failed line search): mean_k max_j |d_kj| / (|u_kj| + 1)
+template <class M>
+__device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int lane, int b) {
+  constexpr int m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
+  const int N = a.P.N;
+  const double* Uc = TILE_PTR(USLOT(a, 0), (N - 1) * m);
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
+  double gs = 0.0;
+  for (int k = 0; k < N - 1; ++k) {
+    double gk = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(pK[(size_t)k * RSK + j * (ne + 1) + ne]) * rcp_fast(fabs(EL(Uc, k * m + j)) + 1.0));
+    gs += gk;
+  }
+  return gs / (N - 1);
+}
+
+// Forward pass of one iLQR iteration.  grid = Bp / TW waves.  Line search: round r evaluates step sizes r*CW .. r*CW+CW-1
+// concurrently (one per lane group) and takes the FIRST accepted one — identical to sequential backtracking
+// (SURVEY.md row S2); then — when a.control — the per-trajectory solver state machine runs: convergence test (row S3)
+// and the hand-over to the AL outer update (row S4, k_outer_*).
+template <class M, int MODE>
+__global__ void __launch_bounds__(64) k_forward(KArgs a) {
+  extern __shared__ double kbuf[];  // M::lds_gains: two buffers of gains_lds_doubles(TW)
+  const DevProblem& P = a.P;
+  const to_solver_opts& o = P.opts;
+  const int hw = threadIdx.x;
+  const int cwl = a.cw_log, CW = 1 << cwl, TW = 64 >> cwl;
+  const int t = hw & (TW - 1), q = hw >> (6 - cwl);
+  const int b0 = blockIdx.x * TW, b = b0 + t;  // b < Bp always (Bp is a multiple of 64)
+  const int tile = b >> 6, lane = b & 63;
+  // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
+  // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
+  // predicated.  The wave leaves only when no lane needs anything.
+  const bool act = b < P.B && a.active[b] != 0;
+  if (__ballot(act) == 0) return;
+  const bool bpfail = act && a.bpfail[b] != 0;
+  const int total = o.iterations_linesearch;
+  const double Jprev = a.J[b];
+  const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
+  // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
+  const bool zero_step = act && !bpfail && (-(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev)));
+  bool need = act && !bpfail && !zero_step;
+  int accepted = zero_step ? 0 : -1, acc = 0;
+  double Jnew = Jprev, grad = 0.0;
+  const double f = o.line_search_decrease_factor;
+  double alpha = 1.0, fCW = 1.0;
+  for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }  // same products the sequential search forms
+  const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
+  const int krow = t * Gains<M>::RSK;
+  for (int c0 = 0; c0 < total; c0 += CW) {
+    if (__ballot(need) == 0) break;
+    const bool cand = need && (c0 + q) < total;
+    double J, gm;
+    bool ok;
+    forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, q + 1, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
+    bool accept = false;
+    if (cand && ok) {
+      const double expected = -alpha * (dV0 + alpha * dV1);
+      const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+      accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
+    }
+    const unsigned long long am = __ballot(accept);
+    int qs = -1;  // first accepted candidate of this lane's trajectory (bits qq*TW + t)
+    for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
+    const int src = (qs >= 0 ? qs : q) * TW + t;
+    const double Js = __shfl(J, src), gs = __shfl(gm, src);
+    if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
+    alpha *= fCW;
+  }
+  if (q != 0 || !act) return;  // one lane per trajectory finishes the iteration
+  double rho = a.rho[b], drho = a.drho[b];
+  if (!bpfail) {
+    if (zero_step) grad = nominal_gradient<M>(a, tile, lane, b);
+    else if (accepted < 0) {  // line search failed: gradient metric on the unchanged nominal controls, regularise harder
+      grad = nominal_gradient<M>(a, tile, lane, b);
+      reg_increase(o, rho, drho);
+      rho += o.bp_reg_fp;
+    }
+  }
+  a.ls_index[b] = accepted;
+  a.acc[b] = acc;
+  if (!a.control) {  // phase API: report and leave the state machine alone
+    a.Jout[b] = Jnew;
+    a.rho[b] = rho; a.drho[b] = drho;
+    if (accepted >= 0) a.J[b] = Jnew;
+    return;
+  }
+  // ---------------- solver state machine ----------------
+  int st = TO_UNSOLVED;
+  bool inner_done = false;
+  const double cost_tol = a.al_mode ? o.cost_tolerance_intermediate : o.cost_tolerance;
+  if (bpfail) { st = TO_REGULARIZATION_MAX; inner_done = true; }
+  else {
+    const bool ls_failed = accepted < 0;
+    const double dJ = Jprev - Jnew;
+    int dz = a.dJzero[b];
+    dz = (ls_failed || zero_step) ? dz + 1 : 0;  // a zero step makes no progress either
+    a.dJzero[b] = dz;
+    a.dJ[b] = dJ; a.grad[b] = grad; a.J[b] = Jnew;
+    const int its = a.iterations[b] + 1, iti = a.it_inner[b] + 1;
+    a.iterations[b] = its; a.it_inner[b] = iti;
+    if (rho > o.bp_reg_max) { st = TO_REGULARIZATION_MAX; inner_done = true; }
+    else if (dJ >= 0.0 && dJ < cost_tol && grad < o.gradient_tolerance && !ls_failed) { st = TO_SOLVE_SUCCEEDED; inner_done = true; }
+    else if (iti >= a.budget[b]) { st = TO_MAX_ITERATIONS; inner_done = true; }
+    else if (dz > o.dJ_counter_limit) { st = TO_NO_PROGRESS; inner_done = true; }
+    else if (!(Jnew <= o.max_cost_value)) { st = TO_MAXIMUM_COST; inner_done = true; }
+  }
+  bool still_active = true;
+  if (inner_done) {
+    if (!a.al_mode) { a.status[b] = st; still_active = false; }
+    else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels
+      a.ost[b] = st; a.oflag[b] = 1;
+      a.rho[b] = rho; a.drho[b] = drho;
+      return;
+    }
+  }
+  a.rho[b] = rho; a.drho[b] = drho;
+  if (!still_active) a.active[b] = 0;
+  else atomicAdd(&a.counter[a.step], 1);
+}
+
+}  // namespace to

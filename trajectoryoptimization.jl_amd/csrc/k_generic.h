@@ -1,0 +1,244 @@
+// k_generic.h — model-independent kernels (accept copy, solver-state initialisation, layout transposes, cones).
+// Non-template __global__ functions: include from ONE translation unit only (trajopt_hip.hip).
+#pragma once
+#include "common.h"
+
+namespace to {
+
+
+// Accepting a step = copying the accepted candidate's slot onto slot 0, so the nominal trajectory of every lane sits in
+// ONE slot and every kernel reads it with full-line coalesced loads (a per-trajectory slot index turned each nominal
+// load of a wave into up to 64 separate lines: measured 2x on the quadrotor forward pass).  Runs once per forward pass:
+// later rounds only store into the slots of lanes that are still searching.  grid (tiles, 1, chunks): wave (tile, z)
+// copies chunk z; every lane reads ITS accepted slot (a gather: as many lines as a per-slot pass would touch) and the
+// stores to slot 0 are whole 512-byte rows.
+__global__ void __launch_bounds__(64) k_accept(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const int s = b < P.B ? a.acc[b] : 0;
+  if (__ballot(s != 0) == 0) return;
+  const int Lx = P.N * P.n, Lu = (P.N - 1) * P.m;
+  const int per = (Lx + Lu + gridDim.z - 1) / gridDim.z;
+  const int e0 = blockIdx.z * per, e1 = min(Lx + Lu, e0 + per);
+  if (s == 0) return;
+  const double* sx = TILE_PTR(XSLOT(a, s), Lx);
+  double* dx = TILE_PTR(XSLOT(a, 0), Lx);
+  const double* su = TILE_PTR(USLOT(a, s), Lu);
+  double* du = TILE_PTR(USLOT(a, 0), Lu);
+#pragma unroll 16
+  for (int e = e0; e < min(e1, Lx); ++e) EL(dx, e) = EL(sx, e);
+#pragma unroll 16
+  for (int e = max(e0, Lx) - Lx; e < e1 - Lx; ++e) EL(du, e) = EL(su, e);
+}
+
+__global__ void k_clear_acc(KArgs a) {
+  TILE_LANE();
+  if (b < a.P.Bp) a.acc[b] = 0;
+}
+
+// start of a solve: reset the per-trajectory solver state.  J must already hold the (AL) cost of the rollout.
+__global__ void k_solve_init(KArgs a, int reset_duals) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.Bp) return;
+  const bool live = b < P.B;
+  a.rho[b] = P.opts.bp_reg_initial; a.drho[b] = 0.0;
+  a.dJzero[b] = 0; a.it_inner[b] = 0; a.iterations[b] = 0; a.outer[b] = 0;
+  a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.acc[b] = 0; a.oflag[b] = 0;
+  a.dJ[b] = 0.0; a.grad[b] = 0.0; a.cmax[b] = 0.0;
+  const int tot = a.al_mode ? P.opts.iterations_total : P.opts.iterations;
+  a.budget[b] = tot < P.opts.iterations ? tot : P.opts.iterations;
+  a.active[b] = (live && a.budget[b] > 0) ? 1 : 0;
+  if (live && a.budget[b] <= 0) a.status[b] = TO_MAX_ITERATIONS;
+  if (reset_duals) {
+    double* lam0 = TILE_PTR(a.lam, P.n_duals);
+    double* mu0 = TILE_PTR(a.mu, P.n_cons);
+    for (long long r = 0; r < P.n_duals; ++r) EL(lam0, r) = 0.0;
+    for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = P.opts.penalty_initial;
+  }
+}
+
+__global__ void k_set_active(KArgs a, int value, int clear_bpfail) {
+  TILE_LANE();
+  if (b >= a.P.Bp) return;
+  a.active[b] = (b < a.P.B) ? value : 0;
+  if (clear_bpfail == 1) a.bpfail[b] = 0;
+}
+
+__global__ void k_penalty_max(KArgs a, double* out) {
+  TILE_LANE();
+  if (b >= a.P.B) return;
+  const double* mu0 = TILE_PTR(a.mu, a.P.n_cons);
+  double mx = 0.0;
+  for (int ci = 0; ci < a.P.n_cons; ++ci) mx = fmax(mx, EL(mu0, ci));
+  out[b] = mx;
+}
+
+// ------------------------------------------------------------------------------------------------ layout transposes
+// host layout h[e + L*b] (e = i + dim*k, column-major (dim, K, B))  <->  tiled device layout, L elements per trajectory.
+// grid: (tiles, L).  Host-side access is strided, device-side coalesced; these are API-boundary copies, not hot.
+// (cnt host elements per trajectory map to device elements e0 .. e0+cnt-1 of an array with L per trajectory)
+__global__ void k_to_device(const double* __restrict__ h, double* __restrict__ d, int L, int e0, int cnt, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
+  if (b >= B) return;
+  EL(TILE_PTR(d, L), e0 + e) = h[(size_t)e + (size_t)cnt * b];
+}
+__global__ void k_to_host(const double* __restrict__ d, double* __restrict__ h, int L, int e0, int cnt, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
+  if (b >= B) return;
+  h[(size_t)e + (size_t)cnt * b] = EL(TILE_PTR(d, L), e0 + e);
+}
+__global__ void k_fill_uniform(double* d, const double* u, int dim, int L, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
+  if (b >= B) return;
+  EL(TILE_PTR(d, L), e) = u[e % dim];
+}
+// gains: Kt rows (trajectory-major, [r][ne gains + 1 feed-forward]) -> host K[m,ne,N-1,B] / d[m,N-1,B] column-major.
+// grid (tiles, (N-1)*m*(ne+1)): e = (k*m + r)*(ne+1) + i
+__global__ void k_gains_to_host(const double* __restrict__ Kt, double* __restrict__ hK, double* __restrict__ hd, int m, int ne, int K, int B) {
+  TILE_LANE();
+  const int e = blockIdx.y;
+  if (b >= B) return;
+  const int i = e % (ne + 1), r = (e / (ne + 1)) % m, k = e / ((ne + 1) * m);
+  const double v = Kt[((size_t)b * K + k) * (m * (ne + 1)) + r * (ne + 1) + i];
+  if (i < ne) { if (hK) hK[(size_t)r + (size_t)m * (i + (size_t)ne * (k + (size_t)K * b))] = v; }
+  else if (hd) hd[(size_t)r + (size_t)m * (k + (size_t)K * b)] = v;
+}
+
+// column-layout arrays -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = col_array(b, column c0+c, entry k*rows_per_knot + r0 + r)
+// grid (ceil(B/64), K*Rr*Cc), one thread per trajectory.
+__global__ void k_col_to_host(const double* __restrict__ src, double* __restrict__ h, int E, int rows_per_knot, int r0, int Rr, int c0,
+                              int Cc, int K, int B, int R, int G) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int e = blockIdx.y;  // (k*Cc + c)*Rr + r
+  if (b >= B) return;
+  const int r = e % Rr, c = (e / Rr) % Cc, k = e / (Rr * Cc);
+  const int gtile = b / G, g = b % G;
+  const size_t idx = ((size_t)gtile * E + (size_t)k * rows_per_knot + r0 + r) * 64 + g * R + (c0 + c);
+  h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = src[idx];
+}
+
+// tangent-matrix layout (k_backward.h) -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0 + r][col0 + c] of
+// trajectory b, X stored with `regs` 64-lane rows per knot.  compact: one row per knot holding, for lane (g, col), the
+// entry of row crow[g*16 + col] (device table, -1: none); everything else is zero.
+__global__ void k_tm_to_host(const double* __restrict__ src, double* __restrict__ h, int regs, int row0, int Rr, int col0, int Cc, int K,
+                             int B, const int* __restrict__ crow) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int e = blockIdx.y;  // (k*Cc + c)*Rr + r
+  if (b >= B) return;
+  const int r = e % Rr, c = (e / Rr) % Cc, k = e / (Rr * Cc);
+  const int row = row0 + r, col = col0 + c, g = row & 3;
+  double v;
+  if (crow) v = (crow[g * 16 + col] == row) ? src[((size_t)b * K + k) * 64 + g * 16 + col] : 0.0;
+  else v = src[(((size_t)b * K + k) * regs + (row >> 2)) * 64 + g * 16 + col];
+  h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = v;
+}
+// gradient vectors of the tangent-matrix layout: gt[(b*K + k)*16 + col] -> h[c + Cc*(k + K*b)]
+__global__ void k_tmvec_to_host(const double* __restrict__ gt, double* __restrict__ h, int col0, int Cc, int K, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int e = blockIdx.y;  // k*Cc + c
+  if (b >= B) return;
+  const int c = e % Cc, k = e / Cc;
+  h[(size_t)c + (size_t)Cc * (k + (size_t)K * b)] = gt[((size_t)b * K + k) * 16 + col0 + c];
+}
+
+// ------------------------------------------------------------------------------------------------ cones (src/cones.jl), stateless
+// x[dim,count] column-major; one thread per vector.
+__global__ void k_cone_projection(int cone, int dim, long long count, const double* x, double* px, int* status) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const double* v = x + t * dim;
+  double* o = px + t * dim;
+  int st = 0;
+  if (cone == TO_CONE_IDENTITY) { for (int i = 0; i < dim; ++i) o[i] = v[i]; }
+  else if (cone == TO_CONE_ZERO) { for (int i = 0; i < dim; ++i) o[i] = 0.0; }
+  else if (cone == TO_CONE_NEGATIVE_ORTHANT) { for (int i = 0; i < dim; ++i) o[i] = fmin(0.0, v[i]); }
+  else if (cone == TO_CONE_POSITIVE_ORTHANT) { for (int i = 0; i < dim; ++i) o[i] = fmax(0.0, v[i]); }
+  else {
+    const double s = v[dim - 1];
+    double a2 = 0.0;
+    for (int i = 0; i < dim - 1; ++i) a2 += v[i] * v[i];
+    const double a = sqrt(a2);
+    if (a <= -s) { for (int i = 0; i < dim; ++i) o[i] = 0.0; st = 0; }
+    else if (a <= s) { for (int i = 0; i < dim; ++i) o[i] = v[i]; st = 1; }
+    else if (a >= fabs(s)) { const double c = 0.5 * (1 + s / a); for (int i = 0; i < dim - 1; ++i) o[i] = v[i] * c; o[dim - 1] = a * c; st = 2; }
+    else st = -1;  // NaN input: src/cones.jl:124 throws
+  }
+  if (status) status[t] = st;
+}
+
+__global__ void k_cone_jacobian(int cone, int dim, long long count, const double* x, double* jac, int* status) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const double* v = x + t * dim;
+  double* J = jac + t * dim * dim;  // column-major: J[r + dim*c]
+  for (int i = 0; i < dim * dim; ++i) J[i] = 0.0;
+  int st = 0;
+  if (cone == TO_CONE_IDENTITY) { for (int i = 0; i < dim; ++i) J[i + dim * i] = 1.0; }
+  else if (cone == TO_CONE_NEGATIVE_ORTHANT) { for (int i = 0; i < dim; ++i) J[i + dim * i] = v[i] <= 0 ? 1.0 : 0.0; }
+  else if (cone == TO_CONE_POSITIVE_ORTHANT) { for (int i = 0; i < dim; ++i) J[i + dim * i] = v[i] >= 0 ? 1.0 : 0.0; }
+  else if (cone == TO_CONE_SECOND_ORDER) {
+    const int nn = dim;
+    const double s = v[nn - 1];
+    double a2 = 0.0;
+    for (int i = 0; i < nn - 1; ++i) a2 += v[i] * v[i];
+    const double a = sqrt(a2);
+    if (a <= -s) st = 0;
+    else if (a <= s) { for (int i = 0; i < nn; ++i) J[i + nn * i] = 1.0; st = 1; }
+    else if (a >= fabs(s)) {
+      const double c = 0.5 * (1 + s / a);
+      for (int i = 0; i < nn - 1; ++i)
+        for (int j = 0; j < nn - 1; ++j) J[i + nn * j] = -0.5 * s / (a * a * a) * v[i] * v[j] + ((i == j) ? c : 0.0);
+      for (int i = 0; i < nn - 1; ++i) J[i + nn * (nn - 1)] = 0.5 * v[i] / a;
+      for (int i = 0; i < nn - 1; ++i) J[(nn - 1) + nn * i] = ((-0.5 * s / (a * a)) + c / a) * v[i];
+      J[(nn - 1) + nn * (nn - 1)] = 0.5;
+      st = 2;
+    } else st = -1;
+  }
+  if (status) status[t] = st;
+}
+
+__global__ void k_cone_hessian(int cone, int dim, long long count, const double* x, const double* bvec, double* hess, int* status) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const double* v = x + t * dim;
+  const double* bb = bvec + t * dim;
+  double* H = hess + t * dim * dim;
+  for (int i = 0; i < dim * dim; ++i) H[i] = 0.0;
+  int st = 0;
+  if (cone == TO_CONE_SECOND_ORDER) {
+    const int nn = dim - 1;
+    const double s = v[nn], bs = bb[nn];
+    double a2 = 0.0, vbv = 0.0;
+    for (int i = 0; i < nn; ++i) { a2 += v[i] * v[i]; vbv += v[i] * bb[i]; }
+    const double a = sqrt(a2);
+    if (a <= -s) st = 0;
+    else if (a <= s) st = 1;
+    else if (a > fabs(s)) {
+      for (int i = 0; i < nn; ++i) {
+        double hi = 0.0;
+        for (int j = 0; j < nn; ++j) hi += (-v[i] * v[j] / (a * a) + ((i == j) ? 1.0 : 0.0)) * bb[j];
+        H[i + dim * nn] = hi / (2 * a);
+        H[nn + dim * i] = H[i + dim * nn];
+        for (int j = 0; j <= i; ++j) {
+          const double vij = v[i] * v[j];
+          const double H1 = hi * v[j] * (-s / (a * a * a));
+          double H2 = vij * (2 * vbv) / (a * a * a * a) - v[i] * bb[j] / (a * a);
+          double H3 = -vij / (a * a);
+          if (i == j) { H2 -= vbv / (a * a); H3 += 1; }
+          H2 *= s / a;
+          H3 *= bs / a;
+          H[i + dim * j] = (H1 + H2 + H3) / 2;
+          H[j + dim * i] = H[i + dim * j];
+        }
+      }
+      st = 2;
+    } else st = -1;
+  }
+  if (status) status[t] = st;
+}
+
+}  // namespace to

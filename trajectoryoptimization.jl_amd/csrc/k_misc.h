@@ -1,0 +1,278 @@
+// k_misc.h — rollout, cost, violation, dual update, the knot-parallel AL outer update and the per-knot API kernels.
+#pragma once
+#include "common.h"
+
+namespace to {
+
+// ------------------------------------------------------------------------------------------------ rollout!
+template <class M, int FIXED_INTEG>
+__global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:334-340 — open-loop simulate from x0
+  constexpr int n = M::n, m = M::m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  constexpr int c = 0;  // nominal slot
+  double* X = TILE_PTR(XSLOT(a, c), P.N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (P.N - 1) * m);
+  const double* x0 = TILE_PTR(a.x0, n);
+  double x[n], u[m], xn[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { x[i] = EL(x0, i); EL(X, i) = x[i]; }
+  for (int k = 0; k < P.N - 1; ++k) {
+#pragma unroll
+    for (int i = 0; i < m; ++i) u[i] = EL(U, k * m + i);
+    rk_step<M, double, FIXED_INTEG>(P.mp, P.integrator, x, u, P.dt[k], xn);
+#pragma unroll
+    for (int i = 0; i < n; ++i) { x[i] = xn[i]; EL(X, (k + 1) * n + i) = x[i]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ cost
+// out[b] = total (AL) cost, or — when Jk is given — per-knot objective values in a tiled array with L = N
+template <class M>
+__global__ void __launch_bounds__(64) k_cost(KArgs a, int with_al, double* out, double* Jk) {
+  constexpr int n = M::n, m = M::m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  const int N = P.N;
+  if (Jk) {
+    constexpr int c = 0;  // nominal slot
+    const double* X = TILE_PTR(XSLOT(a, c), N * n);
+    const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+    double* o = TILE_PTR(Jk, N);
+    for (int k = 0; k < N; ++k) {
+      double x[n], u[m];
+#pragma unroll
+      for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+      for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+      EL(o, k) = knot_cost<M>(P, k, x, u, nullptr, nullptr, false);
+    }
+    return;
+  }
+  double J;
+  trajectory_pass<M>(a, tile, lane, with_al != 0, false, &J, nullptr);
+  out[b] = J;
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_violation(KArgs a, double* out) {
+  TILE_LANE();
+  if (b >= a.P.B) return;
+  double cm;
+  trajectory_pass<M>(a, tile, lane, false, false, nullptr, &cm);
+  out[b] = cm;
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_dual_update(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  trajectory_pass<M>(a, tile, lane, false, true, nullptr, nullptr);
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = fmin(EL(mu0, ci) * P.opts.penalty_scaling, P.opts.penalty_max);
+}
+
+
+// ---- AL outer update of the trajectories whose inner solve just ended (oflag = 1), knot-parallel:
+//   k_outer_violation (tiles, N): constraint violation of every knot -> knotbuf
+//   k_outer_decide    (tiles)   : c_max, termination tests; trajectories that go on get oflag = 2 and their new penalties
+//   k_outer_update    (tiles, N): dual update with the OLD penalties, then the knot's AL cost with the new duals/penalties
+//   k_outer_finish    (tiles)   : J = sum of the knot terms in knot order (same sum as a sequential pass), restart the inner solve
+// One lane per trajectory walking all knots three times was the largest kernel of the constrained solves.
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_violation(KArgs a) {
+  constexpr int n = M::n, m = M::m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const bool want = b < P.B && a.oflag[b] == 1;
+  if (__ballot(want) == 0) return;
+  if (!want) return;
+  const int N = P.N, k = blockIdx.y;
+  const int sl = a.acc[b];  // the step accepted in this iteration (0: none, nominal unchanged)
+  const double* X = TILE_PTR(XSLOT(a, sl), N * n);
+  const double* U = TILE_PTR(USLOT(a, sl), (N - 1) * m);
+  double x[n], u[m];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+  EL(TILE_PTR(a.knotbuf, N), k) = (P.n_cons > 0) ? knot_violation<M>(P, k, x, u) : 0.0;
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_decide(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B || a.oflag[b] != 1) return;
+  const to_solver_opts& o = P.opts;
+  const int N = P.N, st = a.ost[b];
+  const int outer = a.outer[b] + 1;
+  a.outer[b] = outer;
+  const double* vb = TILE_PTR(a.knotbuf, N);
+  double cm = 0.0;
+  for (int k = 0; k < N; ++k) { const double v = EL(vb, k); if (!(v <= cm)) cm = v; }
+  a.cmax[b] = cm;
+  const int its = a.iterations[b];
+  bool go_on = false;
+  if (st != TO_SOLVE_SUCCEEDED && st != TO_MAX_ITERATIONS && st != TO_NO_PROGRESS) a.status[b] = st;
+  else if (cm < o.constraint_tolerance) a.status[b] = TO_SOLVE_SUCCEEDED;
+  else if (its >= o.iterations_total) a.status[b] = TO_MAX_ITERATIONS;
+  else if (outer >= o.iterations_outer) a.status[b] = TO_MAX_ITERATIONS_OUTER;
+  else go_on = true;
+  if (!go_on) { a.active[b] = 0; a.oflag[b] = 0; return; }
+  a.oflag[b] = 2;
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
+  for (int ci = 0; ci < P.n_cons; ++ci) EL(mn0, ci) = fmin(EL(mu0, ci) * o.penalty_scaling, o.penalty_max);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const bool want = b < P.B && a.oflag[b] == 2;
+  if (__ballot(want) == 0) return;
+  if (!want) return;
+  const int N = P.N, k = blockIdx.y;
+  const int sl = a.acc[b];
+  const double* X = TILE_PTR(XSLOT(a, sl), N * n);
+  const double* U = TILE_PTR(USLOT(a, sl), (N - 1) * m);
+  double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  const double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
+  double x[n], u[m], z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { x[i] = EL(X, k * n + i); z[i] = x[i]; }
+#pragma unroll
+  for (int i = 0; i < m; ++i) { u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0; z[n + i] = u[i]; }
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    con_dual_update<nz>(K, z, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
+  }
+  EL(TILE_PTR(a.knotbuf, N), k) = knot_cost<M>(P, k, x, u, lam0, mn0, true);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) k_outer_finish(KArgs a) {
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B || a.oflag[b] != 2) return;
+  const to_solver_opts& o = P.opts;
+  const int N = P.N;
+  const double* jb = TILE_PTR(a.knotbuf, N);
+  double J = 0.0;
+  for (int k = 0; k < N; ++k) J += EL(jb, k);
+  a.J[b] = J;
+  double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  const double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
+  for (int ci = 0; ci < P.n_cons; ++ci) EL(mu0, ci) = EL(mn0, ci);
+  a.rho[b] = o.bp_reg_initial; a.drho[b] = 0.0;
+  a.dJzero[b] = 0; a.it_inner[b] = 0;
+  const int rem = o.iterations_total - a.iterations[b];
+  a.budget[b] = rem < o.iterations ? rem : o.iterations;
+  a.status[b] = TO_UNSOLVED;
+  a.oflag[b] = 0;
+  atomicAdd(&a.counter[a.step], 1);
+}
+
+// ------------------------------------------------------------------------------------------------ per-knot API kernels
+// RD.gradient!/RD.hessian! of the objective on the full state (no AL, no error-state projection):
+// grad[(n+m), N, B], hess[(n+m),(n+m),N,B] column-major host layout, written directly.
+template <class M>
+__global__ void __launch_bounds__(64) k_cost_derivs(KArgs a, double* grad, double* hess) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  const int N = P.N, k = blockIdx.y;
+  const bool terminal = (k == N - 1);
+  constexpr int c = 0;  // nominal slot
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  double x[n], u[m];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(U, k * m + i);
+  const size_t kb = (size_t)k + (size_t)N * b;
+  for (int j = 0; j < nz; ++j) {
+    double v[nz], g[nz], y[nz];
+#pragma unroll
+    for (int i = 0; i < nz; ++i) v[i] = (i == j) ? 1.0 : 0.0;
+    cost_grad_hvp<n, m>(P.costs[P.cost_index[k]], x, u, terminal, v, g, y);
+    const double sc = (P.opts.cost_dt_scaling && !terminal) ? P.dt[k] : 1.0;
+#pragma unroll
+    for (int i = 0; i < nz; ++i) {
+      if (hess) hess[(size_t)i + nz * ((size_t)j + nz * kb)] = sc * y[i];
+      if (grad && j == 0) grad[(size_t)i + nz * kb] = sc * g[i];
+    }
+  }
+}
+
+// RD.jacobian! of the discretised dynamics on the full state: F[n, n+m, N-1, B]
+template <class M>
+__global__ void __launch_bounds__(64) k_discrete_jacobian(KArgs a, double* F) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  const int N = P.N, k = blockIdx.y, j = blockIdx.z;
+  constexpr int c = 0;  // nominal slot
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  Dual xd[n], ud[m], xn[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) xd[i] = Dual(EL(X, k * n + i), (i == j) ? 1.0 : 0.0);
+#pragma unroll
+  for (int i = 0; i < m; ++i) ud[i] = Dual(EL(U, k * m + i), (n + i == j) ? 1.0 : 0.0);
+  rk_step<M, Dual>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+  const size_t kb = (size_t)k + (size_t)(N - 1) * b;
+#pragma unroll
+  for (int i = 0; i < n; ++i) F[(size_t)i + n * ((size_t)j + nz * kb)] = xn[i].d;
+}
+
+// evaluate_constraints! / constraint_jacobians! for one constraint over its knot range, host layout output
+template <class M>
+__global__ void __launch_bounds__(64) k_constraint_eval(KArgs a, int ci, double* vals, double* jac) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  ConC& K = P.cons[ci];
+  const int N = P.N, kk = blockIdx.y, k = K.k1 + kk, nk = K.k2 - K.k1 + 1;
+  constexpr int c = 0;  // nominal slot
+  const double* X = TILE_PTR(XSLOT(a, c), N * n);
+  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+  const size_t kb = (size_t)kk + (size_t)nk * b;
+  const int p = K.p, w = K.width;
+  double coef[nz];
+  for (int r = 0; r < p; ++r) {
+    double cval;
+    if (K.selector) cval = sel_row<nz>(K, z, r); else cval = con_row<nz>(K, z, r, coef);
+    if (vals) vals[(size_t)r + p * kb] = cval;
+    if (jac) {
+      for (int col = 0; col < w; ++col) {
+        double g = 0.0;
+        if (K.selector) g = (K.sidx[r] == col) ? K.ssgn[r] : 0.0;
+        else {
+#pragma unroll
+          for (int t = 0; t < nz; ++t) if (t < K.d.n_inds && K.d.inds[t] - 1 == col) g = coef[t];
+        }
+        jac[(size_t)r + p * ((size_t)col + (size_t)w * kb)] = g;
+      }
+    }
+  }
+}
+
+}  // namespace to

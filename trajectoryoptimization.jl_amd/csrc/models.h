@@ -100,9 +100,9 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr bool lie = false;
   static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
   static constexpr int expand_knots = 1;
-  static constexpr bool tail_in_select = true;         // ... are finished sequentially inside k_select (kernels.h)
-  static constexpr bool accept_write_through = true;   // ... by the next expansion instead (kernels.h, k_expand)
-  static constexpr bool lds_gains = false;
+  static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
+  static constexpr bool lds_gains = false;             // forward pass: the gains row of a knot is a handful of doubles, loaded directly
+  static constexpr bool mfma_backward = false, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double inv_mass = rcp_fast(P[0]);
@@ -119,9 +119,9 @@ struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr bool lie = false;
   static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
   static constexpr int expand_knots = 1;
-  static constexpr bool tail_in_select = true;         // ... are finished sequentially inside k_select (kernels.h)
-  static constexpr bool accept_write_through = true;   // ... by the next expansion instead (kernels.h, k_expand)
-  static constexpr bool lds_gains = false;
+  static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
+  static constexpr bool lds_gains = false;             // forward pass: the gains row of a knot is a handful of doubles, loaded directly
+  static constexpr bool mfma_backward = false, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mc = P[0], mp = P[1], l = P[2], g = P[3];
@@ -151,9 +151,9 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr bool lie = true;
   static constexpr bool pin_rk4 = false;  // compile-time RK4 costs registers here: measured slower than the runtime switch
   static constexpr int expand_knots = 4;               // knots one expansion wave walks (software-pipelined loads)
-  static constexpr bool tail_in_select = false;        // later line-search rounds get their own launches (compacted list)
   static constexpr bool accept_write_through = false;  // accepted steps are copied onto slot 0 by k_accept after every forward pass
-  static constexpr bool lds_gains = true;  // forward pass: the 48 gain rows of a knot come through LDS (DMA), not 96 prefetch VGPRs
+  static constexpr bool lds_gains = true;  // forward pass: the 52-double gains row of a knot comes through LDS (DMA), not prefetch VGPRs
+  static constexpr bool mfma_backward = true, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mass = P[0], J1 = P[1], J2 = P[2], J3 = P[3];

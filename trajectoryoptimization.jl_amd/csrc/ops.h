@@ -1,0 +1,157 @@
+// ops.h — launchers of the model-templated kernels; instantiated per model by the ops_*.hip translation units.
+#pragma once
+#include "handle.h"
+#include "k_backward.h"
+#include "k_expand.h"
+#include "k_forward.h"
+#include "k_misc.h"
+
+namespace to {
+
+template <class M>
+void fill_traits(ModelOps& o) {
+  o.write_through = M::accept_write_through;
+  o.mfma_backward = M::mfma_backward;
+  o.lds_gains = M::lds_gains;
+  o.expand_knots = M::expand_knots;
+  o.gains_lds_pieces = Gains<M>::RSK / 2;
+  o.nep = Tm<M>::NEP; o.rs = Tm<M>::RS;
+  for (int g = 0; g < 4; ++g)
+    for (int c = 0; c < 16; ++c) o.crow[g * 16 + c] = compact_row<M>(g, c);
+}
+
+template <class M>
+int op_rollout(to_handle* h) {
+  bool done = false;
+  if constexpr (M::pin_rk4) {
+    if (h->a.P.integrator == INTEG_RK4) { hipLaunchKernelGGL((k_rollout<M, INTEG_RK4>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a); done = true; }
+  }
+  if (!done) hipLaunchKernelGGL((k_rollout<M, -1>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M>
+int op_cost(to_handle* h, int with_al, double* out, double* Jk) {
+  hipLaunchKernelGGL(k_cost<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, with_al, out, Jk);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M>
+int op_violation(to_handle* h, double* out) {
+  hipLaunchKernelGGL(k_violation<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, out);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M>
+int op_dual_update(to_handle* h) {
+  hipLaunchKernelGGL(k_dual_update<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+// AL outer update of the trajectories whose inner solve ended in this batch step (k_misc.h, k_outer_*)
+template <class M>
+int op_outer(to_handle* h) {
+  const int N = h->a.P.N;
+  hipLaunchKernelGGL(k_outer_violation<M>, grid_b(h, N), dim3(BLOCK), 0, h->stream, h->a);
+  hipLaunchKernelGGL(k_outer_decide<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
+  hipLaunchKernelGGL(k_outer_update<M>, grid_b(h, N), dim3(BLOCK), 0, h->stream, h->a);
+  hipLaunchKernelGGL(k_outer_finish<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M>
+int op_cost_derivs(to_handle* h, double* dg, double* dh) {
+  hipLaunchKernelGGL(k_cost_derivs<M>, grid_b(h, h->a.P.N), dim3(BLOCK), 0, h->stream, h->a, dg, dh);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M>
+int op_discrete_jacobian(to_handle* h, double* F) {
+  const DevProblem& P = h->a.P;
+  hipLaunchKernelGGL(k_discrete_jacobian<M>, grid_b(h, P.N - 1, P.n + P.m), dim3(BLOCK), 0, h->stream, h->a, F);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M>
+int op_constraint_eval(to_handle* h, int ci, double* vals, double* jac) {
+  const DevCon& c = h->cons[ci];
+  hipLaunchKernelGGL(k_constraint_eval<M>, grid_b(h, c.k2 - c.k1 + 1), dim3(BLOCK), 0, h->stream, h->a, ci, vals, jac);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+
+// expansion variants compiled: 0 = diagonal-kind costs, no constraints; 2 = + selector / SOC-selector constraints;
+// 7 = everything.  Layout (k_expand.h LAY): column layout for the cooperative backward pass, tangent-matrix layout
+// (full or compact cost block) for the MFMA one.
+template <class M, int FI>
+int op_expand_fi(to_handle* h) {
+  const DevProblem& P = h->a.P;
+  const dim3 grid((P.B + h->G - 1) / h->G, (P.N + M::expand_knots - 1) / M::expand_knots);
+  const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
+  const int lay = !h->a.bwd_mfma ? 0 : (h->a.h_compact ? 2 : 1);
+#define TO_EXPAND_CASE(V, LY) \
+  if (var == V && lay == LY) { hipLaunchKernelGGL((k_expand<M, FI, V, LY>), grid, dim3(BLOCK), 0, h->stream, h->a); HIPCHECK(hipGetLastError()); return TO_OK; }
+  if constexpr (M::mfma_backward) {
+    TO_EXPAND_CASE(0, 1) TO_EXPAND_CASE(0, 2) TO_EXPAND_CASE(2, 1) TO_EXPAND_CASE(2, 2) TO_EXPAND_CASE(7, 1)
+  }
+  if constexpr (!M::mfma_backward || M::coop_backward) {
+    TO_EXPAND_CASE(0, 0) TO_EXPAND_CASE(2, 0) TO_EXPAND_CASE(7, 0)
+  }
+#undef TO_EXPAND_CASE
+  return fail(TO_ERR_UNSUPPORTED, "expansion variant not compiled for this model");
+}
+template <class M>
+int op_expand(to_handle* h) {
+  if constexpr (M::pin_rk4) {
+    if (h->a.P.integrator == INTEG_RK4) return op_expand_fi<M, INTEG_RK4>(h);
+  }
+  return op_expand_fi<M, -1>(h);
+}
+
+template <class M>
+int op_backward(to_handle* h) {
+  const DevProblem& P = h->a.P;
+  if constexpr (M::mfma_backward) {
+    if (h->a.bwd_mfma) {
+      if (h->a.h_compact) hipLaunchKernelGGL((k_backward_mfma<M, true>), dim3(P.B), dim3(BLOCK), 0, h->stream, h->a);
+      else hipLaunchKernelGGL((k_backward_mfma<M, false>), dim3(P.B), dim3(BLOCK), 0, h->stream, h->a);
+      HIPCHECK(hipGetLastError());
+      return TO_OK;
+    }
+  }
+  if constexpr (!M::mfma_backward || M::coop_backward) {
+    hipLaunchKernelGGL(k_backward_coop<M>, dim3((P.B + h->G - 1) / h->G), dim3(BLOCK), 0, h->stream, h->a);
+    HIPCHECK(hipGetLastError());
+    return TO_OK;
+  }
+  return fail(TO_ERR_UNSUPPORTED, "backward-pass variant not compiled for this model");
+}
+
+// forward pass (line search + state machine) of kernel variant MODE: grid = one wave per TW = 64 / CW trajectories
+template <class M, int MODE>
+int op_forward(to_handle* h) {
+  const KArgs& a = h->a;
+  const int TW = 64 >> a.cw_log;
+  const size_t lds = M::lds_gains ? 2 * sizeof(double) * gains_lds_doubles<M>(TW) : 0;
+  hipLaunchKernelGGL((k_forward<M, MODE>), dim3(a.P.Bp / TW), dim3(BLOCK), lds, h->stream, a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+
+template <class M>
+void fill_misc(ModelOps& o) {
+  fill_traits<M>(o);
+  o.rollout = op_rollout<M>; o.cost = op_cost<M>; o.violation = op_violation<M>; o.dual_update = op_dual_update<M>;
+  o.outer = op_outer<M>; o.cost_derivs = op_cost_derivs<M>; o.discrete_jacobian = op_discrete_jacobian<M>;
+  o.constraint_eval = op_constraint_eval<M>;
+}
+// forward variants [LO, HI): models that do not pin RK4 never run the bit-2 variants
+template <class M, int LO, int HI>
+void fill_forward(ModelOps& o) {
+  if constexpr (LO < HI) {
+    if constexpr (M::pin_rk4 || (LO & 4) == 0) o.forward[LO] = op_forward<M, LO>;
+    fill_forward<M, LO + 1, HI>(o);
+  }
+}
+
+}  // namespace to

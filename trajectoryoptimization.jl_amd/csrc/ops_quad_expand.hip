@@ -1,0 +1,6 @@
+// ops_quad_expand.hip — Quadrotor: expansion variants.
+#include "ops.h"
+
+namespace to {
+void fill_ops_quad_expand(ModelOps* t) { t[4].expand = op_expand<QuadrotorModel>; }
+}  // namespace to

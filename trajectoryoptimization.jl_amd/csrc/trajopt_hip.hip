@@ -10,26 +10,36 @@
 #include <string>
 #include <vector>
 
-#include "kernels.h"
+#include <mutex>
+
+#include "handle.h"
+#include "k_generic.h"
 
 using namespace to;
 
 namespace {
-
 thread_local std::string g_err;
+}
+namespace to {
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+}
 
-#define HIPCHECK(expr)                                                                         \
-  do {                                                                                         \
-    hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess)                                                                      \
-      return fail(TO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
-  } while (0)
+namespace {
+
 #define CHECK_H(h) do { if (!(h)) return fail(TO_ERR_NULL, "null handle"); } while (0)
 #define CHECK_P(p) do { if (!(p)) return fail(TO_ERR_NULL, "null pointer"); } while (0)
-#define TRY(expr) do { int r_ = (expr); if (r_ != TO_OK) return r_; } while (0)
 
-constexpr int BLOCK = 64;  // one wave per workgroup: a small batch is spread over as many CUs as possible
+// launch table, one entry per model key; filled once by the ops_*.hip translation units
+ModelOps g_ops[N_MODEL_KEYS];
+std::once_flag g_ops_once;
+const ModelOps* model_ops(int key) {
+  std::call_once(g_ops_once, [] {
+    fill_ops_small(g_ops); fill_ops_small_forward(g_ops);
+    fill_ops_quad_misc(g_ops); fill_ops_quad_expand(g_ops); fill_ops_quad_backward(g_ops);
+    fill_ops_quad_forward_a(g_ops); fill_ops_quad_forward_b(g_ops);
+  });
+  return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
+}
 
 void default_opts(to_solver_opts* o) {
   std::memset(o, 0, sizeof(*o));
@@ -75,52 +85,7 @@ int model_dims(int id, const double* params, int* n, int* m, int* ne, int* key) 
 
 }  // namespace
 
-struct to_handle_s {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int model_key = -1;
-  int R = 0, G = 0;  // lanes per trajectory / trajectories per wave of the column-layout kernels
-  bool write_through = false;  // model trait accept_write_through (models.h)
-  bool tail = false;           // model trait tail_in_select: only the first line-search round is launched
-  int T1 = 1;  // step sizes evaluated concurrently in the first line-search round (all trajectories take part)
-  int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
-  KArgs a;  // host copy of the kernel argument block (device pointers inside)
-  std::vector<to_cost_desc> costs;
-  std::vector<DevCon> cons;
-  std::vector<double> dt;
-  std::vector<int> cost_index;
-  std::vector<void*> allocs;
-  double* stage = nullptr;  // device staging buffer in host layout
-  size_t stage_bytes = 0;
-  int* counter_host = nullptr;  // pinned
-  int counter_len = 0;
-  size_t nlist_len = 0;
-  // device copies of the descriptor tables
-  to_cost_desc* d_costs = nullptr;
-  DevCon* d_cons = nullptr;
-  double* d_dt = nullptr;
-  int* d_cost_index = nullptr;
-  double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
-  double* d_tmp2 = nullptr;
-  // measurement
-  bool profile = false;
-  std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
-  hipEvent_t sev[4] = {nullptr, nullptr, nullptr, nullptr};  // solve(): start, stop, two chunk read-back events (created once)
-  double prof_ms[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
-  int64_t prof_launches[TO_PROFILE_SLOTS] = {0, 0, 0, 0};
-};
-
 namespace {
-
-#define DISPATCH(h, ...)                                                                        \
-  switch ((h)->model_key) {                                                                     \
-    case 0: { using M = DoubleIntegratorModel<1>; __VA_ARGS__; } break;                         \
-    case 1: { using M = DoubleIntegratorModel<2>; __VA_ARGS__; } break;                         \
-    case 2: { using M = DoubleIntegratorModel<3>; __VA_ARGS__; } break;                         \
-    case 3: { using M = CartpoleModel; __VA_ARGS__; } break;                                    \
-    case 4: { using M = QuadrotorModel; __VA_ARGS__; } break;                                   \
-    default: return fail(TO_ERR_UNSUPPORTED, "unknown model");                                  \
-  }
 
 int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon* out) {
   const int nz = n + m;
@@ -251,8 +216,6 @@ int ensure_stage(to_handle* h, size_t bytes) {
 
 int use_device(to_handle* h) { HIPCHECK(hipSetDevice(h->device)); return TO_OK; }
 
-dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
-
 // host (cnt per trajectory, column-major (dim, K, B)) -> tiled device array (elements e0..e0+cnt-1 of L) via the staging buffer
 int upload_vec(to_handle* h, const double* host, double* d, int cnt, int L = -1, int e0 = 0) {
   if (L < 0) L = cnt;
@@ -285,16 +248,6 @@ int download_nominal(to_handle* h, double* host, const double* slot0, int cnt, v
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
-int download_mat(to_handle* h, double* host, const double* d, int R, int Cc, int K) {
-  if (!host) return TO_OK;
-  const size_t cnt = (size_t)R * Cc * K * h->a.P.B;
-  TRY(ensure_stage(h, cnt * sizeof(double)));
-  hipLaunchKernelGGL(k_mat_to_host, grid_b(h, R * Cc * K), dim3(BLOCK), 0, h->stream, d, h->stage, R, Cc, K, h->a.P.B);
-  HIPCHECK(hipGetLastError());
-  HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
-  return TO_OK;
-}
 int download_scalar(to_handle* h, double* host, const double* d) {
   if (!host) return TO_OK;
   HIPCHECK(hipMemcpyAsync(host, d, sizeof(double) * h->a.P.B, hipMemcpyDeviceToHost, h->stream));
@@ -306,6 +259,23 @@ int download_int(to_handle* h, int32_t* host, const int* d) {
   HIPCHECK(hipMemcpyAsync(host, d, sizeof(int) * h->a.P.B, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
+}
+
+// Is the Q-function cost block of every knot block-diagonal (diagonal Qxx + the attitude block of Lie-group models, no
+// Qux, any Quu)?  Then the tangent-matrix expansion stores ONE row per knot instead of NR (k_backward.h, compact_row).
+bool compact_cost_blocks(const to_handle* h) {
+  const int n = h->a.P.n;
+  for (const auto& c : h->costs) if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_DIAGONAL_QUAT) return false;
+  for (const DevCon& c : h->cons) {
+    if (c.d.kind == TO_CON_GOAL || c.d.kind == TO_CON_BOUND) continue;  // rows pick single entries of [x;u]: diagonal
+    if (c.d.kind == TO_CON_NORM) {  // |z[inds]|: dense over inds — fine when they all sit in the control block
+      bool ctrl = true;
+      for (int i = 0; i < c.d.n_inds; ++i) ctrl = ctrl && c.d.inds[i] > n;
+      if (ctrl) continue;
+    }
+    return false;
+  }
+  return true;
 }
 
 int upload_tables(to_handle* h) {
@@ -321,6 +291,8 @@ int upload_tables(to_handle* h) {
     for (const auto& c : h->costs) dense = dense || c.kind == TO_COST_QUADRATIC || c.kind == TO_COST_ERROR_QUADRATIC;
     for (const auto& c : h->cons) generic = generic || !c.selector;
     P.expand_variant = (dense ? 1 : 0) | (h->cons.empty() ? 0 : 2) | (generic ? 4 : 0);
+    h->a.h_compact = (h->a.bwd_mfma && compact_cost_blocks(h)) ? 1 : 0;
+    if (const char* env = std::getenv("TRAJOPT_FULL_COST_BLOCKS")) if (std::atoi(env)) h->a.h_compact = 0;  // testing knob
   }
   HIPCHECK(hipMemcpyAsync(h->d_costs, h->costs.data(), h->costs.size() * sizeof(to_cost_desc), hipMemcpyHostToDevice, h->stream));
   if (!h->cons.empty()) HIPCHECK(hipMemcpyAsync(h->d_cons, h->cons.data(), h->cons.size() * sizeof(DevCon), hipMemcpyHostToDevice, h->stream));
@@ -333,135 +305,30 @@ int launch_set_active(to_handle* h, int v, int clear_bpfail = 1) {
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
-int launch_rollout(to_handle* h) {
-  if (h->a.P.integrator == INTEG_RK4) { DISPATCH(h, hipLaunchKernelGGL((k_rollout<M, M::pin_rk4 ? INTEG_RK4 : -1>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a)); }
-  else { DISPATCH(h, hipLaunchKernelGGL((k_rollout<M, -1>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a)); }
-  HIPCHECK(hipGetLastError());
-  return TO_OK;
-}
-int launch_cost(to_handle* h, int with_al, double* out, double* Jk) {
-  DISPATCH(h, hipLaunchKernelGGL(k_cost<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, with_al, out, Jk));
-  HIPCHECK(hipGetLastError());
-  return TO_OK;
-}
-int launch_expand(to_handle* h) {
-  const DevProblem& P = h->a.P;
-  int kc = 1;
-  DISPATCH(h, kc = M::expand_knots);
-  const dim3 grid((P.B + h->G - 1) / h->G, (P.N + kc - 1) / kc);
-  // variants compiled: 0 = diagonal-kind costs, no constraints; 2 = + selector / SOC-selector constraints; 7 = everything
-  const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
-#define EXPAND_LAUNCH(FI)                                                                                          \
-  switch (var) {                                                                                                   \
-    case 0: { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, FI, 0>), grid, dim3(BLOCK), 0, h->stream, h->a)); } break; \
-    case 2: { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, FI, 2>), grid, dim3(BLOCK), 0, h->stream, h->a)); } break; \
-    default: { DISPATCH(h, hipLaunchKernelGGL((k_expand<M, FI, 7>), grid, dim3(BLOCK), 0, h->stream, h->a)); } break; \
-  }
-  if (P.integrator == INTEG_RK4) { EXPAND_LAUNCH((M::pin_rk4 ? INTEG_RK4 : -1)); }
-  else { EXPAND_LAUNCH(-1); }
-#undef EXPAND_LAUNCH
-  HIPCHECK(hipGetLastError());
-  return TO_OK;
-}
-int launch_backward(to_handle* h) {
-  DISPATCH(h, hipLaunchKernelGGL(k_backward<M>, dim3((h->a.P.B + h->G - 1) / h->G), dim3(BLOCK), 0, h->stream, h->a));
-  HIPCHECK(hipGetLastError());
-  return TO_OK;
-}
-// compile-time dispatch of a small runtime integer: f(std::integral_constant<int, value>)
-template <int COUNT, int I = 0, class F>
-inline void mode_switch(int value, F&& f) {
-  if constexpr (I < COUNT) {
-    if (value == I) f(std::integral_constant<int, I>{});
-    else mode_switch<COUNT, I + 1>(value, f);
-  }
-}
-// Width of line-search round r starting at step size c0.  Round 0 takes T1 step sizes for every trajectory.  With a
-// wide first round (latency regime, few tiles) the rejecting trajectories are few and the next round takes everything
-// that is left; with a narrow one (throughput regime) many trajectories are still searching, so the widths grow
-// geometrically (T1, T1, 2 T1, ...) instead of spending 18 rollouts on trajectories that accept the third step size.
-int round_width(const to_handle* h, int r, int c0, int total) {
-  const int T1 = h->T1, Tmax = h->a.T;
-  if (r == 0) return std::min(total - c0, T1);
-  if (T1 >= 8) return std::min(total - c0, Tmax);
-  return std::min({total - c0, Tmax, T1 << std::min(r - 1, 8)});
-}
-// number of line-search rounds launch_forward issues
-int ls_rounds(const to_handle* h) {
-  const int total = std::max(1, h->a.P.opts.iterations_linesearch);
-  if (h->tail) return 1;
-  int r = 0;
-  for (int c0 = 0; c0 < total; ++r) c0 += round_width(h, r, c0, total);
-  return r;
-}
-// zeroed (batch step, round) counters of the compacted line-search lists
-int ensure_nlist(to_handle* h, int steps) {
-  KArgs& a = h->a;
-  a.lstride = ls_rounds(h) + 1;
-  const size_t need = (size_t)steps * a.lstride;
-  if (h->nlist_len < need) {
-    int* p = nullptr;
-    HIPCHECK(hipMalloc((void**)&p, sizeof(int) * need));
-    h->allocs.push_back(p);
-    a.nlist = p;
-    h->nlist_len = need;
-  }
-  HIPCHECK(hipMemsetAsync(a.nlist, 0, sizeof(int) * need, h->stream));
-  return TO_OK;
-}
+int launch_rollout(to_handle* h) { return h->ops->rollout(h); }
+int launch_cost(to_handle* h, int with_al, double* out, double* Jk) { return h->ops->cost(h, with_al, out, Jk); }
+int launch_expand(to_handle* h) { return h->ops->expand(h); }
+int launch_backward(to_handle* h) { return h->ops->backward(h); }
 int launch_accept(to_handle* h) {  // materialise accepted candidate slots on slot 0, then forget them
   hipLaunchKernelGGL(k_accept, grid_b(h, 1, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
   hipLaunchKernelGGL(k_clear_acc, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }
-// forward pass = line-search rounds of (concurrent candidates, select).  The first round evaluates the T1 largest step
-// sizes for every trajectory; the trajectories that rejected all of them are few: large models give them further rounds
-// on a compacted list (round_width), small models finish the search sequentially inside the first k_select.
+// forward pass: ONE launch runs the whole line search (CW step sizes per round, concurrently, inside each wave) and the
+// per-trajectory state machine (k_forward.h).  Kernel variants: bit0 simple stage cost, bit1 constraints, bit2
+// compile-time RK4 (models that pin it), bit3 dense costs / generic constraints.
 int launch_forward(to_handle* h, bool accept = true) {
-  KArgs& a = h->a;
-  const int total = std::max(1, a.P.opts.iterations_linesearch);
-  const int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) |
-                   ((a.P.expand_variant & 5) ? 8 : 0);
-  int r = 0;
-  for (int c0 = 0; c0 < total; ++r) {
-    a.round = r;
-    a.cand0 = c0;
-    a.Tr = round_width(h, r, c0, total);
-    // kernel variants (kernels.h, k_forward): bit0 simple stage cost, bit1 constraints, bit2 compile-time RK4 (models that
-    // pin it), bit3 dense costs / generic constraints, bit4 compacted list (rounds after the first)
-    DISPATCH(h, mode_switch<32>(mode | (r > 0 ? 16 : 0), [&](auto I) {
-      constexpr int MD = M::pin_rk4 ? I.value : (I.value & ~4);
-      hipLaunchKernelGGL((k_forward<M, MD>), grid_b(h, a.Tr), dim3(BLOCK), 0, h->stream, a);
-    }));
-    HIPCHECK(hipGetLastError());
-    // k_select only depends on the variant for the models that finish the search inside it (tail_in_select)
-    DISPATCH(h, mode_switch<16>(h->tail ? mode : 0, [&](auto I) {
-      constexpr int MD = M::tail_in_select ? (M::pin_rk4 ? I.value : (I.value & ~4)) : 0;
-      hipLaunchKernelGGL((k_select<M, MD>), grid_b(h), dim3(BLOCK), 0, h->stream, a);
-    }));
-    HIPCHECK(hipGetLastError());
-    if (h->tail) break;  // the rest of the search runs inside k_select
-    c0 += a.Tr;
-  }
+  const KArgs& a = h->a;
+  int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | ((a.P.expand_variant & 5) ? 8 : 0);
+  if (!h->ops->forward[mode]) mode &= ~4;  // the model does not pin RK4
+  if (!h->ops->forward[mode]) return fail(TO_ERR_UNSUPPORTED, "forward-pass variant not compiled for this model");
+  TRY(h->ops->forward[mode](h));
   if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
   return TO_OK;
 }
-// AL outer update of the trajectories whose inner solve ended in this batch step (kernels.h, k_outer_*)
-int launch_outer(to_handle* h) {
-  const int N = h->a.P.N;
-  DISPATCH(h, hipLaunchKernelGGL(k_outer_violation<M>, grid_b(h, N), dim3(BLOCK), 0, h->stream, h->a));
-  DISPATCH(h, hipLaunchKernelGGL(k_outer_decide<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
-  DISPATCH(h, hipLaunchKernelGGL(k_outer_update<M>, grid_b(h, N), dim3(BLOCK), 0, h->stream, h->a));
-  DISPATCH(h, hipLaunchKernelGGL(k_outer_finish<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
-  HIPCHECK(hipGetLastError());
-  return TO_OK;
-}
-int launch_violation(to_handle* h, double* out) {
-  DISPATCH(h, hipLaunchKernelGGL(k_violation<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a, out));
-  HIPCHECK(hipGetLastError());
-  return TO_OK;
-}
+int launch_outer(to_handle* h) { return h->ops->outer(h); }
+int launch_violation(to_handle* h, double* out) { return h->ops->violation(h, out); }
 
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
@@ -486,7 +353,6 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
     h->counter_len = max_steps;
   }
   HIPCHECK(hipMemsetAsync(a.counter, 0, sizeof(int) * max_steps, h->stream));
-  TRY(ensure_nlist(h, max_steps));
   if (!h->sev[0]) {
     HIPCHECK(hipEventCreate(&h->sev[0]));
     HIPCHECK(hipEventCreate(&h->sev[1]));
@@ -521,7 +387,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
       TRY(launch_backward(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
-      TRY(launch_forward(h, !h->write_through));
+      TRY(launch_forward(h, !h->ops->write_through));
       if (al_mode) TRY(launch_outer(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
     }
@@ -661,7 +527,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->model_key = key;
   h->R = (ne + m) <= 4 ? 4 : (ne + m) <= 8 ? 8 : 16;
   h->G = 64 / h->R;
-  DISPATCH(h, h->write_through = M::accept_write_through; h->tail = M::tail_in_select);
+  h->ops = model_ops(key);
+  if (!h->ops || !h->ops->rollout || !h->ops->expand || !h->ops->backward) { delete h; return fail(TO_ERR_UNSUPPORTED, "model kernels not linked"); }
   h->costs.assign(desc->costs, desc->costs + desc->n_costs);
   h->cons = cons; h->dt = dt; h->cost_index = cost_index;
   auto bail = [&](int rc) { std::string e = g_err; to_destroy(h); g_err = e; return rc; };
@@ -685,33 +552,47 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   HIPB(hipMemcpyAsync(h->d_cost_index, cost_index.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
   TRYB(upload_tables(h));
   P.dt = (DoubleC*)h->d_dt; P.cost_index = (IntC*)h->d_cost_index; P.costs = (CostC*)h->d_costs; P.cons = (ConC*)h->d_cons;
-  // line-search candidates evaluated concurrently: enough waves to cover the chip, at most the default search depth
-  // (one candidate = one wave; the register-heavy rollout kernels are resident at one wave per SIMD, 1024 SIMDs per chip,
-  //  so T*tiles <= 1024 keeps a whole round in a single residency pass)
-  h->T1 = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
-  if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) h->T1 = std::max(1, std::min(64, std::atoi(env)));  // tuning knob
-  // later rounds: whatever remains of the default search depth, at once (only the few trajectories still searching take part)
-  a.T = h->tail ? h->T1 : std::max(h->T1, std::min(20, std::max(1, P.opts.iterations_linesearch - h->T1)));
+  // Line-search candidates evaluated concurrently per trajectory, CW (a power of two): a forward wave holds CW
+  // candidates x 64/CW trajectories, so the launch has Bp*CW/64 waves — enough to cover the 1024 SIMDs of the chip for
+  // small batches, at most 16 (the default search depth is 20: a second in-kernel round covers the rest, rarely needed).
+  {
+    int cw = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
+    if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
+    a.cw_log = 0;
+    while ((2 << a.cw_log) <= cw) ++a.cw_log;
+    a.T = 1 << a.cw_log;
+  }
+  // backward-pass flavour: one wave per trajectory on the matrix cores (tangent-matrix expansion) where the model has it,
+  // else the cooperative LDS kernel on the column layout.  TRAJOPT_BACKWARD=coop|mfma overrides (A/B measurements).
+  a.bwd_mfma = h->ops->mfma_backward ? 1 : 0;
+  if (const char* env = std::getenv("TRAJOPT_BACKWARD")) {
+    if (!std::strcmp(env, "coop")) a.bwd_mfma = 0;
+    if (!std::strcmp(env, "mfma") && h->ops->mfma_backward) a.bwd_mfma = 1;
+  }
+  TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
   TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
   TRYB(dev_alloc(h, &a.Us, a.slotU * (a.T + 1)));
-  TRYB(dev_alloc(h, &a.candJ, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.candG, (size_t)a.T * Bp));
-  TRYB(dev_alloc(h, &a.candOk, (size_t)a.T * Bp)); TRYB(dev_alloc(h, &a.ls_round, Bp));
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
-  TRYB(dev_alloc(h, &a.list, Bp));
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
   TRYB(dev_alloc(h, &a.knotbuf, (size_t)N * Bp));
   TRYB(dev_alloc(h, &a.mu_next, (size_t)std::max<size_t>(1, cons.size()) * Bp));
-  {
+  if (a.bwd_mfma) {  // tangent-matrix layout (k_backward.h): RS rows of 64 per knot for [A B], up to RS+1 for the cost block
+    const int rs = h->ops->rs;
+    TRYB(dev_alloc(h, &a.Mt, (size_t)Bp * (N - 1) * rs * 64));
+    TRYB(dev_alloc(h, &a.Ht, (size_t)Bp * N * (rs + 1) * 64));
+    TRYB(dev_alloc(h, &a.gt, (size_t)Bp * N * 16));
+    TRYB(dev_alloc(h, &h->d_crow, 64));
+    HIPB(hipMemcpyAsync(h->d_crow, h->ops->crow, sizeof(int) * 64, hipMemcpyHostToDevice, h->stream));
+  } else {
     const size_t gtiles = ((size_t)B + h->G - 1) / h->G;  // waves of the column-layout kernels
     TRYB(dev_alloc(h, &a.Mc, gtiles * (size_t)(N - 1) * ne * 64));
     TRYB(dev_alloc(h, &a.Hc, gtiles * (size_t)N * (ne + m) * 64));
     TRYB(dev_alloc(h, &a.gc, gtiles * (size_t)N * 64));
   }
-  TRYB(dev_alloc(h, &a.K, (size_t)(N - 1) * m * ne * Bp));
-  TRYB(dev_alloc(h, &a.d, (size_t)(N - 1) * m * Bp));
+  TRYB(dev_alloc(h, &a.Kt, (size_t)Bp * (N - 1) * m * (ne + 1)));  // gains rows, trajectory-major
   TRYB(dev_alloc(h, &a.lam, (size_t)n_duals * Bp));
   TRYB(dev_alloc(h, &a.mu, cons.size() * Bp));
   TRYB(dev_alloc(h, &a.J, Bp)); TRYB(dev_alloc(h, &a.dJ, Bp)); TRYB(dev_alloc(h, &a.grad, Bp));
@@ -888,7 +769,6 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
   TRY(launch_cost(h, 1, h->a.J, nullptr));
   TRY(launch_set_active(h, 1, 2));
   h->a.step = 0;
-  TRY(ensure_nlist(h, 1));
   TRY(launch_forward(h));
   TRY(download_int(h, ls_index, h->a.ls_index));
   TRY(download_scalar(h, J_new, h->a.Jout));
@@ -898,13 +778,42 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
 int to_ilqr_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 0); }
 int to_al_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 1); }
 
-// column-layout array -> host column-major blocks (see k_col_to_host)
-static int download_cols(to_handle* h, double* host, const double* src, int E, int rows_per_knot, int r0, int Rr, int c0, int Cc, int K) {
+// expansion blocks -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0+r][col0+c], rows / columns counted
+// in error-state directions followed by control directions (whichever layout the backward pass uses)
+enum { BLK_M = 0, BLK_H = 1 };
+static int download_block(to_handle* h, double* host, int which, int row0, int Rr, int col0, int Cc) {
   if (!host) return TO_OK;
   const DevProblem& P = h->a.P;
+  const int K = which == BLK_M ? P.N - 1 : P.N;
   const size_t cnt = (size_t)Rr * Cc * K * P.B;
   TRY(ensure_stage(h, cnt * sizeof(double)));
-  hipLaunchKernelGGL(k_col_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, src, h->stage, E, rows_per_knot, r0, Rr, c0, Cc, K, P.B, h->R, h->G);
+  if (h->a.bwd_mfma) {
+    const int nep = h->ops->nep, rs = h->ops->rs;
+    auto tix = [&](int i) { return i < P.ne ? i : nep + (i - P.ne); };  // tangent index (control directions start at NEP)
+    const bool compact = which == BLK_H && h->a.h_compact;
+    hipLaunchKernelGGL(k_tm_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mt : h->a.Ht, h->stage,
+                       which == BLK_M ? rs : rs + 1, tix(row0), Rr, tix(col0), Cc, K, P.B, compact ? h->d_crow : nullptr);
+  } else {
+    const int nc = P.ne + P.m;
+    hipLaunchKernelGGL(k_col_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mc : h->a.Hc, h->stage,
+                       which == BLK_M ? (P.N - 1) * P.ne : P.N * nc, which == BLK_M ? P.ne : nc, row0, Rr, col0, Cc, K, P.B, h->R, h->G);
+  }
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+static int download_gradient(to_handle* h, double* host, int col0, int Cc) {
+  if (!host) return TO_OK;
+  const DevProblem& P = h->a.P;
+  const size_t cnt = (size_t)Cc * P.N * P.B;
+  TRY(ensure_stage(h, cnt * sizeof(double)));
+  if (h->a.bwd_mfma) {
+    const int tcol = col0 < P.ne ? col0 : h->ops->nep + (col0 - P.ne);
+    hipLaunchKernelGGL(k_tmvec_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gt, h->stage, tcol, Cc, P.N, P.B);
+  } else {
+    hipLaunchKernelGGL(k_col_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, h->stage, P.N, 1, 0, 1, col0, Cc, P.N, P.B, h->R, h->G);
+  }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -913,27 +822,33 @@ static int download_cols(to_handle* h, double* host, const double* src, int E, i
 int to_get_dynamics_jacobians(to_handle* h, double* A, double* Bm) {
   CHECK_H(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  const int E = (P.N - 1) * P.ne;
-  TRY(download_cols(h, A, h->a.Mc, E, P.ne, 0, P.ne, 0, P.ne, P.N - 1));
-  TRY(download_cols(h, Bm, h->a.Mc, E, P.ne, 0, P.ne, P.ne, P.m, P.N - 1));
+  TRY(download_block(h, A, BLK_M, 0, P.ne, 0, P.ne));
+  TRY(download_block(h, Bm, BLK_M, 0, P.ne, P.ne, P.m));
   return TO_OK;
 }
 int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, double* qx, double* qu) {
   CHECK_H(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  const int nc = P.ne + P.m, E = P.N * nc;
-  TRY(download_cols(h, Qxx, h->a.Hc, E, nc, 0, P.ne, 0, P.ne, P.N));
-  TRY(download_cols(h, Quu, h->a.Hc, E, nc, P.ne, P.m, P.ne, P.m, P.N));
-  TRY(download_cols(h, Qux, h->a.Hc, E, nc, P.ne, P.m, 0, P.ne, P.N));
-  TRY(download_cols(h, qx, h->a.gc, P.N, 1, 0, 1, 0, P.ne, P.N));
-  TRY(download_cols(h, qu, h->a.gc, P.N, 1, 0, 1, P.ne, P.m, P.N));
+  TRY(download_block(h, Qxx, BLK_H, 0, P.ne, 0, P.ne));
+  TRY(download_block(h, Quu, BLK_H, P.ne, P.m, P.ne, P.m));
+  TRY(download_block(h, Qux, BLK_H, P.ne, P.m, 0, P.ne));
+  TRY(download_gradient(h, qx, 0, P.ne));
+  TRY(download_gradient(h, qu, P.ne, P.m));
   return TO_OK;
 }
 int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
   CHECK_H(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  TRY(download_mat(h, K, h->a.K, P.m, P.ne, P.N - 1));
-  if (d) TRY(download_vec(h, d, h->a.d, P.m * (P.N - 1)));
+  if (K || d) {
+    const size_t nK = (size_t)P.m * P.ne * (P.N - 1) * P.B, nd = (size_t)P.m * (P.N - 1) * P.B;
+    TRY(ensure_stage(h, (nK + nd) * sizeof(double)));
+    double *dK = h->stage, *dd = h->stage + nK;
+    hipLaunchKernelGGL(k_gains_to_host, grid_b(h, (P.N - 1) * P.m * (P.ne + 1)), dim3(BLOCK), 0, h->stream, h->a.Kt, dK, dd, P.m, P.ne, P.N - 1, P.B);
+    HIPCHECK(hipGetLastError());
+    if (K) HIPCHECK(hipMemcpyAsync(K, dK, nK * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (d) HIPCHECK(hipMemcpyAsync(d, dd, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  }
   if (dV) {  // plain [2][Bp] -> host (2, B)
     std::vector<double> tmp(2 * (size_t)P.Bp);
     HIPCHECK(hipMemcpyAsync(tmp.data(), h->a.dV, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -949,8 +864,7 @@ int to_cost_expansion(to_handle* h, double* grad, double* hess) {
   const size_t nz = P.n + P.m, ng = nz * P.N * P.B, nh = nz * nz * P.N * P.B;
   TRY(ensure_stage(h, (ng + nh) * sizeof(double)));
   double* dg = h->stage; double* dh = h->stage + ng;
-  DISPATCH(h, hipLaunchKernelGGL(k_cost_derivs<M>, grid_b(h, P.N), dim3(BLOCK), 0, h->stream, h->a, dg, dh));
-  HIPCHECK(hipGetLastError());
+  TRY(h->ops->cost_derivs(h, dg, dh));
   if (grad) HIPCHECK(hipMemcpyAsync(grad, dg, ng * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (hess) HIPCHECK(hipMemcpyAsync(hess, dh, nh * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -961,8 +875,7 @@ int to_discrete_jacobian(to_handle* h, double* F) {
   const DevProblem& P = h->a.P;
   const size_t cnt = (size_t)P.n * (P.n + P.m) * (P.N - 1) * P.B;
   TRY(ensure_stage(h, cnt * sizeof(double)));
-  DISPATCH(h, hipLaunchKernelGGL(k_discrete_jacobian<M>, grid_b(h, P.N - 1, P.n + P.m), dim3(BLOCK), 0, h->stream, h->a, h->stage));
-  HIPCHECK(hipGetLastError());
+  TRY(h->ops->discrete_jacobian(h, h->stage));
   HIPCHECK(hipMemcpyAsync(F, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
@@ -984,8 +897,7 @@ static int constraint_eval(to_handle* h, int32_t id, double* vals, double* jac) 
   const size_t nv = (size_t)ci.p * nk * P.B, nj = (size_t)ci.p * ci.width * nk * P.B;
   TRY(ensure_stage(h, (nv + nj) * sizeof(double)));
   double* dv = h->stage; double* dj = h->stage + nv;
-  DISPATCH(h, hipLaunchKernelGGL(k_constraint_eval<M>, grid_b(h, nk), dim3(BLOCK), 0, h->stream, h->a, (int)id, vals ? dv : nullptr, jac ? dj : nullptr));
-  HIPCHECK(hipGetLastError());
+  TRY(h->ops->constraint_eval(h, (int)id, vals ? dv : nullptr, jac ? dj : nullptr));
   if (vals) HIPCHECK(hipMemcpyAsync(vals, dv, nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (jac) HIPCHECK(hipMemcpyAsync(jac, dj, nj * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1030,8 +942,7 @@ int to_reset_duals(to_handle* h) {
 int to_dual_update(to_handle* h) {
   CHECK_H(h); TRY(use_device(h));
   if (h->a.P.n_cons == 0) return TO_OK;
-  DISPATCH(h, hipLaunchKernelGGL(k_dual_update<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a));
-  HIPCHECK(hipGetLastError());
+  TRY(h->ops->dual_update(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
