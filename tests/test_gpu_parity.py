@@ -404,6 +404,28 @@ def test_line_search_round_schedule(t1, hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+def test_mfma_backward_on_small_models(hip, oracle, monkeypatch):
+    """The MFMA backward pass (one wave per trajectory, tangent-matrix expansion, compact and full cost blocks) is generic
+    in the model; the small models default to the cooperative kernel, so force it: m = 1 / ne = 4 (Cartpole) and
+    ne = 6 -> padded to 8, m = 3 (3-D double integrator, bounds + goal)."""
+    monkeypatch.setenv("TRAJOPT_BACKWARD", "mfma")
+    ph, po = pair(BUILDERS["cartpole_con"], hip, oracle)
+    perturb_controls((ph, po), 0.02)
+    for p in (ph, po):
+        T.rollout(p); I.dual_update(p); I.expand(p); I.backwardpass(p)
+    Eh, Eo = I.cost_expansion(ph), I.cost_expansion(po)
+    for k in Eh:
+        np.testing.assert_allclose(Eh[k], Eo[k], rtol=1e-9, atol=1e-10, err_msg=k)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-7, atol=1e-9)
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=70, **kw), hip, oracle)
+    assert_solve_parity(T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve(), ph, po)
+    monkeypatch.setenv("TRAJOPT_FULL_COST_BLOCKS", "1")
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=40, constrained=True, **kw), hip, oracle)
+    assert_solve_parity(T.ALSolver(ph).solve(), T.ALSolver(po).solve(), ph, po)
+
+
 @pytest.mark.parametrize("depth", [1, 7, 33])
 def test_line_search_depth_option(depth, hip, oracle):
     """iterations_linesearch other than the default 20 (fewer than one round, more than the candidate slots)."""
@@ -583,10 +605,9 @@ def test_random_configurations(seed, hip, oracle):
     # regularisation limit) stop on an ill-conditioned iterate, where rounding differences are amplified: 1e-4
     done = so.stats["status"] == T.capi.SOLVE_SUCCEEDED
     Xh, Xo, Uh, Uo = T.states(ph), T.states(po), T.controls(ph), T.controls(po)
-    np.testing.assert_allclose(Xh[done], Xo[done], rtol=1e-6, atol=1e-7, err_msg=desc)
-    np.testing.assert_allclose(Uh[done], Uo[done], rtol=1e-6, atol=1e-7, err_msg=desc)
-    np.testing.assert_allclose(Xh[~done], Xo[~done], rtol=1e-4, atol=1e-5, err_msg=desc)
-    np.testing.assert_allclose(Uh[~done], Uo[~done], rtol=1e-4, atol=1e-5, err_msg=desc)
+    tol = np.where(done, 1e-6, 1e-4)
+    assert_trajectories_close(Xh, Xo, tol, desc + " X")
+    assert_trajectories_close(Uh, Uo, tol, desc + " U")
 
 
 def test_error_paths_on_device(hip):

@@ -16,9 +16,12 @@ namespace to {
 
 struct KArgs {
   DevProblem P;
-  double* Xs;     // (T+1) slots of L = N*n: slot 0 holds the nominal trajectory, slot t+1 line-search candidate t of the round
-  double* Us;     // (T+1) slots of L = (N-1)*m
-  size_t slotX, slotU;  // doubles per slot (L * Bp)
+  double* Xs;     // nominal trajectory, tiled, L = N*n        ("slot 0")
+  double* Us;     // nominal controls, tiled, L = (N-1)*m
+  double *Xc, *Uc;  // line-search candidates ("slot q+1" = candidate q), FORWARD-WAVE-major: the forward wave w = b / TW owns the
+                    // contiguous block [w][e][64] and its hardware lane q*TW + (b % TW) holds candidate q of trajectory b, so
+                    // every candidate store of a wave is one 512-byte row of one stream (slot-major candidates made each
+                    // store touch CW streams 85 MB apart: 4x slower forward pass, TLB- and partial-line-bound)
   int T;          // candidate slots = CW = line-search candidates a wave evaluates concurrently (power of two <= 16)
   int cw_log;     // log2(CW); a forward wave holds CW candidates x TW = 64/CW trajectories
   double* x0;     // L = n
@@ -49,8 +52,15 @@ template <class M> struct Gains { static constexpr int RSK = M::m * (M::ne + 1);
 #define TILE_PTR(base, L) ((base) + ((size_t)tile * (size_t)(L)) * 64 + lane)
 #define EL(p, e) (p)[(size_t)(e) * 64]
 #define TILE_LANE() const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane
-#define XSLOT(a, c) ((a).Xs + (size_t)(c) * (a).slotX)
-#define USLOT(a, c) ((a).Us + (size_t)(c) * (a).slotU)
+// pointer to element 0 of trajectory b in slot sl of a trajectory array with L elements (sl = 0: nominal, sl = q+1: line-search
+// candidate q); element e is p[e*64] in both layouts
+__device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, int cw_log, int b, int sl, int L) {
+  if (sl == 0) return nominal + ((size_t)(b >> 6) * (size_t)L) * 64 + (b & 63);
+  const int twl = 6 - cw_log;
+  return cand + ((size_t)(b >> twl) * (size_t)L) * 64 + ((sl - 1) << twl) + (b & ((1 << twl) - 1));
+}
+#define X_SLOT_PTR(a, b, sl) slot_ptr((a).Xs, (a).Xc, (a).cw_log, b, sl, (a).P.N * (a).P.n)
+#define U_SLOT_PTR(a, b, sl) slot_ptr((a).Us, (a).Uc, (a).cw_log, b, sl, ((a).P.N - 1) * (a).P.m)
 
 // objective (+AL) value of one knot.  u must be zeros at the terminal knot (the reference evaluates the
 // terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).
@@ -148,8 +158,8 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int la
   constexpr int n = M::n, m = M::m, nz = n + m;
   const DevProblem& P = a.P;
   const int N = P.N;
-  const double* X = TILE_PTR(XSLOT(a, c), N * n);
-  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  const double* X = X_SLOT_PTR(a, tile * 64 + lane, c);
+  const double* U = U_SLOT_PTR(a, tile * 64 + lane, c);
   double* lam0 = TILE_PTR(a.lam, P.n_duals);
   double* mu0 = TILE_PTR(a.mu, P.n_cons);
   double J = 0.0, cmax = 0.0;

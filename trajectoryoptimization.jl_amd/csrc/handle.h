@@ -68,6 +68,7 @@ struct ModelOps {
   // model traits the host logic needs
   bool write_through = false;  // M::accept_write_through
   bool mfma_backward = false;  // M::mfma_backward: tangent-matrix expansion + one-wave-per-trajectory Riccati
+  bool coop_backward = true;   // M::coop_backward: column-layout expansion + cooperative LDS Riccati
   bool lds_gains = false;      // forward pass stages gains through LDS
   int expand_knots = 1;
   int gains_lds_pieces = 0;    // 16-byte pieces of one gains row (LDS sizing of the forward pass)

@@ -418,9 +418,8 @@ __global__ void __launch_bounds__(64) k_backward_mfma(KArgs a) {
 #pragma unroll
         for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
         if (!(sj > 0.0)) pd_ok = false;
-        const double l = sqrt(sj);
-        Lc[q][q] = l;
-        iL[q] = rcp_fast(l);
+        iL[q] = rsqrt_fast(sj);
+        Lc[q][q] = sj * iL[q];
 #pragma unroll
         for (int i = q + 1; i < m; ++i) {
           double t = Lc[i][q];

@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
   const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
   const int tile = b >> 6, lane64 = b & 63;
-  const double* X = XSLOT(a, c) + ((size_t)tile * (N * n)) * 64 + lane64;
-  const double* U = USLOT(a, c) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+  const double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
   double x[n], u[m], x1[n], x2[n], un[m];
 #pragma unroll
   for (int i = 0; i < n; ++i) { x[i] = EL(X, k0 * n + i); x1[i] = (k0 + 1 < N) ? EL(X, (k0 + 1) * n + i) : 0.0; }
@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
     }
     const bool valid = lane_ok && !(terminal && j >= ne);
     if (M::accept_write_through && c != 0 && j == 0 && valid) {
-      double* X0 = XSLOT(a, 0) + ((size_t)tile * (N * n)) * 64 + lane64;
-      double* U0 = USLOT(a, 0) + ((size_t)tile * ((N - 1) * m)) * 64 + lane64;
+      double* X0 = X_SLOT_PTR(a, b, 0);
+      double* U0 = U_SLOT_PTR(a, b, 0);
 #pragma unroll
       for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
       if (!terminal) {

@@ -10,6 +10,8 @@
 //   * a trajectory that rejected all CW step sizes continues with the next CW inside the same kernel (only the waves
 //     that still hold a searching trajectory keep running): no compacted lists, no further launches.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace to {
@@ -74,10 +76,10 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const to_solver_opts& o = P.opts;
   const int N = P.N;
   constexpr int c = 0;  // nominal slot
-  const double* Xc = TILE_PTR(XSLOT(a, c), N * n);
-  const double* Uc = TILE_PTR(USLOT(a, c), (N - 1) * m);
-  double* Xn = TILE_PTR(XSLOT(a, cs), N * n);
-  double* Un = TILE_PTR(USLOT(a, cs), (N - 1) * m);
+  const double* Xc = X_SLOT_PTR(a, b, c);
+  const double* Uc = U_SLOT_PTR(a, b, c);
+  double* Xn = X_SLOT_PTR(a, b, cs);  // = Xc-array + (wave*L)*64 + hardware lane: a wave's candidate stores are whole 512-byte rows
+  double* Un = U_SLOT_PTR(a, b, cs);
   const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const double* px0 = TILE_PTR(a.x0, n);
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
@@ -89,9 +91,14 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const int integrator = P.integrator;
   const bool dt_scaling = P.opts.cost_dt_scaling != 0;
   const double max_x = o.max_state_value, max_u = o.max_control_value;
-  StageCostDiag<n, m> sc;
+  // stage cost: in VGPRs for the small models, in LDS for the models whose rollout loop has no register to spare
+  typename std::conditional<KLDS, StageCostLds<n, m>, StageCostDiag<n, m>>::type sc;
   double h0 = 0.0;
-  if constexpr (SIMPLE) { sc.load(P.costs[P.cost_index[0]]); h0 = P.dt[0]; }
+  if constexpr (SIMPLE) {
+    if constexpr (KLDS) { sc.load(P.costs[P.cost_index[0]], kbuf + 2 * (size_t)kbuf_len, hw); WAVE_SYNC(); }
+    else sc.load(P.costs[P.cost_index[0]]);
+    h0 = P.dt[0];
+  }
   // stage constraints on the control block (norm / SOC / one-sided bounds on u) are cached in registers once
   ConStage<n, m> cs0, cs1;
   int ncs = 0, uncached = 0;
@@ -124,12 +131,8 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     const FwdKnot<M, !KLDS> cur = nxt;
     if (ncs > 0) cs0.advance();
     if (ncs > 1) cs1.advance();
-    // x̄_k goes out FIRST, then the next knot's loads / DMA: nothing issued from here on is needed before the next wait
-    if (live) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
-    }
-    pXo += n * 64;
+    // The next knot's DMA / loads go out first (the compiler orders an LDS-DMA behind every earlier VMEM operation, so it
+    // must not follow the stores), then x̄_k: nothing issued here is needed before the next wait, a whole knot away
     const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
     if (k + 1 < N - 1) {
       if constexpr (KLDS) stage_gains<M>(a.Kt, b0, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
@@ -138,15 +141,24 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
       if (ncs > 1) cs1.prefetch(k + 1);
     }
     pXn += n * 64; pUn += m * 64; pKn += RSK;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
+    }
+    pXo += n * 64;
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
     double gk = 0.0;
 #pragma unroll
     for (int j = 0; j < m; ++j) {
-      const double dj = KLDS ? kcur[j * (ne + 1) + ne] : cur.kd[KLDS ? 0 : j * (ne + 1) + ne];
+      double kr[ne + 1];  // gains row j: all of it is requested before the first product (one LDS round trip per row, not per pair)
+#pragma unroll
+      for (int i = 0; i <= ne; ++i) kr[i] = KLDS ? kcur[j * (ne + 1) + i] : cur.kd[KLDS ? 0 : j * (ne + 1) + i];
+      if constexpr (KLDS) __builtin_amdgcn_sched_barrier(0);
+      const double dj = kr[ne];
       double du = dj * alpha;
 #pragma unroll
-      for (int i = 0; i < ne; ++i) du += (KLDS ? kcur[j * (ne + 1) + i] : cur.kd[KLDS ? 0 : j * (ne + 1) + i]) * dx[i];
+      for (int i = 0; i < ne; ++i) du += kr[i] * dx[i];
       ub[j] = cur.u[j] + du;
       if (live) EL(pUo, j) = ub[j];
       gk = fmax(gk, fabs(dj) * rcp_fast(fabs(ub[j]) + 1.0));
@@ -195,7 +207,7 @@ template <class M>
 __device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int lane, int b) {
   constexpr int m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
   const int N = a.P.N;
-  const double* Uc = TILE_PTR(USLOT(a, 0), (N - 1) * m);
+  const double* Uc = U_SLOT_PTR(a, b, 0);
   const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   double gs = 0.0;
   for (int k = 0; k < N - 1; ++k) {

@@ -21,10 +21,10 @@ __global__ void __launch_bounds__(64) k_accept(KArgs a) {
   const int per = (Lx + Lu + gridDim.z - 1) / gridDim.z;
   const int e0 = blockIdx.z * per, e1 = min(Lx + Lu, e0 + per);
   if (s == 0) return;
-  const double* sx = TILE_PTR(XSLOT(a, s), Lx);
-  double* dx = TILE_PTR(XSLOT(a, 0), Lx);
-  const double* su = TILE_PTR(USLOT(a, s), Lu);
-  double* du = TILE_PTR(USLOT(a, 0), Lu);
+  const double* sx = X_SLOT_PTR(a, b, s);
+  double* dx = X_SLOT_PTR(a, b, 0);
+  const double* su = U_SLOT_PTR(a, b, s);
+  double* du = U_SLOT_PTR(a, b, 0);
 #pragma unroll 16
   for (int e = e0; e < min(e1, Lx); ++e) EL(dx, e) = EL(sx, e);
 #pragma unroll 16

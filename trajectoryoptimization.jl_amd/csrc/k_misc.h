@@ -12,8 +12,8 @@ __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:33
   const DevProblem& P = a.P;
   if (b >= P.B) return;
   constexpr int c = 0;  // nominal slot
-  double* X = TILE_PTR(XSLOT(a, c), P.N * n);
-  const double* U = TILE_PTR(USLOT(a, c), (P.N - 1) * m);
+  double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
   const double* x0 = TILE_PTR(a.x0, n);
   double x[n], u[m], xn[n];
 #pragma unroll
@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(64) k_cost(KArgs a, int with_al, double* out, 
   const int N = P.N;
   if (Jk) {
     constexpr int c = 0;  // nominal slot
-    const double* X = TILE_PTR(XSLOT(a, c), N * n);
-    const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+    const double* X = X_SLOT_PTR(a, b, c);
+    const double* U = U_SLOT_PTR(a, b, c);
     double* o = TILE_PTR(Jk, N);
     for (int k = 0; k < N; ++k) {
       double x[n], u[m];
@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(64) k_outer_violation(KArgs a) {
   if (!want) return;
   const int N = P.N, k = blockIdx.y;
   const int sl = a.acc[b];  // the step accepted in this iteration (0: none, nominal unchanged)
-  const double* X = TILE_PTR(XSLOT(a, sl), N * n);
-  const double* U = TILE_PTR(USLOT(a, sl), (N - 1) * m);
+  const double* X = X_SLOT_PTR(a, b, sl);
+  const double* U = U_SLOT_PTR(a, b, sl);
   double x[n], u[m];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
   if (!want) return;
   const int N = P.N, k = blockIdx.y;
   const int sl = a.acc[b];
-  const double* X = TILE_PTR(XSLOT(a, sl), N * n);
-  const double* U = TILE_PTR(USLOT(a, sl), (N - 1) * m);
+  const double* X = X_SLOT_PTR(a, b, sl);
+  const double* U = U_SLOT_PTR(a, b, sl);
   double* lam0 = TILE_PTR(a.lam, P.n_duals);
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
   const double* mn0 = TILE_PTR(a.mu_next, P.n_cons);
@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(64) k_cost_derivs(KArgs a, double* grad, doubl
   const int N = P.N, k = blockIdx.y;
   const bool terminal = (k == N - 1);
   constexpr int c = 0;  // nominal slot
-  const double* X = TILE_PTR(XSLOT(a, c), N * n);
-  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  const double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
   double x[n], u[m];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(64) k_discrete_jacobian(KArgs a, double* F) {
   if (b >= P.B) return;
   const int N = P.N, k = blockIdx.y, j = blockIdx.z;
   constexpr int c = 0;  // nominal slot
-  const double* X = TILE_PTR(XSLOT(a, c), N * n);
-  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  const double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
   Dual xd[n], ud[m], xn[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) xd[i] = Dual(EL(X, k * n + i), (i == j) ? 1.0 : 0.0);
@@ -247,8 +247,8 @@ __global__ void __launch_bounds__(64) k_constraint_eval(KArgs a, int ci, double*
   ConC& K = P.cons[ci];
   const int N = P.N, kk = blockIdx.y, k = K.k1 + kk, nk = K.k2 - K.k1 + 1;
   constexpr int c = 0;  // nominal slot
-  const double* X = TILE_PTR(XSLOT(a, c), N * n);
-  const double* U = TILE_PTR(USLOT(a, c), (N - 1) * m);
+  const double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
   double z[nz];
 #pragma unroll
   for (int i = 0; i < n; ++i) z[i] = EL(X, k * n + i);

@@ -21,6 +21,17 @@ __device__ __forceinline__ double rcp_fast(double x) {
   return r;
 }
 
+// 1/sqrt(x) to ~1 ulp: hardware estimate + two Newton steps.  With l = x * rsqrt(x) a Cholesky pivot costs 10 VALU
+// operations instead of the ~30 of an IEEE sqrt followed by a reciprocal.
+__device__ __forceinline__ double rsqrt_fast(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-(x * y), y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-(x * y), y, 1.0);
+  y = fma(0.5 * y, e, y);
+  return y;
+}
+
 struct Dual {
   double v, d;
   __host__ __device__ Dual() : v(0.0), d(0.0) {}
@@ -121,7 +132,7 @@ struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr int expand_knots = 1;
   static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
   static constexpr bool lds_gains = false;             // forward pass: the gains row of a knot is a handful of doubles, loaded directly
-  static constexpr bool mfma_backward = false, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
+  static constexpr bool mfma_backward = true, coop_backward = true;  // both backward passes: MFMA for latency (small batches), cooperative for throughput
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mc = P[0], mp = P[1], l = P[2], g = P[3];
@@ -153,7 +164,7 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr int expand_knots = 4;               // knots one expansion wave walks (software-pipelined loads)
   static constexpr bool accept_write_through = false;  // accepted steps are copied onto slot 0 by k_accept after every forward pass
   static constexpr bool lds_gains = true;  // forward pass: the 52-double gains row of a knot comes through LDS (DMA), not prefetch VGPRs
-  static constexpr bool mfma_backward = true, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
+  static constexpr bool mfma_backward = true, coop_backward = false;  // MFMA backward pass only (the cooperative kernel needed 256 VGPR + 236 AGPR here)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mass = P[0], J1 = P[1], J2 = P[2], J3 = P[3];

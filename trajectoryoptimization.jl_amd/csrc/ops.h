@@ -12,6 +12,7 @@ template <class M>
 void fill_traits(ModelOps& o) {
   o.write_through = M::accept_write_through;
   o.mfma_backward = M::mfma_backward;
+  o.coop_backward = M::coop_backward;
   o.lds_gains = M::lds_gains;
   o.expand_knots = M::expand_knots;
   o.gains_lds_pieces = Gains<M>::RSK / 2;
@@ -132,7 +133,7 @@ template <class M, int MODE>
 int op_forward(to_handle* h) {
   const KArgs& a = h->a;
   const int TW = 64 >> a.cw_log;
-  const size_t lds = M::lds_gains ? 2 * sizeof(double) * gains_lds_doubles<M>(TW) : 0;
+  const size_t lds = M::lds_gains ? sizeof(double) * (2 * gains_lds_doubles<M>(TW) + StageCostLds<M::n, M::m>::size) : 0;  // two gains buffers + the stage-cost table
   hipLaunchKernelGGL((k_forward<M, MODE>), dim3(a.P.Bp / TW), dim3(BLOCK), lds, h->stream, a);
   HIPCHECK(hipGetLastError());
   return TO_OK;

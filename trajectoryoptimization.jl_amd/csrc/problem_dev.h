@@ -232,6 +232,55 @@ struct StageCostDiag {
   }
 };
 
+// The same stage cost kept in LDS instead of 80 VGPRs (n = 13, m = 4): the rollout loops of the large models run at one wave
+// per SIMD with every VGPR taken; 2(n+m)+6 wave-uniform doubles read back with broadcast LDS loads cost ~20 ds_read_b128
+// per knot and free the registers the gains row needs.  Same arithmetic, same order as StageCostDiag::eval.
+template <int n, int m>
+struct StageCostLds {
+  static constexpr int oQ = 0, oR = n, oq = n + m, orr = 2 * n + m, oc = 2 * n + 2 * m, ow = oc + 1, oref = oc + 2, size = oc + 6;
+  const double* t;
+  int qind[4], kind;
+  __device__ __forceinline__ void load(CostC& C, double* tab, int hw) {  // call from every lane of the wave
+    t = tab;
+    double v = 0.0;
+    if (hw < n) v = C.Q[hw < n ? hw : 0];
+    else if (hw < n + m) v = C.R[hw - n];
+    else if (hw < 2 * n + m) v = C.q[hw - n - m];
+    else if (hw < 2 * n + 2 * m) v = C.r[hw - 2 * n - m];
+    else if (hw == oc) v = C.c;
+    else if (hw == ow) v = C.w;
+    else if (hw < size) v = C.q_ref[hw - oref];
+    if (hw < size) tab[hw] = v;
+    kind = C.kind;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qind[i] = C.q_ind[i];
+  }
+  __device__ __forceinline__ double eval(const double* x, const double* u) const {
+    double xQx = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) xQx += x[i] * t[oQ + i] * x[i];
+    double J = 0.5 * xQx;
+    double qx = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) qx += t[oq + i] * x[i];
+    J = J + qx + t[oc];
+    double uRu = 0.0, ru = 0.0;
+#pragma unroll
+    for (int i = 0; i < m; ++i) uRu += u[i] * t[oR + i] * u[i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) ru += t[orr + i] * u[i];
+    J += 0.5 * uRu + ru;
+    if (kind == TO_COST_DIAGONAL_QUAT) {
+      double qref[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qref[i] = t[oref + i];
+      const double dq = quat_dot<n>(qref, qind, x);
+      J += t[ow] * fmin(1 + dq, 1 - dq);
+    }
+    return J;
+  }
+};
+
 // gradient g (n+m) and Hessian-vector product y = H v (n+m) of the cost at (x,u); u-parts zero if terminal
 // DENSE = false compiles the QuadraticCost (full Q, R, H) branches out.
 template <int n, int m, bool DENSE = true>

@@ -556,7 +556,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // candidates x 64/CW trajectories, so the launch has Bp*CW/64 waves — enough to cover the 1024 SIMDs of the chip for
   // small batches, at most 16 (the default search depth is 20: a second in-kernel round covers the rest, rarely needed).
   {
-    int cw = std::max(1, std::min(16, 1024 / (P.Bp / BLOCK)));
+    int cw = std::max(1, std::min(16, 2048 / (P.Bp / BLOCK)));
     if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
     a.cw_log = 0;
     while ((2 << a.cw_log) <= cw) ++a.cw_log;
@@ -564,16 +564,19 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   }
   // backward-pass flavour: one wave per trajectory on the matrix cores (tangent-matrix expansion) where the model has it,
   // else the cooperative LDS kernel on the column layout.  TRAJOPT_BACKWARD=coop|mfma overrides (A/B measurements).
-  a.bwd_mfma = h->ops->mfma_backward ? 1 : 0;
+  // Models that have the cooperative kernel as well (small ones: several trajectories per wave) default to it: measured on
+  // the Cartpole at B = 1024, 78 us cooperative vs 90 us MFMA per backward pass (the 5x5 blocks fill 2 % of a 16x16 tile).
+  a.bwd_mfma = (h->ops->mfma_backward && !h->ops->coop_backward) ? 1 : 0;
   if (const char* env = std::getenv("TRAJOPT_BACKWARD")) {
     if (!std::strcmp(env, "coop")) a.bwd_mfma = 0;
     if (!std::strcmp(env, "mfma") && h->ops->mfma_backward) a.bwd_mfma = 1;
   }
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
-  a.slotX = (size_t)N * n * Bp; a.slotU = (size_t)(N - 1) * m * Bp;
-  TRYB(dev_alloc(h, &a.Xs, a.slotX * (a.T + 1)));
-  TRYB(dev_alloc(h, &a.Us, a.slotU * (a.T + 1)));
+  TRYB(dev_alloc(h, &a.Xs, (size_t)N * n * Bp));
+  TRYB(dev_alloc(h, &a.Us, (size_t)(N - 1) * m * Bp));
+  TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * Bp * a.T));        // candidates, forward-wave-major (common.h)
+  TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * Bp * a.T));
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
