@@ -261,6 +261,16 @@ int to_get_initial_state(to_handle* h, double* x0);
 /* device-to-device copies into caller-provided DEVICE buffers (same (n,N,B) layout), for RCCL all-gather */
 int to_get_states_device(to_handle* h, void* dX);
 int to_get_controls_device(to_handle* h, void* dU);
+/* ---- multi-GPU: one process per GPU, each handle owns a contiguous shard of the batch; no collective inside
+ * the solves; one RCCL all-gather (over xGMI) of the converged trajectories.  librccl.so is dlopen'ed on first use.
+ *   rank 0: to_comm_unique_id(id) -> ship the 128 bytes to the other ranks (MPI, a file, torch.distributed ...)
+ *   all   : to_comm_init_rank(h, nranks, rank, id); ... solve ...; to_allgather(h, dX_all, dU_all)
+ * dX_all / dU_all are caller-owned DEVICE buffers of nranks*n*N*B / nranks*m*(N-1)*B doubles; the result is the host layout
+ * (n, N, B_total) with trajectories in global order (rank-major).  All ranks must hold shards of equal size. */
+int to_comm_unique_id(void* id128 /* [128] bytes */);
+int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id128);
+int to_allgather(to_handle* h, void* dX_all, void* dU_all /* either may be NULL */);
+int to_comm_destroy(to_handle* h);
 /* goal / reference updates between solves (set_goal_state! src/problem.jl:294-310; set_LQR_goal! src/cost_functions.jl:249-258) */
 int to_set_cost(to_handle* h, int32_t cost_id, const to_cost_desc* cost);
 int to_set_constraint(to_handle* h, int32_t con_id, const to_constraint_desc* con);
@@ -308,6 +318,11 @@ int to_reset_profile(to_handle* h);
  * nk = k_last-k_first+1.  jac is fully written (zeros included). */
 int to_evaluate_constraints(to_handle* h, int32_t con_id, double* vals);
 int to_constraint_jacobians(to_handle* h, int32_t con_id, double* jac);
+/* ∇jacobian! (src/abstract_constraint.jl:255-280): H[w,w,nk,B] += sum_r lambda[r,k,b] * Hessian of c_r — ADDS to H like the
+ * reference.  lambda[p,nk,B].  Zero for the kinds whose rows are affine (GOAL src/constraints.jl:70-73, BOUND :767-770,
+ * LINEAR, NORM in SOC form); closed forms for NORM (quadratic), CIRCLE, SPHERE, COLLISION, QUATVEC.  The solver's own
+ * expansion stays Gauss-Newton (it does not use this term). */
+int to_constraint_hessians(to_handle* h, int32_t con_id, const double* lambda, double* H);
 int to_constraint_info(const to_handle* h, int32_t con_id, int32_t* p, int32_t* width, int32_t* nk, int32_t* sense);
 int to_max_violation(to_handle* h, double* c_max /* [B] */);
 int to_get_duals(to_handle* h, int32_t con_id, double* lambda /* [p,nk,B] */, double* mu /* [B] */);

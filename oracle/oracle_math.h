@@ -581,6 +581,48 @@ inline int constraint_output_dim(const to_constraint_desc& K, int n, int m) {
   return -1;
 }
 
+/* H (w x w, column-major, w = n for state constraints else n+m) += sum_r lambda_r * Hessian of c_r — what the reference's
+ * ∇jacobian! accumulates (src/abstract_constraint.jl:255-280; zero for Goal :70-73 and Bound :767-770, ForwardDiff default
+ * elsewhere).  Closed forms: rows that are affine in z contribute nothing; ‖z_I‖² − a² gives 2 I on I; circle / sphere
+ * −2 I on the centre coordinates; collision −2 [I −I; −I I]; QuatVecEq the second derivative of q/‖q‖. */
+inline void constraint_hessian_add(const to_constraint_desc& K, int n, int m, const double* z, const double* lambda, double* H, int w) {
+  const int p = constraint_output_dim(K, n, m);
+  auto at = [&](int i, int j) -> double& { return H[i + (size_t)w * j]; };
+  switch (K.kind) {
+    case TO_CON_NORM:
+      if (K.sense != TO_CONE_SECOND_ORDER) for (int t = 0; t < K.n_inds; ++t) at(K.inds[t] - 1, K.inds[t] - 1) += 2.0 * lambda[0];
+      return;
+    case TO_CON_CIRCLE:
+      for (int i = 0; i < p; ++i) { at(K.inds[0] - 1, K.inds[0] - 1) -= 2.0 * lambda[i]; at(K.inds[1] - 1, K.inds[1] - 1) -= 2.0 * lambda[i]; }
+      return;
+    case TO_CON_SPHERE:
+      for (int i = 0; i < p; ++i) for (int t = 0; t < 3; ++t) at(K.inds[t] - 1, K.inds[t] - 1) -= 2.0 * lambda[i];
+      return;
+    case TO_CON_COLLISION: {
+      const int D = K.n_inds / 2;
+      for (int t = 0; t < D; ++t) {
+        const int a = K.inds[t] - 1, b = K.inds[D + t] - 1;
+        at(a, a) -= 2.0 * lambda[0]; at(b, b) -= 2.0 * lambda[0]; at(a, b) += 2.0 * lambda[0]; at(b, a) += 2.0 * lambda[0];
+      }
+      return;
+    }
+    case TO_CON_QUATVEC: {
+      double q[4], s2 = 0.0;
+      for (int t = 0; t < 4; ++t) { q[t] = z[K.inds[t] - 1]; s2 += q[t] * q[t]; }
+      const double s = std::sqrt(s2), s3 = s2 * s, s5 = s3 * s2;
+      for (int r = 0; r < 3; ++r) {  /* c_r = q_{r+1}/|q| + const:  d2/dq_j dq_k = -(d_ij q_k + d_ik q_j + d_jk q_i)/s^3 + 3 q_i q_j q_k/s^5 */
+        const int i = r + 1;
+        for (int j = 0; j < 4; ++j) for (int k = 0; k < 4; ++k) {
+          const double v = -((i == j ? q[k] : 0.0) + (i == k ? q[j] : 0.0) + (j == k ? q[i] : 0.0)) / s3 + 3.0 * q[i] * q[j] * q[k] / s5;
+          at(K.inds[j] - 1, K.inds[k] - 1) += lambda[r] * v;
+        }
+      }
+      return;
+    }
+    default: return;  /* GOAL, BOUND, LINEAR, NORM (SOC form): affine rows */
+  }
+}
+
 inline void constraint_evaluate(const to_constraint_desc& K, int n, int m, const double* z, double* c, double* jac) {
   const int nz = n + m;
   const int p = constraint_output_dim(K, n, m);

@@ -936,6 +936,18 @@ int oracle_constraint_jacobians(oracle_handle* h, int32_t id, double* jac) {
   }
   return TO_OK;
 }
+int oracle_constraint_hessians(oracle_handle* h, int32_t id, const double* lambda, double* H) {
+  CHECK_H(h); CHECK_P(lambda); CHECK_P(H);
+  if (id < 0 || id >= (int)h->P.cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const ConInfo& ci = h->P.cons[id]; const int nk = ci.k2 - ci.k1 + 1, w = ci.width;
+  double z[MAXZ];
+  for (int b = 0; b < h->P.B; ++b) for (int k = ci.k1; k <= ci.k2; ++k) {
+    knot_z(h->P, h->T[b].X.data(), h->T[b].U.data(), k, z);
+    const size_t kb = (k - ci.k1) + (size_t)nk * b;
+    constraint_hessian_add(ci.d, h->P.n, h->P.m, z, lambda + (size_t)ci.p * kb, H + (size_t)w * w * kb, w);
+  }
+  return TO_OK;
+}
 int oracle_max_violation(oracle_handle* h, double* c_max) {
   CHECK_H(h); CHECK_P(c_max);
   for_batch(h, [&](Traj& t, int b) { c_max[b] = max_violation(h->P, t); });

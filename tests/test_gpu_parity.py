@@ -421,6 +421,20 @@ def test_mfma_backward_on_small_models(hip, oracle, monkeypatch):
     np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-7, atol=1e-9)
     ph, po = pair(lambda **kw: configs.cartpole_problem(batch=70, **kw), hip, oracle)
     assert_solve_parity(T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve(), ph, po)
+    def di3(lib):
+        model = T.DoubleIntegrator(1.3, 3)
+        n, m = model.dims()
+        xf = np.concatenate([np.arange(1, 4, dtype=float), np.zeros(3)])
+        obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 10.0 * np.ones(n), xf, 16)
+        cons = T.ConstraintList(n, m, 16)
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=-2.0, u_max=2.0), range(1, 16))
+        T.add_constraint(cons, T.GoalConstraint(xf), 16)
+        p = T.Problem(model, obj, np.zeros(n), 2.0, xf=xf, constraints=cons, batch=5, lib=lib,
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-5))
+        p.set_initial_state(np.linspace(-0.5, 0.5, 5)[:, None] * np.ones((5, n)))
+        return p
+    ph, po = di3(hip), di3(oracle)
+    assert_solve_parity(T.ALSolver(ph).solve(), T.ALSolver(po).solve(), ph, po)
     monkeypatch.setenv("TRAJOPT_FULL_COST_BLOCKS", "1")
     ph, po = pair(lambda **kw: configs.cartpole_problem(batch=40, constrained=True, **kw), hip, oracle)
     assert_solve_parity(T.ALSolver(ph).solve(), T.ALSolver(po).solve(), ph, po)
@@ -618,3 +632,90 @@ def test_error_paths_on_device(hip):
         p._call("set_cost", 7, None) if False else p._lib.call("set_cost", p._h, 7, T.capi.CostDesc())
     with pytest.raises(T.DimensionMismatch):
         T.initial_controls(p, np.zeros((3, 4, 1)))
+
+
+def test_device_allgather_world1(hip):
+    """The multi-GPU path of the C-ABI (to_comm_init_rank / to_allgather: RCCL all-gather of device-resident shards) with a
+    world of one rank — the same code the N-rank bench runs — must return exactly what to_get_states / to_get_controls do;
+    the device-to-device getters (to_get_*_device) likewise."""
+    import ctypes as C
+    import torch
+    from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
+    p = configs.cartpole_problem(batch=70, N=41, tf=2.0, lib=hip)
+    T.iLQRSolver(p, iterations=15).solve()
+    X, U = T.states(p), T.controls(p)
+    g = TrajectoryGather(p, None, device=torch.device("cuda", 0))
+    Xg, Ug = g()
+    np.testing.assert_array_equal(Xg.cpu().numpy(), X)
+    np.testing.assert_array_equal(Ug.cpu().numpy(), U)
+    with pytest.raises(T.ArgumentError):
+        p._call("comm_init_rank", 1, 0, g._uid)   # already initialised
+    g.close()
+    xs = torch.empty((p.B, p.N, p.n), dtype=torch.float64, device="cuda")
+    us = torch.empty((p.B, p.N - 1, p.m), dtype=torch.float64, device="cuda")
+    p._call("get_states_device", C.c_void_p(xs.data_ptr()))
+    p._call("get_controls_device", C.c_void_p(us.data_ptr()))
+    np.testing.assert_array_equal(xs.cpu().numpy(), X)
+    np.testing.assert_array_equal(us.cpu().numpy(), U)
+
+
+def test_constraint_hessians_on_gpu(hip, oracle):
+    """to_constraint_hessians (∇jacobian!, src/abstract_constraint.jl:255-280) for every kind with curvature, GPU vs oracle."""
+    rng = np.random.default_rng(21)
+    qf = rng.standard_normal(4)
+
+    def build(lib):
+        model = T.Quadrotor(); n, m = model.dims(); N = 9
+        xf = np.zeros(n); xf[3] = 1
+        obj = T.LQRObjective(np.ones(n), np.ones(m), np.ones(n), xf, N)
+        cons = T.ConstraintList(n, m, N)
+        T.add_constraint(cons, T.NormConstraint(n, m, 1.5, T.Inequality(), [8, 9, 10, 14]), range(1, N))
+        T.add_constraint(cons, T.CircleConstraint(n, [0.25, -0.5], [0.1, 0.3], [0.05, 0.2]), range(1, N + 1))
+        T.add_constraint(cons, T.SphereConstraint(n, [0.4], [0.4], [0.2], [0.05]), range(2, N + 1))
+        T.add_constraint(cons, T.CollisionConstraint(n, [1, 2, 3], [8, 9, 10], 0.02), range(1, N + 1))
+        T.add_constraint(cons, T.QuatVecEq(n, m, qf), range(1, N + 1))
+        T.add_constraint(cons, T.GoalConstraint(xf), N)
+        x0 = np.zeros(n); x0[3] = 1
+        p = T.Problem(model, obj, x0, 1.0, xf=xf, constraints=cons, batch=70, lib=lib)
+        p.set_initial_state(configs.quadrotor_x0(70))
+        T.initial_controls(p, model.hover_control() + 0.3 * np.random.default_rng(3).standard_normal((70, N - 1, m)))
+        T.rollout(p)
+        return p
+    ph, po = build(hip), build(oracle)
+    for i, con in enumerate(ph.constraints):
+        nk = ph.constraints.inds[i][1] - ph.constraints.inds[i][0] + 1
+        lam = rng.standard_normal((ph.B, nk, con.p))
+        w = T.constraint_jacobians(po, i).shape[3]
+        H0 = rng.standard_normal((ph.B, nk, w, w))
+        Hh, Ho = T.constraint_hessians(ph, i, lam, H=H0), T.constraint_hessians(po, i, lam, H=H0)
+        np.testing.assert_allclose(Hh, Ho, rtol=1e-12, atol=1e-13, err_msg=type(con).__name__)
+
+
+def test_indexed_constraints_solve(hip, oracle):
+    """IndexedConstraint / change_dimension (src/constraints.jl:820-936): constraints written for a 2-D double integrator's
+    dimensions, moved onto the x-y slice of a 3-D one, through a full AL solve on the GPU vs the oracle."""
+    def build(lib):
+        model = T.DoubleIntegrator(1.0, 3); n, m, N = 6, 3, 21
+        xf = np.array([1.0, 2.0, 0.5, 0, 0, 0])
+        obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 20.0 * np.ones(n), xf, N)
+        inner = T.ConstraintList(2, 2, N)     # written for (position_xy, force_xy)
+        T.add_constraint(inner, T.ControlBound(2, 2, u_max=1.5, u_min=-1.5), range(1, N))
+        T.add_constraint(inner, T.NormConstraint(2, 2, 1.8, T.SecondOrderCone(), "control"), range(1, N))
+        T.add_constraint(inner, T.CircleConstraint(2, [0.5], [1.0], [0.25]), range(2, N))
+        T.add_constraint(inner, T.GoalConstraint(xf[:2]), N)
+        cons = T.change_dimension(inner, n, m, ix=(1, 2), iu=(1, 2))
+        T.add_constraint(cons, T.GoalConstraint(xf, [3, 4, 5, 6]), N)
+        p = T.Problem(model, obj, np.zeros(n), 5.0, xf=xf, constraints=cons, batch=9, lib=lib,
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-5))
+        p.set_initial_state(np.linspace(-0.3, 0.3, 9)[:, None] * np.array([1.0, -1.0, 0.5, 0, 0, 0]))
+        T.initial_controls(p, np.array([0.1, 0.2, 0.05]))
+        return p
+    ph, po = build(hip), build(oracle)
+    for p in (ph, po):
+        T.rollout(p)
+    for i in range(len(ph.constraints)):
+        np.testing.assert_allclose(T.evaluate_constraints(ph, i), T.evaluate_constraints(po, i), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(T.constraint_jacobians(ph, i), T.constraint_jacobians(po, i), rtol=1e-12, atol=1e-13)
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po, rtol=1e-5)
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED)

@@ -362,3 +362,100 @@ def test_error_quadratic_cost(oracle):
         T.set_goal_state(prob, xr)
     with pytest.raises(T.capi.DimensionMismatch):
         T.Problem(T.Cartpole(), T.Objective(cost, term, N), np.zeros(4), 1.0, lib=oracle)
+
+
+# ---------------------------------------------------------------------------------------------- IndexedConstraint / ∇jacobian
+def _fd_problem(oracle, model, cons, z0, eps=1e-6):
+    """A batch whose trajectory 0 sits at z0 = [x; u] on every knot and trajectory 1+j at z0 + eps e_j: one
+    evaluate/jacobian call then yields central-difference-free forward differences along every coordinate."""
+    n, m = model.dims()
+    N, nz = cons.N, n + m
+    obj = T.LQRObjective(np.ones(n), np.ones(m), np.ones(n), np.zeros(n), N)
+    p = T.Problem(model, obj, np.zeros(n), 1.0, constraints=cons, batch=nz + 1, lib=oracle)
+    Z = np.tile(z0, (nz + 1, 1))
+    Z[1:] += eps * np.eye(nz)
+    T.initial_states(p, np.repeat(Z[:, None, :n], N, axis=1))
+    T.initial_controls(p, np.repeat(Z[:, None, n:], N - 1, axis=1))
+    return p
+
+
+def test_indexed_constraint_and_change_dimension(oracle):
+    """src/constraints.jl:820-936, src/constraint_list.jl:208-217: constraints written for (n0, m0) = (3, 2) acting on the
+    slice x[2:4], u[2:3] of a 3-D double integrator (n, m) = (6, 3): values equal the inner constraint on the sliced
+    knot point, Jacobians are the inner Jacobians scattered to the mapped columns (checked by finite differences)."""
+    model = T.DoubleIntegrator(1.0, 3)
+    n, m, N = 6, 3, 4
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((2, 5)); bvec = rng.standard_normal(2)
+    inner = T.ConstraintList(3, 2, N)
+    T.add_constraint(inner, T.BoundConstraint(3, 2, x_max=[1.0, np.inf, 2.0], u_min=[-1.0, -np.inf]), range(1, N))
+    T.add_constraint(inner, T.NormConstraint(3, 2, 2.0, T.SecondOrderCone(), "control"), range(1, N))
+    T.add_constraint(inner, T.LinearConstraint(3, 2, A, bvec, T.Inequality()), range(1, N))
+    T.add_constraint(inner, T.GoalConstraint(np.array([0.1, 0.2, 0.3]), [1, 3]), N)
+    T.add_constraint(inner, T.CircleConstraint(3, [0.4], [0.6], [0.3], xi=1, yi=3), range(2, N + 1))
+    T.add_constraint(inner, T.NormConstraint(3, 2, 1.5, T.Inequality(), [2, 4]), range(1, N))
+    cons = T.change_dimension(inner, n, m, ix=(2, 4), iu=(2, 3))
+    assert len(cons) == len(inner) and cons.inds == inner.inds and cons.p == inner.p
+    assert all(isinstance(c, T.IndexedConstraint) for c in cons)
+    assert T.sense(cons[1]) == T.SecondOrderCone() and cons[0].p == 3
+    z0 = rng.standard_normal(n + m) * 0.5
+    eps = 1e-6
+    p = _fd_problem(oracle, model, cons, z0, eps)
+    x0, u0 = z0[1:4], z0[n + 1:n + 3]          # the inner knot point
+    z_in = np.r_[x0, u0]
+    expect = [np.r_[x0[0] - 1.0, x0[2] - 2.0, -1.0 - u0[0]], np.r_[u0, 2.0], A @ z_in - bvec,
+              np.r_[x0[0] - 0.1, x0[2] - 0.3], np.r_[0.3 ** 2 - (x0[0] - 0.4) ** 2 - (x0[2] - 0.6) ** 2],
+              np.r_[z_in[1] ** 2 + z_in[3] ** 2 - 1.5 ** 2]]
+    mapped = [1, 2, 3, n + 1, n + 2]            # 0-based columns of the new z the slice occupies
+    for i, e in enumerate(expect):
+        c = T.evaluate_constraints(p, i)        # [B, nk, p]
+        np.testing.assert_allclose(c[0, 0], e, rtol=1e-13, atol=1e-14, err_msg=f"constraint {i}")
+        J = T.constraint_jacobians(p, i)[0, 0]  # [p, n+m]
+        assert J.shape == (cons[i].p, n + m)
+        fd = (c[1:, 0, :] - c[0, 0, :]).T / eps
+        np.testing.assert_allclose(J, fd, atol=2e-5, err_msg=f"jacobian {i}")
+        off = np.setdiff1d(np.arange(n + m), mapped)
+        assert np.all(J[:, off] == 0.0)
+    with pytest.raises(T.DimensionMismatch):
+        T.IndexedConstraint(n, m, T.BoundConstraint(3, 2, u_max=1.0), ix=(2, 5), iu=(2, 3))
+    with pytest.raises(T.DimensionMismatch):
+        T.IndexedConstraint(n, m, T.BoundConstraint(3, 2, u_max=1.0), ix=(5, 7), iu=(2, 3))
+    sb, cb = T.StateBound(n, m, x_max=1.0), T.ControlBound(n, m, u_min=-2.0)
+    assert sb.p == n and cb.p == m and sb.inds == list(range(1, n + 1)) and cb.inds == [2 * (n + m) - m + 1 + j for j in range(m)]
+
+
+def test_constraint_hessians_against_finite_differences(oracle):
+    """∇jacobian! (src/abstract_constraint.jl:255-280): H += Σ_r λ_r ∇²c_r.  Closed forms of every kind with curvature vs
+    finite differences of the Jacobians; zero for the affine kinds (src/constraints.jl:70-73, 767-770); the operator ADDS."""
+    model = T.Quadrotor()
+    n, m, N = 13, 4, 3
+    rng = np.random.default_rng(9)
+    cons = T.ConstraintList(n, m, N)
+    qf = rng.standard_normal(4)
+    T.add_constraint(cons, T.NormConstraint(n, m, 1.5, T.Inequality(), [8, 9, 10, 14]), range(1, N))
+    T.add_constraint(cons, T.CircleConstraint(n, [0.25, -0.5], [0.1, 0.3], [0.05, 0.2]), range(1, N + 1))
+    T.add_constraint(cons, T.SphereConstraint(n, [0.4], [0.4], [0.2], [0.05]), range(1, N + 1))
+    T.add_constraint(cons, T.CollisionConstraint(n, [1, 2, 3], [8, 9, 10], 0.02), range(1, N + 1))
+    T.add_constraint(cons, T.QuatVecEq(n, m, qf), range(1, N + 1))
+    T.add_constraint(cons, T.GoalConstraint(rng.standard_normal(n)), N)
+    T.add_constraint(cons, T.BoundConstraint(n, m, u_max=3.0), range(1, N))
+    T.add_constraint(cons, T.NormConstraint(n, m, 5.0, T.SecondOrderCone(), "control"), range(1, N))
+    z0 = rng.standard_normal(n + m) * 0.7
+    z0[3:7] = rng.standard_normal(4) * 1.3      # un-normalised quaternion on purpose
+    eps = 1e-6
+    p = _fd_problem(oracle, model, cons, z0, eps)
+    for i, con in enumerate(cons):
+        nk = cons.inds[i][1] - cons.inds[i][0] + 1
+        lam = rng.standard_normal((p.B, nk, con.p))
+        lam[:] = lam[0]                          # the same multipliers on every trajectory of the FD batch
+        H = T.constraint_hessians(p, i, lam)
+        J = T.constraint_jacobians(p, i)         # [B, nk, p, w]
+        w = J.shape[3]
+        g = np.einsum("bkr,bkrw->bkw", lam, J)   # λᵀ∇c at base and perturbed points
+        fd = (g[1:w + 1, 0, :] - g[0, 0, :]) / eps   # row j = d/dz_j
+        np.testing.assert_allclose(H[0, 0], fd.T, atol=5e-5, err_msg=type(con).__name__)
+        np.testing.assert_allclose(H[0, 0], H[0, 0].T, atol=1e-14)
+        if isinstance(con, (T.GoalConstraint, T.BoundConstraint)) or isinstance(con.sense(), T.SecondOrderCone):
+            assert np.all(H == 0.0)
+        H2 = T.constraint_hessians(p, i, lam, H=np.ones_like(H))
+        np.testing.assert_allclose(H2, H + 1.0, rtol=1e-14, atol=1e-14)

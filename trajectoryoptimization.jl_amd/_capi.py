@@ -168,6 +168,7 @@ SIGNATURES = {
     "discrete_jacobian": [_H, _PD],
     "evaluate_constraints": [_H, C.c_int32, _PD],
     "constraint_jacobians": [_H, C.c_int32, _PD],
+    "constraint_hessians": [_H, C.c_int32, _PD, _PD],
     "constraint_info": [_H, C.c_int32, _PI, _PI, _PI, _PI],
     "max_violation": [_H, _PD],
     "get_duals": [_H, C.c_int32, _PD, _PD],
@@ -183,6 +184,10 @@ SIGNATURES = {
 HIP_ONLY = {
     "get_states_device": [_H, C.c_void_p],
     "get_controls_device": [_H, C.c_void_p],
+    "comm_unique_id": [C.c_void_p],
+    "comm_init_rank": [_H, C.c_int32, C.c_int32, C.c_void_p],
+    "allgather": [_H, C.c_void_p, C.c_void_p],
+    "comm_destroy": [_H],
     "set_profiling": [_H, C.c_int],
     "get_profile": [_H, _PD, C.POINTER(C.c_int64)],
     "reset_profile": [_H],

@@ -39,7 +39,8 @@ __all__ = [
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
     "projection", "grad_projection", "hess_projection", "cone_status", "dualcone",
     "GoalConstraint", "BoundConstraint", "NormConstraint", "CircleConstraint", "SphereConstraint", "CollisionConstraint", "QuatVecEq",
-    "LinearConstraint", "ConstraintList", "add_constraint", "num_constraints",
+    "LinearConstraint", "StateBound", "ControlBound", "IndexedConstraint", "change_dimension",
+    "ConstraintList", "add_constraint", "num_constraints", "constraint_hessians",
     "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
     "set_initial_state", "set_goal_state", "update_trajectory", "get_constraints", "get_objective", "get_model",
     "get_initial_state", "get_final_state", "get_trajectory", "gettimes",
@@ -671,6 +672,81 @@ class LinearConstraint(AbstractConstraint):
         return self.inds, list(self.A.ravel(order="F")) + list(self.b)
 
 
+def StateBound(n, m, x_max=np.inf, x_min=-np.inf):
+    """Bounds on the state only (the reference's `StateBound`, src/constraints.jl:528-631, keeps a separate type over the
+    same arithmetic as BoundConstraint; here it IS a BoundConstraint with infinite control bounds: same rows, same order)."""
+    return BoundConstraint(n, m, x_max=x_max, x_min=x_min)
+
+
+def ControlBound(n, m, u_max=np.inf, u_min=-np.inf):
+    """Bounds on the control only (src/constraints.jl:528-631)."""
+    return BoundConstraint(n, m, u_max=u_max, u_min=u_min)
+
+
+class IndexedConstraint(AbstractConstraint):
+    """A constraint written for dimensions (n0, m0) acting on a slice of a larger problem's [x; u]
+    (src/constraints.jl:820-936): c(z) = con(x[ix], u[iu]), Jacobian columns scattered to ix / n+iu, zero elsewhere.
+    ``ix`` / ``iu`` are 1-based unit ranges (first, last) into the NEW state / control vectors, defaulting to the
+    leading entries like the reference's 3-argument constructor.  The library needs no kernel for it: every descriptor
+    addresses [x; u] through index lists, so the wrapper is lowered by remapping the inner constraint's indices."""
+
+    def __init__(self, n, m, con, ix=None, iu=None):
+        self.n, self.m, self.con = int(n), int(m), con
+        n0 = getattr(con, "n", None)
+        m0 = getattr(con, "m", None)
+        if con.state_only or m0 is None:
+            m0 = self.m if iu is None else _range_len(iu)
+        if n0 is None:
+            n0 = self.n if ix is None else _range_len(ix)
+        ix = (1, n0) if ix is None else _knot_range(ix, self.n)
+        iu = (1, m0) if iu is None else _knot_range(iu, self.m)
+        if ix[1] - ix[0] + 1 != n0 or (not con.state_only and iu[1] - iu[0] + 1 != m0):
+            raise DimensionMismatch("IndexedConstraint: length(ix), length(iu) must equal the inner constraint's dimensions")
+        if not (1 <= ix[0] and ix[1] <= self.n and 1 <= iu[0] and iu[1] <= self.m):
+            raise DimensionMismatch("IndexedConstraint: ix / iu outside the new state / control vector")
+        self.n0, self.m0, self.ix, self.iu = n0, m0, ix, iu
+        self.p, self._sense, self.kind = con.p, con.sense(), con.kind
+        self.state_only = False  # a StageConstraint in the reference: Jacobians are p x (n+m)
+
+    def _map(self, i):  # 1-based index into the inner [x0; u0] -> 1-based index into the new [x; u]
+        return self.ix[0] + i - 1 if i <= self.n0 else self.n + self.iu[0] + (i - self.n0) - 1
+
+    def _fill(self):
+        inds, params = self.con._fill()
+        if self.kind == capi.CON_BOUND:  # params = [z_max; z_min] of the inner dimensions -> padded with +-inf
+            zmax, zmin = np.full(self.n + self.m, np.inf), np.full(self.n + self.m, -np.inf)
+            nz0 = self.n0 + self.m0
+            for i in range(nz0):
+                zmax[self._map(i + 1) - 1] = params[i]
+                zmin[self._map(i + 1) - 1] = params[nz0 + i]
+            return [], list(zmax) + list(zmin)
+        return [self._map(int(i)) for i in inds], params
+
+    def _desc(self, k1, k2):
+        d = super()._desc(k1, k2)
+        return d
+
+    @property
+    def lowered_state_only(self):
+        return self.con.state_only
+
+
+def _range_len(r):
+    a, b = _knot_range(r, 0)
+    return b - a + 1
+
+
+def change_dimension(obj, n, m, ix=None, iu=None):
+    """change_dimension (src/constraints.jl:934-936, src/constraint_list.jl:208-217): wrap a constraint, or every
+    constraint of a list, for a problem of dimensions (n, m) whose state / control contain the old ones at ix / iu."""
+    if isinstance(obj, ConstraintList):
+        new = ConstraintList(n, m, obj.N)
+        for con, inds in zip(obj.constraints, obj.inds):
+            add_constraint(new, change_dimension(con, n, m, ix, iu), inds)
+        return new
+    return IndexedConstraint(n, m, obj, ix, iu)
+
+
 def _knot_range(inds, N):
     if isinstance(inds, (int, np.integer)):
         return int(inds), int(inds)
@@ -1043,14 +1119,37 @@ def evaluate_constraints(prob, i):
     return vals
 
 
+def _lib_width(prob, con):
+    """Jacobian width the library reports for constraint ``con``: n for state constraints, else n+m."""
+    state = con.lowered_state_only if isinstance(con, IndexedConstraint) else con.state_only
+    return prob.n if state else prob.n + prob.m
+
+
 def constraint_jacobians(prob, i):
     """constraint_jacobians! -> [B, nk, p, w]  (src/abstract_constraint.jl:236-248)."""
     con = prob.constraints[i]
     a, b = prob.constraints.inds[i]
-    w = prob.n if con.state_only else prob.n + prob.m
+    w = _lib_width(prob, con)
     jac = np.empty((prob.B, b - a + 1, w, con.p))
     prob._call("constraint_jacobians", i, prob._pd(jac))
-    return jac.transpose(0, 1, 3, 2)
+    jac = jac.transpose(0, 1, 3, 2)
+    if isinstance(con, IndexedConstraint) and w < prob.n + prob.m:  # the reference's wrapper is a stage constraint: p x (n+m)
+        jac = np.concatenate([jac, np.zeros(jac.shape[:3] + (prob.m,))], axis=3)
+    return jac
+
+
+def constraint_hessians(prob, i, lam, H=None):
+    """∇jacobian! over the knot range (src/abstract_constraint.jl:255-280): returns H + Σ_r lam[..., r] ∇²c_r as
+    [B, nk, w, w]; ``lam`` is [B, nk, p]; ``H`` (same shape as the result) defaults to zeros — the operator ADDS."""
+    con = prob.constraints[i]
+    a, b = prob.constraints.inds[i]
+    nk, w = b - a + 1, _lib_width(prob, con)
+    lam = np.ascontiguousarray(np.broadcast_to(np.asarray(lam, dtype=np.float64), (prob.B, nk, con.p)))
+    out = np.zeros((prob.B, nk, w, w)) if H is None else np.ascontiguousarray(np.asarray(H, dtype=np.float64).transpose(0, 1, 3, 2)).copy()
+    if out.shape != (prob.B, nk, w, w):
+        raise DimensionMismatch(f"H must be [B, nk, {w}, {w}]")
+    prob._call("constraint_hessians", i, prob._pd(lam), prob._pd(out))
+    return out.transpose(0, 1, 3, 2)
 
 
 # --------------------------------------------------------------------------------------------- solvers

@@ -53,6 +53,9 @@ struct to_handle_s {
   int* d_crow = nullptr;    // [64] compact_row table of the model (tangent-matrix getters)
   double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
   double* d_tmp2 = nullptr;
+  // multi-GPU: RCCL communicator of the batch shards (to_comm_*; librccl is dlopen'ed on first use)
+  void* comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
   // measurement
   bool profile = false;
   std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
@@ -82,6 +85,7 @@ struct ModelOps {
   int (*cost_derivs)(to_handle*, double* grad, double* hess) = nullptr;
   int (*discrete_jacobian)(to_handle*, double* F) = nullptr;
   int (*constraint_eval)(to_handle*, int ci, double* vals, double* jac) = nullptr;
+  int (*constraint_hessian)(to_handle*, int ci, const double* lambda, double* H) = nullptr;
   int (*expand)(to_handle*) = nullptr;
   int (*backward)(to_handle*) = nullptr;
   int (*forward[16])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null

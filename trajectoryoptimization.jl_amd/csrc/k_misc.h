@@ -275,4 +275,55 @@ __global__ void __launch_bounds__(64) k_constraint_eval(KArgs a, int ci, double*
   }
 }
 
+// ∇jacobian! (src/abstract_constraint.jl:255-280): H[w,w,nk,B] += sum_r lambda_r * Hessian of c_r at the nominal trajectory, for
+// one constraint over its knot range; lambda[p,nk,B], both in host layout on the device.  Closed forms (the reference
+// differentiates the Jacobian with ForwardDiff; Goal :70-73 and Bound :767-770 are zero there too): affine rows contribute
+// nothing, |z_I|^2 - a^2 gives 2 I on I, circle / sphere -2 I on the centre coordinates, collision -2 [I -I; -I I],
+// QuatVecEq the second derivative of q/|q|.
+template <class M>
+__global__ void __launch_bounds__(64) k_constraint_hessian(KArgs a, int ci, const double* lambda, double* H) {
+  constexpr int n = M::n, m = M::m, nz = n + m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  ConC& K = P.cons[ci];
+  const int N = P.N, kk = blockIdx.y, k = K.k1 + kk, nk = K.k2 - K.k1 + 1, w = K.width, p = K.p;
+  const double* X = X_SLOT_PTR(a, b, 0);
+  const double* U = U_SLOT_PTR(a, b, 0);
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
+  const size_t kb = (size_t)kk + (size_t)nk * b;
+  const double* lam = lambda + (size_t)p * kb;
+  double* Hk = H + (size_t)w * w * kb;
+  auto add = [&](int i, int j, double v) { Hk[(size_t)i + (size_t)w * j] += v; };
+  const int kind = K.d.kind;
+  if (kind == TO_CON_NORM) {
+    if (K.d.sense != TO_CONE_SECOND_ORDER) for (int t = 0; t < K.d.n_inds; ++t) add(K.d.inds[t] - 1, K.d.inds[t] - 1, 2.0 * lam[0]);
+  } else if (kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE) {
+    const int D = kind == TO_CON_CIRCLE ? 2 : 3;
+    for (int i = 0; i < p; ++i) for (int t = 0; t < D; ++t) add(K.d.inds[t] - 1, K.d.inds[t] - 1, -2.0 * lam[i]);
+  } else if (kind == TO_CON_COLLISION) {
+    const int D = K.d.n_inds / 2;
+    for (int t = 0; t < D; ++t) {
+      const int ia = K.d.inds[t] - 1, ib = K.d.inds[D + t] - 1;
+      add(ia, ia, -2.0 * lam[0]); add(ib, ib, -2.0 * lam[0]); add(ia, ib, 2.0 * lam[0]); add(ib, ia, 2.0 * lam[0]);
+    }
+  } else if (kind == TO_CON_QUATVEC) {
+    double q[4], s2 = 0.0;
+    for (int t = 0; t < 4; ++t) { q[t] = pick<nz>(z, K.d.inds[t] - 1); s2 += q[t] * q[t]; }
+    const double s = sqrt(s2), s3 = s2 * s, s5 = s3 * s2;
+    for (int r = 0; r < 3; ++r) {
+      const int i = r + 1;
+      for (int j = 0; j < 4; ++j)
+        for (int kq = 0; kq < 4; ++kq) {
+          const double v = -((i == j ? q[kq] : 0.0) + (i == kq ? q[j] : 0.0) + (j == kq ? q[i] : 0.0)) / s3 + 3.0 * q[i] * q[j] * q[kq] / s5;
+          add(K.d.inds[j] - 1, K.d.inds[kq] - 1, lam[r] * v);
+        }
+    }
+  }
+}
+
 }  // namespace to

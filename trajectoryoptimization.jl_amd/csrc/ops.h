@@ -81,6 +81,14 @@ int op_constraint_eval(to_handle* h, int ci, double* vals, double* jac) {
   return TO_OK;
 }
 
+template <class M>
+int op_constraint_hessian(to_handle* h, int ci, const double* lambda, double* H) {
+  const DevCon& c = h->cons[ci];
+  hipLaunchKernelGGL(k_constraint_hessian<M>, grid_b(h, c.k2 - c.k1 + 1), dim3(BLOCK), 0, h->stream, h->a, ci, lambda, H);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+
 // expansion variants compiled: 0 = diagonal-kind costs, no constraints; 2 = + selector / SOC-selector constraints;
 // 7 = everything.  Layout (k_expand.h LAY): column layout for the cooperative backward pass, tangent-matrix layout
 // (full or compact cost block) for the MFMA one.
@@ -144,7 +152,7 @@ void fill_misc(ModelOps& o) {
   fill_traits<M>(o);
   o.rollout = op_rollout<M>; o.cost = op_cost<M>; o.violation = op_violation<M>; o.dual_update = op_dual_update<M>;
   o.outer = op_outer<M>; o.cost_derivs = op_cost_derivs<M>; o.discrete_jacobian = op_discrete_jacobian<M>;
-  o.constraint_eval = op_constraint_eval<M>;
+  o.constraint_eval = op_constraint_eval<M>; o.constraint_hessian = op_constraint_hessian<M>;
 }
 // forward variants [LO, HI): models that do not pin RK4 never run the bit-2 variants
 template <class M, int LO, int HI>

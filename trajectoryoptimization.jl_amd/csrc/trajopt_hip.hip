@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include <mutex>
 
 #include "handle.h"
@@ -453,6 +455,44 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
 
 }  // namespace
 
+namespace {
+struct Rccl {
+  struct Id { char b[128]; };  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES), passed by value
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+int load_rccl() {
+  std::call_once(g_rccl_once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+  });
+  if (!g_rccl.lib || !g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+    return fail(TO_ERR_HIP, "librccl.so not found (or incomplete): the multi-GPU entry points need RCCL");
+  return TO_OK;
+}
+#define RCCLCHECK(expr)                                                                                          \
+  do {                                                                                                           \
+    int r_ = (expr);                                                                                             \
+    if (r_ != 0) return fail(TO_ERR_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
+  } while (0)
+constexpr int kNcclDouble = 8;  // ncclFloat64 (rccl.h)
+}  // namespace
+
+
 extern "C" {
 
 int to_abi_version(void) { return TO_ABI_VERSION; }
@@ -627,6 +667,7 @@ int to_destroy(to_handle* h) {
   if (!h) return TO_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   for (void* p : h->allocs) hipFree(p);
   if (h->stage) hipFree(h->stage);
   if (h->counter_host) hipHostFree(h->counter_host);
@@ -908,6 +949,22 @@ static int constraint_eval(to_handle* h, int32_t id, double* vals, double* jac) 
 }
 int to_evaluate_constraints(to_handle* h, int32_t id, double* vals) { CHECK_H(h); CHECK_P(vals); return constraint_eval(h, id, vals, nullptr); }
 int to_constraint_jacobians(to_handle* h, int32_t id, double* jac) { CHECK_H(h); CHECK_P(jac); return constraint_eval(h, id, nullptr, jac); }
+int to_constraint_hessians(to_handle* h, int32_t id, const double* lambda, double* H) {
+  CHECK_H(h); CHECK_P(lambda); CHECK_P(H); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const DevCon& ci = h->cons[id];
+  const DevProblem& P = h->a.P;
+  const int nk = ci.k2 - ci.k1 + 1;
+  const size_t nl = (size_t)ci.p * nk * P.B, nh = (size_t)ci.width * ci.width * nk * P.B;
+  TRY(ensure_stage(h, (nl + nh) * sizeof(double)));
+  double* dl = h->stage; double* dh = h->stage + nl;
+  HIPCHECK(hipMemcpyAsync(dl, lambda, nl * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(dh, H, nh * sizeof(double), hipMemcpyHostToDevice, h->stream));  // the operator ADDS (src/abstract_constraint.jl:255-266)
+  TRY(h->ops->constraint_hessian(h, (int)id, dl, dh));
+  HIPCHECK(hipMemcpyAsync(H, dh, nh * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
 int to_max_violation(to_handle* h, double* c_max) {
   CHECK_H(h); CHECK_P(c_max); TRY(use_device(h));
   if (h->a.P.n_cons == 0) { std::memset(c_max, 0, sizeof(double) * h->a.P.B); return TO_OK; }
@@ -946,6 +1003,63 @@ int to_dual_update(to_handle* h) {
   CHECK_H(h); TRY(use_device(h));
   if (h->a.P.n_cons == 0) return TO_OK;
   TRY(h->ops->dual_update(h));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+
+// ---- multi-GPU: the batch shards across ranks as independent units; the only collective is one RCCL
+// all-gather of the converged trajectories per solve.  librccl.so is loaded on first use (dlopen), so single-GPU hosts
+// need no RCCL at all; a host in ANY language (Julia ccall, Python ctypes) exchanges the 128-byte id out of band
+// (MPI / a file / torch.distributed) exactly as with ncclGetUniqueId.
+int to_comm_unique_id(void* id128) {
+  CHECK_P(id128);
+  TRY(load_rccl());
+  RCCLCHECK(g_rccl.GetUniqueId(id128));
+  return TO_OK;
+}
+int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id128) {
+  CHECK_H(h); CHECK_P(id128);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TO_ERR_ARGUMENT, "rank outside 0..nranks-1");
+  if (h->comm) return fail(TO_ERR_ARGUMENT, "communicator already initialised (to_comm_destroy first)");
+  TRY(load_rccl());
+  TRY(use_device(h));
+  Rccl::Id id;
+  std::memcpy(id.b, id128, sizeof(id.b));
+  RCCLCHECK(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
+  h->comm_rank = rank; h->comm_size = nranks;
+  return TO_OK;
+}
+int to_comm_destroy(to_handle* h) {
+  CHECK_H(h);
+  if (!h->comm) return TO_OK;
+  TRY(use_device(h));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  RCCLCHECK(g_rccl.CommDestroy(h->comm));
+  h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
+  return TO_OK;
+}
+// All ranks hold shards of the same size.  dX_all / dU_all: caller-owned DEVICE buffers of nranks * (n*N*B) and
+// nranks * (m*(N-1)*B) doubles; on return (after to_sync or the call itself: it synchronises the handle's stream) they
+// hold every rank's trajectories in host layout (n, N, B_total), rank-major = global trajectory order.
+int to_allgather(to_handle* h, void* dX_all, void* dU_all) {
+  CHECK_H(h);
+  if (!dX_all && !dU_all) return fail(TO_ERR_NULL, "null pointer");
+  if (!h->comm) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank first");
+  TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  const size_t nx = (size_t)P.n * P.N * P.B, nu = (size_t)P.m * (P.N - 1) * P.B;
+  if (dX_all) {  // own shard written in place, then one in-place all-gather on the handle's stream
+    double* mine = (double*)dX_all + nx * h->comm_rank;
+    hipLaunchKernelGGL(k_to_host, grid_b(h, P.n * P.N), dim3(BLOCK), 0, h->stream, h->a.Xs, mine, P.n * P.N, 0, P.n * P.N, P.B);
+    HIPCHECK(hipGetLastError());
+    RCCLCHECK(g_rccl.AllGather(mine, dX_all, nx, kNcclDouble, h->comm, h->stream));
+  }
+  if (dU_all) {
+    double* mine = (double*)dU_all + nu * h->comm_rank;
+    hipLaunchKernelGGL(k_to_host, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.Us, mine, P.m * (P.N - 1), 0, P.m * (P.N - 1), P.B);
+    HIPCHECK(hipGetLastError());
+    RCCLCHECK(g_rccl.AllGather(mine, dU_all, nu, kNcclDouble, h->comm, h->stream));
+  }
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
