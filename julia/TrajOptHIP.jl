@@ -1,0 +1,505 @@
+# TrajOptHIP.jl — the Julia side of the drop-in boundary: binds every entry point of include/trajopt_hip.h with `ccall`
+# and hangs them on TrajectoryOptimization.jl's own verbs (src/TrajectoryOptimization.jl:29-71), so that code written
+# against the reference keeps its names while a BATCH of problems runs on one MI355X behind `libtrajopt_hip.so`.
+#
+# Julia is not installed in the build image of this repository: the file is written against Julia 1.x / the v0.7.1
+# sources of the reference and cannot be executed there.  tests/test_julia_shim.py checks it structurally: every `to_*`
+# symbol of the header appears in a `ccall` here with the header's argument count, and every struct mirrors the header's
+# field list.
+module TrajOptHIP
+
+using LinearAlgebra
+using StaticArrays
+import RobotDynamics
+import RobotZoo
+import Rotations
+import TrajectoryOptimization
+const RD = RobotDynamics
+const TO = TrajectoryOptimization
+
+const lib = get(ENV, "TRAJOPT_HIP_LIBRARY", "libtrajopt_hip")   # trajectoryoptimization.jl_amd/csrc/libtrajopt_hip.so
+
+# ------------------------------------------------------------------------------------------------ header mirrors
+const TO_ABI_VERSION = Int32(1)
+const MAXN, MAXM, MAXP, MAXPAR, MAXIND = 16, 8, 40, 400, 48
+const PROFILE_SLOTS = 4
+
+struct CostDesc                      # == to_cost_desc
+    kind::Int32
+    terminal::Int32
+    Q::NTuple{MAXN * MAXN,Float64}
+    R::NTuple{MAXM * MAXM,Float64}
+    H::NTuple{MAXM * MAXN,Float64}
+    q::NTuple{MAXN,Float64}
+    r::NTuple{MAXM,Float64}
+    c::Float64
+    w::Float64
+    q_ref::NTuple{4,Float64}
+    q_ind::NTuple{4,Int32}
+end
+
+struct ConstraintDesc                # == to_constraint_desc
+    kind::Int32
+    sense::Int32
+    k_first::Int32
+    k_last::Int32
+    p::Int32
+    n_inds::Int32
+    inds::NTuple{MAXIND,Int32}
+    n_params::Int32
+    params::NTuple{MAXPAR,Float64}
+end
+
+struct ProblemDesc                   # == to_problem_desc
+    abi_version::Int32
+    model::Int32
+    integrator::Int32
+    n::Int32
+    m::Int32
+    N::Int32
+    B::Int32
+    model_params::NTuple{16,Float64}
+    t0::Float64
+    tf::Float64
+    dt::Ptr{Float64}
+    n_costs::Int32
+    costs::Ptr{CostDesc}
+    cost_index::Ptr{Int32}
+    n_constraints::Int32
+    constraints::Ptr{ConstraintDesc}
+end
+
+mutable struct SolverOpts            # == to_solver_opts (names of Altro.SolverOptions)
+    cost_tolerance::Float64
+    gradient_tolerance::Float64
+    iterations::Int32
+    dJ_counter_limit::Int32
+    iterations_linesearch::Int32
+    reserved0::Int32
+    line_search_lower_bound::Float64
+    line_search_upper_bound::Float64
+    line_search_decrease_factor::Float64
+    bp_reg_initial::Float64
+    bp_reg_increase_factor::Float64
+    bp_reg_min::Float64
+    bp_reg_max::Float64
+    bp_reg_fp::Float64
+    max_cost_value::Float64
+    max_state_value::Float64
+    max_control_value::Float64
+    constraint_tolerance::Float64
+    cost_tolerance_intermediate::Float64
+    penalty_initial::Float64
+    penalty_scaling::Float64
+    penalty_max::Float64
+    dual_max::Float64
+    iterations_outer::Int32
+    cost_dt_scaling::Int32
+    iterations_total::Int32
+    reserved1::Int32
+    SolverOpts() = new()
+end
+
+mutable struct SolveStats            # == to_solve_stats
+    iterations::Ptr{Int32}
+    iterations_outer::Ptr{Int32}
+    status::Ptr{Int32}
+    cost::Ptr{Float64}
+    dJ::Ptr{Float64}
+    gradient::Ptr{Float64}
+    c_max::Ptr{Float64}
+    penalty_max::Ptr{Float64}
+    total_iterations::Int64
+    batch_steps::Int32
+    reserved::Int32
+    solve_ms::Float64
+end
+
+@enum SolverStatus::Int32 UNSOLVED = 0 LINESEARCH_FAIL SOLVE_SUCCEEDED MAX_ITERATIONS MAX_ITERATIONS_OUTER MAXIMUM_COST STATE_LIMIT CONTROL_LIMIT NO_PROGRESS COST_INCREASE REGULARIZATION_MAX
+
+# ------------------------------------------------------------------------------------------------ errors
+last_error() = unsafe_string(ccall((:to_last_error, lib), Cstring, ()))
+abi_version() = ccall((:to_abi_version, lib), Cint, ())
+build_id() = unsafe_string(ccall((:to_build_id, lib), Cstring, ()))
+
+"Negative return codes become the exception the reference throws (include/trajopt_hip.h, to_status_code)."
+function check(rc::Integer)
+    rc >= 0 && return rc
+    msg = last_error()
+    rc == -1 && throw(DimensionMismatch(msg))      # src/problem.jl:64-68, src/constraint_list.jl:109
+    rc == -2 && throw(ArgumentError(msg))          # src/problem.jl:88, src/constraints.jl:712
+    rc == -3 && throw(AssertionError(msg))         # src/problem.jl:49-55
+    rc == -7 && error(msg)                         # "Invalid second-order cone projection" src/cones.jl:124
+    error("libtrajopt_hip: $msg (code $rc)")
+end
+
+function device_count()
+    n = Ref{Cint}(0)
+    check(ccall((:to_device_count, lib), Cint, (Ref{Cint},), n))
+    Int(n[])
+end
+
+function default_options()
+    o = SolverOpts()
+    check(ccall((:to_default_options, lib), Cint, (Ref{SolverOpts},), o))
+    o
+end
+
+"`SolverOpts(; cost_tolerance = 1e-4, penalty_scaling = 10.0, ...)`: the defaults with the given fields replaced."
+function solver_options(; kwargs...)
+    o = default_options()
+    for (k, v) in kwargs
+        setfield!(o, k, convert(fieldtype(SolverOpts, k), v))
+    end
+    o
+end
+
+# ------------------------------------------------------------------------------------------------ descriptors
+pad(v, n) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, n)
+padi(v, n) = ntuple(i -> i <= length(v) ? Int32(v[i]) : Int32(0), n)
+const NOQUAT = ((1.0, 0.0, 0.0, 0.0), Int32.((4, 5, 6, 7)))
+
+# cost functions (src/cost_functions.jl:326-453, src/lie_costs.jl:34-55, 178-241)
+costdesc(c::TO.DiagonalCost) = CostDesc(0, c.terminal, pad(diag(c.Q), MAXN * MAXN), pad(diag(c.R), MAXM * MAXM),
+    pad(Float64[], MAXM * MAXN), pad(c.q, MAXN), pad(c.r, MAXM), c.c, 0.0, NOQUAT...)
+costdesc(c::TO.QuadraticCost) = CostDesc(1, c.terminal, pad(vec(Matrix(c.Q)), MAXN * MAXN), pad(vec(Matrix(c.R)), MAXM * MAXM),
+    pad(vec(Matrix(c.H)), MAXM * MAXN), pad(c.q, MAXN), pad(c.r, MAXM), c.c, 0.0, NOQUAT...)
+costdesc(c::TO.DiagonalQuatCost) = CostDesc(2, c.terminal, pad(diag(c.Q), MAXN * MAXN), pad(diag(c.R), MAXM * MAXM),
+    pad(Float64[], MAXM * MAXN), pad(c.q, MAXN), pad(c.r, MAXM), c.c, c.w, Tuple(Float64.(c.q_ref)), Int32.(Tuple(c.q_ind)))
+costdesc(c::TO.ErrorQuadratic) = CostDesc(3, false, pad(diag(c.Q), MAXN * MAXN), pad(diag(c.R), MAXM * MAXM),
+    pad(Float64[], MAXM * MAXN), pad(c.x_ref, MAXN), pad(c.r, MAXM), c.c, 0.0, (1.0, 0.0, 0.0, 0.0), Int32.(Tuple(c.q_ind)))
+
+# constraints (src/constraints.jl); sense codes = to_cone
+sensecode(::TO.Equality) = Int32(0)
+sensecode(::TO.Inequality) = Int32(1)
+sensecode(::TO.SecondOrderCone) = Int32(2)
+conecode(::TO.ZeroCone) = Int32(0)
+conecode(::TO.NegativeOrthant) = Int32(1)
+conecode(::TO.SecondOrderCone) = Int32(2)
+conecode(::TO.PositiveOrthant) = Int32(3)
+conecode(::TO.IdentityCone) = Int32(4)
+
+_con(kind, sense, r, inds, params) = ConstraintDesc(kind, sense, first(r), last(r), 0,
+    length(inds), padi(inds, MAXIND), length(params), pad(params, MAXPAR))
+
+condesc(con::TO.GoalConstraint, r) = _con(0, 0, r, con.inds, con.xf)                                   # :22-87
+condesc(con::TO.BoundConstraint, r) = _con(1, 1, r, Int[], [con.z_max; con.z_min])                      # :644-783
+condesc(con::TO.NormConstraint, r) = _con(2, sensecode(con.sense), r, con.inds, [con.val])              # :438-521
+condesc(con::TO.CircleConstraint, r) = _con(3, 1, r, [con.xi, con.yi], [con.x; con.y; con.radius])      # :168-233
+condesc(con::TO.SphereConstraint, r) = _con(4, 1, r, [con.xi, con.yi, con.zi], [con.x; con.y; con.z; con.radius])  # :249-326
+condesc(con::TO.LinearConstraint, r) = _con(5, sensecode(con.sense), r, con.inds, [vec(Matrix(con.A)); con.b])     # :103-150
+condesc(con::TO.CollisionConstraint, r) = _con(6, 1, r, [con.x1; con.x2], [con.radius])                 # :332-393
+condesc(con::TO.QuatVecEq, r) = _con(7, 0, r, con.qind, Rotations.params(con.qf))                       # :938-965
+function condesc(con::TO.StateBound, r)                                                                 # :528-631
+    n, m = RD.state_dim(con), RD.control_dim(con)
+    _con(1, 1, r, Int[], [con.z_max; fill(Inf, m); con.z_min; fill(-Inf, m)])
+end
+function condesc(con::TO.ControlBound, r)
+    n, m = RD.state_dim(con), RD.control_dim(con)
+    _con(1, 1, r, Int[], [fill(Inf, n); con.z_max; fill(-Inf, n); con.z_min])
+end
+
+"IndexedConstraint (src/constraints.jl:820-936) needs no kernel: the inner descriptor's indices are moved to the slice."
+function condesc(con::TO.IndexedConstraint, r)
+    d = condesc(con.con, r)
+    n, m, n0, m0 = con.n, con.m, con.n0, con.m0
+    newidx(i) = i <= n0 ? con.ix[i] : con.iu[i - n0]          # con.iu is already offset by n (:853)
+    if d.kind == 1                                             # bounds: params = [z_max; z_min] of the inner dimensions
+        zmax, zmin = fill(Inf, n + m), fill(-Inf, n + m)
+        for i in 1:(n0 + m0)
+            zmax[newidx(i)] = d.params[i]
+            zmin[newidx(i)] = d.params[n0 + m0 + i]
+        end
+        return _con(1, 1, r, Int[], [zmax; zmin])
+    end
+    inds = [newidx(Int(d.inds[i])) for i in 1:d.n_inds]
+    ConstraintDesc(d.kind, d.sense, d.k_first, d.k_last, d.p, d.n_inds, padi(inds, MAXIND), d.n_params, d.params)
+end
+
+# models (to_model_id): parameters in the order documented in the header
+modelid(::RobotZoo.Cartpole) = Int32(1)
+modelid(::RobotZoo.Quadrotor) = Int32(2)
+modelid(::RobotZoo.DoubleIntegrator) = Int32(0)
+modelparams(c::RobotZoo.Cartpole) = pad([c.mc, c.mp, c.l, c.g], 16)
+modelparams(q::RobotZoo.Quadrotor) = pad([q.mass, q.J[1, 1], q.J[2, 2], q.J[3, 3], q.gravity..., q.motor_dist, q.kf, q.km], 16)
+modelparams(d::RobotZoo.DoubleIntegrator{N,M}) where {N,M} = pad([1.0, M], 16)
+continuous(model::RD.DiscretizedDynamics) = model.continuous_dynamics
+integratorid(::RD.DiscretizedDynamics{<:Any,<:RD.RK4}) = Int32(0)
+integratorid(::RD.DiscretizedDynamics{<:Any,<:RD.RK3}) = Int32(1)
+integratorid(::RD.DiscretizedDynamics{<:Any,<:RD.Euler}) = Int32(2)
+
+# ------------------------------------------------------------------------------------------------ BatchProblem
+"A `TO.Problem` replicated over `B` independent trajectories on one GPU (trajectory `b` has its own x0, U0, duals)."
+mutable struct BatchProblem
+    prob::TO.Problem
+    handle::Ptr{Cvoid}
+    B::Int
+    n::Int
+    m::Int
+    ne::Int
+    N::Int
+end
+
+function BatchProblem(prob::TO.Problem, B::Integer; device::Integer = 0, opts::Union{Nothing,SolverOpts} = nothing)
+    n, m, N = RD.dims(prob)
+    costs = unique(prob.obj.cost)
+    descs = [costdesc(c) for c in costs]
+    index = Int32[findfirst(c -> c === prob.obj.cost[k], costs) - 1 for k in 1:N]
+    cons = ConstraintDesc[condesc(con, inds) for (inds, con) in zip(prob.constraints)]
+    dts = Float64[z.dt for z in prob.Z[1:N-1]]
+    model = prob.model[1]
+    desc = ProblemDesc(TO_ABI_VERSION, modelid(continuous(model)), integratorid(model), n, m, N, B,
+        modelparams(continuous(model)), prob.Z[1].t, prob.tf, pointer(dts), length(descs), pointer(descs), pointer(index),
+        length(cons), isempty(cons) ? Ptr{ConstraintDesc}(C_NULL) : pointer(cons))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve descs index cons dts begin
+        if opts === nothing
+            check(ccall((:to_create, lib), Cint, (Ref{ProblemDesc}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), desc, C_NULL, device, h))
+        else
+            check(ccall((:to_create, lib), Cint, (Ref{ProblemDesc}, Ref{SolverOpts}, Cint, Ref{Ptr{Cvoid}}), desc, opts, device, h))
+        end
+    end
+    dn, dm, dne, dN, dB = Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+    check(ccall((:to_dims, lib), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}), h[], dn, dm, dne, dN, dB))
+    bp = BatchProblem(prob, h[], B, dn[], dm[], dne[], dN[])
+    finalizer(p -> ccall((:to_destroy, lib), Cint, (Ptr{Cvoid},), p.handle), bp)
+    TO.set_initial_state!(bp, repeat(Vector(prob.x0), 1, B))
+    TO.initial_controls!(bp, repeat(hcat(Vector.(TO.controls(prob))...), 1, 1, B))
+    bp
+end
+
+set_options!(p::BatchProblem, o::SolverOpts) = check(ccall((:to_set_options, lib), Cint, (Ptr{Cvoid}, Ref{SolverOpts}), p.handle, o))
+function get_options(p::BatchProblem)
+    o = SolverOpts()
+    check(ccall((:to_get_options, lib), Cint, (Ptr{Cvoid}, Ref{SolverOpts}), p.handle, o))
+    o
+end
+sync(p::BatchProblem) = check(ccall((:to_sync, lib), Cint, (Ptr{Cvoid},), p.handle))
+stream(p::BatchProblem) = ccall((:to_stream, lib), Ptr{Cvoid}, (Ptr{Cvoid},), p.handle)   # hipStream_t
+
+# getters of the reference pass through to the wrapped problem (src/problem.jl:198-231)
+for f in (:get_model, :get_objective, :get_constraints, :get_trajectory, :get_initial_state, :get_final_state, :gettimes, :horizonlength)
+    @eval TO.$f(p::BatchProblem) = TO.$f(p.prob)
+end
+RD.dims(p::BatchProblem) = (p.n, p.m, p.N)
+
+"num_constraints (src/constraint_list.jl:198): constraint rows per knot point."
+function TO.num_constraints(p::BatchProblem)
+    v = zeros(Int32, p.N)
+    check(ccall((:to_num_constraints, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), p.handle, v))
+    Int.(v)
+end
+
+# ---- trajectory I/O: arrays (n, N, B) / (m, N-1, B) in Julia's native column-major layout
+TO.set_initial_state!(p::BatchProblem, x0::Matrix{Float64}) = check(ccall((:to_set_initial_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, x0))
+TO.initial_controls!(p::BatchProblem, U::Array{Float64,3}) = check(ccall((:to_set_controls, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, U))
+TO.initial_controls!(p::BatchProblem, u::AbstractVector) = check(ccall((:to_set_controls_uniform, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, Vector{Float64}(u)))
+TO.initial_states!(p::BatchProblem, X::Array{Float64,3}) = check(ccall((:to_set_states, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, X))
+function TO.states(p::BatchProblem)
+    X = zeros(p.n, p.N, p.B)
+    check(ccall((:to_get_states, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, X))
+    X
+end
+function TO.controls(p::BatchProblem)
+    U = zeros(p.m, p.N - 1, p.B)
+    check(ccall((:to_get_controls, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, U))
+    U
+end
+function initial_states(p::BatchProblem)
+    x0 = zeros(p.n, p.B)
+    check(ccall((:to_get_initial_state, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, x0))
+    x0
+end
+"Device-to-device copies into caller-owned device buffers (e.g. `ROCArray` pointers), host layout."
+states_device!(p::BatchProblem, dX::Ptr{Cvoid}) = check(ccall((:to_get_states_device, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), p.handle, dX))
+controls_device!(p::BatchProblem, dU::Ptr{Cvoid}) = check(ccall((:to_get_controls_device, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), p.handle, dU))
+
+# ---- goal / reference updates between solves
+"set_goal_state! (src/problem.jl:294-310): new LQR goal in the costs (`set_LQR_goal!` src/cost_functions.jl:249-258) and the GoalConstraint."
+function TO.set_goal_state!(p::BatchProblem, xf::AbstractVector; objective = true, constraint = true)
+    TO.set_goal_state!(p.prob, xf; objective = objective, constraint = constraint)
+    objective && refresh_costs!(p)
+    if constraint
+        for (i, (inds, con)) in enumerate(zip(p.prob.constraints))
+            con isa TO.GoalConstraint || continue
+            d = condesc(con, inds)
+            check(ccall((:to_set_constraint, lib), Cint, (Ptr{Cvoid}, Int32, Ref{ConstraintDesc}), p.handle, i - 1, d))
+        end
+    end
+    p
+end
+"update_trajectory! (src/objective.jl:198-212): the tracking objective follows a new reference window."
+function TO.update_trajectory!(p::BatchProblem, Z, start = 1)
+    TO.update_trajectory!(p.prob.obj, Z, start)
+    refresh_costs!(p)
+end
+function refresh_costs!(p::BatchProblem)
+    for (i, c) in enumerate(unique(p.prob.obj.cost))
+        check(ccall((:to_set_cost, lib), Cint, (Ptr{Cvoid}, Int32, Ref{CostDesc}), p.handle, i - 1, costdesc(c)))
+    end
+    p
+end
+
+# ---- the hot path, phase by phase
+TO.rollout!(p::BatchProblem) = (check(ccall((:to_rollout, lib), Cint, (Ptr{Cvoid},), p.handle)); p)   # src/problem.jl:330-340
+function TO.cost(p::BatchProblem)                                                                          # src/objective.jl:89-93
+    J = zeros(p.B)
+    check(ccall((:to_cost, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, J))
+    J
+end
+function stage_costs(p::BatchProblem)                                                                      # Objective.J, src/objective.jl:104-106
+    Jk = zeros(p.N, p.B)
+    check(ccall((:to_stage_costs, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, Jk))
+    Jk
+end
+function al_cost(p::BatchProblem)
+    J = zeros(p.B)
+    check(ccall((:to_al_cost, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, J))
+    J
+end
+expand!(p::BatchProblem) = (check(ccall((:to_expand, lib), Cint, (Ptr{Cvoid},), p.handle)); p)
+backwardpass!(p::BatchProblem) = (check(ccall((:to_backward, lib), Cint, (Ptr{Cvoid},), p.handle)); p)
+function forwardpass!(p::BatchProblem)
+    ls, J = zeros(Int32, p.B), zeros(p.B)
+    check(ccall((:to_forward, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}), p.handle, ls, J))
+    (ls_index = ls, cost = J)
+end
+
+function _solve!(p::BatchProblem, al::Bool)
+    its, outer, st = zeros(Int32, p.B), zeros(Int32, p.B), zeros(Int32, p.B)
+    J, dJ, grad, cmax, pen = zeros(p.B), zeros(p.B), zeros(p.B), zeros(p.B), zeros(p.B)
+    stats = SolveStats(pointer(its), pointer(outer), pointer(st), pointer(J), pointer(dJ), pointer(grad), pointer(cmax), pointer(pen), 0, 0, 0, 0.0)
+    GC.@preserve its outer st J dJ grad cmax pen begin
+        if al
+            check(ccall((:to_al_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+        else
+            check(ccall((:to_ilqr_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+        end
+    end
+    (iterations = its, iterations_outer = outer, status = SolverStatus.(st), cost = J, dJ = dJ, gradient = grad, c_max = cmax,
+     penalty_max = pen, total_iterations = stats.total_iterations, batch_steps = stats.batch_steps, solve_ms = stats.solve_ms)
+end
+"Altro.iLQRSolver(prob, opts) |> solve!   for the whole batch."
+solve_ilqr!(p::BatchProblem) = _solve!(p, false)
+"The augmented-Lagrangian stage of Altro.ALTROSolver(prob, opts) |> solve!   for the whole batch."
+solve_al!(p::BatchProblem) = _solve!(p, true)
+
+# ---- expansion / gains (error-state blocks; examples/Internal API.ipynb)
+function dynamics_jacobians(p::BatchProblem)
+    A, Bm = zeros(p.ne, p.ne, p.N - 1, p.B), zeros(p.ne, p.m, p.N - 1, p.B)
+    check(ccall((:to_get_dynamics_jacobians, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), p.handle, A, Bm))
+    (A = A, B = Bm)
+end
+function cost_expansion(p::BatchProblem)
+    Qxx, Quu, Qux = zeros(p.ne, p.ne, p.N, p.B), zeros(p.m, p.m, p.N, p.B), zeros(p.m, p.ne, p.N, p.B)
+    qx, qu = zeros(p.ne, p.N, p.B), zeros(p.m, p.N, p.B)
+    check(ccall((:to_get_cost_expansion, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        p.handle, Qxx, Quu, Qux, qx, qu))
+    (Qxx = Qxx, Quu = Quu, Qux = Qux, qx = qx, qu = qu)
+end
+function gains(p::BatchProblem)
+    K, d, dV, rho = zeros(p.m, p.ne, p.N - 1, p.B), zeros(p.m, p.N - 1, p.B), zeros(2, p.B), zeros(p.B)
+    check(ccall((:to_get_gains, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), p.handle, K, d, dV, rho))
+    (K = K, d = d, dV = dV, rho = rho)
+end
+"RD.gradient! / RD.hessian! of the objective on every knot (src/cost_functions.jl:137-233)."
+function cost_gradient_hessian(p::BatchProblem)
+    nz = p.n + p.m
+    g, H = zeros(nz, p.N, p.B), zeros(nz, nz, p.N, p.B)
+    check(ccall((:to_cost_expansion, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), p.handle, g, H))
+    (grad = g, hess = H)
+end
+"RD.jacobian! of the discretised dynamics on every knot: F = [A B]."
+function discrete_jacobian(p::BatchProblem)
+    F = zeros(p.n, p.n + p.m, p.N - 1, p.B)
+    check(ccall((:to_discrete_jacobian, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, F))
+    F
+end
+
+# ---- constraints (src/abstract_constraint.jl:200-280)
+function constraint_info(p::BatchProblem, i::Integer)
+    cp, cw, cnk, cs = Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+    check(ccall((:to_constraint_info, lib), Cint, (Ptr{Cvoid}, Int32, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int32}), p.handle, i - 1, cp, cw, cnk, cs))
+    (p = Int(cp[]), width = Int(cw[]), nk = Int(cnk[]), sense = Int(cs[]))
+end
+"evaluate_constraints!: values of constraint `i` (1-based, ConstraintList order) over its knot range, (p, nk, B)."
+function TO.evaluate_constraints!(p::BatchProblem, i::Integer)
+    c = constraint_info(p, i)
+    vals = zeros(c.p, c.nk, p.B)
+    check(ccall((:to_evaluate_constraints, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), p.handle, i - 1, vals))
+    vals
+end
+"constraint_jacobians!: (p, w, nk, B) with w = n for state constraints, n+m otherwise; fully written."
+function TO.constraint_jacobians!(p::BatchProblem, i::Integer)
+    c = constraint_info(p, i)
+    jac = zeros(c.p, c.width, c.nk, p.B)
+    check(ccall((:to_constraint_jacobians, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), p.handle, i - 1, jac))
+    jac
+end
+"∇constraint_jacobians!: H += Σ_r λ_r ∇²c_r (ADDS, like the reference; src/abstract_constraint.jl:255-280)."
+function TO.∇constraint_jacobians!(p::BatchProblem, i::Integer, H::Array{Float64,4}, λ::Array{Float64,3})
+    check(ccall((:to_constraint_hessians, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), p.handle, i - 1, λ, H))
+    H
+end
+function TO.max_violation(p::BatchProblem)
+    c = zeros(p.B)
+    check(ccall((:to_max_violation, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, c))
+    c
+end
+function duals(p::BatchProblem, i::Integer)
+    c = constraint_info(p, i)
+    λ, μ = zeros(c.p, c.nk, p.B), zeros(p.B)
+    check(ccall((:to_get_duals, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), p.handle, i - 1, λ, μ))
+    (λ = λ, μ = μ)
+end
+set_duals!(p::BatchProblem, i::Integer, λ::Array{Float64,3}, μ::Vector{Float64}) =
+    check(ccall((:to_set_duals, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), p.handle, i - 1, λ, μ))
+reset_duals!(p::BatchProblem) = check(ccall((:to_reset_duals, lib), Cint, (Ptr{Cvoid},), p.handle))
+dual_update!(p::BatchProblem) = check(ccall((:to_dual_update, lib), Cint, (Ptr{Cvoid},), p.handle))
+
+# ---- cones, batched and stateless (src/cones.jl:96-291); x is (dim, count)
+function TO.projection!(cone::TO.Conic, px::Matrix{Float64}, x::Matrix{Float64}; device = 0)
+    status = zeros(Int32, size(x, 2))
+    check(ccall((:to_cone_projection, lib), Cint, (Cint, Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+        device, conecode(cone), size(x, 1), size(x, 2), x, px, status))
+    px
+end
+function TO.∇projection!(cone::TO.Conic, J::Array{Float64,3}, x::Matrix{Float64}; device = 0)
+    check(ccall((:to_cone_projection_jacobian, lib), Cint, (Cint, Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}),
+        device, conecode(cone), size(x, 1), size(x, 2), x, J))
+    J
+end
+function TO.∇²projection!(cone::TO.Conic, H::Array{Float64,3}, x::Matrix{Float64}, b::Matrix{Float64}; device = 0)
+    check(ccall((:to_cone_projection_hessian, lib), Cint, (Cint, Int32, Int32, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        device, conecode(cone), size(x, 1), size(x, 2), x, b, H))
+    H
+end
+
+# ---- multi-GPU: one process per GPU, the batch shards as independent units, one RCCL all-gather of the results
+"128-byte RCCL id: create on rank 0, ship to the other ranks (MPI.Bcast!, a file, ...)."
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:to_comm_unique_id, lib), Cint, (Ptr{Cvoid},), id))
+    id
+end
+comm_init_rank!(p::BatchProblem, nranks::Integer, rank::Integer, id::Vector{UInt8}) =
+    check(ccall((:to_comm_init_rank, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}), p.handle, nranks, rank, id))
+"All ranks' trajectories into caller-owned device buffers of nranks*n*N*B and nranks*m*(N-1)*B doubles (global order)."
+allgather!(p::BatchProblem, dX_all::Ptr{Cvoid}, dU_all::Ptr{Cvoid}) =
+    check(ccall((:to_allgather, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), p.handle, dX_all, dU_all))
+comm_destroy!(p::BatchProblem) = check(ccall((:to_comm_destroy, lib), Cint, (Ptr{Cvoid},), p.handle))
+
+# ---- measurement
+set_profiling!(p::BatchProblem, on::Bool) = check(ccall((:to_set_profiling, lib), Cint, (Ptr{Cvoid}, Cint), p.handle, on))
+reset_profile!(p::BatchProblem) = check(ccall((:to_reset_profile, lib), Cint, (Ptr{Cvoid},), p.handle))
+function profile(p::BatchProblem)
+    ms, launches = zeros(PROFILE_SLOTS), zeros(Int64, PROFILE_SLOTS)
+    check(ccall((:to_get_profile, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), p.handle, ms, launches))
+    (kernel_ms = ms, launches = launches)
+end
+
+export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, expand!, backwardpass!, forwardpass!,
+    stage_costs, al_cost, dynamics_jacobians, cost_expansion, gains, cost_gradient_hessian, discrete_jacobian, duals, set_duals!,
+    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, comm_destroy!, device_count, build_id
+
+end # module
