@@ -25,6 +25,13 @@ def oracle():
 @pytest.fixture(scope="session")
 def hip():
     """The product library (csrc/libtrajopt_hip.so).  Must exist; must see a GPU for -m gpu tests."""
+    # torch first: it ships its own HIP runtime; whichever libamdhip64 is loaded first serves the whole process, and a torch
+    # initialised AFTER the system runtime finds no devices (the RCCL gather test needs torch device tensors)
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     import trajopt_amd as T
     lib = T.load_hip_library()
     return lib
