@@ -152,12 +152,20 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   }
 }
 
+#ifndef TO_EXPAND_KC_CONS
+#define TO_EXPAND_KC_CONS 0  // 0: the model's expand_knots for every variant
+#endif
+template <class M, int VAR>
+__host__ __device__ constexpr int expand_kc() {
+  return ((VAR & 2) != 0 && TO_EXPAND_KC_CONS > 0 && M::expand_knots > 1) ? TO_EXPAND_KC_CONS : M::expand_knots;
+}
+
 // A wave walks M::expand_knots consecutive knots and fetches the next knot's state/control while it works on the
 // current one: with one wave per SIMD (Quadrotor) nothing else hides the load round trip, which was half of the wave's
 // life (rocprof: SQ_WAIT_ANY 49 % of SQ_WAVE_CYCLES, 60 % with AL terms).  x_{k+1} is shared between neighbours.
 template <class M, int FIXED_INTEG, int VAR, int LAY>
 __global__ void __launch_bounds__(64) k_expand(KArgs a) {
-  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, KC = M::expand_knots;
+  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, KC = expand_kc<M, VAR>();
   constexpr int R = Coop<M>::R, G = Coop<M>::G;
   const int gtile = blockIdx.x, lane = threadIdx.x;
   const int g = lane / R, j = lane % R;

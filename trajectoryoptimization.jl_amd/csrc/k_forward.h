@@ -14,6 +14,9 @@
 
 #include "common.h"
 
+#ifndef TO_FWD_WAVES
+#define TO_FWD_WAVES 1
+#endif
 namespace to {
 
 template <class M, bool WITHK>
@@ -76,11 +79,12 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const to_solver_opts& o = P.opts;
   const int N = P.N;
   constexpr int c = 0;  // nominal slot
-  const double* Xc = X_SLOT_PTR(a, b, c);
-  const double* Uc = U_SLOT_PTR(a, b, c);
-  double* Xn = X_SLOT_PTR(a, b, cs);  // = Xc-array + (wave*L)*64 + hardware lane: a wave's candidate stores are whole 512-byte rows
-  double* Un = U_SLOT_PTR(a, b, cs);
-  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
+  // tile is wave-uniform (the TW trajectories of a wave share a 64-trajectory tile): scalar bases + per-lane 32-bit offsets
+  const double* Xc = TILE_PTR(a.Xs, N * n);
+  const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
+  double* Xn = a.Xc + ((size_t)blockIdx.x * (size_t)(N * n)) * 64 + hw;        // candidates: forward-wave-major (common.h), slot cs = q + 1
+  double* Un = a.Uc + ((size_t)blockIdx.x * (size_t)((N - 1) * m)) * 64 + hw;  // a wave's candidate stores are whole 512-byte rows
+  const double* pK = a.Kt + ((size_t)b0 * (N - 1)) * RSK + (b - b0) * ((N - 1) * RSK);
   const double* px0 = TILE_PTR(a.x0, n);
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
@@ -224,7 +228,7 @@ __device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int
 // (SURVEY.md row S2); then — when a.control — the per-trajectory solver state machine runs: convergence test (row S3)
 // and the hand-over to the AL outer update (row S4, k_outer_*).
 template <class M, int MODE>
-__global__ void __launch_bounds__(64) k_forward(KArgs a) {
+__global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   extern __shared__ double kbuf[];  // M::lds_gains: two buffers of gains_lds_doubles(TW)
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
@@ -232,7 +236,7 @@ __global__ void __launch_bounds__(64) k_forward(KArgs a) {
   const int cwl = a.cw_log, CW = 1 << cwl, TW = 64 >> cwl;
   const int t = hw & (TW - 1), q = hw >> (6 - cwl);
   const int b0 = blockIdx.x * TW, b = b0 + t;  // b < Bp always (Bp is a multiple of 64)
-  const int tile = b >> 6, lane = b & 63;
+  const int tile = b0 >> 6, lane = b & 63;     // TW divides 64: the wave's trajectories share a tile (wave-uniform tile index)
   // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
   // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
   // predicated.  The wave leaves only when no lane needs anything.

@@ -95,8 +95,9 @@ int op_constraint_hessian(to_handle* h, int ci, const double* lambda, double* H)
 template <class M, int FI>
 int op_expand_fi(to_handle* h) {
   const DevProblem& P = h->a.P;
-  const dim3 grid((P.B + h->G - 1) / h->G, (P.N + M::expand_knots - 1) / M::expand_knots);
   const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
+  const int kc = var == 0 ? expand_kc<M, 0>() : expand_kc<M, 2>();
+  const dim3 grid((P.B + h->G - 1) / h->G, (P.N + kc - 1) / kc);
   const int lay = !h->a.bwd_mfma ? 0 : (h->a.h_compact ? 2 : 1);
 #define TO_EXPAND_CASE(V, LY) \
   if (var == V && lay == LY) { hipLaunchKernelGGL((k_expand<M, FI, V, LY>), grid, dim3(BLOCK), 0, h->stream, h->a); HIPCHECK(hipGetLastError()); return TO_OK; }

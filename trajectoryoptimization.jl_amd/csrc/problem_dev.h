@@ -444,8 +444,11 @@ __device__ __forceinline__ void visit_static(int D, F&& f, std::integer_sequence
   ((Is < D ? (f(Is, SIdx<OFF + Is>{}), 0) : 0), ...);
 }
 // calls f(row, idx) for the first D selector rows of K; idx is an SIdx<> on the fast layouts, an int otherwise
-template <int n, int m, class F>
+// CTRL_ONLY: the caller knows K.fast == 2 (register-cached control-block constraints): the other paths, which would index
+// the caller's register arrays with a run-time row and so push them into scratch memory, are not even compiled.
+template <int n, int m, bool CTRL_ONLY = false, class F>
 __device__ __forceinline__ void visit_rows(ConC& K, int D, F&& f) {
+  if constexpr (CTRL_ONLY) { visit_static<n>(D, f, std::make_integer_sequence<int, m>{}); return; }
   if (K.fast == 1) visit_static<0>(D, f, std::make_integer_sequence<int, n>{});
   else if (K.fast == 2) visit_static<n>(D, f, std::make_integer_sequence<int, m>{});
   else for (int r = 0; r < D; ++r) f(r, (int)K.sidx[r]);
@@ -578,7 +581,7 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
   const int p = K.p;
   if (K.d.sense == TO_CONE_SECOND_ORDER) {
     double a2 = 0.0, lw = 0.0;  // lw = lb_v · w_v with w = ∇c v
-    visit_rows<n, m>(K, p - 1, [&](int r, auto idx) {
+    visit_rows<n, m, (REGROWS > 0)>(K, p - 1, [&](int r, auto idx) {
       const double lb = lam[r * stride] - mu * (K.ssgn[r] * (zget<nz>(z, idx) - K.soff[r]));
       a2 += lb * lb;
       lw += lb * (K.ssgn[r] * zget<nz>(v, idx));
@@ -591,7 +594,7 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
     const double ra = rcp_fast(a);  // reciprocal-multiplies: an IEEE double division is ~27 VALU instructions on gfx950
     const double cf = inside ? 1.0 : 0.5 * (1 + s * ra);
     const double k3 = inside ? 0.0 : (0.5 * s) * (ra * ra * ra);
-    visit_rows<n, m>(K, p - 1, [&](int r, auto idx) {
+    visit_rows<n, m, (REGROWS > 0)>(K, p - 1, [&](int r, auto idx) {
       const double sg = K.ssgn[r];
       const double lb = lam[r * stride] - mu * (sg * (zget<nz>(z, idx) - K.soff[r]));
       zadd<nz>(g, idx, -sg * (cf * lb));                       // −∇c'Π(lb)
@@ -600,14 +603,14 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
     });
   } else if (K.selector) {
     const bool eq = (K.d.sense == TO_CONE_ZERO);
-    visit_rows<n, m>(K, p, [&](int r, auto idx) {
+    visit_rows<n, m, (REGROWS > 0)>(K, p, [&](int r, auto idx) {
       const double sg = K.ssgn[r];
       const double l = lam[r * stride], c = sg * (zget<nz>(z, idx) - K.soff[r]);
       const bool active = eq || (c >= 0.0) || (l > 0.0);
       zadd<nz>(g, idx, sg * (l + (active ? mu * c : 0.0)));
       zadd<nz>(y, idx, active ? mu * zget<nz>(v, idx) : 0.0);
     });
-  } else if constexpr (GENERIC) {
+  } else if constexpr (GENERIC && REGROWS == 0) {
     double coef[nz];
     for (int r = 0; r < p; ++r) {
       const double l = lam[r * stride], c = con_row<nz>(K, z, r, coef);
