@@ -201,6 +201,9 @@ __global__ void k_cone_jacobian(int cone, int dim, long long count, const double
   if (status) status[t] = st;
 }
 
+// Hessian of b'Π_K(x).  The second-order-cone branch restates the reference's closed form term by term (src/cones.jl:244-270:
+// the H1/H2/H3 split of the v-v block, the hi/(2a) border) so that the stateless operator returns exactly what ∇²projection!
+// returns; it is not on the solve path (the AL expansion uses the Moreau identities of problem_dev.h instead).
 __global__ void k_cone_hessian(int cone, int dim, long long count, const double* x, const double* bvec, double* hess, int* status) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
