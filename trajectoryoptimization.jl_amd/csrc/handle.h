@@ -74,6 +74,7 @@ struct ModelOps {
   bool coop_backward = true;   // M::coop_backward: column-layout expansion + cooperative LDS Riccati
   bool lds_gains = false;      // forward pass stages gains through LDS
   int expand_knots = 1;
+  int ls_first_round = 16;     // M::ls_first_round
   int gains_lds_pieces = 0;    // 16-byte pieces of one gains row (LDS sizing of the forward pass)
   int crow[64];                // compact_row(g, c) of the tangent-matrix layout
   int nep = 0, rs = 0;         // Tm<M>::NEP, Tm<M>::RS

@@ -113,6 +113,8 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr int expand_knots = 1;
   static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
   static constexpr bool lds_gains = false;             // forward pass: the gains row of a knot is a handful of doubles, loaded directly
+  static constexpr int ls_first_round = 4;             // step sizes tried concurrently (results do not depend on it): these models accept
+                                                       // within the first 4 in 99.9 % of the iterations (tools/ls_hist.py); more only adds candidate traffic
   static constexpr bool mfma_backward = false, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
@@ -132,6 +134,8 @@ struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr int expand_knots = 1;
   static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
   static constexpr bool lds_gains = false;             // forward pass: the gains row of a knot is a handful of doubles, loaded directly
+  static constexpr int ls_first_round = 4;             // step sizes tried concurrently (results do not depend on it): these models accept
+                                                       // within the first 4 in 99.9 % of the iterations (tools/ls_hist.py); more only adds candidate traffic
   static constexpr bool mfma_backward = true, coop_backward = true;  // both backward passes: MFMA for latency (small batches), cooperative for throughput
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
@@ -164,6 +168,7 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr int expand_knots = 4;               // knots one expansion wave walks (software-pipelined loads)
   static constexpr bool accept_write_through = false;  // accepted steps are copied onto slot 0 by k_accept after every forward pass
   static constexpr bool lds_gains = true;  // forward pass: the 52-double gains row of a knot comes through LDS (DMA), not prefetch VGPRs
+  static constexpr int ls_first_round = 16;  // accepted step sizes sit at 2^-5 .. 2^-12 late in these solves (tools/ls_hist.py): a deep first round
   static constexpr bool mfma_backward = true, coop_backward = false;  // MFMA backward pass only (the cooperative kernel needed 256 VGPR + 236 AGPR here)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {

@@ -15,6 +15,7 @@ void fill_traits(ModelOps& o) {
   o.coop_backward = M::coop_backward;
   o.lds_gains = M::lds_gains;
   o.expand_knots = M::expand_knots;
+  o.ls_first_round = M::ls_first_round;
   o.gains_lds_pieces = Gains<M>::RSK / 2;
   o.nep = Tm<M>::NEP; o.rs = Tm<M>::RS;
   for (int g = 0; g < 4; ++g)

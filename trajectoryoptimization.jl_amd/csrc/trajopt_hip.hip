@@ -594,9 +594,10 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   P.dt = (DoubleC*)h->d_dt; P.cost_index = (IntC*)h->d_cost_index; P.costs = (CostC*)h->d_costs; P.cons = (ConC*)h->d_cons;
   // Line-search candidates evaluated concurrently per trajectory, CW (a power of two): a forward wave holds CW
   // candidates x 64/CW trajectories, so the launch has Bp*CW/64 waves — enough to cover the 1024 SIMDs of the chip for
-  // small batches, at most 16 (the default search depth is 20: a second in-kernel round covers the rest, rarely needed).
+  // small batches, at most the model's ls_first_round (4 for the small models, 16 for the Quadrotor; the default search
+  // depth is 20: further in-kernel rounds cover the rest).
   {
-    int cw = std::max(1, std::min(16, 2048 / (P.Bp / BLOCK)));
+    int cw = std::max(1, std::min(h->ops->ls_first_round, 2048 / (P.Bp / BLOCK)));
     if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
     a.cw_log = 0;
     while ((2 << a.cw_log) <= cw) ++a.cw_log;
