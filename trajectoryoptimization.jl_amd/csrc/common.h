@@ -22,8 +22,9 @@ struct KArgs {
                     // contiguous block [w][e][64] and its hardware lane q*TW + (b % TW) holds candidate q of trajectory b, so
                     // every candidate store of a wave is one 512-byte row of one stream (slot-major candidates made each
                     // store touch CW streams 85 MB apart: 4x slower forward pass, TLB- and partial-line-bound)
-  int T;          // candidate slots = CW = line-search candidates a wave evaluates concurrently (power of two <= 16)
-  int cw_log;     // log2(CW); a forward wave holds CW candidates x TW = 64/CW trajectories
+  int CW, TW;     // a forward wave holds CW line-search candidates x TW trajectories, CW*TW <= 64 (hardware lane q*TW + t); candidate
+                  // "slot" q+1 of trajectory b lives in the block of wave b / TW (below).  Two shapes are in use: the base one (CW a
+                  // power of two, TW = 64/CW) and, once the active trajectories fit the chip that way, CW = the whole search depth
   double* x0;     // L = n
   int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): copied onto slot 0 by k_accept, or
                   //      written through by the next k_expand (M::accept_write_through)
@@ -54,13 +55,13 @@ template <class M> struct Gains { static constexpr int RSK = M::m * (M::ne + 1);
 #define TILE_LANE() const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane
 // pointer to element 0 of trajectory b in slot sl of a trajectory array with L elements (sl = 0: nominal, sl = q+1: line-search
 // candidate q); element e is p[e*64] in both layouts
-__device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, int cw_log, int b, int sl, int L) {
+__device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, int TW, int b, int sl, int L) {
   if (sl == 0) return nominal + ((size_t)(b >> 6) * (size_t)L) * 64 + (b & 63);
-  const int twl = 6 - cw_log;
-  return cand + ((size_t)(b >> twl) * (size_t)L) * 64 + ((sl - 1) << twl) + (b & ((1 << twl) - 1));
+  const int w = b / TW;
+  return cand + ((size_t)w * (size_t)L) * 64 + (sl - 1) * TW + (b - w * TW);
 }
-#define X_SLOT_PTR(a, b, sl) slot_ptr((a).Xs, (a).Xc, (a).cw_log, b, sl, (a).P.N * (a).P.n)
-#define U_SLOT_PTR(a, b, sl) slot_ptr((a).Us, (a).Uc, (a).cw_log, b, sl, ((a).P.N - 1) * (a).P.m)
+#define X_SLOT_PTR(a, b, sl) slot_ptr((a).Xs, (a).Xc, (a).TW, b, sl, (a).P.N * (a).P.n)
+#define U_SLOT_PTR(a, b, sl) slot_ptr((a).Us, (a).Uc, (a).TW, b, sl, ((a).P.N - 1) * (a).P.m)
 
 // objective (+AL) value of one knot.  u must be zeros at the terminal knot (the reference evaluates the
 // terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).

@@ -44,6 +44,8 @@ struct to_handle_s {
   size_t stage_bytes = 0;
   int* counter_host = nullptr;  // pinned
   int counter_len = 0;
+  int cw_base = 1, tw_base = 64;  // forward-wave shape: base, and the deep one (0: none) used once the active trajectories fit
+  int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   // device copies of the descriptor tables
   to_cost_desc* d_costs = nullptr;

@@ -41,7 +41,7 @@ struct FwdKnot {  // nominal state/control of one knot (+ its gains row for mode
 // instruction i belongs to trajectory GL / PCS and lands at kbuf + 16 GL, i.e. the rows sit back to back in LDS
 // (row stride RSK doubles: 416 B for the Quadrotor, so the TW rows read together fall on distinct banks).
 template <class M>
-__device__ __forceinline__ void stage_gains(const double* Kt, int b0, int TW, int k, int N, double* kbuf, int hw) {
+__device__ __forceinline__ void stage_gains(const double* Kt, int b0, int bmax, int TW, int k, int N, double* kbuf, int hw) {
   constexpr int RSK = Gains<M>::RSK;
   static_assert(RSK % 2 == 0, "gains rows must be whole 16-byte pieces");
   constexpr int PCS = RSK / 2;
@@ -53,7 +53,8 @@ __device__ __forceinline__ void stage_gains(const double* Kt, int b0, int TW, in
     int t = gl / PCS;
     const int off = gl - t * PCS;
     t = t < TW ? t : TW - 1;  // lanes past the last row re-fetch it (their LDS pieces are never read)
-    const char* src = (const char*)(Kt + ((size_t)(b0 + t) * (N - 1) + k) * RSK) + off * 16;
+    const int bt = (b0 + t) < bmax ? b0 + t : bmax;  // the last wave of a batch may reach past it
+    const char* src = (const char*)(Kt + ((size_t)bt * (N - 1) + k) * RSK) + off * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)((char*)kbuf + (size_t)i0 * 16), 16, 0, 0);
   }
 }
@@ -79,12 +80,11 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const to_solver_opts& o = P.opts;
   const int N = P.N;
   constexpr int c = 0;  // nominal slot
-  // tile is wave-uniform (the TW trajectories of a wave share a 64-trajectory tile): scalar bases + per-lane 32-bit offsets
   const double* Xc = TILE_PTR(a.Xs, N * n);
   const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
   double* Xn = a.Xc + ((size_t)blockIdx.x * (size_t)(N * n)) * 64 + hw;        // candidates: forward-wave-major (common.h), slot cs = q + 1
   double* Un = a.Uc + ((size_t)blockIdx.x * (size_t)((N - 1) * m)) * 64 + hw;  // a wave's candidate stores are whole 512-byte rows
-  const double* pK = a.Kt + ((size_t)b0 * (N - 1)) * RSK + (b - b0) * ((N - 1) * RSK);
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const double* px0 = TILE_PTR(a.x0, n);
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
@@ -120,7 +120,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
-  if constexpr (KLDS) stage_gains<M>(a.Kt, b0, TW, 0, N, kbuf, hw);
+  if constexpr (KLDS) stage_gains<M>(a.Kt, b0, P.Bp - 1, TW, 0, N, kbuf, hw);
   FwdKnot<M, !KLDS> nxt;
   nxt.load(Xc, Uc, pK);
   const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + RSK;  // knot k+1 of the nominal
@@ -139,7 +139,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     // must not follow the stores), then x̄_k: nothing issued here is needed before the next wait, a whole knot away
     const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
     if (k + 1 < N - 1) {
-      if constexpr (KLDS) stage_gains<M>(a.Kt, b0, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
+      if constexpr (KLDS) stage_gains<M>(a.Kt, b0, P.Bp - 1, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
       nxt.load(pXn, pUn, pKn);
       if (ncs > 0) cs0.prefetch(k + 1);
       if (ncs > 1) cs1.prefetch(k + 1);
@@ -233,14 +233,15 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
   const int hw = threadIdx.x;
-  const int cwl = a.cw_log, CW = 1 << cwl, TW = 64 >> cwl;
-  const int t = hw & (TW - 1), q = hw >> (6 - cwl);
-  const int b0 = blockIdx.x * TW, b = b0 + t;  // b < Bp always (Bp is a multiple of 64)
-  const int tile = b0 >> 6, lane = b & 63;     // TW divides 64: the wave's trajectories share a tile (wave-uniform tile index)
+  const int CW = a.CW, TW = a.TW;
+  const int q = hw / TW, t = hw - q * TW;      // lanes with q >= CW (64 is not a multiple of TW) ride along without a candidate
+  const int b0 = blockIdx.x * TW;
+  const int b = (b0 + t) < P.Bp ? b0 + t : P.Bp - 1;  // clamped: the last wave may reach past the batch
+  const int tile = b >> 6, lane = b & 63;
   // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
   // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
   // predicated.  The wave leaves only when no lane needs anything.
-  const bool act = b < P.B && a.active[b] != 0;
+  const bool act = (b0 + t) < P.B && a.active[b] != 0;
   if (__ballot(act) == 0) return;
   const bool bpfail = act && a.bpfail[b] != 0;
   const int total = o.iterations_linesearch;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   const int krow = t * Gains<M>::RSK;
   for (int c0 = 0; c0 < total; c0 += CW) {
     if (__ballot(need) == 0) break;
-    const bool cand = need && (c0 + q) < total;
+    const bool cand = need && q < CW && (c0 + q) < total;
     double J, gm;
     bool ok;
     forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, q + 1, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
     const unsigned long long am = __ballot(accept);
     int qs = -1;  // first accepted candidate of this lane's trajectory (bits qq*TW + t)
     for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
-    const int src = (qs >= 0 ? qs : q) * TW + t;
+    const int src = (qs >= 0 ? qs : 0) * TW + t;
     const double Js = __shfl(J, src), gs = __shfl(gm, src);
     if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
     alpha *= fCW;

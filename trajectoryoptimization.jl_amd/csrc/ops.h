@@ -142,9 +142,9 @@ int op_backward(to_handle* h) {
 template <class M, int MODE>
 int op_forward(to_handle* h) {
   const KArgs& a = h->a;
-  const int TW = 64 >> a.cw_log;
+  const int TW = a.TW;
   const size_t lds = M::lds_gains ? sizeof(double) * (2 * gains_lds_doubles<M>(TW) + StageCostLds<M::n, M::m>::size) : 0;  // two gains buffers + the stage-cost table
-  hipLaunchKernelGGL((k_forward<M, MODE>), dim3(a.P.Bp / TW), dim3(BLOCK), lds, h->stream, a);
+  hipLaunchKernelGGL((k_forward<M, MODE>), dim3((a.P.Bp + TW - 1) / TW), dim3(BLOCK), lds, h->stream, a);
   HIPCHECK(hipGetLastError());
   return TO_OK;
 }

@@ -336,6 +336,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   const int rc = solve_impl(h, st, al_mode);
   h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
+  h->a.CW = h->cw_base; h->a.TW = h->tw_base;
   return rc;
 }
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
@@ -377,7 +378,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   // most one chunk of launches whose kernels find nothing to do (kernels of finished trajectories exit at once).
   constexpr int CHECK_EVERY = 4;
   const hipEvent_t cev[2] = {h->sev[2], h->sev[3]};
-  int launched = 0, checked = 0, nchunks = 0;
+  int launched = 0, checked = 0, nchunks = 0, last_active = P.B;
   bool done = false;
   auto enqueue_chunk = [&]() -> int {
     const int chunk = std::min(CHECK_EVERY, max_steps - launched);
@@ -389,6 +390,9 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
       TRY(launch_backward(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
+      // forward-wave shape of this step, from the last active count the host has seen (results do not depend on it)
+      const bool deep = h->cw_deep && last_active <= h->deep_max_active;
+      a.CW = deep ? h->cw_deep : h->cw_base; a.TW = deep ? h->tw_deep : h->tw_base;
       TRY(launch_forward(h, !h->ops->write_through));
       if (al_mode) TRY(launch_outer(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
@@ -407,11 +411,13 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
     const int upto = std::min(launched, (waited + 1) * CHECK_EVERY);
     for (; checked < upto; ++checked) {
       ++steps;
+      last_active = h->counter_host[checked];
       if (h->counter_host[checked] == 0) { done = true; break; }
     }
     ++waited;
   }
   TRY(launch_accept(h));  // trajectories keep the slot of their last accepted step until here
+  a.CW = h->cw_base; a.TW = h->tw_base;
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -599,9 +605,21 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   {
     int cw = std::max(1, std::min(h->ops->ls_first_round, 2048 / (P.Bp / BLOCK)));
     if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
-    a.cw_log = 0;
-    while ((2 << a.cw_log) <= cw) ++a.cw_log;
-    a.T = 1 << a.cw_log;
+    int lg = 0;
+    while ((2 << lg) <= cw) ++lg;
+    h->cw_base = 1 << lg; h->tw_base = 64 / h->cw_base;
+    a.CW = h->cw_base; a.TW = h->tw_base;
+    // Deep shape: the WHOLE search depth in one round (20 step sizes x 3 trajectories per wave by default).  A trajectory
+    // that rejects the first CW step sizes otherwise costs the batch a second full rollout pass (the Quadrotor solves do so
+    // in half of their steps: forward 1.0 ms instead of 0.55 ms).  It needs 64/TW = 21 waves per 64 trajectories instead of
+    // 16, so the solve loop switches to it once the active trajectories fit the chip that way (one wave per SIMD).
+    const int total = P.opts.iterations_linesearch;
+    if (!h->ops->write_through && total > h->cw_base && total <= 64 && !std::getenv("TRAJOPT_LS_CANDIDATES")) {
+      hipDeviceProp_t prop;
+      HIPB(hipGetDeviceProperties(&prop, device));
+      h->cw_deep = total; h->tw_deep = 64 / total;
+      h->deep_max_active = prop.multiProcessorCount * 4 * h->tw_deep;
+    }
   }
   // backward-pass flavour: one wave per trajectory on the matrix cores (tangent-matrix expansion) where the model has it,
   // else the cooperative LDS kernel on the column layout.  TRAJOPT_BACKWARD=coop|mfma overrides (A/B measurements).
@@ -616,8 +634,12 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   TRYB(dev_alloc(h, &a.Xs, (size_t)N * n * Bp));
   TRYB(dev_alloc(h, &a.Us, (size_t)(N - 1) * m * Bp));
-  TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * Bp * a.T));        // candidates, forward-wave-major (common.h)
-  TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * Bp * a.T));
+  {  // candidates, forward-wave-major (common.h): 64 lanes per wave in either shape
+    size_t waves = (Bp + h->tw_base - 1) / h->tw_base;
+    if (h->cw_deep) waves = std::max(waves, (Bp + h->tw_deep - 1) / h->tw_deep);
+    TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * waves * 64));
+    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * waves * 64));
+  }
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
