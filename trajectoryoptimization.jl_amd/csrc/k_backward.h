@@ -275,6 +275,9 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
 // 12x16 blocks are spread over 64 lanes (3-4 registers each) instead of 16 lanes holding 400 doubles and exchanging
 // every operand through LDS: 256 VGPR + 248 AGPR at one wave per SIMD before, ~100 registers now.
 typedef double v4d __attribute__((ext_vector_type(4)));
+#ifndef TO_BWD_WAVES
+#define TO_BWD_WAVES 1  // minimum waves per SIMD the MFMA backward kernel is compiled for (register cap 512 / waves)
+#endif
 
 template <class M>
 struct Tm {
@@ -307,7 +310,7 @@ struct MfmaLds {  // doubles; rows padded to 17 so that transposed reads spread 
 };
 
 template <class M, bool HC>
-__global__ void __launch_bounds__(64) k_backward_mfma(KArgs a) {
+__global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
   constexpr int m = M::m, ne = M::ne, NEP = Tm<M>::NEP, RS = Tm<M>::RS, NR = Tm<M>::NR, RSK = Gains<M>::RSK;
   constexpr int HR = HC ? 1 : NR;  // rows of the cost block per knot
   using L = MfmaLds<M>;
@@ -361,22 +364,25 @@ __global__ void __launch_bounds__(64) k_backward_mfma(KArgs a) {
     dV0 = 0.0; dV1 = 0.0;
     bool restart = false;
     // operands of the knot being processed are fetched one knot ahead (registers are plentiful in this layout)
-    double Mn[RS], gn;
-    v4d Hn;
+    double Mn[RS], gn, Hn[HR];  // the cost block is prefetched raw (one value per lane when compact) and expanded at its use
 #pragma unroll
     for (int r = 0; r < RS; ++r) Mn[r] = Mt[((size_t)(N - 2) * RS + r) * 64];
-    load_cost(N - 2, Hn);
+#pragma unroll
+    for (int r = 0; r < HR; ++r) Hn[r] = Ht[((size_t)(N - 2) * HR + r) * 64];
     gn = gt[(size_t)(N - 2) * 16 + c];
     for (int k = N - 2; k >= 0; --k) {
       double Mr[RS];
 #pragma unroll
       for (int r = 0; r < RS; ++r) Mr[r] = Mn[r];
-      v4d Hq = Hn;
+      v4d Hq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < NR; ++r) Hq[r] = HC ? ((r == rsel) ? Hn[0] : 0.0) : Hn[HC ? 0 : r];
       const double gcol = gn;
       if (k > 0) {
 #pragma unroll
         for (int r = 0; r < RS; ++r) Mn[r] = Mt[((size_t)(k - 1) * RS + r) * 64];
-        load_cost(k - 1, Hn);
+#pragma unroll
+        for (int r = 0; r < HR; ++r) Hn[r] = Ht[((size_t)(k - 1) * HR + r) * 64];
         gn = gt[(size_t)(k - 1) * 16 + c];
       }
       // 1. T = S M,  Hq = H + M' T  (registers of T beyond RS stay zero: S has no rows there)
@@ -433,13 +439,15 @@ __global__ void __launch_bounds__(64) k_backward_mfma(KArgs a) {
         if (rho > P.opts.bp_reg_max) failed = true; else restart = true;
         break;
       }
-      // 5. gains: own column of K = -(LL')^-1 Qux, and d = -(LL')^-1 Qu
+      // 5. gains: own column of K = -(LL')^-1 Qux.  The feed-forward d = -(LL')^-1 Qu is one more column of the same
+      // solve: the lanes of tangent column NEP (first control column: no K column of their own) carry Qu through it, and
+      // everybody picks the result up with v_readlane — the solve is not run a second time in all 64 lanes.
+      const bool dcol = (c == NEP);
       double Kc[m], dk[m];
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
+      {
         double col[m];
 #pragma unroll
-        for (int i = 0; i < m; ++i) col[i] = pass ? Qu[i] : qx[i];
+        for (int i = 0; i < m; ++i) col[i] = dcol ? Qu[i] : qx[i];
 #pragma unroll
         for (int i = 0; i < m; ++i) { double t = col[i];
 #pragma unroll
@@ -451,7 +459,11 @@ __global__ void __launch_bounds__(64) k_backward_mfma(KArgs a) {
           for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
           col[i] = t * iL[i]; }
 #pragma unroll
-        for (int i = 0; i < m; ++i) { if (pass) dk[i] = -col[i]; else Kc[i] = -col[i]; }
+        for (int i = 0; i < m; ++i) {
+          const double v = -col[i];
+          dk[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), NEP), __builtin_amdgcn_readlane(__double2loint(v), NEP));
+          Kc[i] = ccol ? v : 0.0;
+        }
       }
       const double kown = pick<m>(Kc, g);  // K[g][c]: K as MFMA operand (B: K, A: K')
       if (g < m && c <= ne) Kt[(size_t)k * RSK + g * (ne + 1) + c] = ccol ? kown : pick<m>(dk, g);  // the knot's whole gains row
