@@ -402,11 +402,22 @@ def test_line_search_round_schedule(t1, hip, oracle, monkeypatch):
     """The concurrent line search must equal sequential backtracking for ANY round schedule: with a first round of 1
     or 3 step sizes the later rounds run on the compacted list with geometrically growing widths (throughput regime)."""
     monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", str(t1))
+    monkeypatch.setenv("TRAJOPT_LS_DEEP", "0")
     ph, po = pair(lambda **kw: configs.cartpole_problem(batch=96, **kw), hip, oracle)
     sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
     assert_solve_parity(sh, so, ph, po)
     ph, po = pair(lambda **kw: configs.cartpole_problem(batch=40, constrained=True, **kw), hip, oracle)
     sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    # the Quadrotor path (gains staged through LDS, k_accept): narrow rounds continued inside the kernel ...
+    ph, po = pair(lambda **kw: configs.quadrotor_problem(batch=37, N=61, tf=1.5, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph, iterations=40).solve(), T.iLQRSolver(po, iterations=40).solve()
+    assert_solve_parity(sh, so, ph, po)
+    # ... and the deep shape (the whole search depth in one round: 20 step sizes x 3 trajectories per wave, the last wave
+    # reaching past the batch), which the solve loop switches to once the active trajectories fit the chip
+    monkeypatch.delenv("TRAJOPT_LS_DEEP")
+    ph, po = pair(lambda **kw: configs.quadrotor_problem(batch=37, N=61, tf=1.5, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph, iterations=40).solve(), T.iLQRSolver(po, iterations=40).solve()
     assert_solve_parity(sh, so, ph, po)
 
 
@@ -620,10 +631,11 @@ def test_random_configurations(seed, hip, oracle):
     sh, so = solver(ph).solve(), solver(po).solve()
     for k in ("iterations", "iterations_outer", "status"):
         np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=desc + " " + k)
-    np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6, err_msg=desc)
     # converged trajectories: the north-star tolerance; solves cut off by an iteration limit (or driven to the
     # regularisation limit) stop on an ill-conditioned iterate, where rounding differences are amplified: 1e-4
     done = so.stats["status"] == T.capi.SOLVE_SUCCEEDED
+    np.testing.assert_allclose(sh.stats["cost"][done], so.stats["cost"][done], rtol=1e-6, err_msg=desc)
+    np.testing.assert_allclose(sh.stats["cost"][~done], so.stats["cost"][~done], rtol=1e-4, err_msg=desc)
     Xh, Xo, Uh, Uo = T.states(ph), T.states(po), T.controls(ph), T.controls(po)
     tol = np.where(done, 1e-6, 1e-4)
     assert_trajectories_close(Xh, Xo, tol, desc + " X")

@@ -468,13 +468,13 @@ __global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
       const double kown = pick<m>(Kc, g);  // K[g][c]: K as MFMA operand (B: K, A: K')
       if (g < m && c <= ne) Kt[(size_t)k * RSK + g * (ne + 1) + c] = ccol ? kown : pick<m>(dk, g);  // the knot's whole gains row
       // 6. cost-to-go with the un-regularised Quu:  S' = Qxx + K'(Quu K + Qux) + Qux' K,  s' = Qx + K'(Quu d + Qu) + Qux' d
-      double Wc[m], qd[m];
+      double Wc[m], qd[m], Qd[m];  // Qd = Quu d serves both Quu d + Qu and d' Quu d
 #pragma unroll
       for (int r = 0; r < m; ++r) {
-        double t = qx[r], t2 = Qu[r];
+        double t = qx[r], t2 = 0.0;
 #pragma unroll
         for (int q = 0; q < m; ++q) { t += Quu[r][q] * Kc[q]; t2 += Quu[r][q] * dk[q]; }
-        Wc[r] = t; qd[r] = t2;
+        Wc[r] = t; Qd[r] = t2; qd[r] = t2 + Qu[r];
       }
       const double wown = pick<m>(Wc, g);                  // W[g][c]
       const double qown = (g < m && ccol) ? hctl : 0.0;    // Qux[g][c]
@@ -490,10 +490,7 @@ __global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
 #pragma unroll
       for (int r = 0; r < m; ++r) {
         dv1 += dk[r] * Qu[r];
-        double t = 0.0;
-#pragma unroll
-        for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
-        dv2 += dk[r] * t;
+        dv2 += dk[r] * Qd[r];
       }
       dV0 += dv1;
       dV1 += 0.5 * dv2;

@@ -603,7 +603,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // small batches, at most the model's ls_first_round (4 for the small models, 16 for the Quadrotor; the default search
   // depth is 20: further in-kernel rounds cover the rest).
   {
-    int cw = std::max(1, std::min(h->ops->ls_first_round, 2048 / (P.Bp / BLOCK)));
+    int cw = std::max(1, std::min(h->ops->ls_first_round, 1024 / (P.Bp / BLOCK)));  // one forward wave per SIMD (measured: C5 0.71 M it/s with 8, 0.68 M with 16)
     if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
     int lg = 0;
     while ((2 << lg) <= cw) ++lg;
@@ -614,7 +614,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     // in half of their steps: forward 1.0 ms instead of 0.55 ms).  It needs 64/TW = 21 waves per 64 trajectories instead of
     // 16, so the solve loop switches to it once the active trajectories fit the chip that way (one wave per SIMD).
     const int total = P.opts.iterations_linesearch;
-    if (!h->ops->write_through && total > h->cw_base && total <= 64 && !std::getenv("TRAJOPT_LS_CANDIDATES")) {
+    const char* deep_env = std::getenv("TRAJOPT_LS_DEEP");  // 0: never switch to the deep shape (tests of the round logic)
+    if (!h->ops->write_through && total > h->cw_base && total <= 64 && !(deep_env && std::atoi(deep_env) == 0)) {
       hipDeviceProp_t prop;
       HIPB(hipGetDeviceProperties(&prop, device));
       h->cw_deep = total; h->tw_deep = 64 / total;
