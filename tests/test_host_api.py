@@ -273,3 +273,19 @@ def test_set_duals_shape_checks(oracle):
     with pytest.raises(T.ArgumentError):                # n == N: (n, N) could be either layout
         q = configs.cartpole_problem(batch=2, N=4, tf=0.3, lib=oracle)
         T.initial_states(q, np.zeros((4, 4)))
+
+
+def test_no_vgpr_spill_ahead_of_exec_restore():
+    """hipcc (ROCm 7.2) may place a VGPR->AGPR spill at the top of a join block before EXEC is restored:
+    the value is then lost in the lanes that skipped the divergent region.  tools/check_exec_spill.py scans the gfx950
+    assembly of every translation unit for that pattern; the kernels are written so that it does not occur."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    if os.environ.get("TRAJOPT_SKIP_ASM_SCAN"):
+        pytest.skip("TRAJOPT_SKIP_ASM_SCAN set")
+    tool = Path(__file__).resolve().parent.parent / "tools" / "check_exec_spill.py"
+    res = subprocess.run([sys.executable, str(tool)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-4000:]
+    assert res.stdout.count("0 spill(s)") >= 8, res.stdout[-2000:]

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Scans the gfx950 assembly of csrc/*.hip for the hipcc (ROCm 7.2) spill-placement hazard described in DESIGN.md §6:
+a VGPR spill (v_accvgpr_write / scratch_store) emitted at the top of a join block BEFORE the `s_or_b64 exec, exec, …`
+that re-enables the lanes which skipped the divergent region — the spilled value is then lost in those lanes.
+Usage: tools/check_exec_spill.py [file.hip ...]   (exit status 1 when a kernel has such a site)"""
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent.parent / "trajectoryoptimization.jl_amd" / "csrc"
+SPILL = re.compile(r"^\s*(v_accvgpr_write_b32\s+a\d+,\s*v\d+|scratch_store_\w+)")
+RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
+LABEL = re.compile(r"^(\.LBB\S+|_Z\S+):")
+BRANCH = re.compile(r"^\s*(s_cbranch|s_branch|s_endpgm|s_setpc)")
+
+
+def scan(src):
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "--cuda-device-only", "-S", "-o", "-", str(src)]
+    asm = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC)).stdout
+    hits, kernel, pending, label = [], None, [], None
+    for ln, line in enumerate(asm.splitlines(), 1):
+        m = LABEL.match(line)
+        if m:
+            if m.group(1).startswith("_Z"):
+                kernel = m.group(1)
+            label, pending = m.group(1), []
+            continue
+        if label is None or line.lstrip().startswith(";") or not line.strip():
+            continue
+        if RESTORE.match(line):
+            hits += [(kernel, label, ln, s) for s in pending]
+            label = None  # only the run of instructions before the first exec restore of a block is of interest
+        elif SPILL.match(line):
+            pending.append(line.strip())
+        elif BRANCH.match(line) or re.search(r"saveexec|\bexec\b", line.split(";")[0].split(None, 1)[1].split(",")[0] if len(line.split()) > 1 else "") or "saveexec" in line:
+            label = None
+    return src.name, hits
+
+
+def main():
+    files = [Path(a).resolve() for a in sys.argv[1:]] or sorted(CSRC.glob("*.hip"))
+    bad = 0
+    with ThreadPoolExecutor(8) as ex:
+        for name, hits in ex.map(scan, files):
+            print(f"{name}: {len(hits)} spill(s) ahead of an exec restore")
+            for kernel, label, ln, ins in hits:
+                dem = subprocess.run(["c++filt", kernel or "?"], capture_output=True, text=True).stdout.strip()
+                print(f"   {dem.replace('void to::', '').replace('(to::KArgs)', '')}  {label} line {ln}: {ins}")
+            bad += len(hits)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -22,6 +22,7 @@ struct KArgs {
                     // contiguous block [w][e][64] and its hardware lane q*TW + (b % TW) holds candidate q of trajectory b, so
                     // every candidate store of a wave is one 512-byte row of one stream (slot-major candidates made each
                     // store touch CW streams 85 MB apart: 4x slower forward pass, TLB- and partial-line-bound)
+  int dump_wave;  // index of the spare block behind the last wave's in Xc / Uc: where lanes without a candidate store
   int CW, TW;     // a forward wave holds CW line-search candidates x TW trajectories, CW*TW <= 64 (hardware lane q*TW + t); candidate
                   // "slot" q+1 of trajectory b lives in the block of wave b / TW (below).  Two shapes are in use: the base one (CW a
                   // power of two, TW = 64/CW) and, once the active trajectories fit the chip that way, CW = the whole search depth

@@ -102,8 +102,14 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
     for (int ci = 0; ci < P.n_cons; ++ci) {
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
-      if (ci == lci0) { al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, l0, 1, mu0r, v, gr, y); continue; }
-      if (ci == lci1) { al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, l1, 1, mu1r, v, gr, y); continue; }
+      if (ci == lci0 || ci == lci1) {  // ONE call site with selected values: two call sites were merged by the compiler into one
+        const bool second = (ci == lci1);  // taking POINTERS to l0 / l1 (phi of addresses), which forced them into scratch memory
+        double ls[LR];
+#pragma unroll
+        for (int r = 0; r < LR; ++r) ls[r] = second ? l1[r] : l0[r];
+        al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, ls, 1, second ? mu1r : mu0r, v, gr, y);
+        continue;
+      }
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
       al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
     }

@@ -82,8 +82,12 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   constexpr int c = 0;  // nominal slot
   const double* Xc = TILE_PTR(a.Xs, N * n);
   const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
-  double* Xn = a.Xc + ((size_t)blockIdx.x * (size_t)(N * n)) * 64 + hw;        // candidates: forward-wave-major (common.h), slot cs = q + 1
-  double* Un = a.Uc + ((size_t)blockIdx.x * (size_t)((N - 1) * m)) * 64 + hw;  // a wave's candidate stores are whole 512-byte rows
+  // candidates: forward-wave-major (common.h), slot cs = q + 1; a wave's candidate stores are whole 512-byte rows.  Lanes
+  // without a candidate store as well — into the dump block behind the last wave's, never read — so that the rollout loop
+  // runs with EXEC full throughout (no lane-divergent region: see StageCostLds::load for what one cost here)
+  const size_t cblock = live ? (size_t)blockIdx.x : (size_t)a.dump_wave;
+  double* Xn = a.Xc + (cblock * (size_t)(N * n)) * 64 + hw;
+  double* Un = a.Uc + (cblock * (size_t)((N - 1) * m)) * 64 + hw;
   const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const double* px0 = TILE_PTR(a.x0, n);
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
@@ -145,10 +149,8 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
       if (ncs > 1) cs1.prefetch(k + 1);
     }
     pXn += n * 64; pUn += m * 64; pKn += RSK;
-    if (live) {
 #pragma unroll
-      for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
-    }
+    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
     pXo += n * 64;
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
@@ -164,7 +166,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
 #pragma unroll
       for (int i = 0; i < ne; ++i) du += kr[i] * dx[i];
       ub[j] = cur.u[j] + du;
-      if (live) EL(pUo, j) = ub[j];
+      EL(pUo, j) = ub[j];
       gk = fmax(gk, fabs(dj) * rcp_fast(fabs(ub[j]) + 1.0));
     }
     pUo += m * 64;
@@ -192,9 +194,9 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     if (!(mx <= max_x) || !(mu_ <= max_u)) ok = false;
     if (__ballot(live && ok) == 0) break;
   }
-  if (live && ok) {
+  if (__ballot(live && ok) != 0) {  // wave-uniform: the loop ran to its end, pXo has walked to the terminal knot
 #pragma unroll
-    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];  // x̄_N (pXo has walked to the terminal knot when the loop ran to its end)
+    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];  // x̄_N (a rejected candidate's is never read)
   }
   {
     double u0[m];

@@ -100,7 +100,8 @@ __device__ __forceinline__ void sincos_t(Dual x, Dual* s, Dual* c) {
 }
 // max(0, x): derivative is the indicator x > 0 (the rotor-force clamp of the Quadrotor)
 __device__ __forceinline__ double relu_t(double x) { return fmax(0.0, x); }
-__device__ __forceinline__ Dual relu_t(Dual x) { return x.v > 0.0 ? x : Dual(0.0, 0.0); }
+// (component-wise selects: a select between two Dual objects was lowered through scratch memory in the larger kernels)
+__device__ __forceinline__ Dual relu_t(Dual x) { const bool on = x.v > 0.0; return Dual(on ? x.v : 0.0, on ? x.d : 0.0); }
 
 // ------------------------------------------------------------------------------------------------
 // Models.  P = model_params of the descriptor (wave-uniform, lives in SGPRs).

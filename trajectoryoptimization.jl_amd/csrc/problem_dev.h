@@ -237,20 +237,27 @@ struct StageCostDiag {
 // per knot and free the registers the gains row needs.  Same arithmetic, same order as StageCostDiag::eval.
 template <int n, int m>
 struct StageCostLds {
-  static constexpr int oQ = 0, oR = n, oq = n + m, orr = 2 * n + m, oc = 2 * n + 2 * m, ow = oc + 1, oref = oc + 2, size = oc + 6;
+  static constexpr int oQ = 0, oR = n, oq = n + m, orr = 2 * n + m, oc = 2 * n + 2 * m, ow = oc + 1, oref = oc + 2, used = oc + 6;
+  static constexpr int size = 64;  // one entry per lane: the fill below runs without any lane masked off
+  static_assert(used <= 64, "stage-cost table is filled by one wave-wide store");
   const double* t;
   int qind[4], kind;
-  __device__ __forceinline__ void load(CostC& C, double* tab, int hw) {  // call from every lane of the wave
+  // Call from every lane of the wave.  Branch-free on purpose: every lane stores one entry (the tail entries are
+  // padding).  A lane-divergent region here made hipcc (ROCm 7.2) place a VGPR->AGPR spill of a live value in the join
+  // block BEFORE exec was restored, which lost that value in the lanes outside the region (the line search's step size,
+  // seen as wrong step sizes from the second round on); the forward kernels keep their EXEC mask full for that reason.
+  __device__ __forceinline__ void load(CostC& C, double* tab, int hw) {
     t = tab;
-    double v = 0.0;
-    if (hw < n) v = C.Q[hw < n ? hw : 0];
-    else if (hw < n + m) v = C.R[hw - n];
-    else if (hw < 2 * n + m) v = C.q[hw - n - m];
-    else if (hw < 2 * n + 2 * m) v = C.r[hw - 2 * n - m];
-    else if (hw == oc) v = C.c;
-    else if (hw == ow) v = C.w;
-    else if (hw < size) v = C.q_ref[hw - oref];
-    if (hw < size) tab[hw] = v;
+    DoubleC* src = C.Q;
+    int idx = hw;
+    src = (hw >= oR) ? C.R : src;       idx = (hw >= oR) ? hw - oR : idx;
+    src = (hw >= oq) ? C.q : src;       idx = (hw >= oq) ? hw - oq : idx;
+    src = (hw >= orr) ? C.r : src;      idx = (hw >= orr) ? hw - orr : idx;
+    src = (hw >= oc) ? &C.c : src;      idx = (hw >= oc) ? 0 : idx;
+    src = (hw >= ow) ? &C.w : src;
+    src = (hw >= oref) ? C.q_ref : src; idx = (hw >= oref) ? hw - oref : idx;
+    src = (hw >= used) ? C.Q : src;     idx = (hw >= used) ? 0 : idx;
+    tab[hw] = src[idx];
     kind = C.kind;
 #pragma unroll
     for (int i = 0; i < 4; ++i) qind[i] = C.q_ind[i];

@@ -638,8 +638,9 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   {  // candidates, forward-wave-major (common.h): 64 lanes per wave in either shape
     size_t waves = (Bp + h->tw_base - 1) / h->tw_base;
     if (h->cw_deep) waves = std::max(waves, (Bp + h->tw_deep - 1) / h->tw_deep);
-    TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * waves * 64));
-    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * waves * 64));
+    a.dump_wave = (int)waves;  // one spare block: the store target of lanes that hold no candidate (k_forward.h)
+    TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * (waves + 1) * 64));
+    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * (waves + 1) * 64));
   }
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
