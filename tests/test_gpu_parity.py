@@ -421,6 +421,46 @@ def test_line_search_round_schedule(t1, hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+def test_lane_backward_on_small_models(hip, oracle, monkeypatch):
+    """The one-lane-per-trajectory backward pass (lane-layout expansion; default only for batches that would stack the
+    cooperative waves three deep) forced on small batches: expansion getters, gains, and full solves for m = 1
+    (Cartpole, constrained and not, a batch that is not a multiple of 64) and m = 2 (2-D double integrator with bounds)."""
+    monkeypatch.setenv("TRAJOPT_BACKWARD", "lane")
+    ph, po = pair(BUILDERS["cartpole_con"], hip, oracle)
+    perturb_controls((ph, po), 0.02)
+    for p in (ph, po):
+        T.rollout(p); I.dual_update(p); I.expand(p); I.backwardpass(p)
+    Eh, Eo = I.cost_expansion(ph), I.cost_expansion(po)
+    for k in Eh:
+        np.testing.assert_allclose(Eh[k], Eo[k], rtol=1e-9, atol=1e-10, err_msg=k)
+    Ah, Bh = I.dynamics_jacobians(ph)
+    Ao, Bo = I.dynamics_jacobians(po)
+    np.testing.assert_allclose(Ah, Ao, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(Bh, Bo, rtol=1e-10, atol=1e-12)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_array_equal(gh["rho"], go["rho"])
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-7, atol=1e-9)
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=70, **kw), hip, oracle)
+    assert_solve_parity(T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve(), ph, po)
+    ph, po = pair(BUILDERS["cartpole_con"], hip, oracle)
+    assert_solve_parity(T.ALSolver(ph).solve(), T.ALSolver(po).solve(), ph, po)
+    def di2(lib):
+        model = T.DoubleIntegrator(0.8, 2)
+        n, m = model.dims()
+        xf = np.array([1.0, -2.0, 0.0, 0.0])
+        obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 10.0 * np.ones(n), xf, 21)
+        cons = T.ConstraintList(n, m, 21)
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=-1.5, u_max=1.5), range(1, 21))
+        T.add_constraint(cons, T.GoalConstraint(xf), 21)
+        p = T.Problem(model, obj, np.zeros(n), 2.0, xf=xf, constraints=cons, batch=9, lib=lib,
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-5))
+        p.set_initial_state(np.linspace(-0.5, 0.5, 9)[:, None] * np.ones((9, n)))
+        return p
+    ph, po = di2(hip), di2(oracle)
+    assert_solve_parity(T.ALSolver(ph).solve(), T.ALSolver(po).solve(), ph, po)
+
+
 def test_mfma_backward_on_small_models(hip, oracle, monkeypatch):
     """The MFMA backward pass (one wave per trajectory, tangent-matrix expansion, compact and full cost blocks) is generic
     in the model; the small models default to the cooperative kernel, so force it: m = 1 / ne = 4 (Cartpole) and

@@ -10,14 +10,25 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent.parent / "trajectoryoptimization.jl_amd" / "csrc"
-SPILL = re.compile(r"^\s*(v_accvgpr_write_b32\s+a\d+,\s*v\d+|scratch_store_\w+)")
+# VGPR->AGPR copies, and scratch stores the compiler marks as spills (a plain scratch store is the program's own store to a
+# stack array: the tail of a divergent branch legitimately ends with those)
+SPILL = re.compile(r"^\s*(v_accvgpr_write_b32\s+a\d+,\s*v\d+|scratch_store_\w+.*Folded Spill)")
 RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
 LABEL = re.compile(r"^(\.LBB\S+|_Z\S+):")
 BRANCH = re.compile(r"^\s*(s_cbranch|s_branch|s_endpgm|s_setpc)")
 
 
+def _build_flags(name):
+    """The flags csrc/ is built with (trajectoryoptimization.jl_amd/build.py), loaded without importing the package."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_to_build", CSRC.parent / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.flags_for(name)
+
+
 def scan(src):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "--cuda-device-only", "-S", "-o", "-", str(src)]
+    cmd = ["/opt/rocm/bin/hipcc", *_build_flags(Path(src).name), "--cuda-device-only", "-S", "-o", "-", str(src)]
     asm = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC)).stdout
     hits, kernel, pending, label = [], None, [], None
     for ln, line in enumerate(asm.splitlines(), 1):

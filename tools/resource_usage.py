@@ -10,8 +10,17 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent.parent / "trajectoryoptimization.jl_amd" / "csrc"
 
 
+def _build_flags(name):
+    """The flags csrc/ is built with (trajectoryoptimization.jl_amd/build.py), loaded without importing the package."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_to_build", CSRC.parent / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.flags_for(name)
+
+
 def analyse(src):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c", "-o", "/dev/null",
+    cmd = ["/opt/rocm/bin/hipcc", *_build_flags(Path(src).name), "-c", "-o", "/dev/null",
            str(src), "-Rpass-analysis=kernel-resource-usage"]
     err = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC)).stderr
     rows, cur = [], None

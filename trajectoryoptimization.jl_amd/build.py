@@ -16,6 +16,10 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 INCLUDE = Path(__file__).resolve().parent.parent / "include"
 TARGET = CSRC / "libtrajopt_hip.so"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# Per translation unit.  The Quadrotor expansion: SimplifyCFG's common-code sinking merges the per-row blocks of the AL
+# terms into one block that takes the ADDRESSES of the gradient / Hessian-vector register arrays (a phi of pointers),
+# which forces those arrays into scratch memory (96 B per lane, a memory round trip per use at one wave per SIMD).
+FILE_FLAGS = {"ops_quad_expand.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 OBJDIR = CSRC / "build"
 
 
@@ -30,6 +34,11 @@ def source_files():
     return sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + [INCLUDE / "trajopt_hip.h"]
 
 
+def flags_for(name, extra_flags=()):
+    """hipcc flags of one translation unit (the tools that re-compile a file for analysis use the same ones)."""
+    return [*FLAGS, *FILE_FLAGS.get(name, []), *extra_flags]
+
+
 def source_id(extra_flags=()):
     """Hash of every source the library is compiled from, the flags included."""
     h = hashlib.sha256()
@@ -37,6 +46,7 @@ def source_id(extra_flags=()):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     h.update(" ".join(list(FLAGS) + list(extra_flags)).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()[:16]
 
 
@@ -76,7 +86,7 @@ def build_hip(force=False, verbose=False, extra_flags=(), target=TARGET, jobs=No
         obj = OBJDIR / f"{src.stem}.{sid}.o"
         objs.append(obj)
         if force or not obj.exists():
-            flags = [*FLAGS, *extra_flags] + ([f'-DTO_BUILD_ID="{sid}"'] if src.name == "trajopt_hip.hip" else [])
+            flags = flags_for(src.name, extra_flags) + ([f'-DTO_BUILD_ID="{sid}"'] if src.name == "trajopt_hip.hip" else [])
             work.append(([hipcc, *flags, "-c", "-o", str(obj), str(src)], src))
     with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
         for src, rc, err in ex.map(_compile, work):

@@ -33,6 +33,7 @@ struct KArgs {
   double* Kt;                         // gains, trajectory-major rows: Kt[(b*(N-1) + k)*RSK + r*(ne+1) + i] = K_k[r][i], i = ne: d_k[r]
   double *Mt, *Ht, *gt;               // tangent-matrix layout of the expansion for the MFMA backward pass (k_backward.h)
   int bwd_mfma;                       // 1: expansion writes Mt/Ht/gt and the MFMA backward pass runs; 0: column layout + cooperative pass
+  int bwd_lane;                       // 1: expansion writes the lane layout into Mc/Hc/gc and the one-lane-per-trajectory backward pass runs
   int h_compact;                      // Ht holds one row per knot (block-diagonal Qxx, Quu, no Qux): see k_expand.h
   double *lam, *mu;                   // L = n_duals, n_cons
   double *J, *dJ, *grad, *rho, *drho, *dV, *cmax, *Jout;  // [Bp] plain (dV: [2][Bp])

@@ -74,6 +74,7 @@ struct ModelOps {
   bool write_through = false;  // M::accept_write_through
   bool mfma_backward = false;  // M::mfma_backward: tangent-matrix expansion + one-wave-per-trajectory Riccati
   bool coop_backward = true;   // M::coop_backward: column-layout expansion + cooperative LDS Riccati
+  bool lane_backward = false;  // M::lane_backward: lane-layout expansion + one-lane-per-trajectory Riccati (ne + m <= 6)
   bool lds_gains = false;      // forward pass stages gains through LDS
   int expand_knots = 1;
   int ls_first_round = 16;     // M::ls_first_round

@@ -261,6 +261,245 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ lane backward pass
+// Small models (ne + m <= 6): ONE LANE per trajectory, the whole recursion in that lane's registers — no LDS, no
+// barrier, no operand exchanged between lanes.  The cooperative kernel above spends a knot of a 4-state model mostly in
+// its four LDS exchange rounds (0.78 us per knot on the Cartpole at one wave per SIMD); a single lane runs the same
+// ~230 FMAs back to back.  Latency, not throughput, is what a batch of 1 024 needs: it is 16 waves either way.
+// "Lane layout" of the expansion (k_expand.h LAY = 3), tile = b >> 6, l = b & 63, kept in the Mc / Hc / gc allocations:
+//   M[i][j]        at Mc[((tile*(N-1) + k)*ne*nc + i*nc + j)*64 + l]
+//   H[i][j], i<=j  at Hc[((tile*N + k)*NS + j*(j+1)/2 + i)*64 + l]      NS = nc(nc+1)/2 (upper triangle, column by column)
+//   g[j]           at gc[((tile*N + k)*nc + j)*64 + l]
+// so a knot's operands are nc*(ne + (nc+1)/2 + 1) fully coalesced 512-byte rows per wave.
+template <class M>
+struct LaneLay {
+  static constexpr int ne = M::ne, m = M::m, nc = ne + m, NS = nc * (nc + 1) / 2, EM = ne * nc;
+  __host__ __device__ static constexpr int sym(int i, int j) { return i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j; }
+};
+
+template <class M>
+__global__ void __launch_bounds__(64) k_backward_lane(KArgs a) {
+  constexpr int m = M::m, ne = M::ne, nc = ne + m, RSK = Gains<M>::RSK;
+  using L = LaneLay<M>;
+  constexpr int NS = L::NS, EM = L::EM;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane;  // b < Bp always (Bp is a multiple of 64)
+  // lanes without a trajectory to solve run along on their own (valid) data and only their stores are predicated
+  const bool live = (b < P.B) && a.active[b] != 0;
+  if (__ballot(live) == 0) return;
+  const double* Ml = a.Mc + ((size_t)tile * (size_t)(N - 1) * EM) * 64 + lane;
+  const double* Hl = a.Hc + ((size_t)tile * (size_t)N * NS) * 64 + lane;
+  const double* gl = a.gc + ((size_t)tile * (size_t)N * nc) * 64 + lane;
+  double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
+  double rho = a.rho[b], drho = a.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;
+  bool failed = false, init = true, fresh = true;
+  int k = N - 2;
+  double S[ne][ne], s[ne];
+  double Mn[EM], Hn[NS], gn[nc];  // the next knot's operands, fetched one knot ahead
+  const double *pMk = Ml, *pHk = Hl, *pgk = gl;
+  double* pKk = pK;
+  while (true) {
+    if (init) {  // (re)start: S = Qxx_N, s = qx_N
+#pragma unroll
+      for (int i = 0; i < ne; ++i) {
+#pragma unroll
+        for (int j = 0; j < ne; ++j) S[i][j] = EL(Hl, (size_t)(N - 1) * NS + L::sym(i, j));
+        s[i] = EL(gl, (size_t)(N - 1) * nc + i);
+      }
+      dV0 = 0.0; dV1 = 0.0; k = N - 2; init = false; fresh = true;
+      pMk = Ml + (size_t)(N - 2) * EM * 64; pHk = Hl + (size_t)(N - 2) * NS * 64; pgk = gl + (size_t)(N - 2) * nc * 64;
+      pKk = pK + (size_t)(N - 2) * RSK;
+    }
+    if (k < 0) break;
+    if (fresh) {
+#pragma unroll
+      for (int e = 0; e < EM; ++e) Mn[e] = EL(pMk, e);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) Hn[e] = EL(pHk, e);
+#pragma unroll
+      for (int e = 0; e < nc; ++e) gn[e] = EL(pgk, e);
+      fresh = false;
+    }
+    double Mk[ne][nc], H[NS], g[nc];
+#pragma unroll
+    for (int i = 0; i < ne; ++i)
+#pragma unroll
+      for (int j = 0; j < nc; ++j) Mk[i][j] = Mn[i * nc + j];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) H[e] = Hn[e];
+#pragma unroll
+    for (int e = 0; e < nc; ++e) g[e] = gn[e];
+    if (k > 0) {
+#pragma unroll
+      for (int e = 0; e < EM; ++e) Mn[e] = (pMk - (size_t)EM * 64)[(size_t)e * 64];
+#pragma unroll
+      for (int e = 0; e < NS; ++e) Hn[e] = (pHk - (size_t)NS * 64)[(size_t)e * 64];
+#pragma unroll
+      for (int e = 0; e < nc; ++e) gn[e] = (pgk - (size_t)nc * 64)[(size_t)e * 64];
+    }
+    // T = S M;  Q = H + M'T (state columns in full, of the control columns only the Quu block);  gq = g + M's
+    double T[ne][nc];
+#pragma unroll
+    for (int i = 0; i < ne; ++i)
+#pragma unroll
+      for (int j = 0; j < nc; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += S[i][r] * Mk[r][j];
+        T[i][j] = t;
+      }
+    double Qxx[ne][ne], Qux[m][ne], Quu[m][m], gq[nc];
+#pragma unroll
+    for (int j = 0; j < ne; ++j) {
+#pragma unroll
+      for (int i = 0; i < nc; ++i) {
+        double t = H[L::sym(i, j)];
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += Mk[r][i] * T[r][j];
+        if (i < ne) Qxx[i][j] = t; else Qux[i - ne][j] = t;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < m; ++q)
+#pragma unroll
+      for (int p = 0; p < m; ++p) {
+        double t = H[L::sym(ne + p, ne + q)];
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += Mk[r][ne + p] * T[r][ne + q];
+        Quu[p][q] = t;
+      }
+#pragma unroll
+    for (int j = 0; j < nc; ++j) {
+      double t = g[j];
+#pragma unroll
+      for (int r = 0; r < ne; ++r) t += Mk[r][j] * s[r];
+      gq[j] = t;
+    }
+    // Cholesky of Quu + rho I
+    double Lc[m][m], iL[m];
+    bool pd_ok = true;
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+#pragma unroll
+      for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
+#pragma unroll
+    for (int q = 0; q < m; ++q) {
+      double sj = Lc[q][q];
+#pragma unroll
+      for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
+      if (!(sj > 0.0) && live) pd_ok = false;  // lanes that only ride along never restart
+      const double l = sqrt(sj);
+      Lc[q][q] = l;
+      iL[q] = rcp_fast(l);
+#pragma unroll
+      for (int i = q + 1; i < m; ++i) {
+        double t = Lc[i][q];
+#pragma unroll
+        for (int r = 0; r < q; ++r) t -= Lc[i][r] * Lc[q][r];
+        Lc[i][q] = t * iL[q];
+      }
+    }
+    if (!pd_ok) {
+      reg_increase(P.opts, rho, drho);
+      if (rho > P.opts.bp_reg_max) { failed = true; break; }
+      init = true;
+      continue;
+    }
+    // gains K = -(LL')^-1 Qux (column by column), d = -(LL')^-1 Qu
+    double Kg[m][ne], dk[m];
+#pragma unroll
+    for (int c = 0; c <= ne; ++c) {
+      double col[m];
+#pragma unroll
+      for (int i = 0; i < m; ++i) col[i] = (c < ne) ? Qux[i][c < ne ? c : 0] : gq[ne + i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) { double t = col[i];
+#pragma unroll
+        for (int r = 0; r < i; ++r) t -= Lc[i][r] * col[r];
+        col[i] = t * iL[i]; }
+#pragma unroll
+      for (int i = m - 1; i >= 0; --i) { double t = col[i];
+#pragma unroll
+        for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
+        col[i] = t * iL[i]; }
+#pragma unroll
+      for (int i = 0; i < m; ++i) { if (c < ne) Kg[i][c < ne ? c : 0] = -col[i]; else dk[i] = -col[i]; }
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < m; ++r) {
+#pragma unroll
+        for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
+        pKk[r * (ne + 1) + ne] = dk[r];
+      }
+    }
+    // cost-to-go with the un-regularised Quu:  S' = Qxx + K'(Quu K + Qux) + Qux'K,  s' = Qx + K'(Quu d + Qu) + Qux'd
+    double W[m][ne], qd[m];
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+#pragma unroll
+      for (int j = 0; j < ne; ++j) {
+        double t = Qux[r][j];
+#pragma unroll
+        for (int q = 0; q < m; ++q) t += Quu[r][q] * Kg[q][j];
+        W[r][j] = t;
+      }
+      double t2 = gq[ne + r];
+#pragma unroll
+      for (int q = 0; q < m; ++q) t2 += Quu[r][q] * dk[q];
+      qd[r] = t2;
+    }
+    double Sn[ne][ne], sn[ne];
+#pragma unroll
+    for (int j = 0; j < ne; ++j) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i) {
+        double t = Qxx[i][j];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Kg[r][i] * W[r][j];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Qux[r][i] * Kg[r][j];
+        Sn[i][j] = t;
+      }
+      double t = gq[j];
+#pragma unroll
+      for (int r = 0; r < m; ++r) t += Kg[r][j] * qd[r];
+#pragma unroll
+      for (int r = 0; r < m; ++r) t += Qux[r][j] * dk[r];
+      sn[j] = t;
+    }
+    double dv1 = 0.0, dv2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+      dv1 += dk[r] * gq[ne + r];
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
+      dv2 += dk[r] * t;
+    }
+    dV0 += dv1;
+    dV1 += 0.5 * dv2;
+#pragma unroll
+    for (int i = 0; i < ne; ++i) {
+#pragma unroll
+      for (int j = 0; j < ne; ++j) S[i][j] = 0.5 * (Sn[i][j] + Sn[j][i]);
+      s[i] = sn[i];
+    }
+    --k;
+    pMk -= (size_t)EM * 64; pHk -= (size_t)NS * 64; pgk -= (size_t)nc * 64; pKk -= RSK;
+  }
+  if (!failed) reg_decrease(P.opts, rho, drho);
+  if (live) {
+    a.rho[b] = rho;
+    a.drho[b] = drho;
+    a.dV[b] = dV0;
+    a.dV[(size_t)P.Bp + b] = dV1;
+    a.bpfail[b] = failed ? 1 : 0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ MFMA backward pass
 // One WAVE per trajectory; the per-knot blocks live in the result layout of v_mfma_f64_16x16x4_f64 ("tangent-matrix
 // layout"): a 16x16 matrix X sits in 4 registers, lane (g, c) = hardware lane g*16 + c holds X[g + 4r][c] in register r.

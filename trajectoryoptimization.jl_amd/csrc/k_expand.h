@@ -15,10 +15,11 @@ namespace to {
 // problem cannot reach is compiled out: the all-purpose Quadrotor kernel needed 256 VGPRs + 140 AGPRs + 480 B of scratch.
 // one knot of the expansion for lane (g, j): x = x_k, u = u_k (zeros at the terminal knot), x1 = x_{k+1}
 // LAY: where the columns go.  0: column layout (cooperative backward pass); 1: tangent-matrix layout, full cost block;
-// 2: tangent-matrix layout, compact cost block (k_backward.h).
+// 2: tangent-matrix layout, compact cost block; 3: lane layout (one lane per trajectory backward pass) — all in k_backward.h.
 template <class M, int FIXED_INTEG, int VAR, int LAY>
 __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane, int tile, int lane64, int b, int j, int k, bool valid,
-                                            const double* x, const double* u, const double* x1) {
+                                            const double* x, const double* u, const double* x1, const ConExp<M::m>& ce0,
+                                            const ConExp<M::m>& ce1, bool table_cons) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
   constexpr int NEP = Tm<M>::NEP, RS = Tm<M>::RS, NR = Tm<M>::NR;
   const int ct = j < ne ? j : NEP + (j - ne);  // tangent index of this lane's column
@@ -38,23 +39,21 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   // terms below would otherwise pay a memory round trip of their own (the stores in between pin their loads in place)
   constexpr int LR = m + 1;
   double l0[LR], l1[LR], mu0r = 0.0, mu1r = 0.0;
-  int lci0 = -1, lci1 = -1;
-  if ((VAR & 2) != 0 && P.n_cons > 0) {
+  const bool on0 = (VAR & 2) != 0 && ce0.at(k), on1 = (VAR & 2) != 0 && ce1.at(k);  // wave-uniform (descriptors cached by k_expand)
+  if ((VAR & 2) != 0) {
     const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
     const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
-    for (int ci = 0; ci < P.n_cons; ++ci) {
-      ConC& K = P.cons[ci];
-      if (k < K.k1 || k > K.k2 || K.fast != 2 || K.p > LR) continue;
-      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-      if (lci0 < 0) {
-        lci0 = ci; mu0r = EL(mu0, ci);
+    if (on0) {
+      const double* lam = lam0 + (size_t)(ce0.dual_off + (long long)(k - ce0.k1) * ce0.p) * 64;
+      mu0r = EL(mu0, ce0.ci);
 #pragma unroll
-        for (int r = 0; r < LR; ++r) l0[r] = (r < K.p) ? lam[r * 64] : 0.0;
-      } else if (lci1 < 0) {
-        lci1 = ci; mu1r = EL(mu0, ci);
+      for (int r = 0; r < LR; ++r) l0[r] = (r < ce0.p) ? lam[r * 64] : 0.0;
+    }
+    if (on1) {
+      const double* lam = lam0 + (size_t)(ce1.dual_off + (long long)(k - ce1.k1) * ce1.p) * 64;
+      mu1r = EL(mu0, ce1.ci);
 #pragma unroll
-        for (int r = 0; r < LR; ++r) l1[r] = (r < K.p) ? lam[r * 64] : 0.0;
-      }
+      for (int r = 0; r < LR; ++r) l1[r] = (r < ce1.p) ? lam[r * 64] : 0.0;
     }
   }
   // ---- dynamics column
@@ -75,6 +74,12 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
 #pragma unroll
         for (int i = 0; i < ne; ++i) EL(Mc, k * ne + i) = col[i];
       }
+    } else if constexpr (LAY == 3) {
+      double* Ml = a.Mc + (((size_t)tile * (size_t)(N - 1) + k) * (ne * nc) + j) * 64 + lane64;
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) EL(Ml, i * nc) = col[i];
+      }
     } else {
       double* Mt = a.Mt + (((size_t)b * (N - 1) + k) * RS) * 64 + ct;
       if (valid) {
@@ -91,27 +96,28 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
 #pragma unroll
     for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
   }
-  if ((VAR & 2) != 0 && P.n_cons > 0) {
+  if ((VAR & 2) != 0) {
     double z[nz];
 #pragma unroll
     for (int i = 0; i < n; ++i) z[i] = x[i];
 #pragma unroll
     for (int i = 0; i < m; ++i) z[n + i] = u[i];
-    const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
-    const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
-    for (int ci = 0; ci < P.n_cons; ++ci) {
-      ConC& K = P.cons[ci];
-      if (k < K.k1 || k > K.k2) continue;
-      if (ci == lci0 || ci == lci1) {  // ONE call site with selected values: two call sites were merged by the compiler into one
-        const bool second = (ci == lci1);  // taking POINTERS to l0 / l1 (phi of addresses), which forced them into scratch memory
-        double ls[LR];
-#pragma unroll
-        for (int r = 0; r < LR; ++r) ls[r] = second ? l1[r] : l0[r];
-        al_grad_hvp<n, m, (VAR & 4) != 0, LR>(K, z, ls, 1, second ? mu1r : mu0r, v, gr, y);
-        continue;
+    // constraints in the order of the list (the sums below are order-sensitive in the last bits): the cached ones from
+    // registers, the rest — only where table_cons says one applies to this wave's knots — through the descriptor table
+    if (!table_cons) {
+      if (on0) al_grad_hvp_ctrl<n, m>(ce0, z, l0, mu0r, v, gr, y);
+      if (on1) al_grad_hvp_ctrl<n, m>(ce1, z, l1, mu1r, v, gr, y);
+    } else {
+      const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane64;
+      const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane64;
+      for (int ci = 0; ci < P.n_cons; ++ci) {
+        if (ci == ce0.ci) { if (on0) al_grad_hvp_ctrl<n, m>(ce0, z, l0, mu0r, v, gr, y); continue; }
+        if (ci == ce1.ci) { if (on1) al_grad_hvp_ctrl<n, m>(ce1, z, l1, mu1r, v, gr, y); continue; }
+        ConC& K = P.cons[ci];
+        if (k < K.k1 || k > K.k2) continue;
+        const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
       }
-      const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-      al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
     }
   }
   double col[ne], qxe[ne];
@@ -136,6 +142,17 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
     for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
     double* gc = COL_PTR(a.gc, N);
     EL(gc, k) = gj;
+  } else if constexpr (LAY == 3) {  // upper triangle of the symmetric block, column j from its own lane
+    using L = LaneLay<M>;
+    double* Hl = a.Hc + (((size_t)tile * (size_t)N + k) * L::NS + (size_t)(j * (j + 1) / 2)) * 64 + lane64;
+#pragma unroll
+    for (int i = 0; i < ne; ++i)
+      if (i <= j) EL(Hl, i) = col[i];
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+      if (ne + r <= j) EL(Hl, ne + r) = terminal ? 0.0 : y[n + r];
+    double* gl = a.gc + (((size_t)tile * (size_t)N + k) * nc + j) * 64 + lane64;
+    gl[0] = gj;
   } else {
     if constexpr (LAY == 1) {
       double* Ht = a.Ht + (((size_t)b * N + k) * NR) * 64 + ct;
@@ -189,6 +206,17 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
   const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
   const int tile = b >> 6, lane64 = b & 63;
+  // constraint descriptors, once per wave: up to two control-block constraints go to registers; table_cons: some other
+  // constraint applies to one of this wave's knots (for the usual goal constraint: only the wave at the terminal knot)
+  ConExp<m> ce0, ce1;
+  bool table_cons = false;
+  if constexpr ((VAR & 2) != 0) {
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (K.fast == 2 && K.p <= m + 1 && ce1.ci < 0) { if (ce0.ci < 0) ce0.load(K, ci); else ce1.load(K, ci); }
+      else if (K.k1 <= k0 + KC - 1 && K.k2 >= k0) table_cons = true;
+    }
+  }
   const double* X = X_SLOT_PTR(a, b, c);
   const double* U = U_SLOT_PTR(a, b, c);
   double x[n], u[m], x1[n], x2[n], un[m];
@@ -218,7 +246,7 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
         for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
       }
     }
-    expand_knot<M, FIXED_INTEG, VAR, LAY>(a, gtile, lane, tile, lane64, b, j, k, valid, x, u, x1);
+    expand_knot<M, FIXED_INTEG, VAR, LAY>(a, gtile, lane, tile, lane64, b, j, k, valid, x, u, x1, ce0, ce1, table_cons);
     if (KC > 1) {
 #pragma unroll
       for (int i = 0; i < n; ++i) { x[i] = x1[i]; x1[i] = x2[i]; }

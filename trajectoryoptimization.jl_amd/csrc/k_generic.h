@@ -121,6 +121,21 @@ __global__ void k_col_to_host(const double* __restrict__ src, double* __restrict
   h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = src[idx];
 }
 
+// lane layout (k_backward.h, LaneLay) -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0 + r][col0 + c].
+// E entries of 64 lanes per knot; sym: X symmetric, upper triangle stored column by column; else row-major with ld columns
+// (a vector: Rr = 1, row0 = 0, ld = its length).
+__global__ void k_lane_to_host(const double* __restrict__ src, double* __restrict__ h, int E, int sym, int ld, int row0, int Rr, int col0,
+                               int Cc, int K, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int e = blockIdx.y;  // (k*Cc + c)*Rr + r
+  if (b >= B) return;
+  const int r = e % Rr, c = (e / Rr) % Cc, k = e / (Rr * Cc);
+  const int row = row0 + r, col = col0 + c;
+  const int lo = row < col ? row : col, hi = row < col ? col : row;
+  const int ent = sym ? hi * (hi + 1) / 2 + lo : row * ld + col;
+  h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = src[(((size_t)(b >> 6) * K + k) * E + ent) * 64 + (b & 63)];
+}
+
 // tangent-matrix layout (k_backward.h) -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0 + r][col0 + c] of
 // trajectory b, X stored with `regs` 64-lane rows per knot.  compact: one row per knot holding, for lane (g, col), the
 // entry of row crow[g*16 + col] (device table, -1: none); everything else is zero.

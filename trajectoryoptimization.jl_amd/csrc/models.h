@@ -63,15 +63,14 @@ __device__ __forceinline__ Dual recip_t(Dual x) { const double r = rcp_fast(x.v)
 // ≈ |x|·2e-16 in the angle): such states only occur in diverged line-search candidates, whose cost is astronomically
 // large either way; NaN/Inf propagate to NaN and are caught by the state-limit check.
 __device__ __forceinline__ void sincos_fast(double x, double* s, double* c) {
-  if (!(fabs(x) < 8.2e5)) {
+  if (!(fabs(x) < 8.2e5)) {  // (a wave-uniform skip of this fold measured slower: 100 -> 105 us per Cartpole forward pass)
     const double t = x * 1.59154943091895335769e-01;  // 1/(2π)
     x = (t - rint(t)) * 6.28318530717958647693e+00;
   }
   const double fn = rint(x * 6.36619772367581382433e-01);
   double r = fma(-fn, 1.57079632673412561417e+00, x);   // pio2_1  (33 bits)
   r = fma(-fn, 6.07710050630396597660e-11, r);          // pio2_2  (33 bits)
-  r = fma(-fn, 2.02226624871116645580e-21, r);          // pio2_3  (33 bits)
-  r = fma(-fn, 8.47842766036889956997e-32, r);          // pio2_3t
+  r = fma(-fn, 2.02226624871116645580e-21, r);          // pio2_3  (33 bits); the tail beyond it is < 5e-26 for |fn| < 5.3e5
   const double z = r * r;
   // sin(r) = r + r^3 (S1 + z (S2 + ...)),  cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ...))
   double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
@@ -117,6 +116,7 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr int ls_first_round = 4;             // step sizes tried concurrently (results do not depend on it): these models accept
                                                        // within the first 4 in 99.9 % of the iterations (tools/ls_hist.py); more only adds candidate traffic
   static constexpr bool mfma_backward = false, coop_backward = true;  // backward-pass kernels instantiated (k_backward.h)
+  static constexpr bool lane_backward = (3 * D <= 6);  // one lane per trajectory while the blocks fit a lane's registers
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double inv_mass = rcp_fast(P[0]);
@@ -137,7 +137,8 @@ struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr bool lds_gains = false;             // forward pass: the gains row of a knot is a handful of doubles, loaded directly
   static constexpr int ls_first_round = 4;             // step sizes tried concurrently (results do not depend on it): these models accept
                                                        // within the first 4 in 99.9 % of the iterations (tools/ls_hist.py); more only adds candidate traffic
-  static constexpr bool mfma_backward = true, coop_backward = true;  // both backward passes: MFMA for latency (small batches), cooperative for throughput
+  static constexpr bool mfma_backward = true, coop_backward = true;  // MFMA and cooperative backward passes stay built for A/B runs (TRAJOPT_BACKWARD)
+  static constexpr bool lane_backward = true;  // default: one lane per trajectory
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mc = P[0], mp = P[1], l = P[2], g = P[3];
@@ -171,6 +172,7 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr bool lds_gains = true;  // forward pass: the 52-double gains row of a knot comes through LDS (DMA), not prefetch VGPRs
   static constexpr int ls_first_round = 16;  // accepted step sizes sit at 2^-5 .. 2^-12 late in these solves (tools/ls_hist.py): a deep first round
   static constexpr bool mfma_backward = true, coop_backward = false;  // MFMA backward pass only (the cooperative kernel needed 256 VGPR + 236 AGPR here)
+  static constexpr bool lane_backward = false;
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     const double mass = P[0], J1 = P[1], J2 = P[2], J3 = P[3];

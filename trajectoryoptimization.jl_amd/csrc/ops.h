@@ -13,6 +13,7 @@ void fill_traits(ModelOps& o) {
   o.write_through = M::accept_write_through;
   o.mfma_backward = M::mfma_backward;
   o.coop_backward = M::coop_backward;
+  o.lane_backward = M::lane_backward;
   o.lds_gains = M::lds_gains;
   o.expand_knots = M::expand_knots;
   o.ls_first_round = M::ls_first_round;
@@ -92,14 +93,14 @@ int op_constraint_hessian(to_handle* h, int ci, const double* lambda, double* H)
 
 // expansion variants compiled: 0 = diagonal-kind costs, no constraints; 2 = + selector / SOC-selector constraints;
 // 7 = everything.  Layout (k_expand.h LAY): column layout for the cooperative backward pass, tangent-matrix layout
-// (full or compact cost block) for the MFMA one.
+// (full or compact cost block) for the MFMA one, lane layout for the one-lane-per-trajectory one.
 template <class M, int FI>
 int op_expand_fi(to_handle* h) {
   const DevProblem& P = h->a.P;
   const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
   const int kc = var == 0 ? expand_kc<M, 0>() : expand_kc<M, 2>();
   const dim3 grid((P.B + h->G - 1) / h->G, (P.N + kc - 1) / kc);
-  const int lay = !h->a.bwd_mfma ? 0 : (h->a.h_compact ? 2 : 1);
+  const int lay = h->a.bwd_lane ? 3 : !h->a.bwd_mfma ? 0 : (h->a.h_compact ? 2 : 1);
 #define TO_EXPAND_CASE(V, LY) \
   if (var == V && lay == LY) { hipLaunchKernelGGL((k_expand<M, FI, V, LY>), grid, dim3(BLOCK), 0, h->stream, h->a); HIPCHECK(hipGetLastError()); return TO_OK; }
   if constexpr (M::mfma_backward) {
@@ -107,6 +108,9 @@ int op_expand_fi(to_handle* h) {
   }
   if constexpr (!M::mfma_backward || M::coop_backward) {
     TO_EXPAND_CASE(0, 0) TO_EXPAND_CASE(2, 0) TO_EXPAND_CASE(7, 0)
+  }
+  if constexpr (M::lane_backward) {
+    TO_EXPAND_CASE(0, 3) TO_EXPAND_CASE(2, 3) TO_EXPAND_CASE(7, 3)
   }
 #undef TO_EXPAND_CASE
   return fail(TO_ERR_UNSUPPORTED, "expansion variant not compiled for this model");
@@ -126,6 +130,13 @@ int op_backward(to_handle* h) {
     if (h->a.bwd_mfma) {
       if (h->a.h_compact) hipLaunchKernelGGL((k_backward_mfma<M, true>), dim3(P.B), dim3(BLOCK), 0, h->stream, h->a);
       else hipLaunchKernelGGL((k_backward_mfma<M, false>), dim3(P.B), dim3(BLOCK), 0, h->stream, h->a);
+      HIPCHECK(hipGetLastError());
+      return TO_OK;
+    }
+  }
+  if constexpr (M::lane_backward) {
+    if (h->a.bwd_lane) {
+      hipLaunchKernelGGL(k_backward_lane<M>, dim3((P.B + 63) / 64), dim3(BLOCK), 0, h->stream, h->a);
       HIPCHECK(hipGetLastError());
       return TO_OK;
     }

@@ -634,6 +634,69 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
   }
 }
 
+// A control-block selector constraint (fast == 2, p <= m + 1) with its descriptor fields held in registers (SGPRs: they are
+// wave-uniform).  The expansion walks several knots per wave; read through the descriptor table, every knot of the C5
+// constraint set paid ~85 dependent scalar-load round trips (388 `s_waitcnt lgkmcnt(0)` in the 4-knot kernel against 48
+// without constraints) that one wave per SIMD cannot hide.  Same expressions as al_grad_hvp<..., REGROWS>.
+template <int m>
+struct ConExp {
+  int ci = -1, p = 0, sense = 0, k1 = 0, k2 = -1;
+  long long dual_off = 0;
+  double ssgn[m + 1], soff[m + 1];
+  __device__ __forceinline__ void load(ConC& K, int ci_) {
+    ci = ci_; p = K.p; sense = K.d.sense; k1 = K.k1; k2 = K.k2; dual_off = K.dual_off;
+#pragma unroll
+    for (int r = 0; r < m + 1; ++r) { ssgn[r] = (r < p) ? K.ssgn[r] : 0.0; soff[r] = (r < p) ? K.soff[r] : 0.0; }
+  }
+  __device__ __forceinline__ bool at(int k) const { return ci >= 0 && k >= k1 && k <= k2; }
+};
+// l: this knot's duals of the constraint (m + 1 registers), z = [x; u], v the direction; g += grad, y += Hessian-vector
+template <int n, int m>
+__device__ __forceinline__ void al_grad_hvp_ctrl(const ConExp<m>& C, const double* z, const double* l, double mu, const double* v,
+                                                 double* g, double* y) {
+  const int p = C.p;
+  if (C.sense == TO_CONE_SECOND_ORDER) {
+    double a2 = 0.0, lw = 0.0, llast = 0.0, solast = 0.0;
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+      if (r < p - 1) {
+        const double lb = l[r] - mu * (C.ssgn[r] * (z[n + r] - C.soff[r]));
+        a2 += lb * lb;
+        lw += lb * (C.ssgn[r] * v[n + r]);
+      }
+#pragma unroll
+    for (int r = 0; r < m + 1; ++r)
+      if (r == p - 1) { llast = l[r]; solast = C.soff[r]; }
+    const double s = llast - mu * solast;
+    const double a = sqrt(a2);
+    if (a <= -s) return;  // Π = 0, ∇Π = 0
+    const bool inside = (a <= s);
+    const double ra = rcp_fast(a);
+    const double cf = inside ? 1.0 : 0.5 * (1 + s * ra);
+    const double k3 = inside ? 0.0 : (0.5 * s) * (ra * ra * ra);
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+      if (r < p - 1) {
+        const double sg = C.ssgn[r];
+        const double lb = l[r] - mu * (sg * (z[n + r] - C.soff[r]));
+        g[n + r] += -sg * (cf * lb);
+        const double w = sg * v[n + r];
+        y[n + r] += mu * sg * (cf * w - k3 * lb * lw);
+      }
+  } else {
+    const bool eq = (C.sense == TO_CONE_ZERO);
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+      if (r < p) {
+        const double sg = C.ssgn[r];
+        const double c = sg * (z[n + r] - C.soff[r]);
+        const bool active = eq || (c >= 0.0) || (l[r] > 0.0);
+        g[n + r] += sg * (l[r] + (active ? mu * c : 0.0));
+        y[n + r] += active ? mu * v[n + r] : 0.0;
+      }
+  }
+}
+
 // max violation of one constraint at one knot
 template <int nz>
 __device__ __forceinline__ double con_violation(ConC& K, const double* z) {

@@ -627,9 +627,20 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // Models that have the cooperative kernel as well (small ones: several trajectories per wave) default to it: measured on
   // the Cartpole at B = 1024, 78 us cooperative vs 90 us MFMA per backward pass (the 5x5 blocks fill 2 % of a 16x16 tile).
   a.bwd_mfma = (h->ops->mfma_backward && !h->ops->coop_backward) ? 1 : 0;
+  // Small models: the cooperative kernel (R lanes per trajectory, LDS exchanges) has the shorter critical path — 78 vs 111 us
+  // per pass on the Cartpole at B = 1024, a single lane issues every FMA of a knot itself — and the lane kernel the fewer
+  // instructions: it takes over once the cooperative waves would stack three deep on every SIMD (measured at B = 32 768:
+  // 12.0 vs 9.8 M trajectory-iterations/s).
+  {
+    int cus = 256;
+    HIPB(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const long coop_waves = ((long)B + h->G - 1) / h->G;
+    a.bwd_lane = (h->ops->lane_backward && coop_waves >= 3L * 4 * cus) ? 1 : 0;
+  }
   if (const char* env = std::getenv("TRAJOPT_BACKWARD")) {
-    if (!std::strcmp(env, "coop")) a.bwd_mfma = 0;
-    if (!std::strcmp(env, "mfma") && h->ops->mfma_backward) a.bwd_mfma = 1;
+    if (!std::strcmp(env, "coop") && h->ops->coop_backward) { a.bwd_mfma = 0; a.bwd_lane = 0; }
+    if (!std::strcmp(env, "mfma") && h->ops->mfma_backward) { a.bwd_mfma = 1; a.bwd_lane = 0; }
+    if (!std::strcmp(env, "lane") && h->ops->lane_backward) { a.bwd_mfma = 0; a.bwd_lane = 1; }
   }
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
@@ -654,6 +665,11 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     TRYB(dev_alloc(h, &a.gt, (size_t)Bp * N * 16));
     TRYB(dev_alloc(h, &h->d_crow, 64));
     HIPB(hipMemcpyAsync(h->d_crow, h->ops->crow, sizeof(int) * 64, hipMemcpyHostToDevice, h->stream));
+  } else if (a.bwd_lane) {  // lane layout (k_backward.h LaneLay), in the column-layout pointers
+    const size_t tiles = (size_t)Bp / 64, nc = (size_t)ne + m;
+    TRYB(dev_alloc(h, &a.Mc, tiles * (size_t)(N - 1) * ne * nc * 64));
+    TRYB(dev_alloc(h, &a.Hc, tiles * (size_t)N * (nc * (nc + 1) / 2) * 64));
+    TRYB(dev_alloc(h, &a.gc, tiles * (size_t)N * nc * 64));
   } else {
     const size_t gtiles = ((size_t)B + h->G - 1) / h->G;  // waves of the column-layout kernels
     TRYB(dev_alloc(h, &a.Mc, gtiles * (size_t)(N - 1) * ne * 64));
@@ -856,7 +872,13 @@ static int download_block(to_handle* h, double* host, int which, int row0, int R
   const int K = which == BLK_M ? P.N - 1 : P.N;
   const size_t cnt = (size_t)Rr * Cc * K * P.B;
   TRY(ensure_stage(h, cnt * sizeof(double)));
-  if (h->a.bwd_mfma) {
+  if (h->a.bwd_lane) {
+    const int nc = P.ne + P.m;
+    if (which == BLK_M)
+      hipLaunchKernelGGL(k_lane_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, h->a.Mc, h->stage, P.ne * nc, 0, nc, row0, Rr, col0, Cc, K, P.B);
+    else
+      hipLaunchKernelGGL(k_lane_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, h->a.Hc, h->stage, nc * (nc + 1) / 2, 1, nc, row0, Rr, col0, Cc, K, P.B);
+  } else if (h->a.bwd_mfma) {
     const int nep = h->ops->nep, rs = h->ops->rs;
     auto tix = [&](int i) { return i < P.ne ? i : nep + (i - P.ne); };  // tangent index (control directions start at NEP)
     const bool compact = which == BLK_H && h->a.h_compact;
@@ -877,7 +899,10 @@ static int download_gradient(to_handle* h, double* host, int col0, int Cc) {
   const DevProblem& P = h->a.P;
   const size_t cnt = (size_t)Cc * P.N * P.B;
   TRY(ensure_stage(h, cnt * sizeof(double)));
-  if (h->a.bwd_mfma) {
+  if (h->a.bwd_lane) {
+    const int nc = P.ne + P.m;
+    hipLaunchKernelGGL(k_lane_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, h->stage, nc, 0, nc, 0, 1, col0, Cc, P.N, P.B);
+  } else if (h->a.bwd_mfma) {
     const int tcol = col0 < P.ne ? col0 : h->ops->nep + (col0 - P.ne);
     hipLaunchKernelGGL(k_tmvec_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gt, h->stage, tcol, Cc, P.N, P.B);
   } else {
