@@ -174,9 +174,13 @@ def test_al_solve_cartpole(hip, oracle):
     assert np.all(sh.stats["c_max"][ok] < 1e-6)
 
 
-def test_al_solve_quadrotor_soc(hip, oracle):
+@pytest.mark.parametrize("unit_variants", [True, False])
+def test_al_solve_quadrotor_soc(hip, oracle, monkeypatch, unit_variants):
     # C5 shape (Goal@N + ‖u‖₂≤6 SOC) at N=101; constraint_tolerance 1e-4 keeps the solve out of the µ=1e8 tail where
-    # any two FP implementations diverge chaotically
+    # any two FP implementations diverge chaotically.  The norm constraint is a "unit SOC": by default the
+    # kernel variants specialised for it run (problem_dev.h unit_soc_desc); TRAJOPT_UNIT_SOC=0 takes the general ones.
+    if not unit_variants:
+        monkeypatch.setenv("TRAJOPT_UNIT_SOC", "0")
     def build(lib):
         o = T.SolverOptions(lib=lib, constraint_tolerance=1e-4)
         return configs.quadrotor_problem(batch=24, N=101, tf=5.0, constrained=True, lib=lib, options=o)

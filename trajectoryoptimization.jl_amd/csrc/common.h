@@ -96,10 +96,9 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
 // AL penalty terms of one knot only
 // AL terms of one stage knot with up to two register-cached control-block constraints (ConStage); the others take the
 // descriptor-table path.  Terms are summed in constraint order, like knot_al.
-template <class M, bool GEN>
+template <class M, bool GEN, class CS>
 __device__ __forceinline__ double knot_al_cached(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
-                                                 const double* mu0, int ncs, const ConStage<M::n, M::m>& c0,
-                                                 const ConStage<M::n, M::m>& c1) {
+                                                 const double* mu0, int ncs, const CS& c0, const CS& c1) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   double Ja = 0.0;
   for (int ci = 0; ci < P.n_cons; ++ci) {

@@ -92,7 +92,7 @@ struct ModelOps {
   int (*constraint_hessian)(to_handle*, int ci, const double* lambda, double* H) = nullptr;
   int (*expand)(to_handle*) = nullptr;
   int (*backward)(to_handle*) = nullptr;
-  int (*forward[16])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
+  int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
 };
 
 // each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole, 4 Quadrotor)
@@ -104,6 +104,7 @@ void fill_ops_quad_expand(ModelOps* table);
 void fill_ops_quad_backward(ModelOps* table);
 void fill_ops_quad_forward_a(ModelOps* table);
 void fill_ops_quad_forward_b(ModelOps* table);
+void fill_ops_quad_forward_c(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

@@ -68,7 +68,8 @@ __host__ __device__ inline int gains_lds_doubles(int TW) {  // per buffer, whole
 // its (AL) cost J, gradient metric gsum/(N-1) and admissibility ok.  Lanes with live == false roll out as well (a
 // partially masked wave issues FP64 ~1.3x slower on gfx950) but store nothing.
 // MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms);
-// bit2: RK4 fixed at compile time; bit3: dense costs / non-selector constraints possible (else compiled out).
+// bit2: RK4 fixed at compile time; bit3: dense costs / non-selector constraints possible (else compiled out);
+// bit4: the register-cached control constraints are unit SOCs (problem_dev.h unit_soc_desc).
 // kbuf: the wave's two LDS buffers for DMA-staged gains (M::lds_gains); krow: this lane's row offset in a buffer.
 template <class M, int MODE>
 __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int lane, int b, bool live, double alpha, int cs, double* kbuf,
@@ -108,7 +109,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     h0 = P.dt[0];
   }
   // stage constraints on the control block (norm / SOC / one-sided bounds on u) are cached in registers once
-  ConStage<n, m> cs0, cs1;
+  ConStage<n, m, (MODE & 16) != 0> cs0, cs1;  // bit4: every cacheable control constraint is a unit SOC (DevProblem::unit_soc)
   int ncs = 0, uncached = 0;
   cs0.ci = -1; cs1.ci = -1;
   if constexpr (CONS) {

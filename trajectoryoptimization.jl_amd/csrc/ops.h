@@ -122,7 +122,6 @@ int op_expand(to_handle* h) {
   }
   return op_expand_fi<M, -1>(h);
 }
-
 template <class M>
 int op_backward(to_handle* h) {
   const DevProblem& P = h->a.P;

@@ -36,6 +36,7 @@ typedef const int TO_CONST_AS IntC;
 struct DevProblem {
   int n, m, ne, N, B, Bp, integrator, n_costs, n_cons;
   int expand_variant;  // bit0: a QuadraticCost / ErrorQuadratic exists; bit1: constraints exist; bit2: a non-selector constraint exists
+  int unit_soc;      // 1: constraints exist and every control-block selector constraint (fast == 2) is a unit SOC (unit_soc_desc)
   int simple_stage;  // 1: every stage knot (k < N-1) uses the same diagonal-kind cost and the same dt (the common LQR-style objective)
   long long n_duals;
   double mp[16];
@@ -511,48 +512,69 @@ __device__ __forceinline__ double al_term(ConC& K, const double* z, const double
   return J;
 }
 
+// NormConstraint(SECOND_ORDER) over the whole control vector as the reference builds it: rows r < m are u_r itself (sign 1,
+// offset 0), row m is the constant bound.  When every register-cacheable control constraint of a problem has this form
+// (DevProblem::unit_soc) the forward pass runs variants compiled with UNIT = true, whose hot loops hold neither ssgn/soff (20
+// SGPRs per constraint, spilled to VGPR lanes and reloaded one by one every knot) nor the per-row predicates: C5 forward
+// pass 2325 -> 2021 us per batch step.  (A run-time branch to the same code does not help: the other path keeps the
+// registers live.)  The expressions are those of the general path with ssgn = 1, soff = 0 substituted: bit-identical.
+template <int m>
+__host__ __device__ inline bool unit_soc_desc(int sense, int fast, int p, const double* ssgn, const double* soff) {
+  bool unit = sense == TO_CONE_SECOND_ORDER && fast == 2 && p == m + 1;
+  for (int r = 0; r < m && unit; ++r) unit = ssgn[r] == 1.0 && soff[r] == 0.0;
+  return unit;
+}
 // A constraint whose selector rows are the control block (fast == 2) and that applies to every stage knot, cached in
 // registers for the rollout loops: al_term re-reads k1/k2/p/sense/ssgn/soff from the descriptor table on every knot —
 // ~80 dependent scalar loads per Quadrotor knot with the C5 constraint set.  Same expressions as al_term.
-template <int n, int m>
+template <int n, int m, bool UNIT = false>
 struct ConStage {
   int ci, p, sense;
-  double ssgn[m + 1], soff[m + 1], mu;
+  double ssgn[UNIT ? 1 : m + 1], soff[UNIT ? 1 : m + 1], mu;  // UNIT: soff[0] holds the bound (the general soff[m])
   double lcur[m + 1], lnxt[m + 1];  // duals of the current knot / fetched one knot ahead (a load at the point of use
                                     // costs a full memory round trip per knot: measured 2.2x the waits of the unconstrained loop)
   const double* lam;  // this lane's dual row 0 at knot 0; row r of knot k at lam[(k*p + r)*64]
   __device__ __forceinline__ void prefetch(int k) {
     const double* lk = lam + (size_t)k * p * 64;
 #pragma unroll
-    for (int r = 0; r < m + 1; ++r) lnxt[r] = (r < p) ? lk[r * 64] : 0.0;
+    for (int r = 0; r < m + 1; ++r) lnxt[r] = (UNIT || r < p) ? lk[r * 64] : 0.0;
   }
   __device__ __forceinline__ void advance() {
 #pragma unroll
     for (int r = 0; r < m + 1; ++r) lcur[r] = lnxt[r];
   }
   __device__ __forceinline__ void load(ConC& K, int ci_, const double* lam0, const double* mu0) {
-    ci = ci_; p = K.p; sense = K.d.sense;
+    ci = ci_; p = UNIT ? m + 1 : K.p; sense = K.d.sense;
+    if constexpr (UNIT) { ssgn[0] = 1.0; soff[0] = K.soff[m]; }
+    else {
 #pragma unroll
-    for (int r = 0; r < m + 1; ++r) { ssgn[r] = (r < p) ? K.ssgn[r] : 0.0; soff[r] = (r < p) ? K.soff[r] : 0.0; }
+      for (int r = 0; r < m + 1; ++r) { ssgn[r] = (r < p) ? K.ssgn[r] : 0.0; soff[r] = (r < p) ? K.soff[r] : 0.0; }
+    }
     mu = mu0[(size_t)ci_ * 64];
     lam = lam0 + (size_t)K.dual_off * 64;
   }
   // uses the duals in lcur (prefetch(k) + advance() by the caller)
   __device__ __forceinline__ double term(const double* u) const {
     double J = 0.0;
-    if (sense == TO_CONE_SECOND_ORDER) {
+    if (UNIT || sense == TO_CONE_SECOND_ORDER) {
       double a2 = 0.0, l2 = 0.0, ls = 0.0, so = 0.0;
+      if constexpr (UNIT) {
 #pragma unroll
-      for (int r = 0; r < m; ++r)
-        if (r < p - 1) {
-          const double l = lcur[r];
-          const double lb = l - mu * (ssgn[r] * (u[r] - soff[r]));
-          l2 += l * l;
-          a2 += lb * lb;
-        }
+        for (int r = 0; r < m; ++r) { const double l = lcur[r]; const double lb = l - mu * u[r]; l2 += l * l; a2 += lb * lb; }
+        ls = lcur[m]; so = soff[0];
+      } else {
 #pragma unroll
-      for (int r = 0; r < m + 1; ++r)
-        if (r == p - 1) { ls = lcur[r]; so = soff[r]; }
+        for (int r = 0; r < m; ++r)
+          if (r < p - 1) {
+            const double l = lcur[r];
+            const double lb = l - mu * (ssgn[r] * (u[r] - soff[r]));
+            l2 += l * l;
+            a2 += lb * lb;
+          }
+#pragma unroll
+        for (int r = 0; r < m + 1; ++r)
+          if (r == p - 1) { ls = lcur[r]; so = soff[r]; }
+      }
       const double s = ls - mu * so;
       l2 += ls * ls;
       const double a = sqrt(a2);
@@ -654,6 +676,7 @@ struct ConExp {
 template <int n, int m>
 __device__ __forceinline__ void al_grad_hvp_ctrl(const ConExp<m>& C, const double* z, const double* l, double mu, const double* v,
                                                  double* g, double* y) {
+  // (a variant specialised for unit SOCs, as the forward pass has, measured SLOWER here: C5 expansion 1580 -> 1675 us)
   const int p = C.p;
   if (C.sense == TO_CONE_SECOND_ORDER) {
     double a2 = 0.0, lw = 0.0, llast = 0.0, solast = 0.0;

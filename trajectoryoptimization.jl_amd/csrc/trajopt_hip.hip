@@ -38,7 +38,7 @@ const ModelOps* model_ops(int key) {
   std::call_once(g_ops_once, [] {
     fill_ops_small(g_ops); fill_ops_small_forward(g_ops);
     fill_ops_quad_misc(g_ops); fill_ops_quad_expand(g_ops); fill_ops_quad_backward(g_ops);
-    fill_ops_quad_forward_a(g_ops); fill_ops_quad_forward_b(g_ops);
+    fill_ops_quad_forward_a(g_ops); fill_ops_quad_forward_b(g_ops); fill_ops_quad_forward_c(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
 }
@@ -293,6 +293,17 @@ int upload_tables(to_handle* h) {
     for (const auto& c : h->costs) dense = dense || c.kind == TO_COST_QUADRATIC || c.kind == TO_COST_ERROR_QUADRATIC;
     for (const auto& c : h->cons) generic = generic || !c.selector;
     P.expand_variant = (dense ? 1 : 0) | (h->cons.empty() ? 0 : 2) | (generic ? 4 : 0);
+    // unit-SOC forward-pass variants (problem_dev.h unit_soc_desc): at least one control-block constraint, and all of them unit
+    bool any_ctrl = false, all_unit = true;
+    for (const auto& c : h->cons)
+      if (c.fast == 2) {
+        any_ctrl = true;
+        const bool u = P.m == 1 ? unit_soc_desc<1>(c.d.sense, c.fast, c.p, c.ssgn, c.soff) : P.m == 2 ? unit_soc_desc<2>(c.d.sense, c.fast, c.p, c.ssgn, c.soff)
+                     : P.m == 3 ? unit_soc_desc<3>(c.d.sense, c.fast, c.p, c.ssgn, c.soff) : unit_soc_desc<4>(c.d.sense, c.fast, c.p, c.ssgn, c.soff);
+        all_unit = all_unit && u;
+      }
+    P.unit_soc = (any_ctrl && all_unit) ? 1 : 0;
+    if (const char* env = std::getenv("TRAJOPT_UNIT_SOC")) if (!std::atoi(env)) P.unit_soc = 0;  // A/B knob
     h->a.h_compact = (h->a.bwd_mfma && compact_cost_blocks(h)) ? 1 : 0;
     if (const char* env = std::getenv("TRAJOPT_FULL_COST_BLOCKS")) if (std::atoi(env)) h->a.h_compact = 0;  // testing knob
   }
@@ -324,6 +335,7 @@ int launch_forward(to_handle* h, bool accept = true) {
   const KArgs& a = h->a;
   int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | ((a.P.expand_variant & 5) ? 8 : 0);
   if (!h->ops->forward[mode]) mode &= ~4;  // the model does not pin RK4
+  if (a.P.unit_soc && h->ops->forward[mode | 16]) mode |= 16;
   if (!h->ops->forward[mode]) return fail(TO_ERR_UNSUPPORTED, "forward-pass variant not compiled for this model");
   TRY(h->ops->forward[mode](h));
   if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
