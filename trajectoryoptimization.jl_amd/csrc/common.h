@@ -40,6 +40,8 @@ struct KArgs {
   int *status, *iterations, *it_inner, *outer, *dJzero, *ls_index, *active, *budget, *bpfail;
   int* counter;   // [steps] number of trajectories still active after each batch step
   int *oflag, *ost;   // [Bp] AL outer update pending (1: evaluate, 2: update duals) and the inner solve's status
+  int *olist, *ocount;  // trajectories whose inner solve ended in batch step s: olist[(s&1)*Bp + 0 .. ocount[s&1]) (appended by k_forward,
+                        // consumed by the k_outer_* kernels of the same step, which also clear the other parity's count)
   double* knotbuf;    // tiled, L = N: per-knot scratch of the outer update (violations, then AL cost terms)
   double* mu_next;    // tiled, L = n_cons: penalties after the pending outer update
   int al_mode;    // 0: iLQR, 1: AL-iLQR

@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
     if (!a.al_mode) { a.status[b] = st; still_active = false; }
     else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels
       a.ost[b] = st; a.oflag[b] = 1;
+      a.olist[(size_t)(a.step & 1) * P.Bp + atomicAdd(&a.ocount[a.step & 1], 1)] = b;  // order is irrelevant: the outer update is per trajectory
       a.rho[b] = rho; a.drho[b] = drho;
       return;
     }

@@ -41,6 +41,7 @@ __global__ void k_solve_init(KArgs a, int reset_duals) {
   TILE_LANE();
   const DevProblem& P = a.P;
   if (b >= P.Bp) return;
+  if (b < 2) a.ocount[b] = 0;  // both parities of the outer-update list (common.h)
   const bool live = b < P.B;
   a.rho[b] = P.opts.bp_reg_initial; a.drho[b] = 0.0;
   a.dJzero[b] = 0; a.it_inner[b] = 0; a.iterations[b] = 0; a.outer[b] = 0;

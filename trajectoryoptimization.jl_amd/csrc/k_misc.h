@@ -77,17 +77,28 @@ __global__ void __launch_bounds__(64) k_dual_update(KArgs a) {
 
 
 // ---- AL outer update of the trajectories whose inner solve just ended (oflag = 1), knot-parallel:
-//   k_outer_violation (tiles, N): constraint violation of every knot -> knotbuf
-//   k_outer_decide    (tiles)   : c_max, termination tests; trajectories that go on get oflag = 2 and their new penalties
-//   k_outer_update    (tiles, N): dual update with the OLD penalties, then the knot's AL cost with the new duals/penalties
-//   k_outer_finish    (tiles)   : J = sum of the knot terms in knot order (same sum as a sequential pass), restart the inner solve
-// One lane per trajectory walking all knots three times was the largest kernel of the constrained solves.
+//   k_outer_violation (waves, N): constraint violation of every knot -> knotbuf
+//   k_outer_decide    (waves)   : c_max, termination tests; trajectories that go on get oflag = 2 and their new penalties
+//   k_outer_update    (waves, N): dual update with the OLD penalties, then the knot's AL cost with the new duals/penalties
+//   k_outer_finish    (waves)   : J = sum of the knot terms in knot order (same sum as a sequential pass), restart the inner solve
+// One lane per trajectory walking all knots three times was the largest kernel of the constrained solves.  The lanes of a
+// wave take their trajectories from the COMPACTED list k_forward appended them to (a.olist): in C5 some 6 % of the batch
+// ends an inner solve in any given batch step, scattered over nearly every 64-trajectory tile — mapped tile by tile, every
+// (tile, knot) wave ran for three or four useful lanes (the four kernels: 236 us per step, 5 % of the solve).
+#define OUTER_LANE(FLAG)                                                                      \
+  const DevProblem& P = a.P;                                                                  \
+  const int cnt_ = a.ocount[a.step & 1];                                                      \
+  if ((int)blockIdx.x * 64 >= cnt_) return;                                                   \
+  const int li_ = blockIdx.x * 64 + threadIdx.x;                                              \
+  const int b = a.olist[(size_t)(a.step & 1) * P.Bp + (li_ < cnt_ ? li_ : cnt_ - 1)];         \
+  const int tile = b >> 6, lane = b & 63;                                                     \
+  const bool want = li_ < cnt_ && a.oflag[b] == (FLAG)
+
 template <class M>
 __global__ void __launch_bounds__(64) k_outer_violation(KArgs a) {
   constexpr int n = M::n, m = M::m;
-  TILE_LANE();
-  const DevProblem& P = a.P;
-  const bool want = b < P.B && a.oflag[b] == 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.ocount[(a.step + 1) & 1] = 0;  // next step's list starts empty
+  OUTER_LANE(1);
   if (__ballot(want) == 0) return;
   if (!want) return;
   const int N = P.N, k = blockIdx.y;
@@ -104,15 +115,15 @@ __global__ void __launch_bounds__(64) k_outer_violation(KArgs a) {
 
 template <class M>
 __global__ void __launch_bounds__(64) k_outer_decide(KArgs a) {
-  TILE_LANE();
-  const DevProblem& P = a.P;
-  if (b >= P.B || a.oflag[b] != 1) return;
+  OUTER_LANE(1);
+  if (!want) return;
   const to_solver_opts& o = P.opts;
   const int N = P.N, st = a.ost[b];
   const int outer = a.outer[b] + 1;
   a.outer[b] = outer;
   const double* vb = TILE_PTR(a.knotbuf, N);
   double cm = 0.0;
+#pragma unroll 8
   for (int k = 0; k < N; ++k) { const double v = EL(vb, k); if (!(v <= cm)) cm = v; }
   a.cmax[b] = cm;
   const int its = a.iterations[b];
@@ -132,9 +143,7 @@ __global__ void __launch_bounds__(64) k_outer_decide(KArgs a) {
 template <class M>
 __global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  TILE_LANE();
-  const DevProblem& P = a.P;
-  const bool want = b < P.B && a.oflag[b] == 2;
+  OUTER_LANE(2);
   if (__ballot(want) == 0) return;
   if (!want) return;
   const int N = P.N, k = blockIdx.y;
@@ -160,13 +169,13 @@ __global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
 
 template <class M>
 __global__ void __launch_bounds__(64) k_outer_finish(KArgs a) {
-  TILE_LANE();
-  const DevProblem& P = a.P;
-  if (b >= P.B || a.oflag[b] != 2) return;
+  OUTER_LANE(2);
+  if (!want) return;
   const to_solver_opts& o = P.opts;
   const int N = P.N;
   const double* jb = TILE_PTR(a.knotbuf, N);
   double J = 0.0;
+#pragma unroll 8
   for (int k = 0; k < N; ++k) J += EL(jb, k);
   a.J[b] = J;
   double* mu0 = TILE_PTR(a.mu, P.n_cons);
@@ -180,6 +189,7 @@ __global__ void __launch_bounds__(64) k_outer_finish(KArgs a) {
   a.oflag[b] = 0;
   atomicAdd(&a.counter[a.step], 1);
 }
+#undef OUTER_LANE
 
 // ------------------------------------------------------------------------------------------------ per-knot API kernels
 // RD.gradient!/RD.hessian! of the objective on the full state (no AL, no error-state projection):

@@ -668,6 +668,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
+  TRYB(dev_alloc(h, &a.olist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.ocount, 2));
   TRYB(dev_alloc(h, &a.knotbuf, (size_t)N * Bp));
   TRYB(dev_alloc(h, &a.mu_next, (size_t)std::max<size_t>(1, cons.size()) * Bp));
   if (a.bwd_mfma) {  // tangent-matrix layout (k_backward.h): RS rows of 64 per knot for [A B], up to RS+1 for the cost block
