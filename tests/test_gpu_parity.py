@@ -425,6 +425,37 @@ def test_line_search_round_schedule(t1, hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+@pytest.mark.parametrize("width", [8, 4])
+def test_forward_wave_shape_is_invisible_constrained_quadrotor(width, hip, monkeypatch):
+    """The forward-wave shape (step sizes per round x trajectories per wave) must not change a single bit: the constrained
+    Quadrotor batch stepped through the phase API with 16 step sizes per round and with `width`.  This is the scenario that
+    exposed the compiler's spill-placement hazard: with >= 6 candidates of a trajectory in lanes >= 40 the
+    second round of the line search ran with a corrupted step size, 40 iterations into the solve."""
+    monkeypatch.setenv("TRAJOPT_LS_DEEP", "0")
+    probs = []
+    for cw in (16, width):
+        monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", str(cw))
+        o = T.SolverOptions(lib=hip, constraint_tolerance=1e-4)
+        p = configs.quadrotor_problem(batch=24, N=101, tf=5.0, constrained=True, lib=hip, options=o)
+        T.rollout(p)
+        probs.append(p)
+    deep_rounds = 0
+    for it in range(48):
+        out = []
+        for p in probs:
+            if it % 15 == 14:
+                I.dual_update(p)
+            I.expand(p); I.backwardpass(p)
+            ls, J = I.forwardpass(p)
+            out.append((ls, J, T.states(p)))
+        (l0, J0, X0), (l1, J1, X1) = out
+        np.testing.assert_array_equal(l0, l1, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(J0, J1, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(X0, X1, err_msg=f"iteration {it}")
+        deep_rounds += int((l0 >= width).sum())
+    assert deep_rounds > 20  # the narrow shape really went through second and third rounds
+
+
 def test_lane_backward_on_small_models(hip, oracle, monkeypatch):
     """The one-lane-per-trajectory backward pass (lane-layout expansion; default only for batches that would stack the
     cooperative waves three deep) forced on small batches: expansion getters, gains, and full solves for m = 1
