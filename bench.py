@@ -236,6 +236,12 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything native code prints while we run (RCCL's version banner
+    # goes to stdout on communicator creation) is routed to stderr at the file-descriptor level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import trajopt_amd as T
     from trajectoryoptimization_jl_amd import configs
@@ -303,7 +309,8 @@ def main():
                 extra[key] = {"error": repr(e)}
         out["extra_workloads"] = extra
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
