@@ -149,9 +149,8 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
 #pragma unroll
       for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
       if (!(sj > 0.0) && glive) pd_ok = false;  // groups that only ride along never restart
-      const double l = sqrt(sj);
-      Lc[q][q] = l;
-      iL[q] = rcp_fast(l);
+      iL[q] = rsqrt_fast(sj);  // the diagonal of L is only ever divided by: 10 dependent operations instead of the ~30
+      Lc[q][q] = sj * iL[q];   // of an IEEE sqrt followed by a reciprocal (as in the MFMA kernel)
 #pragma unroll
       for (int i = q + 1; i < m; ++i) {
         double t = Lc[i][q];
@@ -390,9 +389,8 @@ __global__ void __launch_bounds__(64) k_backward_lane(KArgs a) {
 #pragma unroll
       for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
       if (!(sj > 0.0) && live) pd_ok = false;  // lanes that only ride along never restart
-      const double l = sqrt(sj);
-      Lc[q][q] = l;
-      iL[q] = rcp_fast(l);
+      iL[q] = rsqrt_fast(sj);  // the diagonal of L is only ever divided by: 10 dependent operations instead of the ~30
+      Lc[q][q] = sj * iL[q];   // of an IEEE sqrt followed by a reciprocal (as in the MFMA kernel)
 #pragma unroll
       for (int i = q + 1; i < m; ++i) {
         double t = Lc[i][q];
