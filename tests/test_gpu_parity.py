@@ -425,6 +425,21 @@ def test_line_search_round_schedule(t1, hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+def test_long_horizons(hip, oracle):
+    """Horizons well past the BASELINE shapes (index arithmetic, per-knot buffers, double-buffered gains): Cartpole N=1501,
+    constrained Cartpole N=801, Quadrotor N=601 — a few iterations each, batches that are not multiples of anything."""
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=5, N=1501, tf=15.0, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph, iterations=12).solve(), T.iLQRSolver(po, iterations=12).solve()
+    assert_solve_parity(sh, so, ph, po, unconverged_rtol=1e-4)
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=3, N=801, tf=8.0, constrained=True, **kw), hip, oracle)
+    kw = dict(iterations=8, iterations_outer=2, iterations_total=16)
+    sh, so = T.ALSolver(ph, **kw).solve(), T.ALSolver(po, **kw).solve()
+    assert_solve_parity(sh, so, ph, po, unconverged_rtol=1e-4)
+    ph, po = pair(lambda **kw: configs.quadrotor_problem(batch=3, N=601, tf=15.0, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph, iterations=6).solve(), T.iLQRSolver(po, iterations=6).solve()
+    assert_solve_parity(sh, so, ph, po, unconverged_rtol=1e-4)
+
+
 @pytest.mark.parametrize("width", [8, 4])
 def test_forward_wave_shape_is_invisible_constrained_quadrotor(width, hip, monkeypatch):
     """The forward-wave shape (step sizes per round x trajectories per wave) must not change a single bit: the constrained
