@@ -35,6 +35,8 @@ struct KArgs {
   int bwd_mfma;                       // 1: expansion writes Mt/Ht/gt and the MFMA backward pass runs; 0: column layout + cooperative pass
   int bwd_lane;                       // 1: expansion writes the lane layout into Mc/Hc/gc and the one-lane-per-trajectory backward pass runs
   int h_compact;                      // Ht holds one row per knot (block-diagonal Qxx, Quu, no Qux): see k_expand.h
+  int h_diag;                         // column layout: Hc holds ONE row per knot, the diagonal entry of the lane's own column (diagonal
+                                      // costs, goal / bound constraints only: every off-diagonal entry of the cost block is an exact zero)
   double *lam, *mu;                   // L = n_duals, n_cons
   double *J, *dJ, *grad, *rho, *drho, *dV, *cmax, *Jout;  // [Bp] plain (dV: [2][Bp])
   int *status, *iterations, *it_inner, *outer, *dJzero, *ls_index, *active, *budget, *bpfail;

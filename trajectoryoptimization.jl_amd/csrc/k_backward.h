@@ -22,7 +22,8 @@ struct BwdLds {
   static constexpr int stride = raw + ((34 - (raw % 32)) % 32);  // stride % 32 == 2 doubles: groups land on distinct banks
 };
 
-template <class M>
+// HD: diagonal cost blocks (KArgs::h_diag) — one row of Hc per knot, the lane's own diagonal entry.
+template <class M, bool HD>
 __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
   constexpr int m = M::m, ne = M::ne, nc = ne + m;
   constexpr int R = Coop<M>::R, G = Coop<M>::G;
@@ -47,7 +48,8 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
   double* gl = lds + g * L::stride + L::oG;
   double* sl = lds + g * L::stride + L::os;
   const double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
-  const double* Hc = COL_PTR(a.Hc, N * nc);
+  constexpr int HR = HD ? 1 : nc;  // rows of Hc per knot
+  const double* Hc = COL_PTR(a.Hc, N * HR);
   const double* gc = COL_PTR(a.gc, N);
   constexpr int RSK = Gains<M>::RSK;
   double* pK = a.Kt + ((size_t)(b < P.B ? b : 0) * (N - 1)) * RSK;  // this trajectory's gains rows (trajectory-major)
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
   bool failed = false;
   int k = N - 2;
   bool init = true, fresh = true;
-  double Mn[ne], Hn[nc], gn = 0.0;  // prefetched column of the next knot
+  double Mn[ne], Hn[HR], gn = 0.0;  // prefetched column of the next knot
   const double *pMk = Mc, *pHk = Hc, *pgk = gc;
   double* pKk = pK;
   while (true) {
@@ -64,8 +66,14 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
       fresh = true;
       {
         double Sc[ne];
+        if constexpr (HD) {
+          const double hd = EL(Hc, N - 1);
 #pragma unroll
-        for (int i = 0; i < ne; ++i) Sc[i] = EL(Hc, (N - 1) * nc + i);
+          for (int i = 0; i < ne; ++i) Sc[i] = (i == j) ? hd : 0.0;
+        } else {
+#pragma unroll
+          for (int i = 0; i < ne; ++i) Sc[i] = EL(Hc, (N - 1) * nc + i);
+        }
         const double s0 = EL(gc, N - 1);
         if (j < ne) {
 #pragma unroll
@@ -75,7 +83,7 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
       }
       dV0 = 0.0; dV1 = 0.0; k = N - 2; init = false;
       // per-knot pointers walk backwards with the recursion: constant offsets instead of 64-bit address arithmetic per load
-      pMk = Mc + (size_t)(N - 2) * ne * 64; pHk = Hc + (size_t)(N - 2) * nc * 64; pgk = gc + (size_t)(N - 2) * 64;
+      pMk = Mc + (size_t)(N - 2) * ne * 64; pHk = Hc + (size_t)(N - 2) * HR * 64; pgk = gc + (size_t)(N - 2) * 64;
       pKk = pK + (size_t)(N - 2) * RSK;
       WAVE_SYNC();
     }
@@ -86,21 +94,21 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
 #pragma unroll
       for (int i = 0; i < ne; ++i) Mn[i] = EL(pMk, i);
 #pragma unroll
-      for (int i = 0; i < nc; ++i) Hn[i] = EL(pHk, i);
+      for (int i = 0; i < HR; ++i) Hn[i] = EL(pHk, i);
       gn = EL(pgk, 0);
       fresh = false;
     }
 #pragma unroll
     for (int i = 0; i < ne; ++i) Mj[i] = Mn[i];
 #pragma unroll
-    for (int i = 0; i < nc; ++i) Hj[i] = Hn[i];
+    for (int i = 0; i < nc; ++i) Hj[i] = HD ? ((i == j) ? Hn[0] : 0.0) : Hn[HD ? 0 : i];
     gj = gn;
     if constexpr (ne > 6) fresh = true;  // large models: the extra live registers cost more than the latency they hide
     else if (k > 0) {
 #pragma unroll
       for (int i = 0; i < ne; ++i) Mn[i] = (pMk - ne * 64)[(size_t)i * 64];
 #pragma unroll
-      for (int i = 0; i < nc; ++i) Hn[i] = (pHk - nc * 64)[(size_t)i * 64];
+      for (int i = 0; i < HR; ++i) Hn[i] = (pHk - HR * 64)[(size_t)i * 64];
       gn = (pgk - 64)[0];
     }
 #pragma unroll
@@ -248,7 +256,7 @@ __global__ void __launch_bounds__(64) k_backward_coop(KArgs a) {
     }
     WAVE_SYNC();
     --k;
-    pMk -= ne * 64; pHk -= nc * 64; pgk -= 64; pKk -= RSK;
+    pMk -= ne * 64; pHk -= HR * 64; pgk -= 64; pKk -= RSK;
   }
   if (!failed) reg_decrease(P.opts, rho, drho);
   if (j == 0 && glive) {

@@ -135,11 +135,20 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   for (int r = 0; r < m; ++r) gj = (ne + r == j) ? gr[n + r] : gj;
   if (!valid) return;
   if constexpr (LAY == 0) {
-    double* Hc = COL_PTR(a.Hc, N * nc);
+    if (a.h_diag) {  // the column is zero off its diagonal entry (KArgs::h_diag): one row per knot instead of nc
+      double dj = 0.0;
 #pragma unroll
-    for (int i = 0; i < ne; ++i) EL(Hc, k * nc + i) = col[i];
+      for (int i = 0; i < ne; ++i) dj = (i == j) ? col[i] : dj;
 #pragma unroll
-    for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
+      for (int r = 0; r < m; ++r) dj = (ne + r == j) ? (terminal ? 0.0 : y[n + r]) : dj;
+      EL(COL_PTR(a.Hc, N), k) = dj;
+    } else {
+      double* Hc = COL_PTR(a.Hc, N * nc);
+#pragma unroll
+      for (int i = 0; i < ne; ++i) EL(Hc, k * nc + i) = col[i];
+#pragma unroll
+      for (int r = 0; r < m; ++r) EL(Hc, k * nc + ne + r) = terminal ? 0.0 : y[n + r];
+    }
     double* gc = COL_PTR(a.gc, N);
     EL(gc, k) = gj;
   } else if constexpr (LAY == 3) {  // upper triangle of the symmetric block, column j from its own lane

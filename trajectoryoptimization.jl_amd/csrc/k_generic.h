@@ -111,15 +111,18 @@ __global__ void k_gains_to_host(const double* __restrict__ Kt, double* __restric
 
 // column-layout arrays -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = col_array(b, column c0+c, entry k*rows_per_knot + r0 + r)
 // grid (ceil(B/64), K*Rr*Cc), one thread per trajectory.
+// diag: the array holds one row per knot, entry (c, c) of the block (KArgs::h_diag); every other entry reads as zero.
 __global__ void k_col_to_host(const double* __restrict__ src, double* __restrict__ h, int E, int rows_per_knot, int r0, int Rr, int c0,
-                              int Cc, int K, int B, int R, int G) {
+                              int Cc, int K, int B, int R, int G, int diag) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int e = blockIdx.y;  // (k*Cc + c)*Rr + r
   if (b >= B) return;
   const int r = e % Rr, c = (e / Rr) % Cc, k = e / (Rr * Cc);
   const int gtile = b / G, g = b % G;
-  const size_t idx = ((size_t)gtile * E + (size_t)k * rows_per_knot + r0 + r) * 64 + g * R + (c0 + c);
-  h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = src[idx];
+  double v;
+  if (diag) v = (r0 + r == c0 + c) ? src[((size_t)gtile * E + k) * 64 + g * R + (c0 + c)] : 0.0;
+  else v = src[((size_t)gtile * E + (size_t)k * rows_per_knot + r0 + r) * 64 + g * R + (c0 + c)];
+  h[(size_t)r + (size_t)Rr * (c + (size_t)Cc * (k + (size_t)K * b))] = v;
 }
 
 // lane layout (k_backward.h, LaneLay) -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0 + r][col0 + c].

@@ -141,7 +141,8 @@ int op_backward(to_handle* h) {
     }
   }
   if constexpr (!M::mfma_backward || M::coop_backward) {
-    hipLaunchKernelGGL(k_backward_coop<M>, dim3((P.B + h->G - 1) / h->G), dim3(BLOCK), 0, h->stream, h->a);
+    if (h->a.h_diag) hipLaunchKernelGGL((k_backward_coop<M, true>), dim3((P.B + h->G - 1) / h->G), dim3(BLOCK), 0, h->stream, h->a);
+    else hipLaunchKernelGGL((k_backward_coop<M, false>), dim3((P.B + h->G - 1) / h->G), dim3(BLOCK), 0, h->stream, h->a);
     HIPCHECK(hipGetLastError());
     return TO_OK;
   }

@@ -280,6 +280,14 @@ bool compact_cost_blocks(const to_handle* h) {
   return true;
 }
 
+// Column layout (cooperative backward pass; vector-space models only): is the cost block of every knot DIAGONAL — diagonal
+// costs, and constraints whose rows pick single entries of [x; u] (goal, bounds)?  Then lane j keeps one entry per knot.
+bool diagonal_cost_blocks(const to_handle* h) {
+  for (const auto& c : h->costs) if (c.kind != TO_COST_DIAGONAL) return false;
+  for (const DevCon& c : h->cons) if (c.d.kind != TO_CON_GOAL && c.d.kind != TO_CON_BOUND) return false;
+  return h->a.P.ne == h->a.P.n;
+}
+
 int upload_tables(to_handle* h) {
   {  // kernel-variant flags derived from the tables (refreshed whenever a cost or constraint is replaced)
     DevProblem& P = h->a.P;
@@ -305,7 +313,8 @@ int upload_tables(to_handle* h) {
     P.unit_soc = (any_ctrl && all_unit) ? 1 : 0;
     if (const char* env = std::getenv("TRAJOPT_UNIT_SOC")) if (!std::atoi(env)) P.unit_soc = 0;  // A/B knob
     h->a.h_compact = (h->a.bwd_mfma && compact_cost_blocks(h)) ? 1 : 0;
-    if (const char* env = std::getenv("TRAJOPT_FULL_COST_BLOCKS")) if (std::atoi(env)) h->a.h_compact = 0;  // testing knob
+    h->a.h_diag = (!h->a.bwd_mfma && !h->a.bwd_lane && diagonal_cost_blocks(h)) ? 1 : 0;
+    if (const char* env = std::getenv("TRAJOPT_FULL_COST_BLOCKS")) if (std::atoi(env)) { h->a.h_compact = 0; h->a.h_diag = 0; }  // testing knob
   }
   HIPCHECK(hipMemcpyAsync(h->d_costs, h->costs.data(), h->costs.size() * sizeof(to_cost_desc), hipMemcpyHostToDevice, h->stream));
   if (!h->cons.empty()) HIPCHECK(hipMemcpyAsync(h->d_cons, h->cons.data(), h->cons.size() * sizeof(DevCon), hipMemcpyHostToDevice, h->stream));
@@ -899,8 +908,10 @@ static int download_block(to_handle* h, double* host, int which, int row0, int R
                        which == BLK_M ? rs : rs + 1, tix(row0), Rr, tix(col0), Cc, K, P.B, compact ? h->d_crow : nullptr);
   } else {
     const int nc = P.ne + P.m;
+    const int diag = (which == BLK_H && h->a.h_diag) ? 1 : 0;
     hipLaunchKernelGGL(k_col_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mc : h->a.Hc, h->stage,
-                       which == BLK_M ? (P.N - 1) * P.ne : P.N * nc, which == BLK_M ? P.ne : nc, row0, Rr, col0, Cc, K, P.B, h->R, h->G);
+                       which == BLK_M ? (P.N - 1) * P.ne : (diag ? P.N : P.N * nc), which == BLK_M ? P.ne : nc, row0, Rr, col0, Cc, K, P.B,
+                       h->R, h->G, diag);
   }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -919,7 +930,7 @@ static int download_gradient(to_handle* h, double* host, int col0, int Cc) {
     const int tcol = col0 < P.ne ? col0 : h->ops->nep + (col0 - P.ne);
     hipLaunchKernelGGL(k_tmvec_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gt, h->stage, tcol, Cc, P.N, P.B);
   } else {
-    hipLaunchKernelGGL(k_col_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, h->stage, P.N, 1, 0, 1, col0, Cc, P.N, P.B, h->R, h->G);
+    hipLaunchKernelGGL(k_col_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, h->stage, P.N, 1, 0, 1, col0, Cc, P.N, P.B, h->R, h->G, 0);
   }
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
