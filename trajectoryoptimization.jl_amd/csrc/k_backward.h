@@ -573,7 +573,6 @@ __global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
   const double* gt = a.gt + ((size_t)b * N) * 16;
   double* Kt = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const bool ccol = c < ne;            // this lane's column is a state direction
-  const bool ctl = c >= NEP && c < NEP + m;
   bool rowok[RS];                      // register r of this lane holds a state row
 #pragma unroll
   for (int r = 0; r < RS; ++r) rowok[r] = (g + 4 * r) < ne;

@@ -80,8 +80,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
   const int N = P.N;
-  constexpr int c = 0;  // nominal slot
-  const double* Xc = TILE_PTR(a.Xs, N * n);
+  const double* Xc = TILE_PTR(a.Xs, N * n);  // the nominal (slot 0)
   const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
   // candidates: forward-wave-major (common.h), slot cs = q + 1; a wave's candidate stores are whole 512-byte rows.  Lanes
   // without a candidate store as well — into the dump block behind the last wave's, never read — so that the rollout loop
