@@ -289,3 +289,75 @@ def test_no_vgpr_spill_ahead_of_exec_restore():
     res = subprocess.run([sys.executable, str(tool)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-4000:]
     assert res.stdout.count("0 spill(s)") >= 8, res.stdout[-2000:]
+
+
+def test_spill_scanner_recognises_the_hazard():
+    """Unit test of tools/check_exec_spill.py on assembly snippets: the miscompiled join block of round 2 (VGPR->AGPR copies
+    ahead of the exec restore) is flagged; a divergent branch that ends in the program's own scratch store, an MFMA
+    accumulator set up under full EXEC, and a spill after the restore are not."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("check_exec_spill", Path(__file__).resolve().parent.parent / "tools" / "check_exec_spill.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = """
+_ZN2to9k_forwardINS_14QuadrotorModelELi3EEEvNS_5KArgsE:
+	s_and_saveexec_b64 s[4:5], s[6:7]
+	s_cbranch_execz .LBB1_41
+; %bb.40:
+	global_load_dwordx2 v[10:11], v[10:11], off
+	ds_write_b64 v12, v[10:11]
+.LBB1_41:                               ;   in Loop: Header=BB1_11 Depth=1
+	v_accvgpr_write_b32 a75, v25
+	v_accvgpr_write_b32 a74, v24
+	s_mov_b64 s[28:29], 0x200
+	v_writelane_b32 v251, s78, 29
+	s_or_b64 exec, exec, s[4:5]
+	s_load_dword s62, s[2:3], 0x0
+"""
+    hits = mod.scan_text(bad)
+    assert [h[3] for h in hits] == ["v_accvgpr_write_b32 a75, v25", "v_accvgpr_write_b32 a74, v24"]
+    assert hits[0][1] == ".LBB1_41" and "k_forward" in hits[0][0]
+    good = """
+_ZN2to8k_expandINS_13CartpoleModelELi0ELi2ELi0EEEvNS_5KArgsE:
+.LBB14_181:
+	v_add_f64 v[46:47], v[24:25], v[46:47]
+	scratch_store_dwordx2 off, v[46:47], off offset:32
+	s_or_b64 exec, exec, s[20:21]
+.LBB0_32:
+	v_mfma_f64_16x16x4_f64 a[8:15], v[66:67], v[4:5], 0
+	v_accvgpr_write_b32 a0, v13
+	s_and_saveexec_b64 s[0:1], s[14:15]
+	ds_write_b64 v38, v[72:73] offset:544
+	s_or_b64 exec, exec, s[0:1]
+.LBB0_40:
+	s_or_b64 exec, exec, s[2:3]
+	v_accvgpr_write_b32 a3, v9
+	s_or_b64 exec, exec, s[8:9]
+"""
+    assert mod.scan_text(good) == []
+    spilled = good.replace("scratch_store_dwordx2 off, v[46:47], off offset:32", "scratch_store_dwordx2 off, v[46:47], off offset:32 ; 8-byte Folded Spill")
+    assert len(mod.scan_text(spilled)) == 1
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r02_bench_default.json is the driver-format line of a plain `python bench.py` on the MI355X: the keys the
+    driver and the judge read must be there, for the headline workload and for the extra ones."""
+    import json
+    from pathlib import Path
+    line = (Path(__file__).resolve().parent.parent / "profiles" / "r02_bench_default.json").read_text().strip().splitlines()
+    assert len(line) == 1  # stdout of bench.py is exactly one line
+    d = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "build_id"):
+        assert k in d, k
+    assert d["metric"] == "iLQR iterations/sec (batched trajectories)" and d["n_gpus"] == 1 and d["dtype"] == "f64"
+    assert "model" not in d["config"] and "workload" in d["config"]
+    for w in [d] + list(d["extra_workloads"].values()):
+        r, c = w["roofline"], w["cpu_baseline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, k
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+        assert c["kind"] == "port" and w["value"] > 0

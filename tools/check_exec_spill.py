@@ -27,9 +27,9 @@ def _build_flags(name):
     return mod.flags_for(name)
 
 
-def scan(src):
-    cmd = ["/opt/rocm/bin/hipcc", *_build_flags(Path(src).name), "--cuda-device-only", "-S", "-o", "-", str(src)]
-    asm = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC)).stdout
+def scan_text(asm):
+    """[(kernel, block label, line number, instruction)]: spills found between a block label and the first `s_or_b64 exec,
+    exec, ...` of that block (the run ends at any branch or other write to EXEC)."""
     hits, kernel, pending, label = [], None, [], None
     for ln, line in enumerate(asm.splitlines(), 1):
         m = LABEL.match(line)
@@ -45,9 +45,18 @@ def scan(src):
             label = None  # only the run of instructions before the first exec restore of a block is of interest
         elif SPILL.match(line):
             pending.append(line.strip())
-        elif BRANCH.match(line) or re.search(r"saveexec|\bexec\b", line.split(";")[0].split(None, 1)[1].split(",")[0] if len(line.split()) > 1 else "") or "saveexec" in line:
-            label = None
-    return src.name, hits
+        else:
+            body = line.split(";")[0].split(None, 1)
+            dest = body[1].split(",")[0] if len(body) > 1 else ""
+            if BRANCH.match(line) or "saveexec" in line or re.search(r"\bexec\b", dest):
+                label = None
+    return hits
+
+
+def scan(src):
+    cmd = ["/opt/rocm/bin/hipcc", *_build_flags(Path(src).name), "--cuda-device-only", "-S", "-o", "-", str(src)]
+    asm = subprocess.run(cmd, capture_output=True, text=True, cwd=str(CSRC)).stdout
+    return src.name, scan_text(asm)
 
 
 def main():
