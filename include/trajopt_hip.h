@@ -201,7 +201,9 @@ typedef struct {
   int32_t iterations_outer;           /* 30 */
   int32_t cost_dt_scaling;            /* 0 (v0.7 semantics, NEWS.md:11-12); 1 = legacy: stage costs multiplied by dt */
   int32_t iterations_total;           /* 1000: cap on inner iterations summed over AL outer loops */
-  int32_t reserved1;
+  int32_t al_full_newton;             /* 0: Gauss-Newton AL Hessian (Altro's default).  1: the expansion adds the constraint curvature
+                                         sum_r ybar_r * d2c_r/dz2, ybar = the multiplier estimate lambda + I_mu c, with the closed forms of
+                                         to_constraint_hessians (src/abstract_constraint.jl:255-280: the nabla-jacobian! term) */
 } to_solver_opts;
 
 /* caller-allocated outputs of a solve; any pointer may be NULL */

@@ -96,7 +96,7 @@ mutable struct SolverOpts            # == to_solver_opts (names of Altro.SolverO
     iterations_outer::Int32
     cost_dt_scaling::Int32
     iterations_total::Int32
-    reserved1::Int32
+    al_full_newton::Int32
     SolverOpts() = new()
 end
 

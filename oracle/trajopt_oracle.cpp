@@ -111,6 +111,7 @@ int validate_opts(const to_solver_opts& o) {
   if (!(o.penalty_initial > 0.0) || !(o.penalty_scaling >= 1.0) || !(o.penalty_max >= o.penalty_initial) || !(o.dual_max > 0.0)) return bad("penalty parameters");
   if (!(o.max_cost_value > 0.0) || !(o.max_state_value > 0.0) || !(o.max_control_value > 0.0)) return bad("max_*_value must be > 0");
   if (o.cost_dt_scaling != 0 && o.cost_dt_scaling != 1) return bad("cost_dt_scaling must be 0 or 1");
+  if (o.al_full_newton != 0 && o.al_full_newton != 1) return bad("al_full_newton must be 0 or 1");
   return TO_OK;
 }
 
@@ -398,6 +399,9 @@ void knot_expansion_full(const Problem& P, const Traj& t, int k, double* grad, d
         W[r * p + q] = mu * (s + Hp[r * p + q]);
       }
     }
+    /* full Newton (opts.al_full_newton): + sum_r y_r d2c_r/dz2 with the multiplier estimate y; the SOC branch already carries the
+       curvature of the projection and its constraints are linear in z */
+    if (P.opts.al_full_newton && ci.d.sense != TO_CONE_SECOND_ORDER) constraint_hessian_add(ci.d, n, m, z, y, hess, nz);
     /* grad += jac' y ; hess += jac' W jac */
     for (int a = 0; a < nz; ++a) { double s = 0.0; for (int r = 0; r < p; ++r) s += jac[r * nz + a] * y[r]; grad[a] += s; }
     double WJ[TO_MAX_P * MAXZ];

@@ -346,8 +346,11 @@ def test_minimal_horizon_and_nonuniform_dt(hip, oracle):
         assert_solve_parity(sh, so, ph, po)
 
 
-def test_every_constraint_kind_and_dense_cost(hip, oracle):
-    """All six constraint kinds + QuadraticCost with a cross term H + per-knot distinct costs in one problem."""
+@pytest.mark.parametrize("full_newton", [0, 1])
+def test_every_constraint_kind_and_dense_cost(full_newton, hip, oracle):
+    """All six constraint kinds + QuadraticCost with a cross term H + per-knot distinct costs in one problem; with
+    al_full_newton = 1 the expansion also carries the constraint curvature (circle, sphere, collision, quadratic norm,
+    QuatVecEq) — the cost blocks and the solves must still match the oracle."""
     rng = np.random.default_rng(11)
 
     def build(lib):
@@ -374,7 +377,7 @@ def test_every_constraint_kind_and_dense_cost(hip, oracle):
         T.add_constraint(cons, T.QuatVecEq(n, m, xf[3:7]), N)
         x0 = np.zeros(n); x0[3] = 1
         p = T.Problem(model, obj, x0, 1.1, xf=xf, constraints=cons, batch=6, lib=lib,
-                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-4, iterations_outer=6))
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-4, iterations_outer=6, al_full_newton=full_newton))
         T.initial_controls(p, u0)
         return p
     rng = np.random.default_rng(11); ph = build(hip)

@@ -459,3 +459,47 @@ def test_constraint_hessians_against_finite_differences(oracle):
             assert np.all(H == 0.0)
         H2 = T.constraint_hessians(p, i, lam, H=np.ones_like(H))
         np.testing.assert_allclose(H2, H + 1.0, rtol=1e-14, atol=1e-14)
+
+
+def test_al_full_newton_hessian_matches_finite_differences(oracle):
+    """to_solver_opts::al_full_newton: the AL cost block of the expansion gains sum_r ybar_r d2c_r/dz2.  On a vector-space
+    model (error state = state) the state block must then equal the finite-difference Jacobian of the AL gradient along
+    state perturbations (equality rows and rows away from the active-set boundary), which the Gauss-Newton block does not."""
+    def build(full):
+        model = T.DoubleIntegrator(1.0, 3)
+        n, m = model.dims()
+        N = 6
+        xf = np.array([1.0, 0.5, -0.5, 0.0, 0.0, 0.0])
+        obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 10.0 * np.ones(n), xf, N)
+        cons = T.ConstraintList(n, m, N)
+        T.add_constraint(cons, T.SphereConstraint(n, [0.3], [0.2], [0.1], [0.9]), range(2, N))      # violated: active
+        T.add_constraint(cons, T.CollisionConstraint(n, [1, 2, 3], [4, 5, 6], 1.5), range(2, N + 1))  # violated: active
+        T.add_constraint(cons, T.NormConstraint(n, m, 0.2, T.Inequality(), [1, 2]), range(2, N))      # |x_{1:2}|^2 <= 0.04: active
+        p = T.Problem(model, obj, np.array([0.4, 0.3, 0.2, 0.1, -0.1, 0.05]), 1.0, xf=xf, constraints=cons, batch=1, lib=oracle,
+                      options=T.SolverOptions(lib=oracle, al_full_newton=full))
+        T.initial_controls(p, np.array([0.3, -0.2, 0.1]))
+        T.rollout(p)
+        I.dual_update(p); I.dual_update(p)  # non-trivial multipliers and penalties
+        return p
+
+    def al_gradient(p, X):
+        T.initial_states(p, X)
+        I.expand(p)
+        E = I.cost_expansion(p)
+        return E["qx"][0].copy()  # [N, n]
+
+    pf, pg = build(1), build(0)
+    X0 = T.states(pf).copy()
+    I.expand(pf); I.expand(pg)
+    Hf, Hg = I.cost_expansion(pf)["Qxx"][0], I.cost_expansion(pg)["Qxx"][0]  # [N, n, n]
+    n = X0.shape[2]
+    eps = 1e-6
+    k = 3
+    fd = np.zeros((n, n))
+    for j in range(n):
+        Xp, Xm = X0.copy(), X0.copy()
+        Xp[0, k, j] += eps; Xm[0, k, j] -= eps
+        fd[:, j] = (al_gradient(pf, Xp)[k] - al_gradient(pf, Xm)[k]) / (2 * eps)
+    T.initial_states(pf, X0)
+    np.testing.assert_allclose(Hf[k], fd, rtol=1e-5, atol=1e-5 * np.abs(fd).max())
+    assert np.abs(Hg[k] - fd).max() > 1e-2 * np.abs(fd).max()  # Gauss-Newton drops the curvature term

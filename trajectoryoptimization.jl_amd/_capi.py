@@ -113,7 +113,7 @@ class SolverOpts(C.Structure):
         ("penalty_initial", C.c_double), ("penalty_scaling", C.c_double), ("penalty_max", C.c_double),
         ("dual_max", C.c_double),
         ("iterations_outer", C.c_int32), ("cost_dt_scaling", C.c_int32),
-        ("iterations_total", C.c_int32), ("reserved1", C.c_int32),
+        ("iterations_total", C.c_int32), ("al_full_newton", C.c_int32),
     ]
 
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
         ConC& K = P.cons[ci];
         if (k < K.k1 || k > K.k2) continue;
         const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-        al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y);
+        al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
       }
     }
   }

@@ -602,9 +602,43 @@ struct ConStage {
 // ∇Π(x)'Π(x) = Π(x); the closed forms below are those identities (checked against the explicit composition in tests).
 // GENERIC = false compiles the non-selector constraint kinds (circle, sphere, linear, quadratic-form norm) out.
 // REGROWS > 0: lam points to a register copy of the first REGROWS dual rows (stride 1, fetched early by the caller).
+// y += yr * (d2 c_r / dz2) v for row r of a non-selector constraint: the closed forms of to_constraint_hessians
+// (k_constraint_hessian; src/abstract_constraint.jl:255-280).  Affine rows (LINEAR) contribute nothing.
+template <int nz>
+__device__ __forceinline__ void con_curvature_v(ConC& K, int r, const double* z, const double* v, double yr, double* y) {
+  const int kind = K.d.kind;
+  if (kind == TO_CON_NORM) {  // |z_I|^2 - a^2 (the SOC form is a selector constraint and never gets here): 2 I on I
+    for (int t = 0; t < K.d.n_inds; ++t) { const int i = K.d.inds[t] - 1; add_at<nz>(y, i, 2.0 * yr * pick<nz>(v, i)); }
+  } else if (kind == TO_CON_CIRCLE || kind == TO_CON_SPHERE) {  // r^2 - |x - c|^2: -2 I on the centre coordinates
+    const int D = kind == TO_CON_CIRCLE ? 2 : 3;
+    for (int t = 0; t < D; ++t) { const int i = K.d.inds[t] - 1; add_at<nz>(y, i, -2.0 * yr * pick<nz>(v, i)); }
+  } else if (kind == TO_CON_COLLISION) {  // r^2 - |x_a - x_b|^2: -2 [I -I; -I I]
+    const int D = K.d.n_inds / 2;
+    for (int t = 0; t < D; ++t) {
+      const int ia = K.d.inds[t] - 1, ib = K.d.inds[D + t] - 1;
+      const double d = pick<nz>(v, ia) - pick<nz>(v, ib);
+      add_at<nz>(y, ia, -2.0 * yr * d);
+      add_at<nz>(y, ib, 2.0 * yr * d);
+    }
+  } else if (kind == TO_CON_QUATVEC) {  // second derivative of q_{r+1} / |q|
+    double q[4], vq[4], s2 = 0.0;
+    for (int t = 0; t < 4; ++t) { q[t] = pick<nz>(z, K.d.inds[t] - 1); vq[t] = pick<nz>(v, K.d.inds[t] - 1); s2 += q[t] * q[t]; }
+    const double s = sqrt(s2), s3 = s2 * s, s5 = s3 * s2;
+    const int i = r + 1;
+    for (int j = 0; j < 4; ++j) {
+      double t = 0.0;
+      for (int kq = 0; kq < 4; ++kq)
+        t += (-((i == j ? q[kq] : 0.0) + (i == kq ? q[j] : 0.0) + (j == kq ? q[i] : 0.0)) / s3 + 3.0 * q[i] * q[j] * q[kq] / s5) * vq[kq];
+      add_at<nz>(y, K.d.inds[j] - 1, yr * t);
+    }
+  }
+}
+
+// full_newton (to_solver_opts::al_full_newton): the Hessian-vector product also carries the constraint curvature
+// sum_r ybar_r d2c_r/dz2 v (non-selector constraints; selector rows are affine and the SOC closed forms are already exact).
 template <int n, int m, bool GENERIC = true, int REGROWS = 0>
 __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const double* lam, size_t stride_rt, double mu,
-                                            const double* v, double* g, double* y) {
+                                            const double* v, double* g, double* y, bool full_newton = false) {
   constexpr int nz = n + m;
   const size_t stride = REGROWS > 0 ? (size_t)1 : stride_rt;
   const int p = K.p;
@@ -652,6 +686,7 @@ __device__ __forceinline__ void al_grad_hvp(ConC& K, const double* z, const doub
 #pragma unroll
       for (int t = 0; t < nz; ++t)
         if (t < K.d.n_inds) { add_at<nz>(g, K.d.inds[t] - 1, coef[t] * yr); add_at<nz>(y, K.d.inds[t] - 1, coef[t] * wv); }
+      if (full_newton) con_curvature_v<nz>(K, r, z, v, yr, y);
     }
   }
 }
