@@ -271,35 +271,62 @@ def test_full_size_C5_vs_oracle_subsample(hip, oracle):
     """BASELINE config C5 at its own shape (Quadrotor + GoalConstraint@N + SOC norm cone@1..N-1, N=201, B=8192 =
     128 tiles, first line-search round of 8 step sizes) with the feasible goal (position + velocities) and the default
     constraint_tolerance 1e-6: the sub-sample against the oracle.  AL-iLQR without the projected-Newton polish creeps
-    towards 1e-6 over hundreds of iterations at penalty 1e8 (the oracle itself leaves part of the batch at
-    MAX_ITERATIONS_OUTER); over such tails a last-bit difference eventually flips one line-search decision, so the
-    test pins (a) exact integer agreement on the overwhelming majority, (b) 1e-6 on X / U / J wherever the iteration
-    paths coincide, (c) the same outcome class and final violation scale everywhere."""
+    towards 1e-6 over hundreds of iterations at penalty 1e8, which amplifies last-bit differences: the ORACLE AGAINST
+    ITSELF with x0 moved by 1 ulp separates in 1 integer path of 128 and reaches 8.5e-6 on identical paths
+    (tests/test_oracle_sensitivity.py, CPU suite).  The GPU is held to exactly those measured levels: >= 99 % identical
+    integer paths, >= 99 % of those within the north-star 1e-6 on X / U / J, none beyond 5e-5, and the same outcome
+    class and final violation scale everywhere."""
+    from test_oracle_sensitivity import C5_MAX_ERR_SAME_PATH, C5_MIN_IDENTICAL_PATHS, C5_MIN_WITHIN_1E6, c5_compare
     build = lambda **kw: configs.quadrotor_problem(N=201, constrained=True, goal_inds=configs.C5_GOAL_INDS, **{"lib": hip, **kw})
     sh, ph, blocks = _subsample_vs_oracle(build, 8192, oracle, T.ALSolver)
     Xh, Uh = T.states(ph), T.controls(ph)
     same_total, total, errs = 0, 0, []
     for idx, so, po in blocks:
-        same = (sh.stats["iterations"][idx] == so.stats["iterations"]) & (sh.stats["status"][idx] == so.stats["status"]) \
-            & (sh.stats["iterations_outer"][idx] == so.stats["iterations_outer"])
+        same, err = c5_compare({k: v[idx] for k, v in sh.stats.items()}, Xh[idx], Uh[idx], so.stats, T.states(po), T.controls(po))
         same_total += int(same.sum()); total += same.size
-        for A, R in ((Xh[idx][same], T.states(po)[same]), (Uh[idx][same], T.controls(po)[same]),
-                     (sh.stats["cost"][idx][same][:, None], so.stats["cost"][same][:, None])):
-            err = np.abs(A - R).reshape(A.shape[0], -1).max(axis=1) / np.maximum(1.0, np.abs(R).reshape(A.shape[0], -1).max(axis=1))
-            errs.append(err)
+        errs.append(err)
         # where the paths separated: same problem, same optimum to the accuracy the outer loop reached
         np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=2e-3)
         assert np.all(sh.stats["c_max"][idx] < 1e-3) and np.all(so.stats["c_max"] < 1e-3)
     errs = np.concatenate(errs)
     print(f"C5 sub-sample: {same_total}/{total} trajectories with identical iterations/outer/status; on those, X/U/J agree to "
           f"1e-6 for {np.mean(errs <= 1e-6):.1%} (max {errs.max():.2e})")
-    assert same_total >= 0.9 * total
-    # identical iteration paths: the north-star 1e-6 on all but the few trajectories whose several hundred iterations at
-    # penalty 1e8 amplify last-bit differences further (those stay within 1e-4: they are the same iterates)
-    assert np.mean(errs <= 1e-6) >= 0.95 and errs.max() <= 1e-4
+    assert same_total >= C5_MIN_IDENTICAL_PATHS * total
+    assert np.mean(errs <= 1e-6) >= C5_MIN_WITHIN_1E6 and errs.max() <= C5_MAX_ERR_SAME_PATH
     ok = sh.stats["status"] == T.capi.SOLVE_SUCCEEDED
     assert np.all(sh.stats["c_max"][ok] < 1e-6)
     assert set(np.unique(sh.stats["status"])) <= {T.capi.SOLVE_SUCCEEDED, T.capi.MAX_ITERATIONS, T.capi.MAX_ITERATIONS_OUTER}
+
+
+def test_G4_quadrotor_zigzag_on_gpu(hip, oracle):
+    """The reference's Quadrotor zig-zag (examples/Quadrotor.ipynb cells 10-22, golden G4_quadrotor_altro: 90
+    iterations, J = 0.29928, violation 7.6e-10) solved on the GPU: per-knot waypoint costs + control bounds, AL-iLQR.
+    Sanity against the notebook (the S4 pin SURVEY §8c prescribes: cost to 1 %, feasible to 1e-6) and parity against the
+    oracle on a batch of slightly different start positions."""
+    g = G["G4_quadrotor_altro"]
+
+    def build(lib):
+        prob, wpts, times = configs.quadrotor_zigzag_problem(lib=lib, batch=8)
+        x0 = prob.x0.copy()
+        x0[1:, :3] += 1e-2 * np.random.default_rng(0).uniform(-1, 1, (7, 3))
+        prob.set_initial_state(x0)
+        return prob, wpts, times
+
+    (ph, wpts, times), (po, _, _) = build(hip), build(oracle)
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert int(sh.stats["status"][0]) == T.capi.SOLVE_SUCCEEDED
+    assert sh.stats["c_max"][0] < 1e-6
+    assert sh.stats["cost"][0] == pytest.approx(g["cost"], rel=1e-2)
+    assert abs(int(sh.stats["iterations"][0]) - g["iterations"]) <= g["iterations"] // 3
+    Xh = T.states(ph)
+    for r, k in zip(wpts[:2], times[:2]):
+        assert np.linalg.norm(Xh[0, k - 1, :3] - r) < 0.6
+    assert np.linalg.norm(Xh[0, -1, :3] - wpts[2]) < 5e-3
+    for k in ("iterations", "iterations_outer", "status"):
+        np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
+    np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6)
+    assert_trajectories_close(Xh, T.states(po), 1e-6, "X")
+    assert_trajectories_close(T.controls(ph), T.controls(po), 1e-6, "U")
 
 
 # ---------------------------------------------------------------------------------------------- edge cases

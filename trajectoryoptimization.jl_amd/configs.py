@@ -100,6 +100,40 @@ def quadrotor_problem(batch=4096, N=201, tf=5.0, b_offset=0, constrained=False, 
     return prob
 
 
+def quadrotor_zigzag_problem(batch=1, legacy=True, device=0, lib=None, **optkw):
+    """examples/Quadrotor.ipynb cells 10-22 (golden G4_quadrotor_altro): the quadrotor flies a zig-zag through two
+    waypoints.  N=101, tf=5; x0 r=(0,-10,1), goal r=(0,10,1), identity attitude; nominal cost LQRCost(Q=diag(1e-5 r,
+    1e-5 q, 1e-3 v, 1e-3 ω), R=1e-4 I, x_nom=0) on every knot except the waypoint knots 33 / 66 (Q = 1e-3·diag(1e3,1,1,1
+    per block), goal r=(±10,0,1)) and the final knot 101 (Q = diag(10,100,10,10 per block)) — a distinct cost per knot
+    class, src/objective.jl:27-45; controls bounded 0 ≤ u ≤ 12 on 1..N-1 (cell 18); U0 ≡ 0.5·mass/m (cell 16: the notebook
+    calls it hover, it is 1/20 of it); ALTRO options penalty_scaling=100, penalty_initial=0.1 (cell 22).
+    ``legacy`` = the stack the notebook was saved with (RK3, stage costs × dt), like G3."""
+    model = T.Quadrotor()
+    n, m = model.dims()
+    N, tf = 101, 5.0
+
+    def build_state(r, q=(1.0, 0.0, 0.0, 0.0), v=(0.0, 0.0, 0.0), w=(0.0, 0.0, 0.0)):
+        return np.array([*r, *q, *v, *w], dtype=np.float64)
+
+    def fill_state(a, b, c, d):
+        return np.array([a] * 3 + [b] * 4 + [c] * 3 + [d] * 3, dtype=np.float64)
+
+    x0, xf = build_state([0.0, -10.0, 1.0]), build_state([0.0, 10.0, 1.0])
+    wpts, times = [[10.0, 0.0, 1.0], [-10.0, 0.0, 1.0], [0.0, 10.0, 1.0]], [33, 66, 101]
+    R = np.full(m, 1e-4)
+    cost_nom = T.LQRCost(fill_state(1e-5, 1e-5, 1e-3, 1e-3), R, build_state([0.0, 0.0, 0.0]))
+    Qw, Qf = fill_state(1e3, 1.0, 1.0, 1.0), fill_state(10.0, 100.0, 10.0, 10.0)
+    wcosts = [T.LQRCost(Qf if t == N else 1e-3 * Qw, R, build_state(r), terminal=(t == N)) for r, t in zip(wpts, times)]
+    obj = T.Objective([wcosts[times.index(k)] if k in times else cost_nom for k in range(1, N + 1)])
+    cons = T.ConstraintList(n, m, N)
+    T.add_constraint(cons, T.BoundConstraint(n, m, u_min=0.0, u_max=12.0), range(1, N))
+    opts = T.SolverOptions(lib=lib, cost_dt_scaling=1 if legacy else 0, penalty_scaling=100.0, penalty_initial=0.1, **optkw)
+    prob = T.Problem(model, obj, x0, tf, xf=xf, constraints=cons, batch=batch, device=device, lib=lib, options=opts,
+                     integration=T.RK3 if legacy else T.RK4)
+    T.initial_controls(prob, np.full(m, 0.5 * model.mass / m))
+    return prob, wpts, times
+
+
 def quickstart_problem(N=21, tf=3.0, batch=1, device=0, lib=None, options=None):
     """C1 = examples/quickstart.jl:28-59: 2-D double integrator, Goal@N, Circle(0,1,r=.5)@2:N-1,
     Norm-SOC(5,:control)@1:N-1, Bound(|u|≤10)@1:N-1, U0≡0."""
