@@ -60,25 +60,31 @@ def initial_controls_value(T, prob, name):
     return np.full(prob.m, 0.01) if name == "cartpole" else prob.model.hover_control()
 
 
-def pmc_traffic(name, batch, phase):
+def pmc_traffic(name, batch, phase, build_id):
     """HBM bytes per launch of `phase` from the committed rocprofv3 PMC passes of this same command
     (tools/run_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 note of
-    MI355X_MICROARCH.md).  PMC collection cannot run inside the timed bench, so the figure is read from profiles/;
-    returns (None, None) when no matching profile was committed."""
+    MI355X_MICROARCH.md).  PMC collection cannot run inside the timed bench, so the figure is read from profiles/ —
+    and only from a profile taken with THIS binary: every *_pmc.json carries the build id of the library it measured
+    (`__meta__.build_id`); a profile of another build is refused (traffic = null, the reason in traffic_source).
+    Returns (bytes, source, flops)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_b%d_hbm_traffic_pmc.json" % (name, batch))))
     if not files:
-        return None, None, None
+        return None, "no profile committed for this workload", None
     with open(files[-1]) as f:
         tab = json.load(f)
-    steps = sum(v["launches"] for k, v in tab.items() if "k_expand" in k)
+    rel = os.path.relpath(files[-1], ROOT)
+    meta = tab.pop("__meta__", {})
+    if meta.get("build_id") != build_id:
+        return None, "%s is stale: it measured build %s, the loaded library is %s" % (rel, meta.get("build_id"), build_id), None
+    steps = sum(v["launches"] for k, v in tab.items() if "k_expand" in k or "k_fused" in k)
     mine = [v for k, v in tab.items() if ("k_" + phase) in k
             or (phase == "forward" and any(s in k for s in ("k_select", "k_accept", "k_outer")))]
     total = sum(v["hbm_bytes_per_launch_fetch_x2"] * v["launches"] for v in mine)
     if steps == 0 or total == 0:
-        return None, None, None
+        return None, rel + " holds no launches of this phase", None
     flops = sum(v.get("fp64_flops_per_launch", 0.0) * v["launches"] for v in mine) / steps
-    return total / steps, os.path.relpath(files[-1], ROOT), (flops or None)
+    return total / steps, rel, (flops or None)
 
 
 def kernel_split_bytes(n, m, ne, N, duals):
@@ -91,8 +97,8 @@ def kernel_split_bytes(n, m, ne, N, duals):
 
 def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     """Oracle (port) on the host cores, bounded sample of the same workload."""
-    from oracle_binding import load_oracle, set_threads
-    o = load_oracle()
+    from oracle_binding import load_oracle_native, set_threads
+    o, flags = load_oracle_native()
     threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
     sample = min(batch, 1024 if name == "cartpole" else 256 if name == "quadrotor" else 128)
     Solver = T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver
@@ -119,12 +125,44 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
         d1 = min(d1, time.perf_counter() - t1)
     single = {"value": s1.total_iterations / d1, "cores": 1,
               "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms (best of 5 after a warm call)"}
-    return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "single_thread": single,
+    return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "build": flags, "single_thread": single,
             "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve after a warm call, "
                       f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
 
 
-def roofline_block(configs, name, batch, dims, iters, value_per_gpu, kms, kln):
+def c1_cpu_line(T, configs):
+    """BASELINE config C1: examples/quickstart.jl:28-59 as written (2-D double integrator, N=21, tf=3, Goal +
+    Circle + Norm-SOC + Bound) and the N=51 variant BASELINE.json's label names, AL-iLQR on ONE trajectory on ONE host core —
+    the reference's own CPU-runnable case, timed on the oracle (best of 5 after a warm call).  Initial controls: the file
+    draws U0 = randn (:63); U0 = 0 is the one start that cannot work — the straight line from x0 to xf runs through the
+    centre of the circular obstacle and the problem is mirror-symmetric about it, so the iterates stay on the axis (a saddle:
+    c_max stalls at 0.24) — hence the deterministic symmetry-breaking U0 = (0.1, 0) on every knot."""
+    from oracle_binding import load_oracle_native, set_threads
+    o, flags = load_oracle_native()
+    out = {"kind": "port", "build": flags, "cores": 1, "unit": "trajectory-iterations/s"}
+    for N in (21, 51):
+        p = configs.quickstart_problem(N=N, lib=o)
+        set_threads(p, 1)
+        u0 = np.array([0.1, 0.0])
+        T.initial_controls(p, u0)
+        s = T.ALSolver(p)
+        s.solve()
+        best = float("inf")
+        for _ in range(5):
+            T.initial_controls(p, u0)
+            p._call("reset_duals")
+            t0 = time.perf_counter()
+            s.solve()
+            best = min(best, time.perf_counter() - t0)
+        out["N%d" % N] = {"value": s.total_iterations / best, "iterations": int(s.total_iterations), "ms": 1e3 * best,
+                          "outer": int(s.stats["iterations_outer"][0]), "c_max": float(s.stats["c_max"][0]),
+                          "status": int(s.stats["status"][0])}
+    out["value"] = out["N21"]["value"]
+    out["sample"] = "quickstart.jl values (N=21, tf=3) -> value; N=51 variant alongside; one trajectory, one core; U0 = (0.1, 0)"
+    return out
+
+
+def roofline_block(configs, name, batch, dims, iters, value_per_gpu, kms, kln, build_id):
     """roofline object from the hipEvent phase timings of the PROFILED pass (same workload, run right after the timed one)."""
     n, m, ne, N, duals = dims
     bytes_it = configs.algorithmic_bytes_per_iteration(n, m, ne, N, duals)
@@ -139,7 +177,7 @@ def roofline_block(configs, name, batch, dims, iters, value_per_gpu, kms, kln):
     # a launch processes, on average, (trajectory-iterations of this rank) / launches units
     units_per_launch = iters / kern[dom]["launches"]
     achieved = split[dom] * units_per_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
-    traffic, traffic_src, flops = pmc_traffic(name, batch, dom)
+    traffic, traffic_src, flops = pmc_traffic(name, batch, dom, build_id)
     return {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_unit": split[dom], "units_per_launch": units_per_launch,
@@ -174,6 +212,7 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
         solver.solve()
         if gather is not None:
             gather()
+            gather.stats()
         return solver.total_iterations, solver.batch_steps
 
     def barrier():
@@ -195,11 +234,12 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     dt = time.perf_counter() - t0
     status = solver.stats["status"].copy()
     kms, kln = (C.c_double * 4)(), (C.c_int64 * 4)()
-    if profile:
+    iters_prof = 0
+    if profile:  # the per-phase launch counts AND the iteration count of the roofline block both come from this pass
         prob._call("reset_profile")
         prob._call("set_profiling", 1)
         for _ in range(steps):
-            one_step()
+            iters_prof += one_step()[0]
         prob._call("set_profiling", 0)
         prob._call("get_profile", kms, kln)
     if dist is not None:
@@ -217,8 +257,10 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
            "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
                       "trajectory_iterations_per_step": iters_all / steps, "batch_steps_per_solve": bsteps / steps,
                       "converged_fraction": float(np.mean(status == T.capi.SOLVE_SUCCEEDED)),
-                      "collective": "RCCL all_gather of converged (X,U), once per solve" if dist is not None else "none"},
-           "roofline": roofline_block(configs, name, batch, dims, iters, value / world, kms, kln) if profile else None}
+                      "collective": ("RCCL all_gather of converged (X,U) once per solve + stats gather (to_allgather / to_allgather_stats); "
+                                     "ranks the RCCL communicator saw: %d, shards %s" % (len(gather.counts), gather.counts))
+                      if gather is not None else "none"},
+           "roofline": roofline_block(configs, name, batch, dims, iters_prof, value / world, kms, kln, lib.build_id()) if profile else None}
     return res, prob, u0
 
 
@@ -293,6 +335,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(T, configs, name, batch)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+            if name == "cartpole" and world == 1:
+                try:
+                    out["c1_cpu"] = c1_cpu_line(T, configs)
+                except Exception as e:
+                    out["c1_cpu"] = {"error": repr(e)}
     del prob
     # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
     if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:

@@ -45,7 +45,12 @@
 extern "C" {
 #endif
 
-#define TO_ABI_VERSION 1
+/* ABI history.  1: round 1.  2: to_solver_opts::reserved1 became al_full_newton (validated: 0 or 1), new entry points
+ * to_constraint_hessians, to_comm_*, to_allgather, to_allgather_stats, to_comm_shards, to_build_id; to_cost_desc gained the
+ * ERROR_QUADRATIC error maps.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
+ * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
+ * a descriptor stamped with another version. */
+#define TO_ABI_VERSION 2
 
 #define TO_MAX_N 16       /* max state dimension            */
 #define TO_MAX_M 8        /* max control dimension          */
@@ -267,11 +272,16 @@ int to_get_controls_device(to_handle* h, void* dU);
  * the solves; one RCCL all-gather (over xGMI) of the converged trajectories.  librccl.so is dlopen'ed on first use.
  *   rank 0: to_comm_unique_id(id) -> ship the 128 bytes to the other ranks (MPI, a file, torch.distributed ...)
  *   all   : to_comm_init_rank(h, nranks, rank, id); ... solve ...; to_allgather(h, dX_all, dU_all)
- * dX_all / dU_all are caller-owned DEVICE buffers of nranks*n*N*B / nranks*m*(N-1)*B doubles; the result is the host layout
- * (n, N, B_total) with trajectories in global order (rank-major).  All ranks must hold shards of equal size. */
+ * dX_all / dU_all are caller-owned DEVICE buffers of n*N*B_total / m*(N-1)*B_total doubles; the result is the host layout
+ * (n, N, B_total) with trajectories in global order (rank-major).  Shards may differ in size (a batch that does not divide
+ * by the number of GPUs): the sizes are exchanged at to_comm_init_rank, to_comm_shards reports them; equal shards take one
+ * in-place ncclAllGather, unequal ones one grouped ncclBroadcast per rank.  to_allgather_stats is the small gather of
+ * iterations / status / objective cost of every trajectory (HOST arrays of B_total entries, any may be NULL). */
 int to_comm_unique_id(void* id128 /* [128] bytes */);
 int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id128);
+int to_comm_shards(const to_handle* h, int32_t* nranks, int32_t* rank, int64_t* B_total, int32_t* counts /* [nranks], nullable */);
 int to_allgather(to_handle* h, void* dX_all, void* dU_all /* either may be NULL */);
+int to_allgather_stats(to_handle* h, int32_t* iterations_all, int32_t* status_all, double* J_all /* HOST [B_total]; any may be NULL */);
 int to_comm_destroy(to_handle* h);
 /* goal / reference updates between solves (set_goal_state! src/problem.jl:294-310; set_LQR_goal! src/cost_functions.jl:249-258) */
 int to_set_cost(to_handle* h, int32_t cost_id, const to_cost_desc* cost);

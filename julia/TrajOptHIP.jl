@@ -20,7 +20,7 @@ const TO = TrajectoryOptimization
 const lib = get(ENV, "TRAJOPT_HIP_LIBRARY", "libtrajopt_hip")   # trajectoryoptimization.jl_amd/csrc/libtrajopt_hip.so
 
 # ------------------------------------------------------------------------------------------------ header mirrors
-const TO_ABI_VERSION = Int32(1)
+const TO_ABI_VERSION = Int32(2)
 const MAXN, MAXM, MAXP, MAXPAR, MAXIND = 16, 8, 40, 400, 48
 const PROFILE_SLOTS = 4
 
@@ -121,6 +121,11 @@ end
 last_error() = unsafe_string(ccall((:to_last_error, lib), Cstring, ()))
 abi_version() = ccall((:to_abi_version, lib), Cint, ())
 build_id() = unsafe_string(ccall((:to_build_id, lib), Cstring, ()))
+"A library of another ABI version is refused at load time (include/trajopt_hip.h: the version changes with every new symbol or field)."
+function __init__()
+    v = abi_version()
+    v == TO_ABI_VERSION || error("libtrajopt_hip.so has ABI version $v, this shim was written for $TO_ABI_VERSION: rebuild one of them")
+end
 
 "Negative return codes become the exception the reference throws (include/trajopt_hip.h, to_status_code)."
 function check(rc::Integer)
@@ -484,9 +489,24 @@ function comm_unique_id()
 end
 comm_init_rank!(p::BatchProblem, nranks::Integer, rank::Integer, id::Vector{UInt8}) =
     check(ccall((:to_comm_init_rank, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}), p.handle, nranks, rank, id))
-"All ranks' trajectories into caller-owned device buffers of nranks*n*N*B and nranks*m*(N-1)*B doubles (global order)."
+"All ranks' trajectories into caller-owned device buffers of n*N*B_total and m*(N-1)*B_total doubles (global order; shards may differ in size)."
 allgather!(p::BatchProblem, dX_all::Ptr{Cvoid}, dU_all::Ptr{Cvoid}) =
     check(ccall((:to_allgather, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), p.handle, dX_all, dU_all))
+"(nranks, rank, B_total, counts): the shard sizes exchanged at comm_init_rank!."
+function comm_shards(p::BatchProblem)
+    nr, rk, tot = Ref{Int32}(0), Ref{Int32}(0), Ref{Int64}(0)
+    check(ccall((:to_comm_shards, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}), p.handle, nr, rk, tot, C_NULL))
+    counts = zeros(Int32, nr[])
+    check(ccall((:to_comm_shards, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}), p.handle, nr, rk, tot, counts))
+    (nranks = Int(nr[]), rank = Int(rk[]), B_total = Int(tot[]), counts = counts)
+end
+"iterations, status and objective cost of every rank's trajectories (host vectors of B_total entries, global order)."
+function allgather_stats(p::BatchProblem)
+    T = comm_shards(p).B_total
+    its, st, J = zeros(Int32, T), zeros(Int32, T), zeros(T)
+    check(ccall((:to_allgather_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}), p.handle, its, st, J))
+    (iterations = its, status = SolverStatus.(st), cost = J)
+end
 comm_destroy!(p::BatchProblem) = check(ccall((:to_comm_destroy, lib), Cint, (Ptr{Cvoid},), p.handle))
 
 # ---- measurement
@@ -500,6 +520,6 @@ end
 
 export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, expand!, backwardpass!, forwardpass!,
     stage_costs, al_cost, dynamics_jacobians, cost_expansion, gains, cost_gradient_hessian, discrete_jacobian, duals, set_duals!,
-    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, comm_destroy!, device_count, build_id
+    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, device_count, build_id
 
 end # module

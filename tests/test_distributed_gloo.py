@@ -13,39 +13,55 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, B, out_dir):
+def _worker(rank, world, port, total, out_dir):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import torch.distributed as dist
     import trajopt_amd as T
     from oracle_binding import load_oracle
     from trajectoryoptimization_jl_amd import configs
-    from trajectoryoptimization_jl_amd.distributed import TrajectoryGather, gather_stats, shard_offset
+    from trajectoryoptimization_jl_amd.distributed import TrajectoryGather, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    prob = configs.cartpole_problem(batch=B, N=41, tf=2.0, b_offset=shard_offset(rank, B), lib=load_oracle())
+    b0, cnt = shard_range(rank, world, total)     # 13 trajectories over 2 ranks: shards of 7 and 6
+    prob = configs.cartpole_problem(batch=cnt, N=41, tf=2.0, b_offset=b0, lib=load_oracle())
     s = T.iLQRSolver(prob, iterations=25).solve()
-    X, U = TrajectoryGather(prob, dist)()
-    its = gather_stats(dist, s.stats["iterations"])
+    g = TrajectoryGather(prob, dist)
+    X, U = g()
+    its, st, J = g.stats(s)
     if rank == 0:
-        np.savez(Path(out_dir) / "gathered.npz", X=X.numpy(), U=U.numpy(), its=its)
+        np.savez(Path(out_dir) / "gathered.npz", X=X.numpy(), U=U.numpy(), its=its, st=st, J=J, counts=np.array(g.counts))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_shard_and_allgather(tmp_path, oracle):
+    """Unequal shards (13 = 7 + 6): trajectories and the per-trajectory stats gathered in global order equal a
+    single-process solve of the whole batch."""
     import torch.multiprocessing as mp
     import trajopt_amd as T
     from trajectoryoptimization_jl_amd import configs
-    B, world = 6, 2
+    total, world = 13, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
     g = np.load(tmp_path / "gathered.npz")
-    prob = configs.cartpole_problem(batch=world * B, N=41, tf=2.0, lib=oracle)
+    assert list(g["counts"]) == [7, 6]
+    prob = configs.cartpole_problem(batch=total, N=41, tf=2.0, lib=oracle)
     s = T.iLQRSolver(prob, iterations=25).solve()
     np.testing.assert_array_equal(g["its"], s.stats["iterations"])
+    np.testing.assert_array_equal(g["st"], s.stats["status"])
+    np.testing.assert_array_equal(g["J"], s.stats["cost"])
     np.testing.assert_array_equal(g["X"], T.states(prob))
     np.testing.assert_array_equal(g["U"], T.controls(prob))
+
+
+def test_shard_range_partitions_the_batch():
+    from trajectoryoptimization_jl_amd.distributed import shard_range
+    for total, world in ((13, 2), (32768, 8), (10, 4), (3, 3)):
+        parts = [shard_range(r, world, total) for r in range(world)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+        assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
 
 
 def test_global_index_sharding():

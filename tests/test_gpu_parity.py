@@ -780,12 +780,17 @@ def test_device_allgather_world1(hip):
     import torch
     from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
     p = configs.cartpole_problem(batch=70, N=41, tf=2.0, lib=hip)
-    T.iLQRSolver(p, iterations=15).solve()
+    sv = T.iLQRSolver(p, iterations=15).solve()
     X, U = T.states(p), T.controls(p)
     g = TrajectoryGather(p, None, device=torch.device("cuda", 0))
     Xg, Ug = g()
     np.testing.assert_array_equal(Xg.cpu().numpy(), X)
     np.testing.assert_array_equal(Ug.cpu().numpy(), U)
+    assert g.counts == [70] and g.total == 70      # to_comm_shards: what the RCCL communicator itself saw
+    its, st, J = g.stats()                         # to_allgather_stats: the small gather of SURVEY §8e, through RCCL
+    np.testing.assert_array_equal(its, sv.stats["iterations"])
+    np.testing.assert_array_equal(st, sv.stats["status"])
+    np.testing.assert_allclose(J, sv.stats["cost"], rtol=0, atol=0)
     with pytest.raises(T.ArgumentError):
         p._call("comm_init_rank", 1, 0, g._uid)   # already initialised
     g.close()

@@ -424,6 +424,48 @@ def test_indexed_constraint_and_change_dimension(oracle):
     assert sb.p == n and cb.p == m and sb.inds == list(range(1, n + 1)) and cb.inds == [2 * (n + m) - m + 1 + j for j in range(m)]
 
 
+def test_nested_change_dimension(oracle):
+    """change_dimension applied to a list that already holds IndexedConstraints (src/constraint_list.jl:208-217 on the output of
+    itself): a 1-D double integrator's constraints (n0, m0) = (2, 1) lifted to (4, 2) and again to (6, 3).  Jacobian and
+    Hessian buffers are sized from the library's own answer (to_constraint_info), so a state-only constraint two wrappers
+    deep (Goal, Circle) cannot be mis-strided; outputs are padded to the wrapper's p x (n+m) / (n+m) x (n+m) like the
+    reference's stage-constraint wrapper; bounds and is_bound forward to the innermost constraint."""
+    model = T.DoubleIntegrator(1.0, 3)
+    n, m, N = 6, 3, 4
+    inner = T.ConstraintList(2, 1, N)
+    T.add_constraint(inner, T.GoalConstraint(np.array([0.3, -0.2])), N)
+    T.add_constraint(inner, T.CircleConstraint(2, [0.4], [0.6], [0.3], xi=1, yi=2), range(2, N + 1))
+    T.add_constraint(inner, T.BoundConstraint(2, 1, x_max=[1.0, np.inf], u_min=[-1.0]), range(1, N))
+    mid = T.change_dimension(inner, 4, 2, ix=(2, 3), iu=(2, 2))
+    cons = T.change_dimension(mid, n, m, ix=(3, 6), iu=(2, 3))       # inner x -> mid x[2:3] -> new x[4:5]; u -> u[3]
+    assert all(isinstance(c, T.IndexedConstraint) and isinstance(c.con, T.IndexedConstraint) for c in cons)
+    assert T.is_bound(cons[0]) and T.is_bound(cons[2]) and not T.is_bound(cons[1])
+    np.testing.assert_array_equal(T.upper_bound(cons[2]), inner[2].z_max)
+    np.testing.assert_array_equal(T.lower_bound(cons[2]), inner[2].z_min)
+    rng = np.random.default_rng(9)
+    z0, eps = rng.standard_normal(n + m) * 0.5, 1e-6
+    p = _fd_problem(oracle, model, cons, z0, eps)
+    x_in, u_in = z0[3:5], z0[n + 2]
+    expect = [x_in - np.array([0.3, -0.2]), np.r_[0.3 ** 2 - (x_in[0] - 0.4) ** 2 - (x_in[1] - 0.6) ** 2], np.r_[x_in[0] - 1.0, -1.0 - u_in]]
+    mapped = [3, 4, n + 2]
+    for i, e in enumerate(expect):
+        c = T.evaluate_constraints(p, i)
+        np.testing.assert_allclose(c[0, 0], e, rtol=1e-13, atol=1e-14, err_msg=f"constraint {i}")
+        J = T.constraint_jacobians(p, i)[0, 0]
+        assert J.shape == (cons[i].p, n + m)
+        np.testing.assert_allclose(J, (c[1:, 0, :] - c[0, 0, :]).T / eps, atol=2e-5, err_msg=f"jacobian {i}")
+        assert np.all(J[:, np.setdiff1d(np.arange(n + m), mapped)] == 0.0)
+        H = T.constraint_hessians(p, i, np.ones(cons[i].p))
+        assert H.shape == (p.B, p.constraints.inds[i][1] - p.constraints.inds[i][0] + 1, n + m, n + m)
+        off = np.setdiff1d(np.arange(n + m), mapped)
+        assert np.all(H[0, 0][off] == 0.0) and np.all(H[0, 0][:, off] == 0.0)
+    Hc = T.constraint_hessians(p, 1, np.full(1, 2.0))[0, 0]           # circle: -2 lambda on the two centre coordinates
+    np.testing.assert_allclose(Hc[3, 3], -4.0); np.testing.assert_allclose(Hc[4, 4], -4.0)
+    base = rng.standard_normal(Hc.shape)
+    Hadd = T.constraint_hessians(p, 1, np.full(1, 2.0), H=np.broadcast_to(base, (p.B, N - 1) + base.shape).copy())[0, 0]
+    np.testing.assert_allclose(Hadd, base + Hc, rtol=1e-14, atol=1e-14)   # the operator ADDS, also through the padding
+
+
 def test_constraint_hessians_against_finite_differences(oracle):
     """∇jacobian! (src/abstract_constraint.jl:255-280): H += Σ_r λ_r ∇²c_r.  Closed forms of every kind with curvature vs
     finite differences of the Jacobians; zero for the affine kinds (src/constraints.jl:70-73, 767-770); the operator ADDS."""

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Fold rocprofv3 --pmc counter_collection CSVs (one pass per counter) into per-kernel HBM bytes per launch.
 
-Usage: pmc_traffic.py OUT.json CSV [CSV ...]
+Usage: pmc_traffic.py OUT.json BUILD_ID CSV [CSV ...]
+
+BUILD_ID = to_build_id() of the library the passes ran (tools/run_profiles.sh passes it): stored under "__meta__" so
+that bench.py only quotes a traffic figure measured on the binary it is timing.
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Following /opt/skills/guides/MI355X_MICROARCH.md (HBM
 section) FETCH_SIZE on gfx950 tallies 128-byte requests at 64 bytes, so the corrected figure doubles it; WRITE_SIZE is
@@ -19,7 +22,7 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
-def main(out, paths):
+def main(out, build_id, paths):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for p in paths:
         with open(p, newline="") as f:
@@ -47,9 +50,10 @@ def main(out, paths):
             e["fp64_flops_per_launch"] = 64.0 * (2.0 * e["SQ_INSTS_VALU_FMA_F64_per_launch"] + e.get("SQ_INSTS_VALU_ADD_F64_per_launch", 0.0)
                                                  + e.get("SQ_INSTS_VALU_MUL_F64_per_launch", 0.0) + e.get("SQ_INSTS_VALU_TRANS_F64_per_launch", 0.0))
         res[k] = e
+    res["__meta__"] = {"build_id": build_id}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])

@@ -13,7 +13,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format 
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 > /dev/null 2> "$out/write.log"
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$out/valu" -o valu --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 > /dev/null 2> "$out/valu.log"
 cd "$repo"
-python tools/pmc_traffic.py "$out/hbm_traffic_pmc.json" $(find "$out/fetch" "$out/write" "$out/valu" -name '*counter_collection.csv')
+bid=$(python -c "import trajopt_amd as T; print(T.load_hip_library().build_id())")
+python tools/pmc_traffic.py "$out/hbm_traffic_pmc.json" "$bid" $(find "$out/fetch" "$out/write" "$out/valu" -name '*counter_collection.csv')
 cp $(find "$out/kt" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
 python bench.py "$@" --no-extra > "$out/bench.json" 2> "$out/bench.log"
 tail -c 600 "$out/bench.json"

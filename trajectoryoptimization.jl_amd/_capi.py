@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-TO_ABI_VERSION = 1
+TO_ABI_VERSION = 2
 TO_MAX_N, TO_MAX_M, TO_MAX_P = 16, 8, 40
 TO_MAX_CON_PARAMS, TO_MAX_CON_INDS = 400, 48
 
@@ -187,6 +187,8 @@ HIP_ONLY = {
     "comm_unique_id": [C.c_void_p],
     "comm_init_rank": [_H, C.c_int32, C.c_int32, C.c_void_p],
     "allgather": [_H, C.c_void_p, C.c_void_p],
+    "comm_shards": [_H, _PI, _PI, C.POINTER(C.c_int64), _PI],
+    "allgather_stats": [_H, _PI, _PI, _PD],
     "comm_destroy": [_H],
     "set_profiling": [_H, C.c_int],
     "get_profile": [_H, _PD, C.POINTER(C.c_int64)],

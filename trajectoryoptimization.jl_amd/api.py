@@ -494,7 +494,9 @@ def sense(con):
 
 
 def upper_bound(con):
-    """src/abstract_constraint.jl:107-123."""
+    """src/abstract_constraint.jl:107-123; an IndexedConstraint forwards to the constraint it wraps (src/constraints.jl:877-879)."""
+    if isinstance(con, IndexedConstraint):
+        return upper_bound(con.con)
     s = con.sense()
     if isinstance(con, BoundConstraint):
         return con.z_max
@@ -502,6 +504,8 @@ def upper_bound(con):
 
 
 def lower_bound(con):
+    if isinstance(con, IndexedConstraint):
+        return lower_bound(con.con)
     s = con.sense()
     if isinstance(con, BoundConstraint):
         return con.z_min
@@ -509,6 +513,8 @@ def lower_bound(con):
 
 
 def is_bound(con):
+    if isinstance(con, IndexedConstraint):
+        return is_bound(con.con)
     return isinstance(con, (GoalConstraint, BoundConstraint))
 
 
@@ -728,7 +734,9 @@ class IndexedConstraint(AbstractConstraint):
 
     @property
     def lowered_state_only(self):
-        return self.con.state_only
+        """Does the LOWERED descriptor act on the state alone (the library then reports Jacobians of width n)?  Follows
+        nested wrappers down to the innermost constraint (change_dimension of an already wrapped list)."""
+        return getattr(self.con, "lowered_state_only", self.con.state_only)
 
 
 def _range_len(r):
@@ -1119,17 +1127,19 @@ def evaluate_constraints(prob, i):
     return vals
 
 
-def _lib_width(prob, con):
-    """Jacobian width the library reports for constraint ``con``: n for state constraints, else n+m."""
-    state = con.lowered_state_only if isinstance(con, IndexedConstraint) else con.state_only
-    return prob.n if state else prob.n + prob.m
+def _lib_width(prob, i):
+    """Jacobian width the LIBRARY reports for constraint ``i`` (to_constraint_info): n for state constraints, else n+m.
+    Asked, not inferred from the Python classes, so that buffer sizes can never disagree with what the kernels write."""
+    p, w, nk, sn = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    prob._call("constraint_info", i, C.byref(p), C.byref(w), C.byref(nk), C.byref(sn))
+    return int(w.value)
 
 
 def constraint_jacobians(prob, i):
     """constraint_jacobians! -> [B, nk, p, w]  (src/abstract_constraint.jl:236-248)."""
     con = prob.constraints[i]
     a, b = prob.constraints.inds[i]
-    w = _lib_width(prob, con)
+    w = _lib_width(prob, i)
     jac = np.empty((prob.B, b - a + 1, w, con.p))
     prob._call("constraint_jacobians", i, prob._pd(jac))
     jac = jac.transpose(0, 1, 3, 2)
@@ -1143,13 +1153,25 @@ def constraint_hessians(prob, i, lam, H=None):
     [B, nk, w, w]; ``lam`` is [B, nk, p]; ``H`` (same shape as the result) defaults to zeros — the operator ADDS."""
     con = prob.constraints[i]
     a, b = prob.constraints.inds[i]
-    nk, w = b - a + 1, _lib_width(prob, con)
+    nk, w = b - a + 1, _lib_width(prob, i)
+    nz = prob.n + prob.m
+    # the reference's IndexedConstraint is a stage constraint whatever it wraps: its Jacobians are p x (n+m) and its
+    # Hessians (n+m) x (n+m) (src/constraints.jl:820-936); the library works on the lowered (possibly state-only) form
+    pad = isinstance(con, IndexedConstraint) and w < nz
+    wo = nz if pad else w
     lam = np.ascontiguousarray(np.broadcast_to(np.asarray(lam, dtype=np.float64), (prob.B, nk, con.p)))
-    out = np.zeros((prob.B, nk, w, w)) if H is None else np.ascontiguousarray(np.asarray(H, dtype=np.float64).transpose(0, 1, 3, 2)).copy()
-    if out.shape != (prob.B, nk, w, w):
-        raise DimensionMismatch(f"H must be [B, nk, {w}, {w}]")
+    if H is not None:
+        H = np.asarray(H, dtype=np.float64)
+        if H.shape != (prob.B, nk, wo, wo):
+            raise DimensionMismatch(f"H must be [B, nk, {wo}, {wo}]")
+    out = np.zeros((prob.B, nk, w, w)) if H is None else np.ascontiguousarray(H[:, :, :w, :w].transpose(0, 1, 3, 2)).copy()
     prob._call("constraint_hessians", i, prob._pd(lam), prob._pd(out))
-    return out.transpose(0, 1, 3, 2)
+    out = out.transpose(0, 1, 3, 2)
+    if pad:
+        full = np.zeros((prob.B, nk, nz, nz)) if H is None else H.copy()
+        full[:, :, :w, :w] = out
+        return full
+    return out
 
 
 # --------------------------------------------------------------------------------------------- solvers

@@ -58,6 +58,9 @@ struct to_handle_s {
   // multi-GPU: RCCL communicator of the batch shards (to_comm_*; librccl is dlopen'ed on first use)
   void* comm = nullptr;
   int comm_rank = 0, comm_size = 1;
+  std::vector<int32_t> comm_counts;  // shard size of every rank (exchanged at to_comm_init_rank)
+  long long comm_offset = 0, comm_total = 0;  // global index of this rank's first trajectory; sum of the shards
+  bool comm_equal = true;            // all shards equal: one in-place all-gather, else grouped broadcasts
   // measurement
   bool profile = false;
   std::vector<hipEvent_t> ev;  // event pool, 4 per batch step

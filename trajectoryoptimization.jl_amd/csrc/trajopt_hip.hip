@@ -490,6 +490,9 @@ struct Rccl {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, Id, int) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -505,10 +508,14 @@ int load_rccl() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.Broadcast = (decltype(g_rccl.Broadcast))dlsym(g_rccl.lib, "ncclBroadcast");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
   });
-  if (!g_rccl.lib || !g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+  if (!g_rccl.lib || !g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.Broadcast ||
+      !g_rccl.GroupStart || !g_rccl.GroupEnd)
     return fail(TO_ERR_HIP, "librccl.so not found (or incomplete): the multi-GPU entry points need RCCL");
   return TO_OK;
 }
@@ -518,6 +525,7 @@ int load_rccl() {
     if (r_ != 0) return fail(TO_ERR_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
   } while (0)
 constexpr int kNcclDouble = 8;  // ncclFloat64 (rccl.h)
+constexpr int kNcclInt32 = 2;   // ncclInt32
 }  // namespace
 
 
@@ -637,7 +645,10 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     // 16, so the solve loop switches to it once the active trajectories fit the chip that way (one wave per SIMD).
     const int total = P.opts.iterations_linesearch;
     const char* deep_env = std::getenv("TRAJOPT_LS_DEEP");  // 0: never switch to the deep shape (tests of the round logic)
-    if (!h->ops->write_through && total > h->cw_base && total <= 64 && !(deep_env && std::atoi(deep_env) == 0)) {
+    // Only while a wave still holds >= 2 trajectories that way (total <= 32): with 33..64 step sizes a deep wave would carry
+    // ONE trajectory and the candidate arrays 64x the nominal storage (several GB on C5) — those depths run as further
+    // rounds of the base shape instead.
+    if (!h->ops->write_through && total > h->cw_base && total <= 32 && !(deep_env && std::atoi(deep_env) == 0)) {
       hipDeviceProp_t prop;
       HIPB(hipGetDeviceProperties(&prop, device));
       h->cw_deep = total; h->tw_deep = 64 / total;
@@ -1102,6 +1113,37 @@ int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id
   std::memcpy(id.b, id128, sizeof(id.b));
   RCCLCHECK(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
   h->comm_rank = rank; h->comm_size = nranks;
+  // shard sizes of every rank (they may differ: a batch that does not divide by the number of GPUs)
+  int32_t* dcnt = nullptr;
+  HIPCHECK(hipMalloc((void**)&dcnt, sizeof(int32_t) * nranks));
+  const int32_t mine = h->a.P.B;
+  hipError_t e1 = hipMemcpyAsync(dcnt + rank, &mine, sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+  int rc = e1 == hipSuccess ? g_rccl.AllGather(dcnt + rank, dcnt, 1, kNcclInt32, h->comm, h->stream) : 0;
+  h->comm_counts.assign(nranks, 0);
+  hipError_t e2 = hipMemcpyAsync(h->comm_counts.data(), dcnt, sizeof(int32_t) * nranks, hipMemcpyDeviceToHost, h->stream);
+  hipError_t e3 = hipStreamSynchronize(h->stream);
+  hipFree(dcnt);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || rc != 0) {
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1; h->comm_counts.clear();
+    return fail(TO_ERR_HIP, "to_comm_init_rank: exchanging the shard sizes failed");
+  }
+  h->comm_offset = 0; h->comm_total = 0; h->comm_equal = true;
+  for (int r = 0; r < nranks; ++r) {
+    if (h->comm_counts[r] < 1) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank: a rank reported an empty shard");
+    if (r < rank) h->comm_offset += h->comm_counts[r];
+    h->comm_total += h->comm_counts[r];
+    h->comm_equal = h->comm_equal && h->comm_counts[r] == h->comm_counts[0];
+  }
+  return TO_OK;
+}
+int to_comm_shards(const to_handle* h, int32_t* nranks, int32_t* rank, int64_t* B_total, int32_t* counts) {
+  CHECK_H(h);
+  if (!h->comm) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank first");
+  if (nranks) *nranks = h->comm_size;
+  if (rank) *rank = h->comm_rank;
+  if (B_total) *B_total = h->comm_total;
+  if (counts) for (int r = 0; r < h->comm_size; ++r) counts[r] = h->comm_counts[r];
   return TO_OK;
 }
 int to_comm_destroy(to_handle* h) {
@@ -1110,32 +1152,85 @@ int to_comm_destroy(to_handle* h) {
   TRY(use_device(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
   RCCLCHECK(g_rccl.CommDestroy(h->comm));
-  h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
+  h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1; h->comm_counts.clear();
   return TO_OK;
 }
-// All ranks hold shards of the same size.  dX_all / dU_all: caller-owned DEVICE buffers of nranks * (n*N*B) and
-// nranks * (m*(N-1)*B) doubles; on return (after to_sync or the call itself: it synchronises the handle's stream) they
-// hold every rank's trajectories in host layout (n, N, B_total), rank-major = global trajectory order.
+// Every rank's block, gathered in rank order into `all` (count[r] * per doubles / int32 from rank r at offset[r] * per):
+// one in-place ncclAllGather when the shards are equal, else one grouped ncclBroadcast per rank (same bytes on the wire).
+static int gather_blocks(to_handle* h, void* all, size_t per, int dtype, size_t elt) {
+  char* base = (char*)all;
+  char* mine = base + (size_t)h->comm_offset * per * elt;
+  if (h->comm_equal) {
+    RCCLCHECK(g_rccl.AllGather(mine, all, (size_t)h->a.P.B * per, dtype, h->comm, h->stream));
+    return TO_OK;
+  }
+  RCCLCHECK(g_rccl.GroupStart());
+  size_t off = 0;
+  for (int r = 0; r < h->comm_size; ++r) {
+    char* blk = base + off * per * elt;
+    const int rc = g_rccl.Broadcast(blk, blk, (size_t)h->comm_counts[r] * per, dtype, r, h->comm, h->stream);
+    if (rc != 0) { g_rccl.GroupEnd(); return fail(TO_ERR_HIP, std::string("ncclBroadcast: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error")); }
+    off += (size_t)h->comm_counts[r];
+  }
+  RCCLCHECK(g_rccl.GroupEnd());
+  return TO_OK;
+}
+// dX_all / dU_all: caller-owned DEVICE buffers of n*N*B_total and m*(N-1)*B_total doubles (B_total = sum of the ranks' shard
+// sizes, to_comm_shards); on return (the call synchronises the handle's stream) they hold every rank's trajectories in host
+// layout (n, N, B_total), rank-major = global trajectory order.  Shards may differ in size.
 int to_allgather(to_handle* h, void* dX_all, void* dU_all) {
   CHECK_H(h);
   if (!dX_all && !dU_all) return fail(TO_ERR_NULL, "null pointer");
   if (!h->comm) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank first");
   TRY(use_device(h));
   const DevProblem& P = h->a.P;
-  const size_t nx = (size_t)P.n * P.N * P.B, nu = (size_t)P.m * (P.N - 1) * P.B;
-  if (dX_all) {  // own shard written in place, then one in-place all-gather on the handle's stream
-    double* mine = (double*)dX_all + nx * h->comm_rank;
+  const size_t px = (size_t)P.n * P.N, pu = (size_t)P.m * (P.N - 1);
+  if (dX_all) {  // own shard written in place, then one in-place gather on the handle's stream
+    double* mine = (double*)dX_all + px * (size_t)h->comm_offset;
     hipLaunchKernelGGL(k_to_host, grid_b(h, P.n * P.N), dim3(BLOCK), 0, h->stream, h->a.Xs, mine, P.n * P.N, 0, P.n * P.N, P.B);
     HIPCHECK(hipGetLastError());
-    RCCLCHECK(g_rccl.AllGather(mine, dX_all, nx, kNcclDouble, h->comm, h->stream));
+    TRY(gather_blocks(h, dX_all, px, kNcclDouble, sizeof(double)));
   }
   if (dU_all) {
-    double* mine = (double*)dU_all + nu * h->comm_rank;
+    double* mine = (double*)dU_all + pu * (size_t)h->comm_offset;
     hipLaunchKernelGGL(k_to_host, grid_b(h, P.m * (P.N - 1)), dim3(BLOCK), 0, h->stream, h->a.Us, mine, P.m * (P.N - 1), 0, P.m * (P.N - 1), P.B);
     HIPCHECK(hipGetLastError());
-    RCCLCHECK(g_rccl.AllGather(mine, dU_all, nu, kNcclDouble, h->comm, h->stream));
+    TRY(gather_blocks(h, dU_all, pu, kNcclDouble, sizeof(double)));
   }
   HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
+// The small gather SURVEY.md §8e names next to the trajectories: iterations[B_total], status[B_total] (int32) and the
+// objective cost J[B_total] of every rank's CURRENT trajectories, rank-major, into caller-owned HOST arrays (any may be
+// NULL).  Staged through a device buffer of the library (a few bytes per trajectory), gathered over the same communicator.
+int to_allgather_stats(to_handle* h, int32_t* iterations_all, int32_t* status_all, double* J_all) {
+  CHECK_H(h);
+  if (!h->comm) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank first");
+  if (!iterations_all && !status_all && !J_all) return fail(TO_ERR_NULL, "null pointer");
+  TRY(use_device(h));
+  const DevProblem& P = h->a.P;
+  const size_t T = (size_t)h->comm_total, off = (size_t)h->comm_offset, B = (size_t)P.B;
+  struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) hipFree(p); } } buf;
+  HIPCHECK(hipMalloc(&buf.p, T * sizeof(double)));
+  auto gather_int = [&](const int* src, int32_t* host) -> int {
+    if (!host) return TO_OK;
+    int32_t* all = (int32_t*)buf.p;
+    HIPCHECK(hipMemcpyAsync(all + off, src, B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    TRY(gather_blocks(h, all, 1, kNcclInt32, sizeof(int32_t)));
+    HIPCHECK(hipMemcpyAsync(host, all, T * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    return TO_OK;
+  };
+  TRY(gather_int(h->a.iterations, iterations_all));
+  TRY(gather_int(h->a.status, status_all));
+  if (J_all) {
+    double* all = (double*)buf.p;
+    TRY(launch_cost(h, 0, h->d_tmp, nullptr));
+    HIPCHECK(hipMemcpyAsync(all + off, h->d_tmp, B * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    TRY(gather_blocks(h, all, 1, kNcclDouble, sizeof(double)));
+    HIPCHECK(hipMemcpyAsync(J_all, all, T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  }
   return TO_OK;
 }
 

@@ -1,9 +1,11 @@
 """Multi-GPU plumbing: the batch shards across ranks as independent units — no collective
-inside the iLQR/AL loops — and the converged trajectories are all-gathered once per solve.
+inside the iLQR/AL loops — and the converged trajectories are all-gathered once per solve, plus one small gather of
+the per-trajectory stats (iterations, status, cost).
 
-On GPUs the gather is the library's own RCCL all-gather over xGMI (``to_comm_init_rank`` / ``to_allgather`` of the
-C-ABI: what a Julia host calls as well); ``torch.distributed`` only ships the 128-byte communicator id and provides
-the barrier.  The CPU tests (gloo, oracle as the per-rank library) gather host arrays with ``torch.distributed``."""
+On GPUs both gathers are the library's own RCCL collectives over xGMI (``to_comm_init_rank`` / ``to_allgather`` /
+``to_allgather_stats`` of the C-ABI: what a Julia host calls as well); ``torch.distributed`` only ships the 128-byte
+communicator id and provides the barrier.  Shards may differ in size (``to_comm_shards`` reports what the communicator
+saw).  The CPU tests (gloo, oracle as the per-rank library) gather host arrays with ``torch.distributed``."""
 from __future__ import annotations
 
 import ctypes as C
@@ -12,12 +14,20 @@ import numpy as np
 
 
 def shard_offset(rank, batch_per_rank):
-    """Global index of the first trajectory owned by ``rank`` (contiguous block partition)."""
+    """Global index of the first trajectory owned by ``rank`` (contiguous block partition of equal shards)."""
     return int(rank) * int(batch_per_rank)
 
 
+def shard_range(rank, world, total):
+    """Contiguous block partition of ``total`` trajectories over ``world`` ranks when it does not divide: the first
+    ``total % world`` ranks own one more.  -> (first global index, count)."""
+    base, extra = divmod(int(total), int(world))
+    cnt = base + (1 if rank < extra else 0)
+    return rank * base + min(rank, extra), cnt
+
+
 class TrajectoryGather:
-    """Pre-allocated buffers + one all-gather per array.  Rank-major output: X[world*B, N, n], U[world*B, N-1, m]
+    """Pre-allocated buffers + one all-gather per array.  Rank-major output: X[B_total, N, n], U[B_total, N-1, m]
     (= the C-ABI's (n, N, B_total) column-major layout in global trajectory order)."""
 
     def __init__(self, prob, dist, device=None):
@@ -30,8 +40,6 @@ class TrajectoryGather:
         B = prob.B
         self.on_device = device is not None
         dev = device if self.on_device else "cpu"
-        self.xg = torch.empty((self.world * B, N, n), dtype=torch.float64, device=dev)
-        self.ug = torch.empty((self.world * B, N - 1, m), dtype=torch.float64, device=dev)
         if self.on_device:  # native RCCL communicator behind the handle; world == 1 runs the same code
             uid = torch.zeros(128, dtype=torch.uint8)
             if self.rank == 0:
@@ -44,9 +52,38 @@ class TrajectoryGather:
                 uid = uid.cpu()
             self._uid = (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
             prob._call("comm_init_rank", self.world, self.rank, self._uid)
+            nr, rk, tot = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+            cnt = (C.c_int32 * self.world)()
+            prob._call("comm_shards", C.byref(nr), C.byref(rk), C.byref(tot), cnt)
+            assert (nr.value, rk.value) == (self.world, self.rank), "RCCL communicator disagrees with torch.distributed"
+            self.counts = [int(c) for c in cnt]   # what RCCL itself saw
         else:
+            self.counts = [B]
+            if self.world > 1:
+                lst = [None] * self.world
+                dist.all_gather_object(lst, B)
+                self.counts = [int(c) for c in lst]
             self.xs = torch.empty((B, N, n), dtype=torch.float64)
             self.us = torch.empty((B, N - 1, m), dtype=torch.float64)
+        self.total = sum(self.counts)
+        self.xg = torch.empty((self.total, N, n), dtype=torch.float64, device=dev)
+        self.ug = torch.empty((self.total, N - 1, m), dtype=torch.float64, device=dev)
+
+    def _cpu_gather(self, out, mine):
+        """torch.distributed gather of per-rank blocks of possibly different length (padded to the longest)."""
+        torch = self.torch
+        if self.world == 1:
+            out.copy_(mine)
+            return
+        mx = max(self.counts)
+        pad = torch.zeros((mx,) + tuple(mine.shape[1:]), dtype=mine.dtype)
+        pad[: mine.shape[0]] = mine
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(parts, pad)
+        off = 0
+        for r, c in enumerate(self.counts):
+            out[off:off + c] = parts[r][:c]
+            off += c
 
     def __call__(self):
         torch, prob = self.torch, self.prob
@@ -56,13 +93,25 @@ class TrajectoryGather:
         from . import api
         self.xs.copy_(torch.from_numpy(api.states(prob)))
         self.us.copy_(torch.from_numpy(api.controls(prob)))
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.xg, self.xs)
-            self.dist.all_gather_into_tensor(self.ug, self.us)
-        else:
-            self.xg.copy_(self.xs)
-            self.ug.copy_(self.us)
+        self._cpu_gather(self.xg, self.xs)
+        self._cpu_gather(self.ug, self.us)
         return self.xg, self.ug
+
+    def stats(self, solver=None):
+        """The small gather of SURVEY.md §8e: (iterations[B_total], status[B_total], cost[B_total]) in global order.  On
+        the GPU: ``to_allgather_stats`` (RCCL, same communicator); on CPU ``solver.stats`` through torch.distributed."""
+        if self.on_device:
+            its, st, J = np.zeros(self.total, np.int32), np.zeros(self.total, np.int32), np.zeros(self.total)
+            pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+            self.prob._call("allgather_stats", pi(its), pi(st), J.ctypes.data_as(C.POINTER(C.c_double)))
+            return its, st, J
+        torch, out = self.torch, []
+        for key in ("iterations", "status", "cost"):
+            a = torch.from_numpy(np.ascontiguousarray(solver.stats[key]))
+            g = torch.empty((self.total,), dtype=a.dtype)
+            self._cpu_gather(g, a)
+            out.append(g.numpy())
+        return tuple(out)
 
     def close(self):
         if self.on_device:
@@ -70,7 +119,7 @@ class TrajectoryGather:
 
 
 def gather_stats(dist, arr):
-    """all_gather of a per-trajectory numpy stats array (iterations, status, cost) -> rank-major numpy array."""
+    """all_gather of a per-trajectory numpy stats array (equal shards) -> rank-major numpy array."""
     import torch
     t = torch.from_numpy(np.ascontiguousarray(arr))
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
