@@ -118,7 +118,7 @@ def _create_rc(desc_mut):
     T.add_constraint(cons, T.GoalConstraint(np.zeros(4)), N)
     cdesc = cons._descs()
     d = T.capi.ProblemDesc()
-    d.abi_version, d.model, d.integrator, d.n, d.m, d.N, d.B = 1, model.model_id, T.RK4, 4, 1, N, 2
+    d.abi_version, d.model, d.integrator, d.n, d.m, d.N, d.B = T.capi.TO_ABI_VERSION, model.model_id, T.RK4, 4, 1, N, 2
     d.model_params[:4] = model.params()
     d.t0, d.tf = 0.0, 1.0
     d.n_costs, d.costs, d.cost_index = len(uniq), costs, None
