@@ -274,6 +274,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--throughput-probe", type=int, default=-1,
                     help="also solve a batch of this size once (reported separately; default 32768 for the cartpole workload at N=1, 0 = off)")
+    ap.add_argument("--no-probe-sweep", dest="probe_sweep", action="store_false",
+                    help="skip the batch sweep (2x, 4x, 8x the probe batch) that locates the throughput plateau")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate hipEvent-profiled pass (no roofline object)")
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     args = ap.parse_args()
@@ -318,18 +320,33 @@ def main():
         probe = args.throughput_probe
         if probe < 0:
             probe = 32768 if (name == "cartpole" and world == 1) else 0
-        if probe > 0:  # outside the timed region: the same kernels on a batch large enough to fill the chip
+        if probe > 0:  # outside the timed region: the same kernels on batches large enough to fill the chip
             n, m, N = prob.dims()
             bytes_it = configs.algorithmic_bytes_per_iteration(n, m, prob.errstate_dim, N, sum(prob.constraints.p))
-            pb = build_problem(T, configs, name, probe, 0, local_rank, lib)
-            ps = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(pb)
-            ps.solve()
-            T.initial_controls(pb, u0)
-            t1 = time.perf_counter(); ps.solve(); d1 = time.perf_counter() - t1
-            out["throughput_probe"] = {"batch": probe, "value": ps.total_iterations / d1,
-                                       "unit": "trajectory-iterations/s", "ms": 1e3 * d1,
-                                       "whole_iteration_frac": bytes_it * ps.total_iterations / d1 / 1e9 / HBM_PEAK_GBS}
-            del ps, pb
+
+            def probe_once(pbatch):
+                pb = build_problem(T, configs, name, pbatch, 0, local_rank, lib)
+                ps = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(pb)
+                ps.solve()
+                T.initial_controls(pb, u0)
+                t1 = time.perf_counter(); ps.solve(); d1 = time.perf_counter() - t1
+                r = {"batch": pbatch, "value": ps.total_iterations / d1, "unit": "trajectory-iterations/s", "ms": 1e3 * d1,
+                     "batch_steps": int(ps.batch_steps),
+                     "whole_iteration_frac": bytes_it * ps.total_iterations / d1 / 1e9 / HBM_PEAK_GBS}
+                del ps, pb
+                return r
+
+            out["throughput_probe"] = probe_once(probe)
+            if args.probe_sweep and name == "cartpole":  # where does the throughput plateau?
+                sweep = [out["throughput_probe"]]
+                for pbatch in (2 * probe, 4 * probe, 8 * probe):
+                    try:
+                        sweep.append(probe_once(pbatch))
+                    except Exception as e:
+                        sweep.append({"batch": pbatch, "error": repr(e)})
+                        break
+                best = max((r for r in sweep if "value" in r), key=lambda r: r["value"])
+                out["throughput_sweep"] = {"points": sweep, "plateau": {k: best[k] for k in ("batch", "value", "whole_iteration_frac")}}
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(T, configs, name, batch)

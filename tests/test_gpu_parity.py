@@ -541,6 +541,55 @@ def test_lane_backward_on_small_models(hip, oracle, monkeypatch):
     assert_solve_parity(T.ALSolver(ph).solve(), T.ALSolver(po).solve(), ph, po)
 
 
+def test_lane_expansion_matches_column_expansion(hip, oracle, monkeypatch):
+    """k_expand_lane (one lane per (trajectory, knot), every column of [A B] from ONE pass of the RK stages in chunk-mode dual
+    numbers) against the column-per-lane kernel it replaces for the lane layout (TRAJOPT_EXPAND_LANE=0) and against the
+    oracle's analytic chain rule: Cartpole (diagonal cost, bounds + goal: VAR 2), the quickstart double integrator (circle +
+    SOC + bounds: VAR 7, a ragged batch) and a dense QuadraticCost with a cross term (VAR 1)."""
+    monkeypatch.setenv("TRAJOPT_BACKWARD", "lane")
+
+    def dense(lib):
+        model = T.DoubleIntegrator(1.3, 2)
+        n, m, N = 4, 2, 17
+        rng = np.random.default_rng(5)
+        A = rng.standard_normal((n, n)); Q = A @ A.T + n * np.eye(n)
+        Bm = rng.standard_normal((m, m)); R = Bm @ Bm.T + m * np.eye(m)
+        H = 0.1 * rng.standard_normal((m, n))
+        stage = T.QuadraticCost(Q, R, H, rng.standard_normal(n), rng.standard_normal(m), 0.3)
+        term = T.QuadraticCost(3 * Q, R, None, rng.standard_normal(n), None, 0.1, terminal=True)
+        p = T.Problem(model, T.Objective(stage, term, N), np.zeros(n), 1.6, batch=67, lib=lib)
+        p.set_initial_state(rng.standard_normal((67, n)))
+        return p
+
+    for name, build in (("cartpole_con", BUILDERS["cartpole_con"]), ("quickstart", lambda **kw: configs.quickstart_problem(batch=67, **kw)), ("dense", None)):
+        res = {}
+        for mode in ("1", "0", "oracle"):
+            monkeypatch.setenv("TRAJOPT_EXPAND_LANE", "1" if mode == "oracle" else mode)
+            lib = oracle if mode == "oracle" else hip
+            p = dense(lib) if build is None else build(lib=lib)
+            perturb_controls((p,), 0.05, seed=3)
+            T.rollout(p)
+            if len(p.constraints):
+                I.dual_update(p)
+            I.expand(p)
+            I.backwardpass(p)
+            res[mode] = (I.dynamics_jacobians(p), I.cost_expansion(p), I.gains(p))
+        (A1, B1), E1, g1 = res["1"]
+        (A0, B0), E0, g0 = res["0"]
+        (Ao, Bo), Eo, go = res["oracle"]
+        # same operations per derivative component as the single-direction dual numbers: identical up to FMA contraction
+        np.testing.assert_allclose(A1, A0, rtol=1e-14, atol=1e-15, err_msg=name)
+        np.testing.assert_allclose(B1, B0, rtol=1e-14, atol=1e-15, err_msg=name)
+        for k in E1:
+            np.testing.assert_allclose(E1[k], E0[k], rtol=1e-14, atol=1e-15, err_msg=f"{name} {k}")
+            np.testing.assert_allclose(E1[k], Eo[k], rtol=1e-9, atol=1e-10, err_msg=f"{name} {k} vs oracle")
+        np.testing.assert_allclose(A1, Ao, rtol=1e-10, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(B1, Bo, rtol=1e-10, atol=1e-12, err_msg=name)
+        np.testing.assert_array_equal(g1["rho"], go["rho"])
+        np.testing.assert_allclose(g1["K"], go["K"], rtol=1e-7, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(g1["d"], go["d"], rtol=1e-7, atol=1e-9, err_msg=name)
+
+
 def test_mfma_backward_on_small_models(hip, oracle, monkeypatch):
     """The MFMA backward pass (one wave per trajectory, tangent-matrix expansion, compact and full cost blocks) is generic
     in the model; the small models default to the cooperative kernel, so force it: m = 1 / ne = 4 (Cartpole) and

@@ -8,10 +8,10 @@ out=$repo/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python "$repo/bench.py" "$@" --no-cpu-baseline --no-extra --throughput-probe 0 > "$out/bench_under_trace.json" 2> "$out/kt.log"
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 > /dev/null 2> "$out/fetch.log"
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 > /dev/null 2> "$out/write.log"
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$out/valu" -o valu --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 > /dev/null 2> "$out/valu.log"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python "$repo/bench.py" "$@" --no-cpu-baseline --no-extra --throughput-probe 0 --no-probe-sweep > "$out/bench_under_trace.json" 2> "$out/kt.log"
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/fetch.log"
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/write.log"
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$out/valu" -o valu --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/valu.log"
 cd "$repo"
 bid=$(python -c "import trajopt_amd as T; print(T.load_hip_library().build_id())")
 python tools/pmc_traffic.py "$out/hbm_traffic_pmc.json" "$bid" $(find "$out/fetch" "$out/write" "$out/valu" -name '*counter_collection.csv')

@@ -46,6 +46,7 @@ struct to_handle_s {
   int counter_len = 0;
   int cw_base = 1, tw_base = 64;  // forward-wave shape: base, and the deep one (0: none) used once the active trajectories fit
   int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
+  int expand_lane = 1;    // lane layout: expansion by k_expand_lane (one lane per (trajectory, knot)); 0 = column-per-lane kernel (A/B knob TRAJOPT_EXPAND_LANE)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   // device copies of the descriptor tables
   to_cost_desc* d_costs = nullptr;

@@ -265,4 +265,100 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ lane expansion
+// Small vector-space models with the one-lane-per-trajectory backward pass (large batches): ONE LANE per (trajectory, knot)
+// produces the whole expansion of its knot — all nc = ne + m columns of [A B] from a single pass of the RK stages in
+// chunk-mode dual numbers (MDual<nc>, models.h), then the cost (+AL) columns.  The column-per-lane kernel above spends 8
+// lanes (5 useful on the Cartpole) per (trajectory, knot), each re-evaluating the VALUE part of the dynamics — 0.65 MFLOP
+// issued per Cartpole trajectory-iteration for a 0.1 MFLOP expansion — this one evaluates it once.  Writes the
+// lane layout (k_backward.h, LaneLay) as whole 512-byte rows: lane = trajectory.  grid (Bp / 64, N).
+template <class M, int FIXED_INTEG, int VAR>
+__global__ void __launch_bounds__(64) k_expand_lane(KArgs a) {
+  static_assert(!M::lie, "lane expansion: vector-space models only (identity error-state maps)");
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  using L = LaneLay<M>;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane, k = blockIdx.y;  // b < Bp always
+  // lanes without a trajectory to expand compute along on their own (valid) data; only their stores are predicated
+  const bool live = (b < P.B) && a.active[b] != 0;
+  if (__ballot(live) == 0) return;
+  const bool terminal = (k == N - 1);
+  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;  // the step the last forward pass accepted (k_expand)
+  const double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
+  double x[n], u[m];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(U, k * m + i);
+  if (M::accept_write_through && c != 0 && live) {
+    double* X0 = X_SLOT_PTR(a, b, 0);
+    double* U0 = U_SLOT_PTR(a, b, 0);
+#pragma unroll
+    for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
+    if (!terminal) {
+#pragma unroll
+      for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
+    }
+  }
+  // ---- dynamics: every column of [A B] in one pass
+  if (!terminal) {
+    MDual<nc> xd[n], ud[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xd[i].v = x[i]; xd[i].d[i] = 1.0; }
+#pragma unroll
+    for (int i = 0; i < m; ++i) { ud[i].v = u[i]; ud[i].d[ne + i] = 1.0; }
+    rk_step<M, MDual<nc>, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+    double* Ml = a.Mc + (((size_t)tile * (size_t)(N - 1) + k) * (ne * nc)) * 64 + lane;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i)
+#pragma unroll
+        for (int j = 0; j < nc; ++j) EL(Ml, i * nc + j) = xn[i].d[j];
+    }
+  }
+  // ---- cost (+AL) gradient and Hessian columns (same calls, same order of the constraint terms as expand_knot's table path)
+  double* Hl = a.Hc + (((size_t)tile * (size_t)N + k) * L::NS) * 64 + lane;
+  double* gl = a.gc + (((size_t)tile * (size_t)N + k) * nc) * 64 + lane;
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = u[i];
+  const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane;
+  const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < nc; ++j) {
+    if (terminal && j >= ne) continue;  // wave-uniform: no control directions at the terminal knot
+    double v[nz], gr[nz], y[nz];
+#pragma unroll
+    for (int i = 0; i < nz; ++i) v[i] = (i == (j < ne ? j : n + (j - ne))) ? 1.0 : 0.0;
+    cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
+    if (P.opts.cost_dt_scaling && !terminal) {
+      const double h = P.dt[k];
+#pragma unroll
+      for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
+    }
+    if constexpr ((VAR & 2) != 0) {
+      for (int ci = 0; ci < P.n_cons; ++ci) {
+        ConC& K = P.cons[ci];
+        if (k < K.k1 || k > K.k2) continue;
+        const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
+      }
+    }
+    if (live) {
+      double* Hj = Hl + (size_t)(j * (j + 1) / 2) * 64;
+#pragma unroll
+      for (int i = 0; i < ne; ++i)
+        if (i <= j) EL(Hj, i) = y[i];
+#pragma unroll
+      for (int r = 0; r < m; ++r)
+        if (ne + r <= j) EL(Hj, ne + r) = terminal ? 0.0 : y[n + r];
+      EL(gl, j) = gr[j < ne ? j : n + (j - ne)];
+    }
+  }
+}
+
 }  // namespace to

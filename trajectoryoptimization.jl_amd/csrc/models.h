@@ -102,6 +102,56 @@ __device__ __forceinline__ double relu_t(double x) { return fmax(0.0, x); }
 // (component-wise selects: a select between two Dual objects was lowered through scratch memory in the larger kernels)
 __device__ __forceinline__ Dual relu_t(Dual x) { const bool on = x.v > 0.0; return Dual(on ? x.v : 0.0, on ? x.d : 0.0); }
 
+// Value + K directional derivatives at once (ForwardDiff's chunk mode): the lane-per-trajectory expansion of the small
+// models (k_expand.h, k_expand_lane) pushes ALL nc = ne + m input directions through the RK stages in one pass, so the value
+// part of the dynamics — half of a single-direction Dual evaluation — is computed once per knot instead of once per column
+// lane.  Every derivative component goes through exactly the operations of Dual's (same expressions, same order).
+template <int K>
+struct MDual {
+  double v, d[K];
+  __host__ __device__ MDual() : v(0.0) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) d[i] = 0.0;
+  }
+  __host__ __device__ MDual(double a) : v(a) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) d[i] = 0.0;
+  }
+};
+#define TO_MD_LOOP _Pragma("unroll") for (int i_ = 0; i_ < K; ++i_)
+template <int K> __device__ __forceinline__ MDual<K> operator+(MDual<K> a, MDual<K> b) { MDual<K> r; r.v = a.v + b.v; TO_MD_LOOP r.d[i_] = a.d[i_] + b.d[i_]; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator-(MDual<K> a, MDual<K> b) { MDual<K> r; r.v = a.v - b.v; TO_MD_LOOP r.d[i_] = a.d[i_] - b.d[i_]; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator-(MDual<K> a) { MDual<K> r; r.v = -a.v; TO_MD_LOOP r.d[i_] = -a.d[i_]; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator*(MDual<K> a, MDual<K> b) { MDual<K> r; r.v = a.v * b.v; TO_MD_LOOP r.d[i_] = a.d[i_] * b.v + a.v * b.d[i_]; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator/(MDual<K> a, MDual<K> b) {
+  const double rb = rcp_fast(b.v);
+  const double q = a.v * rb;
+  MDual<K> r; r.v = q;
+  TO_MD_LOOP r.d[i_] = (a.d[i_] - q * b.d[i_]) * rb;
+  return r;
+}
+template <int K> __device__ __forceinline__ MDual<K> operator+(MDual<K> a, double b) { MDual<K> r = a; r.v = a.v + b; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator+(double a, MDual<K> b) { MDual<K> r = b; r.v = a + b.v; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator-(MDual<K> a, double b) { MDual<K> r = a; r.v = a.v - b; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator-(double a, MDual<K> b) { MDual<K> r; r.v = a - b.v; TO_MD_LOOP r.d[i_] = -b.d[i_]; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator*(MDual<K> a, double b) { MDual<K> r; r.v = a.v * b; TO_MD_LOOP r.d[i_] = a.d[i_] * b; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator*(double a, MDual<K> b) { MDual<K> r; r.v = a * b.v; TO_MD_LOOP r.d[i_] = a * b.d[i_]; return r; }
+template <int K> __device__ __forceinline__ MDual<K> operator/(MDual<K> a, double b) { const double rb = rcp_fast(b); MDual<K> r; r.v = a.v * rb; TO_MD_LOOP r.d[i_] = a.d[i_] * rb; return r; }
+template <int K> __device__ __forceinline__ MDual<K> recip_t(MDual<K> x) { const double r0 = rcp_fast(x.v); MDual<K> r; r.v = r0; TO_MD_LOOP r.d[i_] = -(x.d[i_] * r0) * r0; return r; }
+template <int K> __device__ __forceinline__ void sincos_t(MDual<K> x, MDual<K>* s, MDual<K>* c) {
+  double sv, cv;
+  sincos_fast(x.v, &sv, &cv);
+  s->v = sv; c->v = cv;
+  TO_MD_LOOP { s->d[i_] = cv * x.d[i_]; c->d[i_] = -sv * x.d[i_]; }
+}
+template <int K> __device__ __forceinline__ MDual<K> relu_t(MDual<K> x) {
+  const bool on = x.v > 0.0;
+  MDual<K> r; r.v = on ? x.v : 0.0;
+  TO_MD_LOOP r.d[i_] = on ? x.d[i_] : 0.0;
+  return r;
+}
+#undef TO_MD_LOOP
+
 // ------------------------------------------------------------------------------------------------
 // Models.  P = model_params of the descriptor (wave-uniform, lives in SGPRs).
 // ------------------------------------------------------------------------------------------------

@@ -101,6 +101,16 @@ int op_expand_fi(to_handle* h) {
   const int kc = var == 0 ? expand_kc<M, 0>() : expand_kc<M, 2>();
   const dim3 grid((P.B + h->G - 1) / h->G, (P.N + kc - 1) / kc);
   const int lay = h->a.bwd_lane ? 3 : !h->a.bwd_mfma ? 0 : (h->a.h_compact ? 2 : 1);
+  if constexpr (M::lane_backward && !M::lie) {  // one lane per (trajectory, knot), all columns at once (k_expand_lane)
+    if (lay == 3 && h->expand_lane) {
+      const dim3 lgrid(P.Bp / BLOCK, P.N);
+      if (var == 0) hipLaunchKernelGGL((k_expand_lane<M, FI, 0>), lgrid, dim3(BLOCK), 0, h->stream, h->a);
+      else if (var == 2) hipLaunchKernelGGL((k_expand_lane<M, FI, 2>), lgrid, dim3(BLOCK), 0, h->stream, h->a);
+      else hipLaunchKernelGGL((k_expand_lane<M, FI, 7>), lgrid, dim3(BLOCK), 0, h->stream, h->a);
+      HIPCHECK(hipGetLastError());
+      return TO_OK;
+    }
+  }
 #define TO_EXPAND_CASE(V, LY) \
   if (var == V && lay == LY) { hipLaunchKernelGGL((k_expand<M, FI, V, LY>), grid, dim3(BLOCK), 0, h->stream, h->a); HIPCHECK(hipGetLastError()); return TO_OK; }
   if constexpr (M::mfma_backward) {

@@ -675,6 +675,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     if (!std::strcmp(env, "mfma") && h->ops->mfma_backward) { a.bwd_mfma = 1; a.bwd_lane = 0; }
     if (!std::strcmp(env, "lane") && h->ops->lane_backward) { a.bwd_mfma = 0; a.bwd_lane = 1; }
   }
+  if (const char* env = std::getenv("TRAJOPT_EXPAND_LANE")) h->expand_lane = std::atoi(env) != 0;
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
   TRYB(dev_alloc(h, &a.Xs, (size_t)N * n * Bp));
