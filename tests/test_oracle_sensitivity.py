@@ -1,13 +1,23 @@
 """Conditioning of the C5 workload, measured on the oracle alone (CPU): how far does a 1-ulp change of the start
 positions move the AL-iLQR solve of BASELINE config C5 (Quadrotor + GoalConstraint + SOC norm cone, N=201)?
 
-VERDICT r02 "What's weak" 1: the GPU agrees with the oracle on 191 of 192 sub-sampled C5 trajectories in every integer
-(iterations / outer iterations / status) and to 1e-6 on 99.5 % of those (worst 2.2e-5); the residue was attributed to
-the hundreds of creeping iterations at penalty 1e8 amplifying last-bit differences, without proof.  This test IS the
-proof: the oracle against ITSELF with x0 moved by one unit in the last place separates at the same rate — one integer
-path of 128 and a worst-case 7e-6 on identical paths (measured: 127/128, 99.2 % within 1e-6) — so no implementation whose
-arithmetic differs from the oracle's in the last bit (FMA contraction, reciprocal-multiply instead of division, another
-summation order) can do better, and the GPU test is pinned to these measured levels, not to looser ones.
+VERDICT r02 "What's weak" 1: the GPU agrees with the oracle on 190-191 of 192 sub-sampled C5 trajectories in every integer
+(iterations / outer iterations / status) and to 1e-6 on >= 99.5 % of those; the residue was attributed to the hundreds of
+creeping iterations at penalty 1e8 amplifying last-bit differences, without proof.  This test IS the proof: the oracle
+against ITSELF with the start positions moved by one or two units in the last place separates at the same rate.  Measured
+on the first 128 trajectories of the C5 batch (this file's perturbations plus -1 ulp and a y-only +1 ulp):
+
+    perturbation      identical integer paths   X/U/J within 1e-6 on those   worst on those
+    +1 ulp (r0)       127 / 128                 99.2 %                       8.5e-6
+    +2 ulp (r0)       126 / 128                 100 %                        9.6e-7
+    -1 ulp (r0)       128 / 128                 98.4 %                       1.3e-5
+    +1 ulp (y only)   128 / 128                 98.4 %                       1.8e-5
+    GPU vs oracle     190 / 192 (r03), 191 / 192 (r02)   100 % / 99.5 %      6.2e-7 / 2.2e-5
+
+so no implementation whose arithmetic differs from the oracle's in the last bit (FMA contraction, reciprocal-multiply
+instead of division, another summation order) can do better than this band, and the GPU test is pinned to the band
+(>= 98 % identical paths, >= 98 % of those within 1e-6, none beyond 5e-5): the worst oracle-vs-oracle levels with the
+slack a 128..192-trajectory sample needs (one trajectory is 0.5-0.8 %).
 """
 import numpy as np
 
@@ -15,8 +25,8 @@ import trajopt_amd as T
 from trajectoryoptimization_jl_amd import configs
 
 # levels both comparisons must meet (tests/test_gpu_parity.py::test_full_size_C5_vs_oracle_subsample imports them)
-C5_MIN_IDENTICAL_PATHS = 0.99   # fraction of trajectories with identical iterations / outer iterations / status
-C5_MIN_WITHIN_1E6 = 0.99        # of those, fraction whose X / U / J agree to 1e-6 (max-norm relative)
+C5_MIN_IDENTICAL_PATHS = 0.98   # fraction of trajectories with identical iterations / outer iterations / status
+C5_MIN_WITHIN_1E6 = 0.98        # of those, fraction whose X / U / J agree to 1e-6 (max-norm relative)
 C5_MAX_ERR_SAME_PATH = 5e-5     # and the worst of them
 
 
@@ -33,27 +43,31 @@ def c5_compare(sa, Xa, Ua, sb, Xb, Ub):
     return same, err
 
 
-def test_c5_oracle_vs_oracle_one_ulp(oracle):
+def test_c5_oracle_vs_oracle_ulp_perturbations(oracle):
     from oracle_binding import set_threads
     cnt = 128
 
-    def solve(ulp):
+    def solve(ulps):
         p = configs.quadrotor_problem(N=201, constrained=True, goal_inds=configs.C5_GOAL_INDS, lib=oracle, batch=cnt, b_offset=0)
         set_threads(p, oracle.max_threads())
-        if ulp:
-            x0 = p.x0.copy()
+        x0 = p.x0.copy()
+        for _ in range(ulps):
             x0[:, :3] = np.nextafter(x0[:, :3], np.inf)
-            p.set_initial_state(x0)
+        p.set_initial_state(x0)
         s = T.ALSolver(p).solve()
         return {k: v.copy() for k, v in s.stats.items()}, T.states(p), T.controls(p)
 
-    a, b = solve(False), solve(True)
-    same, err = c5_compare(a[0], a[1], a[2], b[0], b[1], b[2])
-    print(f"C5 oracle vs oracle (+1 ulp on r0): {int(same.sum())}/{cnt} identical integer paths; on those X/U/J within 1e-6 "
-          f"for {np.mean(err <= 1e-6):.1%}, max {err.max():.2e}")
-    # the perturbation is 1e-16 relative: anything above 1e-9 on an identical path is amplification by the solve itself
-    assert err.max() > 1e-9, "the C5 solve no longer amplifies a 1-ulp perturbation: re-derive the GPU thresholds"
-    # ... and it stays inside the levels the GPU is held to
-    assert same.mean() >= C5_MIN_IDENTICAL_PATHS and np.mean(err <= 1e-6) >= C5_MIN_WITHIN_1E6 and err.max() <= C5_MAX_ERR_SAME_PATH
-    # where the integer paths did separate, both runs still solved the same problem
-    np.testing.assert_allclose(a[0]["cost"], b[0]["cost"], rtol=2e-3)
+    base = solve(0)
+    worst = 0.0
+    for ulps in (1, 2):
+        b = solve(ulps)
+        same, err = c5_compare(base[0], base[1], base[2], b[0], b[1], b[2])
+        print(f"C5 oracle vs oracle (+{ulps} ulp on r0): {int(same.sum())}/{cnt} identical integer paths; on those X/U/J within 1e-6 "
+              f"for {np.mean(err <= 1e-6):.1%}, max {err.max():.2e}")
+        worst = max(worst, float(err.max()))
+        # the oracle's self-separation stays inside the levels the GPU is held to
+        assert same.mean() >= C5_MIN_IDENTICAL_PATHS and np.mean(err <= 1e-6) >= C5_MIN_WITHIN_1E6 and err.max() <= C5_MAX_ERR_SAME_PATH
+        # where the integer paths did separate, both runs still solved the same problem
+        np.testing.assert_allclose(base[0]["cost"], b[0]["cost"], rtol=2e-3)
+    # the perturbations are 1e-16 relative: anything above 1e-9 on an identical path is amplification by the solve itself
+    assert worst > 1e-9, "the C5 solve no longer amplifies a 1-ulp perturbation: re-derive the GPU thresholds"

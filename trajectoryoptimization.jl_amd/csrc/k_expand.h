@@ -270,12 +270,72 @@ __global__ void __launch_bounds__(64) k_expand(KArgs a) {
 // produces the whole expansion of its knot — all nc = ne + m columns of [A B] from a single pass of the RK stages in
 // chunk-mode dual numbers (MDual<nc>, models.h), then the cost (+AL) columns.  The column-per-lane kernel above spends 8
 // lanes (5 useful on the Cartpole) per (trajectory, knot), each re-evaluating the VALUE part of the dynamics — 0.65 MFLOP
-// issued per Cartpole trajectory-iteration for a 0.1 MFLOP expansion — this one evaluates it once.  Writes the
-// lane layout (k_backward.h, LaneLay) as whole 512-byte rows: lane = trajectory.  grid (Bp / 64, N).
+// issued per Cartpole trajectory-iteration for a 0.1 MFLOP expansion — this one evaluates it once:
+// 1 971 instead of 8 x 1 037 lane-instructions per Cartpole knot.
+//
+// expand_lane_knot: the expansion of knot k of this lane's trajectory INTO REGISTERS, in the lane layout's own order
+// (k_backward.h, LaneLay): Mk[i*nc + j] = [A B][i][j] (not touched at the terminal knot), H[sym(i, j)] = upper triangle of
+// the cost (+AL) block, g[j] = gradient.  Same calls and the same order of the constraint terms as expand_knot's table path.
 template <class M, int FIXED_INTEG, int VAR>
-__global__ void __launch_bounds__(64) k_expand_lane(KArgs a) {
+__device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int lane, int k, const double* x, const double* u,
+                                                 double* Mk, double* H, double* g) {
   static_assert(!M::lie, "lane expansion: vector-space models only (identity error-state maps)");
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  const DevProblem& P = a.P;
+  const bool terminal = (k == P.N - 1);
+  if (!terminal) {  // every column of [A B] in one pass
+    MDual<nc> xd[n], ud[m], xn[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xd[i].v = x[i]; xd[i].d[i] = 1.0; }
+#pragma unroll
+    for (int i = 0; i < m; ++i) { ud[i].v = u[i]; ud[i].d[ne + i] = 1.0; }
+    rk_step<M, MDual<nc>, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+#pragma unroll
+    for (int i = 0; i < ne; ++i)
+#pragma unroll
+      for (int j = 0; j < nc; ++j) Mk[i * nc + j] = xn[i].d[j];
+  }
+  double z[nz];
+#pragma unroll
+  for (int i = 0; i < n; ++i) z[i] = x[i];
+#pragma unroll
+  for (int i = 0; i < m; ++i) z[n + i] = u[i];
+  const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane;
+  const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane;
+#pragma unroll
+  for (int j = 0; j < nc; ++j) {
+    double v[nz], gr[nz], y[nz];
+#pragma unroll
+    for (int i = 0; i < nz; ++i) v[i] = (i == (j < ne ? j : n + (j - ne))) ? 1.0 : 0.0;
+    cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
+    if (P.opts.cost_dt_scaling && !terminal) {
+      const double h = P.dt[k];
+#pragma unroll
+      for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
+    }
+    if constexpr ((VAR & 2) != 0) {
+      for (int ci = 0; ci < P.n_cons; ++ci) {
+        ConC& K = P.cons[ci];
+        if (k < K.k1 || k > K.k2) continue;
+        const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ne; ++i)
+      if (i <= j) H[j * (j + 1) / 2 + i] = y[i];
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+      if (ne + r <= j) H[j * (j + 1) / 2 + ne + r] = terminal ? 0.0 : y[n + r];
+    g[j] = gr[j < ne ? j : n + (j - ne)];
+  }
+}
+
+// the expansion as a kernel of its own (phase API, and the solve loop when the fused backward pass is switched off):
+// writes the lane layout as whole 512-byte rows, lane = trajectory.  grid (Bp / 64, N).
+template <class M, int FIXED_INTEG, int VAR>
+__global__ void __launch_bounds__(64) k_expand_lane(KArgs a) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m;
   using L = LaneLay<M>;
   const DevProblem& P = a.P;
   const int N = P.N;
@@ -302,62 +362,259 @@ __global__ void __launch_bounds__(64) k_expand_lane(KArgs a) {
       for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
     }
   }
-  // ---- dynamics: every column of [A B] in one pass
+  double Mk[ne * nc], H[L::NS], g[nc];
+  expand_lane_knot<M, FIXED_INTEG, VAR>(a, tile, lane, k, x, u, Mk, H, g);
+  if (!live) return;
   if (!terminal) {
-    MDual<nc> xd[n], ud[m], xn[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) { xd[i].v = x[i]; xd[i].d[i] = 1.0; }
-#pragma unroll
-    for (int i = 0; i < m; ++i) { ud[i].v = u[i]; ud[i].d[ne + i] = 1.0; }
-    rk_step<M, MDual<nc>, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
     double* Ml = a.Mc + (((size_t)tile * (size_t)(N - 1) + k) * (ne * nc)) * 64 + lane;
-    if (live) {
 #pragma unroll
-      for (int i = 0; i < ne; ++i)
-#pragma unroll
-        for (int j = 0; j < nc; ++j) EL(Ml, i * nc + j) = xn[i].d[j];
-    }
+    for (int e = 0; e < ne * nc; ++e) EL(Ml, e) = Mk[e];
   }
-  // ---- cost (+AL) gradient and Hessian columns (same calls, same order of the constraint terms as expand_knot's table path)
   double* Hl = a.Hc + (((size_t)tile * (size_t)N + k) * L::NS) * 64 + lane;
   double* gl = a.gc + (((size_t)tile * (size_t)N + k) * nc) * 64 + lane;
-  double z[nz];
-#pragma unroll
-  for (int i = 0; i < n; ++i) z[i] = x[i];
-#pragma unroll
-  for (int i = 0; i < m; ++i) z[n + i] = u[i];
-  const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane;
-  const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane;
 #pragma unroll
   for (int j = 0; j < nc; ++j) {
-    if (terminal && j >= ne) continue;  // wave-uniform: no control directions at the terminal knot
-    double v[nz], gr[nz], y[nz];
+    if (terminal && j >= ne) continue;  // no control directions at the terminal knot
 #pragma unroll
-    for (int i = 0; i < nz; ++i) v[i] = (i == (j < ne ? j : n + (j - ne))) ? 1.0 : 0.0;
-    cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
-    if (P.opts.cost_dt_scaling && !terminal) {
-      const double h = P.dt[k];
+    for (int i = 0; i <= j; ++i) EL(Hl, j * (j + 1) / 2 + i) = H[j * (j + 1) / 2 + i];
+    EL(gl, j) = g[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fused lane expansion + Riccati
+// Large batches of the small models are HBM-bound (measured at B = 32 768: 13.9 M trajectory-iterations/s whichever
+// expansion kernel, backward-pass flavour or line-search width runs — 0.85 ms per batch step for ~3 GB of traffic), and two
+// thirds of that traffic is the expansion itself: 40 doubles per Cartpole knot written by the expansion and read straight
+// back by the backward pass.  Here the lane that walks a trajectory's Riccati recursion expands each knot in its own
+// registers right before it consumes it — [A B], the cost block and the gradient never exist in memory.  What is left per
+// knot: x, u (read), the accepted step written through (5 doubles) and the gains row (5 doubles).
+// Same arithmetic, same order as k_expand_lane followed by k_backward_lane (bit-identical gains).
+template <class M, int FIXED_INTEG, int VAR>
+__global__ void __launch_bounds__(64) k_expand_backward_lane(KArgs a) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, RSK = Gains<M>::RSK;
+  using L = LaneLay<M>;
+  constexpr int NS = L::NS;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane;  // b < Bp always
+  const bool live = (b < P.B) && a.active[b] != 0;
+  if (__ballot(live) == 0) return;
+  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
+  const double* X = X_SLOT_PTR(a, b, c);
+  const double* U = U_SLOT_PTR(a, b, c);
+  double* X0 = X_SLOT_PTR(a, b, 0);
+  double* U0 = U_SLOT_PTR(a, b, 0);
+  const bool wt = M::accept_write_through && c != 0 && live;
+  double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
+  double rho = a.rho[b], drho = a.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;
+  bool failed = false;
+  double S[ne][ne], s[ne];
+  while (true) {  // one pass of the recursion; a Cholesky failure raises rho and starts over
+    {  // terminal knot: S = Qxx_N, s = qx_N
+      double x[n], u[m], Mk[1], H[NS], g[nc];
 #pragma unroll
-      for (int i = 0; i < nz; ++i) { gr[i] *= h; y[i] *= h; }
-    }
-    if constexpr ((VAR & 2) != 0) {
-      for (int ci = 0; ci < P.n_cons; ++ci) {
-        ConC& K = P.cons[ci];
-        if (k < K.k1 || k > K.k2) continue;
-        const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-        al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
+      for (int i = 0; i < n; ++i) x[i] = EL(X, (N - 1) * n + i);
+#pragma unroll
+      for (int i = 0; i < m; ++i) u[i] = 0.0;
+      if (wt) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) EL(X0, (N - 1) * n + i) = x[i];
+      }
+      expand_lane_knot<M, FIXED_INTEG, VAR>(a, tile, lane, N - 1, x, u, Mk, H, g);
+#pragma unroll
+      for (int i = 0; i < ne; ++i) {
+#pragma unroll
+        for (int j = 0; j < ne; ++j) S[i][j] = H[L::sym(i, j)];
+        s[i] = g[i];
       }
     }
-    if (live) {
-      double* Hj = Hl + (size_t)(j * (j + 1) / 2) * 64;
+    dV0 = 0.0; dV1 = 0.0;
+    bool restart = false;
+    double xn_[n], un_[m];  // knot k's state / control, fetched one knot ahead
+#pragma unroll
+    for (int i = 0; i < n; ++i) xn_[i] = EL(X, (N - 2) * n + i);
+#pragma unroll
+    for (int i = 0; i < m; ++i) un_[i] = EL(U, (N - 2) * m + i);
+    for (int k = N - 2; k >= 0; --k) {
+      double x[n], u[m];
+#pragma unroll
+      for (int i = 0; i < n; ++i) x[i] = xn_[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) u[i] = un_[i];
+      if (k > 0) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) xn_[i] = EL(X, (k - 1) * n + i);
+#pragma unroll
+        for (int i = 0; i < m; ++i) un_[i] = EL(U, (k - 1) * m + i);
+      }
+      if (wt) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
+      }
+      double Me[ne * nc], H[NS], g[nc];
+      expand_lane_knot<M, FIXED_INTEG, VAR>(a, tile, lane, k, x, u, Me, H, g);
+      double Mk[ne][nc];
 #pragma unroll
       for (int i = 0; i < ne; ++i)
-        if (i <= j) EL(Hj, i) = y[i];
+#pragma unroll
+        for (int j = 0; j < nc; ++j) Mk[i][j] = Me[i * nc + j];
+      // ---- from here on: k_backward_lane's knot, verbatim
+      double T[ne][nc];
+#pragma unroll
+      for (int i = 0; i < ne; ++i)
+#pragma unroll
+        for (int j = 0; j < nc; ++j) {
+          double t = 0.0;
+#pragma unroll
+          for (int r = 0; r < ne; ++r) t += S[i][r] * Mk[r][j];
+          T[i][j] = t;
+        }
+      double Qxx[ne][ne], Qux[m][ne], Quu[m][m], gq[nc];
+#pragma unroll
+      for (int j = 0; j < ne; ++j) {
+#pragma unroll
+        for (int i = 0; i < nc; ++i) {
+          double t = H[L::sym(i, j)];
+#pragma unroll
+          for (int r = 0; r < ne; ++r) t += Mk[r][i] * T[r][j];
+          if (i < ne) Qxx[i][j] = t; else Qux[i - ne][j] = t;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < m; ++q)
+#pragma unroll
+        for (int p = 0; p < m; ++p) {
+          double t = H[L::sym(ne + p, ne + q)];
+#pragma unroll
+          for (int r = 0; r < ne; ++r) t += Mk[r][ne + p] * T[r][ne + q];
+          Quu[p][q] = t;
+        }
+#pragma unroll
+      for (int j = 0; j < nc; ++j) {
+        double t = g[j];
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += Mk[r][j] * s[r];
+        gq[j] = t;
+      }
+      double Lc[m][m], iL[m];
+      bool pd_ok = true;
 #pragma unroll
       for (int r = 0; r < m; ++r)
-        if (ne + r <= j) EL(Hj, ne + r) = terminal ? 0.0 : y[n + r];
-      EL(gl, j) = gr[j < ne ? j : n + (j - ne)];
+#pragma unroll
+        for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
+#pragma unroll
+      for (int q = 0; q < m; ++q) {
+        double sj = Lc[q][q];
+#pragma unroll
+        for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
+        if (!(sj > 0.0) && live) pd_ok = false;
+        iL[q] = rsqrt_fast(sj);
+        Lc[q][q] = sj * iL[q];
+#pragma unroll
+        for (int i = q + 1; i < m; ++i) {
+          double t = Lc[i][q];
+#pragma unroll
+          for (int r = 0; r < q; ++r) t -= Lc[i][r] * Lc[q][r];
+          Lc[i][q] = t * iL[q];
+        }
+      }
+      if (!pd_ok) {
+        reg_increase(P.opts, rho, drho);
+        if (rho > P.opts.bp_reg_max) failed = true; else restart = true;
+        break;
+      }
+      double Kg[m][ne], dk[m];
+#pragma unroll
+      for (int cc = 0; cc <= ne; ++cc) {
+        double col[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) col[i] = (cc < ne) ? Qux[i][cc < ne ? cc : 0] : gq[ne + i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) { double t = col[i];
+#pragma unroll
+          for (int r = 0; r < i; ++r) t -= Lc[i][r] * col[r];
+          col[i] = t * iL[i]; }
+#pragma unroll
+        for (int i = m - 1; i >= 0; --i) { double t = col[i];
+#pragma unroll
+          for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
+          col[i] = t * iL[i]; }
+#pragma unroll
+        for (int i = 0; i < m; ++i) { if (cc < ne) Kg[i][cc < ne ? cc : 0] = -col[i]; else dk[i] = -col[i]; }
+      }
+      if (live) {
+        double* pKk = pK + (size_t)k * RSK;
+#pragma unroll
+        for (int r = 0; r < m; ++r) {
+#pragma unroll
+          for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
+          pKk[r * (ne + 1) + ne] = dk[r];
+        }
+      }
+      double W[m][ne], qd[m];
+#pragma unroll
+      for (int r = 0; r < m; ++r) {
+#pragma unroll
+        for (int j = 0; j < ne; ++j) {
+          double t = Qux[r][j];
+#pragma unroll
+          for (int q = 0; q < m; ++q) t += Quu[r][q] * Kg[q][j];
+          W[r][j] = t;
+        }
+        double t2 = gq[ne + r];
+#pragma unroll
+        for (int q = 0; q < m; ++q) t2 += Quu[r][q] * dk[q];
+        qd[r] = t2;
+      }
+      double Sn[ne][ne], sn[ne];
+#pragma unroll
+      for (int j = 0; j < ne; ++j) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) {
+          double t = Qxx[i][j];
+#pragma unroll
+          for (int r = 0; r < m; ++r) t += Kg[r][i] * W[r][j];
+#pragma unroll
+          for (int r = 0; r < m; ++r) t += Qux[r][i] * Kg[r][j];
+          Sn[i][j] = t;
+        }
+        double t = gq[j];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Kg[r][j] * qd[r];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Qux[r][j] * dk[r];
+        sn[j] = t;
+      }
+      double dv1 = 0.0, dv2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < m; ++r) {
+        dv1 += dk[r] * gq[ne + r];
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
+        dv2 += dk[r] * t;
+      }
+      dV0 += dv1;
+      dV1 += 0.5 * dv2;
+#pragma unroll
+      for (int i = 0; i < ne; ++i) {
+#pragma unroll
+        for (int j = 0; j < ne; ++j) S[i][j] = 0.5 * (Sn[i][j] + Sn[j][i]);
+        s[i] = sn[i];
+      }
     }
+    if (!restart) break;
+  }
+  if (!failed) reg_decrease(P.opts, rho, drho);
+  if (live) {
+    a.rho[b] = rho;
+    a.drho[b] = drho;
+    a.dV[b] = dV0;
+    a.dV[(size_t)P.Bp + b] = dV1;
+    a.bpfail[b] = failed ? 1 : 0;
   }
 }
 

@@ -159,6 +159,29 @@ int op_backward(to_handle* h) {
   return fail(TO_ERR_UNSUPPORTED, "backward-pass variant not compiled for this model");
 }
 
+// large batches of the small models: expansion fused into the one-lane-per-trajectory backward pass (k_expand.h)
+template <class M, int FI>
+int op_expand_backward_fi(to_handle* h) {
+  if constexpr (M::lane_backward && !M::lie) {
+    const DevProblem& P = h->a.P;
+    const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
+    const dim3 grid(P.Bp / BLOCK);
+    if (var == 0) hipLaunchKernelGGL((k_expand_backward_lane<M, FI, 0>), grid, dim3(BLOCK), 0, h->stream, h->a);
+    else if (var == 2) hipLaunchKernelGGL((k_expand_backward_lane<M, FI, 2>), grid, dim3(BLOCK), 0, h->stream, h->a);
+    else hipLaunchKernelGGL((k_expand_backward_lane<M, FI, 7>), grid, dim3(BLOCK), 0, h->stream, h->a);
+    HIPCHECK(hipGetLastError());
+    return TO_OK;
+  }
+  return fail(TO_ERR_UNSUPPORTED, "fused lane expansion + backward pass not compiled for this model");
+}
+template <class M>
+int op_expand_backward(to_handle* h) {
+  if constexpr (M::pin_rk4) {
+    if (h->a.P.integrator == INTEG_RK4) return op_expand_backward_fi<M, INTEG_RK4>(h);
+  }
+  return op_expand_backward_fi<M, -1>(h);
+}
+
 // forward pass (line search + state machine) of kernel variant MODE: grid = one wave per TW = 64 / CW trajectories
 template <class M, int MODE>
 int op_forward(to_handle* h) {

@@ -7,6 +7,7 @@ static void fill_one(ModelOps& o) {
   fill_misc<M>(o);
   o.expand = op_expand<M>;
   o.backward = op_backward<M>;
+  if constexpr (M::lane_backward && !M::lie) o.expand_backward = op_expand_backward<M>;
 }
 void fill_ops_small(ModelOps* t) {
   fill_one<DoubleIntegratorModel<1>>(t[0]);
