@@ -29,6 +29,14 @@ struct KArgs {
   double* x0;     // L = n
   int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): copied onto slot 0 by k_accept, or
                   //      written through by the next k_expand (M::accept_write_through)
+  int* accp;      // [Bp] where that candidate sits: forward wave * 64 + hardware lane (slot_ptr)
+  // Active-list compaction (lane path of the small models, large batches): the forward pass of batch step s appends every
+  // trajectory that goes on to alist[(s+1)&1]; the kernels of step s+1 take their trajectories from that list, so the waves
+  // stay full while the batch drains (a 300-step Cartpole solve averages 36 % active trajectories: tile-granular skipping
+  // left most lanes of most waves idle).  Which lane processes which trajectory changes nothing in its arithmetic.
+  int compact;    // 1: on
+  int* alist;     // [2][Bp]
+  int* acount;    // [2]
   double *Mc, *Hc, *gc;               // column layout (see "column layout" below): [Ā B̄], Q-function cost blocks, gradient
   double* Kt;                         // gains, trajectory-major rows: Kt[(b*(N-1) + k)*RSK + r*(ne+1) + i] = K_k[r][i], i = ne: d_k[r]
   double *Mt, *Ht, *gt;               // tangent-matrix layout of the expansion for the MFMA backward pass (k_backward.h)
@@ -59,15 +67,17 @@ template <class M> struct Gains { static constexpr int RSK = M::m * (M::ne + 1);
 #define TILE_PTR(base, L) ((base) + ((size_t)tile * (size_t)(L)) * 64 + lane)
 #define EL(p, e) (p)[(size_t)(e) * 64]
 #define TILE_LANE() const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane
-// pointer to element 0 of trajectory b in slot sl of a trajectory array with L elements (sl = 0: nominal, sl = q+1: line-search
-// candidate q); element e is p[e*64] in both layouts
-__device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, int TW, int b, int sl, int L) {
+// pointer to element 0 of trajectory b in slot sl of a trajectory array with L elements (sl = 0: nominal, otherwise the line-search
+// candidate the last forward pass ACCEPTED for b); element e is p[e*64] in both layouts.  Where the accepted candidate sits —
+// forward wave w, hardware lane l — is recorded by the forward pass itself as accp[b] = w*64 + l, so that readers need not
+// know the wave shape (CW x TW) or, with active-list compaction, which wave happened to process the trajectory.
+__device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, const int* accp, int b, int sl, int L) {
   if (sl == 0) return nominal + ((size_t)(b >> 6) * (size_t)L) * 64 + (b & 63);
-  const int w = b / TW;
-  return cand + ((size_t)w * (size_t)L) * 64 + (sl - 1) * TW + (b - w * TW);
+  const int pos = accp[b];
+  return cand + ((size_t)(pos >> 6) * (size_t)L) * 64 + (pos & 63);
 }
-#define X_SLOT_PTR(a, b, sl) slot_ptr((a).Xs, (a).Xc, (a).TW, b, sl, (a).P.N * (a).P.n)
-#define U_SLOT_PTR(a, b, sl) slot_ptr((a).Us, (a).Uc, (a).TW, b, sl, ((a).P.N - 1) * (a).P.m)
+#define X_SLOT_PTR(a, b, sl) slot_ptr((a).Xs, (a).Xc, (a).accp, b, sl, (a).P.N * (a).P.n)
+#define U_SLOT_PTR(a, b, sl) slot_ptr((a).Us, (a).Uc, (a).accp, b, sl, ((a).P.N - 1) * (a).P.m)
 
 // objective (+AL) value of one knot.  u must be zeros at the terminal knot (the reference evaluates the
 // terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).

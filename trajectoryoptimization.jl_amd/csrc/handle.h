@@ -47,6 +47,7 @@ struct to_handle_s {
   int cw_base = 1, tw_base = 64;  // forward-wave shape: base, and the deep one (0: none) used once the active trajectories fit
   int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
+  int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
   int expand_lane = 1;    // lane layout: expansion by k_expand_lane (one lane per (trajectory, knot)); 0 = column-per-lane kernel (A/B knob TRAJOPT_EXPAND_LANE)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   // device copies of the descriptor tables

@@ -195,8 +195,11 @@ __host__ __device__ constexpr int expand_kc() {
 // A wave walks M::expand_knots consecutive knots and fetches the next knot's state/control while it works on the
 // current one: with one wave per SIMD (Quadrotor) nothing else hides the load round trip, which was half of the wave's
 // life (rocprof: SQ_WAIT_ANY 49 % of SQ_WAVE_CYCLES, 60 % with AL terms).  x_{k+1} is shared between neighbours.
+#ifndef TO_EXPAND_WAVES
+#define TO_EXPAND_WAVES 1  // minimum waves per SIMD k_expand is compiled for (register cap 512 / waves)
+#endif
 template <class M, int FIXED_INTEG, int VAR, int LAY>
-__global__ void __launch_bounds__(64) k_expand(KArgs a) {
+__global__ void __launch_bounds__(64, TO_EXPAND_WAVES) k_expand(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, KC = expand_kc<M, VAR>();
   constexpr int R = Coop<M>::R, G = Coop<M>::G;
   const int gtile = blockIdx.x, lane = threadIdx.x;
@@ -396,10 +399,23 @@ __global__ void __launch_bounds__(64) k_expand_backward_lane(KArgs a) {
   constexpr int NS = L::NS;
   const DevProblem& P = a.P;
   const int N = P.N;
-  const int tile = blockIdx.x, lane = threadIdx.x, b = tile * 64 + lane;  // b < Bp always
-  const bool live = (b < P.B) && a.active[b] != 0;
+  // this lane's trajectory: lane of the tile, or — with active-list compaction — entry blockIdx.x*64 + lane of this step's list
+  int b, inrange;
+  if (a.compact) {
+    const int cnt = a.acount[a.step & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.acount[(a.step + 1) & 1] = 0;  // the list this step's forward pass fills starts empty
+    if ((int)blockIdx.x * 64 >= cnt) return;  // wave-uniform
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    inrange = li < cnt;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? li : cnt - 1)];
+  } else {
+    b = blockIdx.x * 64 + threadIdx.x;  // b < Bp always
+    inrange = b < P.B;
+  }
+  const int tile = b >> 6, lane = b & 63;
+  const bool live = inrange && a.active[b] != 0;
   if (__ballot(live) == 0) return;
-  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
+  const int c = (M::accept_write_through && inrange) ? a.acc[b] : 0;
   const double* X = X_SLOT_PTR(a, b, c);
   const double* U = U_SLOT_PTR(a, b, c);
   double* X0 = X_SLOT_PTR(a, b, 0);

@@ -238,12 +238,22 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   const int CW = a.CW, TW = a.TW;
   const int q = hw / TW, t = hw - q * TW;      // lanes with q >= CW (64 is not a multiple of TW) ride along without a candidate
   const int b0 = blockIdx.x * TW;
-  const int b = (b0 + t) < P.Bp ? b0 + t : P.Bp - 1;  // clamped: the last wave may reach past the batch
+  // trajectory of this lane: position b0 + t of the batch, or — with active-list compaction — of this step's list
+  int b, inrange;
+  if (a.compact) {
+    const int cnt = a.acount[a.step & 1];
+    if (b0 >= cnt) return;  // wave-uniform
+    inrange = (b0 + t) < cnt;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? b0 + t : cnt - 1)];
+  } else {
+    inrange = (b0 + t) < P.B;
+    b = (b0 + t) < P.Bp ? b0 + t : P.Bp - 1;  // clamped: the last wave may reach past the batch
+  }
   const int tile = b >> 6, lane = b & 63;
   // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
   // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
   // predicated.  The wave leaves only when no lane needs anything.
-  const bool act = (b0 + t) < P.B && a.active[b] != 0;
+  const bool act = inrange && a.active[b] != 0;
   if (__ballot(act) == 0) return;
   const bool bpfail = act && a.bpfail[b] != 0;
   const int total = o.iterations_linesearch;
@@ -279,57 +289,82 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
     if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
     alpha *= fCW;
   }
-  if (q != 0 || !act) return;  // one lane per trajectory finishes the iteration
-  double rho = a.rho[b], drho = a.drho[b];
-  if (!bpfail) {
-    if (zero_step) grad = nominal_gradient<M>(a, tile, lane, b);
-    else if (accepted < 0) {  // line search failed: gradient metric on the unchanged nominal controls, regularise harder
-      grad = nominal_gradient<M>(a, tile, lane, b);
-      reg_increase(o, rho, drho);
-      rho += o.bp_reg_fp;
+  // one lane per trajectory finishes the iteration; `settle`: the trajectory leaves the plain next-iteration path (it is done, or
+  // its inner solve ended and the AL outer update takes over) while its accepted step still only exists as a candidate
+  bool settle = false;
+  if (q == 0 && act) {
+    double rho = a.rho[b], drho = a.drho[b];
+    if (!bpfail) {
+      if (zero_step) grad = nominal_gradient<M>(a, tile, lane, b);
+      else if (accepted < 0) {  // line search failed: gradient metric on the unchanged nominal controls, regularise harder
+        grad = nominal_gradient<M>(a, tile, lane, b);
+        reg_increase(o, rho, drho);
+        rho += o.bp_reg_fp;
+      }
     }
-  }
-  a.ls_index[b] = accepted;
-  a.acc[b] = acc;
-  if (!a.control) {  // phase API: report and leave the state machine alone
-    a.Jout[b] = Jnew;
-    a.rho[b] = rho; a.drho[b] = drho;
-    if (accepted >= 0) a.J[b] = Jnew;
-    return;
-  }
-  // ---------------- solver state machine ----------------
-  int st = TO_UNSOLVED;
-  bool inner_done = false;
-  const double cost_tol = a.al_mode ? o.cost_tolerance_intermediate : o.cost_tolerance;
-  if (bpfail) { st = TO_REGULARIZATION_MAX; inner_done = true; }
-  else {
-    const bool ls_failed = accepted < 0;
-    const double dJ = Jprev - Jnew;
-    int dz = a.dJzero[b];
-    dz = (ls_failed || zero_step) ? dz + 1 : 0;  // a zero step makes no progress either
-    a.dJzero[b] = dz;
-    a.dJ[b] = dJ; a.grad[b] = grad; a.J[b] = Jnew;
-    const int its = a.iterations[b] + 1, iti = a.it_inner[b] + 1;
-    a.iterations[b] = its; a.it_inner[b] = iti;
-    if (rho > o.bp_reg_max) { st = TO_REGULARIZATION_MAX; inner_done = true; }
-    else if (dJ >= 0.0 && dJ < cost_tol && grad < o.gradient_tolerance && !ls_failed) { st = TO_SOLVE_SUCCEEDED; inner_done = true; }
-    else if (iti >= a.budget[b]) { st = TO_MAX_ITERATIONS; inner_done = true; }
-    else if (dz > o.dJ_counter_limit) { st = TO_NO_PROGRESS; inner_done = true; }
-    else if (!(Jnew <= o.max_cost_value)) { st = TO_MAXIMUM_COST; inner_done = true; }
-  }
-  bool still_active = true;
-  if (inner_done) {
-    if (!a.al_mode) { a.status[b] = st; still_active = false; }
-    else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels
-      a.ost[b] = st; a.oflag[b] = 1;
-      a.olist[(size_t)(a.step & 1) * P.Bp + atomicAdd(&a.ocount[a.step & 1], 1)] = b;  // order is irrelevant: the outer update is per trajectory
+    a.ls_index[b] = accepted;
+    a.acc[b] = acc;
+    if (acc) a.accp[b] = blockIdx.x * 64 + (acc - 1) * TW + t;  // wave and hardware lane that hold the accepted candidate (slot_ptr)
+    if (!a.control) {  // phase API: report and leave the state machine alone
+      a.Jout[b] = Jnew;
       a.rho[b] = rho; a.drho[b] = drho;
-      return;
+      if (accepted >= 0) a.J[b] = Jnew;
+    } else {
+      // ---------------- solver state machine ----------------
+      int st = TO_UNSOLVED;
+      bool inner_done = false;
+      const double cost_tol = a.al_mode ? o.cost_tolerance_intermediate : o.cost_tolerance;
+      if (bpfail) { st = TO_REGULARIZATION_MAX; inner_done = true; }
+      else {
+        const bool ls_failed = accepted < 0;
+        const double dJ = Jprev - Jnew;
+        int dz = a.dJzero[b];
+        dz = (ls_failed || zero_step) ? dz + 1 : 0;  // a zero step makes no progress either
+        a.dJzero[b] = dz;
+        a.dJ[b] = dJ; a.grad[b] = grad; a.J[b] = Jnew;
+        const int its = a.iterations[b] + 1, iti = a.it_inner[b] + 1;
+        a.iterations[b] = its; a.it_inner[b] = iti;
+        if (rho > o.bp_reg_max) { st = TO_REGULARIZATION_MAX; inner_done = true; }
+        else if (dJ >= 0.0 && dJ < cost_tol && grad < o.gradient_tolerance && !ls_failed) { st = TO_SOLVE_SUCCEEDED; inner_done = true; }
+        else if (iti >= a.budget[b]) { st = TO_MAX_ITERATIONS; inner_done = true; }
+        else if (dz > o.dJ_counter_limit) { st = TO_NO_PROGRESS; inner_done = true; }
+        else if (!(Jnew <= o.max_cost_value)) { st = TO_MAXIMUM_COST; inner_done = true; }
+      }
+      a.rho[b] = rho; a.drho[b] = drho;
+      if (!inner_done) {
+        atomicAdd(&a.counter[a.step], 1);
+        if (a.compact) a.alist[(size_t)((a.step + 1) & 1) * P.Bp + atomicAdd(&a.acount[(a.step + 1) & 1], 1)] = b;  // next step's list
+      } else {
+        settle = a.compact && acc != 0;
+        if (!a.al_mode) { a.status[b] = st; a.active[b] = 0; }
+        else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels
+          a.ost[b] = st; a.oflag[b] = 1;
+          a.olist[(size_t)(a.step & 1) * P.Bp + atomicAdd(&a.ocount[a.step & 1], 1)] = b;  // order is irrelevant: the outer update is per trajectory
+        }
+      }
     }
   }
-  a.rho[b] = rho; a.drho[b] = drho;
-  if (!still_active) a.active[b] = 0;
-  else atomicAdd(&a.counter[a.step], 1);
+  // Active-list compaction: the lanes of this wave hold OTHER trajectories in the next step, so an accepted step that is not
+  // going to be written through by the next expansion is settled now — the whole wave copies the candidate (its own block,
+  // lane sl) onto the trajectory's nominal slot, 64 elements per pass, and the slot index is cleared.
+  if (a.compact) {
+    unsigned long long todo = __ballot(settle);
+    const int Lx = P.N * M::n, Lu = (P.N - 1) * M::m;
+    if (todo) __threadfence();  // the candidate was stored by other lanes of this wave: make those stores visible to the loads below
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int bs = __shfl(b, src), sl = __shfl(acc, src);
+      const int hl = (sl - 1) * TW + (src - (src / TW) * TW);  // hardware lane of the accepted candidate: q*TW + t with t = src % TW (src has q = 0)
+      const double* cx = a.Xc + ((size_t)blockIdx.x * (size_t)Lx) * 64 + hl;
+      const double* cu = a.Uc + ((size_t)blockIdx.x * (size_t)Lu) * 64 + hl;
+      double* nx = a.Xs + ((size_t)(bs >> 6) * (size_t)Lx) * 64 + (bs & 63);
+      double* nu = a.Us + ((size_t)(bs >> 6) * (size_t)Lu) * 64 + (bs & 63);
+      for (int e = hw; e < Lx; e += 64) EL(nx, e) = EL(cx, e);
+      for (int e = hw; e < Lu; e += 64) EL(nu, e) = EL(cu, e);
+      if (hw == src) a.acc[bs] = 0;
+    }
+  }
 }
 
 }  // namespace to

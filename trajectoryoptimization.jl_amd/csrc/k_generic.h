@@ -43,6 +43,11 @@ __global__ void k_solve_init(KArgs a, int reset_duals) {
   if (b >= P.Bp) return;
   if (b < 2) a.ocount[b] = 0;  // both parities of the outer-update list (common.h)
   const bool live = b < P.B;
+  if (a.compact) {  // step 0 works on the whole batch
+    if (live) a.alist[b] = b;
+    const int tot0 = a.al_mode ? P.opts.iterations_total : P.opts.iterations;
+    if (b == 0) { a.acount[0] = (tot0 > 0 && P.opts.iterations > 0) ? P.B : 0; a.acount[1] = 0; }
+  }
   a.rho[b] = P.opts.bp_reg_initial; a.drho[b] = 0.0;
   a.dJzero[b] = 0; a.it_inner[b] = 0; a.iterations[b] = 0; a.outer[b] = 0;
   a.status[b] = TO_UNSOLVED; a.ls_index[b] = -1; a.bpfail[b] = 0; a.acc[b] = 0; a.oflag[b] = 0;

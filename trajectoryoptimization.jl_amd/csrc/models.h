@@ -217,7 +217,10 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr int n = 13, m = 4, ne = 12;
   static constexpr bool lie = true;
   static constexpr bool pin_rk4 = false;  // compile-time RK4 costs registers here: measured slower than the runtime switch
-  static constexpr int expand_knots = 4;               // knots one expansion wave walks (software-pipelined loads)
+#ifndef TO_QUAD_EXPAND_KNOTS
+#define TO_QUAD_EXPAND_KNOTS 4
+#endif
+  static constexpr int expand_knots = TO_QUAD_EXPAND_KNOTS;  // knots one expansion wave walks (software-pipelined loads)
   static constexpr bool accept_write_through = false;  // accepted steps are copied onto slot 0 by k_accept after every forward pass
   static constexpr bool lds_gains = true;  // forward pass: the 52-double gains row of a knot comes through LDS (DMA), not prefetch VGPRs
   static constexpr int ls_first_round = 16;  // accepted step sizes sit at 2^-5 .. 2^-12 late in these solves (tools/ls_hist.py): a deep first round

@@ -358,6 +358,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   const int rc = solve_impl(h, st, al_mode);
   h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
+  h->a.compact = 0;  // ... nor take its trajectories from a solve's active list
   h->a.CW = h->cw_base; h->a.TW = h->tw_base;
   return rc;
 }
@@ -367,6 +368,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   const DevProblem& P = a.P;
   a.al_mode = al_mode;
   a.control = 1;
+  a.compact = h->compact;
   const int max_steps = (al_mode ? P.opts.iterations_total : P.opts.iterations) + 1;
   if (h->counter_len < max_steps) {
     int* c = nullptr;
@@ -635,6 +637,10 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // depth is 20: further in-kernel rounds cover the rest).
   {
     int cw = std::max(1, std::min(h->ops->ls_first_round, 1024 / (P.Bp / BLOCK)));  // one forward wave per SIMD (measured: C5 0.71 M it/s with 8, 0.68 M with 16)
+    // ... but never fewer than two step sizes per round for the models that search narrowly anyway (the small ones): at
+    // B = 131 072 one candidate per round ran 29.6 M trajectory-iterations/s, two 32.5 M (a second full pass costs more than
+    // the second lane)
+    if (h->ops->ls_first_round <= 4) cw = std::max(cw, std::min(2, h->ops->ls_first_round));
     if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
     int lg = 0;
     while ((2 << lg) <= cw) ++lg;
@@ -669,7 +675,9 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     int cus = 256;
     HIPB(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const long coop_waves = ((long)B + h->G - 1) / h->G;
-    a.bwd_lane = (h->ops->lane_backward && coop_waves >= 3L * 4 * cus) ? 1 : 0;
+    // (with the expansion fused into the lane kernel the crossover moved down: measured 14.7 vs 13.9 M it/s at B = 16 384,
+    // 7.9 vs 9.9 M at B = 8 192)
+    a.bwd_lane = (h->ops->lane_backward && coop_waves >= (h->ops->expand_backward ? 2L : 3L) * 4 * cus) ? 1 : 0;
   }
   if (const char* env = std::getenv("TRAJOPT_BACKWARD")) {
     if (!std::strcmp(env, "coop") && h->ops->coop_backward) { a.bwd_mfma = 0; a.bwd_lane = 0; }
@@ -692,6 +700,10 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   }
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
+  TRYB(dev_alloc(h, &a.accp, Bp));
+  TRYB(dev_alloc(h, &a.alist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.acount, 2));
+  h->compact = h->fused_lane;  // active-list compaction goes with the fused lane path (large batches of the small models);
+  if (const char* env = std::getenv("TRAJOPT_COMPACT")) if (!std::atoi(env)) h->compact = 0;  // armed only inside a solve
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
   TRYB(dev_alloc(h, &a.olist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.ocount, 2));
   TRYB(dev_alloc(h, &a.knotbuf, (size_t)N * Bp));
