@@ -90,8 +90,15 @@ typedef enum {
   TO_MODEL_DOUBLE_INTEGRATOR = 0, /* examples/quickstart.jl:11-23; n=2D, m=D; params[0]=mass, params[1]=D (1,2,3) */
   TO_MODEL_CARTPOLE = 1,          /* docs/src/model.md:20-51; params = mc, mp, l, g                               */
   TO_MODEL_QUADROTOR = 2          /* examples/Quadrotor.ipynb cells 4,8; params = mass, Jx,Jy,Jz, gx,gy,gz,
-                                     motor_dist, kf, km                                                           */
+                                     motor_dist, kf, km, rotation (to_rotation, params[10]; 0 = the notebook's
+                                     Quadrotor{QuatRotation}: n = 13)                                            */
 } to_model_id;
+
+/* Attitude representation R of a RigidBody{R} state (examples/Quadrotor.ipynb cell 5: "typically one of QuatRotation{T},
+ * MRP{T}, or RodriguesParam{T}"; src/lie_costs.jl:1-3).  QUATERNION: x = [r, q(w,x,y,z), v, w], n = 13.  MRP / RODRIGUES:
+ * x = [r, p(3), v, w], n = 12.  The error state has 12 entries in every case (RD.state_diff with the Cayley map: the
+ * Rodrigues vector of the relative rotation). */
+typedef enum { TO_ROT_QUATERNION = 0, TO_ROT_MRP = 1, TO_ROT_RODRIGUES = 2 } to_rotation;
 
 typedef enum { TO_RK4 = 0, TO_RK3 = 1, TO_EULER = 2 } to_integrator; /* default RK4: src/problem.jl:120 */
 
@@ -102,8 +109,9 @@ typedef enum {
   TO_COST_DIAGONAL_QUAT = 2, /* DiagonalQuatCost  src/lie_costs.jl:34-55: diagonal + w*min(1 +/- q_ref'q) */
   TO_COST_ERROR_QUADRATIC = 3 /* ErrorQuadratic  src/lie_costs.jl:178-241 (rigid bodies, n = 13): 0.5 dx'Q dx + c + 0.5 u'Ru + r'u with
                                  dx = state_diff(x, x_ref, CayleyMap) in R^12; Q[0..12) = error-state diagonal, R/r diagonal/linear
-                                 control terms, q[0..13) = x_ref, q_ind = quaternion indices (4,5,6,7).  Gradient and Hessian are
-                                 exact (ForwardDiff in the reference). */
+                                 control terms, q[0..n) = x_ref, q_ind = quaternion indices (4,5,6,7).  Gradient and Hessian are
+                                 exact (ForwardDiff in the reference).  w = attitude representation of the model's state
+                                 (to_rotation as a double): ErrorQuadratic{QuatRotation} (n = 13), {MRP}, {RodriguesParam} (n = 12). */
 } to_cost_kind;
 
 typedef struct {
@@ -115,7 +123,7 @@ typedef struct {
   double q[TO_MAX_N];
   double r[TO_MAX_M];
   double c;
-  double w;                         /* DIAGONAL_QUAT */
+  double w;                         /* DIAGONAL_QUAT: weight of the geodesic term; ERROR_QUADRATIC: to_rotation of the state */
   double q_ref[4];                  /* DIAGONAL_QUAT: reference quaternion (w,x,y,z) */
   int32_t q_ind[4];                 /* DIAGONAL_QUAT: 1-based state indices of the quaternion (default 4:7) */
 } to_cost_desc;

@@ -31,6 +31,9 @@ struct Model {
   int id = 0;
   int n = 0, m = 0, ne = 0; /* ne = error-state dim (RD.errstate_dim): n, or 12 for the quadrotor */
   double p[16];
+  /* attitude representation of a rigid-body state (to_rotation; -1: vector-space model) */
+  int rot() const { return id == TO_MODEL_QUADROTOR ? (int)p[10] : -1; }
+  bool lie() const { return id == TO_MODEL_QUADROTOR; }
 };
 
 inline int model_dims(int id, const double* params, int* n, int* m, int* ne) {
@@ -41,9 +44,87 @@ inline int model_dims(int id, const double* params, int* n, int* m, int* ne) {
       *n = 2 * D; *m = D; *ne = 2 * D; return 0;
     }
     case TO_MODEL_CARTPOLE: *n = 4; *m = 1; *ne = 4; return 0;
-    case TO_MODEL_QUADROTOR: *n = 13; *m = 4; *ne = 12; return 0;
+    case TO_MODEL_QUADROTOR: { /* params[10] = to_rotation: RigidBody{QuatRotation} n = 13, {MRP} / {RodriguesParam} n = 12 */
+      int rot = (int)params[10];
+      if (rot < TO_ROT_QUATERNION || rot > TO_ROT_RODRIGUES) return -1;
+      *n = rot == TO_ROT_QUATERNION ? 13 : 12; *m = 4; *ne = 12; return 0;
+    }
   }
   return -1;
+}
+
+/* ---- three-parameter attitudes (RigidBody{MRP}, RigidBody{RodriguesParam}; src/lie_costs.jl:1-3) -------------------------
+ * Rotations.kinematics:  MRP  pdot = 1/4 [(1-|p|^2) w + 2 p x w + 2 p (p.w)]     RodriguesParam  gdot = 1/2 [w + g x w + g (g.w)]
+ * D(p) = d(p (+) phi)/dphi at 0 with the Cayley error map (so pdot = D(p) w / 2):
+ *   MRP  1/2 [(1-|p|^2) I + 2[p]x + 2pp']        RodriguesParam  I + [g]x + gg'                      (row-major 3x3) */
+inline void att_differential(int rot, const double* p, double* D) {
+  const double a = p[0], b = p[1], c = p[2];
+  const double h = rot == TO_ROT_MRP ? 0.5 * (1.0 - (a * a + b * b + c * c)) : 1.0;
+  D[0] = h + a * a;  D[1] = -c + a * b; D[2] = b + a * c;
+  D[3] = c + b * a;  D[4] = h + b * b;  D[5] = -a + b * c;
+  D[6] = -b + c * a; D[7] = a + c * b;  D[8] = h + c * c;
+}
+/* Hessian of phi -> b.(p (+) phi) at 0 (Rotations ∇²differential): the second-order term of the error-state cost Hessian.
+ *   MRP  1/2 [a p' + p a'] - (b.p) [(1+|p|^2)/2 I - 2 pp'],  a = (1-|p|^2) b + 2 b x p
+ *   RP   c g' + g c' + 2 (b.g) g g',                         c = b + b x g */
+inline void att_differential2(int rot, const double* p, const double* b, double* H) {
+  const double bp = b[0] * p[0] + b[1] * p[1] + b[2] * p[2];
+  const double cx[3] = {b[1] * p[2] - b[2] * p[1], b[2] * p[0] - b[0] * p[2], b[0] * p[1] - b[1] * p[0]};
+  if (rot == TO_ROT_MRP) {
+    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    double a[3];
+    for (int i = 0; i < 3; ++i) a[i] = (1.0 - n2) * b[i] + 2.0 * cx[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+      H[3 * i + j] = 0.5 * (a[i] * p[j] + p[i] * a[j]) - bp * ((i == j ? 0.5 * (1.0 + n2) : 0.0) - 2.0 * p[i] * p[j]);
+  } else {
+    double c[3];
+    for (int i = 0; i < 3; ++i) c[i] = b[i] + cx[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[3 * i + j] = c[i] * p[j] + p[i] * c[j] + 2.0 * bp * p[i] * p[j];
+  }
+}
+/* unnormalised quaternion of a three-parameter attitude: MRP [1-|p|^2, 2p] (norm 1+|p|^2), RodriguesParam [1, g] */
+inline void att_quat(int rot, const double* p, double* q) {
+  if (rot == TO_ROT_MRP) { q[0] = 1.0 - (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); q[1] = 2 * p[0]; q[2] = 2 * p[1]; q[3] = 2 * p[2]; }
+  else { q[0] = 1.0; q[1] = p[0]; q[2] = p[1]; q[3] = p[2]; }
+}
+/* a(p) = R(p) e3 (third column of the rotation matrix) and its Jacobian da/dp (row-major 3x3), in closed form:
+ *   MRP  a = [c0 e3 + 8 p3 p + 4 s (p x e3)] / (1+n)^2,  s = 1-n, c0 = s^2 - 4n, n = |p|^2
+ *   RP   a = [(1-n) e3 + 2 g3 g + 2 (g x e3)] / (1+n) */
+inline void att_thrust_axis(int rot, const double* p, double* a, double* da) {
+  const double n = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  const double pxe[3] = {p[1], -p[0], 0.0}; /* p x e3 */
+  double N[3], dN[9], W, dW[3];
+  if (rot == TO_ROT_MRP) {
+    const double s = 1.0 - n, c0 = s * s - 4.0 * n;
+    for (int i = 0; i < 3; ++i) N[i] = (i == 2 ? c0 : 0.0) + 8.0 * p[2] * p[i] + 4.0 * s * pxe[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      double d = 0.0;
+      if (i == 2) d += -4.0 * p[j] * (3.0 - n);                 /* d c0 / d p_j */
+      d += 8.0 * ((j == 2 ? p[i] : 0.0) + (i == j ? p[2] : 0.0)); /* d (8 p3 p_i) */
+      d += 4.0 * (-2.0 * p[j]) * pxe[i];                         /* d (4 s) (p x e3)_i */
+      if (i == 0 && j == 1) d += 4.0 * s;
+      if (i == 1 && j == 0) d += -4.0 * s;
+      dN[3 * i + j] = d;
+    }
+    W = 1.0 / ((1.0 + n) * (1.0 + n));
+    for (int j = 0; j < 3; ++j) dW[j] = -4.0 * W * p[j] / (1.0 + n);
+  } else {
+    for (int i = 0; i < 3; ++i) N[i] = (i == 2 ? 1.0 - n : 0.0) + 2.0 * p[2] * p[i] + 2.0 * pxe[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      double d = 0.0;
+      if (i == 2) d += -2.0 * p[j];
+      d += 2.0 * ((j == 2 ? p[i] : 0.0) + (i == j ? p[2] : 0.0));
+      if (i == 0 && j == 1) d += 2.0;
+      if (i == 1 && j == 0) d += -2.0;
+      dN[3 * i + j] = d;
+    }
+    W = 1.0 / (1.0 + n);
+    for (int j = 0; j < 3; ++j) dW[j] = -2.0 * W * W * p[j];
+  }
+  for (int i = 0; i < 3; ++i) {
+    a[i] = N[i] * W;
+    if (da) for (int j = 0; j < 3; ++j) da[3 * i + j] = dN[3 * i + j] * W + N[i] * dW[j];
+  }
 }
 
 /* ---------------------------------------------------------------- continuous dynamics xdot = f(x,u) */
@@ -71,6 +152,27 @@ inline void dynamics(const Model& M, const double* x, const double* u, double* x
       return;
     }
     case TO_MODEL_QUADROTOR: { /* RigidBody dynamics, world-frame velocity (bodyframe=false) */
+      if (M.rot() != TO_ROT_QUATERNION) { /* x = [r, p, v, w]: three-parameter attitude */
+        const int rot = M.rot();
+        const double mass = M.p[0], J1 = M.p[1], J2 = M.p[2], J3 = M.p[3], L = M.p[7], kf = M.p[8], km = M.p[9];
+        const double* p = x + 3; const double* w = x + 9;
+        double F[4], Fz = 0.0;
+        for (int i = 0; i < 4; ++i) { F[i] = std::fmax(0.0, kf * u[i]); Fz += F[i]; }
+        const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], pw = p[0] * w[0] + p[1] * w[1] + p[2] * w[2];
+        const double c[3] = {p[1] * w[2] - p[2] * w[1], p[2] * w[0] - p[0] * w[2], p[0] * w[1] - p[1] * w[0]};
+        for (int i = 0; i < 3; ++i) {
+          xd[i] = x[6 + i];
+          xd[3 + i] = rot == TO_ROT_MRP ? 0.25 * ((1.0 - n2) * w[i] + 2.0 * c[i] + 2.0 * p[i] * pw) : 0.5 * (w[i] + c[i] + p[i] * pw);
+        }
+        double a[3]; att_thrust_axis(rot, p, a, nullptr);
+        for (int i = 0; i < 3; ++i) xd[6 + i] = (mass * M.p[4 + i] + a[i] * Fz) / mass;
+        const double t1 = L * (F[1] - F[3]), t2 = L * (F[2] - F[0]), t3 = km * u[0] - km * u[1] + km * u[2] - km * u[3];
+        const double Jw1 = J1 * w[0], Jw2 = J2 * w[1], Jw3 = J3 * w[2];
+        xd[9] = (1.0 / J1) * (t1 - (w[1] * Jw3 - w[2] * Jw2));
+        xd[10] = (1.0 / J2) * (t2 - (w[2] * Jw1 - w[0] * Jw3));
+        xd[11] = (1.0 / J3) * (t3 - (w[0] * Jw2 - w[1] * Jw1));
+        return;
+      }
       double mass = M.p[0], J1 = M.p[1], J2 = M.p[2], J3 = M.p[3];
       double g1 = M.p[4], g2 = M.p[5], g3 = M.p[6];
       double L = M.p[7], kf = M.p[8], km = M.p[9];
@@ -145,6 +247,42 @@ inline void dynamics_jacobian(const Model& M, const double* x, const double* u, 
       return;
     }
     case TO_MODEL_QUADROTOR: {
+      if (M.rot() != TO_ROT_QUATERNION) { /* hand-derived, like the quaternion case below; x = [r, p, v, w], n = 12 */
+        const int rot = M.rot();
+        const double mass = M.p[0], J1 = M.p[1], J2 = M.p[2], J3 = M.p[3], L = M.p[7], kf = M.p[8], km = M.p[9];
+        const double* p = x + 3; const double* w = x + 9;
+        double dF[4], Fz = 0.0;
+        for (int i = 0; i < 4; ++i) { dF[i] = (kf * u[i] > 0.0) ? kf : 0.0; Fz += std::fmax(0.0, kf * u[i]); }
+        for (int i = 0; i < 3; ++i) fx[i * 12 + 6 + i] = 1.0;
+        const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], pw = p[0] * w[0] + p[1] * w[1] + p[2] * w[2];
+        /* [w]x */
+        const double Wx[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        const double Px[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+          const double I = (i == j) ? 1.0 : 0.0;
+          if (rot == TO_ROT_MRP) {
+            /* d/dp 1/4[(1-n2) w + 2 p x w + 2 p (p.w)] = 1/4[-2 w p' - 2 [w]x + 2 (p.w) I + 2 p w'] */
+            fx[(3 + i) * 12 + 3 + j] = 0.25 * (-2.0 * w[i] * p[j] - 2.0 * Wx[3 * i + j] + 2.0 * pw * I + 2.0 * p[i] * w[j]);
+            fx[(3 + i) * 12 + 9 + j] = 0.25 * ((1.0 - n2) * I + 2.0 * Px[3 * i + j] + 2.0 * p[i] * p[j]);
+          } else {
+            /* d/dg 1/2[w + g x w + g (g.w)] = 1/2[-[w]x + (g.w) I + g w'] */
+            fx[(3 + i) * 12 + 3 + j] = 0.5 * (-Wx[3 * i + j] + pw * I + p[i] * w[j]);
+            fx[(3 + i) * 12 + 9 + j] = 0.5 * (I + Px[3 * i + j] + p[i] * p[j]);
+          }
+        }
+        double a[3], da[9]; att_thrust_axis(rot, p, a, da);
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) fx[(6 + i) * 12 + 3 + j] = da[3 * i + j] * Fz / mass;
+          for (int j = 0; j < 4; ++j) fu[(6 + i) * 4 + j] = a[i] * dF[j] / mass;
+        }
+        fx[9 * 12 + 10] = -(J3 - J2) * w[2] / J1;  fx[9 * 12 + 11] = -(J3 - J2) * w[1] / J1;
+        fx[10 * 12 + 9] = -(J1 - J3) * w[2] / J2;  fx[10 * 12 + 11] = -(J1 - J3) * w[0] / J2;
+        fx[11 * 12 + 9] = -(J2 - J1) * w[1] / J3;  fx[11 * 12 + 10] = -(J2 - J1) * w[0] / J3;
+        fu[9 * 4 + 1] = L * dF[1] / J1;  fu[9 * 4 + 3] = -L * dF[3] / J1;
+        fu[10 * 4 + 2] = L * dF[2] / J2; fu[10 * 4 + 0] = -L * dF[0] / J2;
+        fu[11 * 4 + 0] = km / J3; fu[11 * 4 + 1] = -km / J3; fu[11 * 4 + 2] = km / J3; fu[11 * 4 + 3] = -km / J3;
+        return;
+      }
       double mass = M.p[0], J1 = M.p[1], J2 = M.p[2], J3 = M.p[3];
       double L = M.p[7], kf = M.p[8], km = M.p[9];
       double qw = x[3], qx = x[4], qy = x[5], qz = x[6];
@@ -300,6 +438,12 @@ inline void errstate_jacobian(const Model& M, const double* x, double* G) {
   const int n = M.n, ne = M.ne;
   std::memset(G, 0, sizeof(double) * n * ne);
   if (M.id != TO_MODEL_QUADROTOR) { for (int i = 0; i < n; ++i) G[i * ne + i] = 1.0; return; }
+  if (M.rot() != TO_ROT_QUATERNION) { /* blkdiag(I3, D(p), I3, I3) */
+    for (int i = 0; i < n; ++i) G[i * ne + i] = 1.0;
+    double D[9]; att_differential(M.rot(), x + 3, D);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) G[(3 + i) * ne + 3 + j] = D[3 * i + j];
+    return;
+  }
   for (int i = 0; i < 3; ++i) G[i * ne + i] = 1.0;
   double w = x[3], a = x[4], b = x[5], c = x[6];
   /* L(q) H : 4x3, no 1/2 factor (Cayley map) */
@@ -308,10 +452,39 @@ inline void errstate_jacobian(const Model& M, const double* x, double* G) {
   for (int i = 0; i < 6; ++i) G[(7 + i) * ne + 6 + i] = 1.0;
 }
 
+/* E(x) = d(y (-) x)/dy at y = x: ne x n row-major, the left inverse of G(x).  Unit quaternions: G' (its columns are
+ * orthonormal), which is what the reference stack multiplies by (Altro error_expansion!: A_err = G(x+)' A G(x)).  For a
+ * three-parameter attitude G' is NOT an inverse of G (G'G != I), so the consistent Jacobian of state_diff is used instead —
+ * D(p)^-1 in closed form (MRP: 4 D'/(1+|p|^2)^2, RodriguesParam: (I - [g]x)/(1+|g|^2)) — so that the expansion linearises
+ * exactly the map the forward pass applies (checked against finite differences of x+(x (+) d) (-) x+(x) in the tests). */
+inline void errstate_left_inverse(const Model& M, const double* x, double* E) {
+  const int n = M.n, ne = M.ne;
+  static thread_local std::vector<double> G;
+  G.resize((size_t)n * ne);
+  errstate_jacobian(M, x, G.data());
+  for (int i = 0; i < ne; ++i) for (int r = 0; r < n; ++r) E[i * n + r] = G[r * ne + i];
+  if (M.id == TO_MODEL_QUADROTOR && M.rot() != TO_ROT_QUATERNION) {
+    const double* p = x + 3; const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    double D[9]; att_differential(M.rot(), p, D);
+    const double Px[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+      E[(3 + i) * n + 3 + j] = M.rot() == TO_ROT_MRP ? 4.0 * D[3 * j + i] / ((1.0 + n2) * (1.0 + n2)) : ((i == j ? 1.0 : 0.0) - Px[3 * i + j]) / (1.0 + n2);
+  }
+}
+
 /* dx (ne) = x (-) x0  (RD.state_diff with the Cayley map) */
 inline void state_diff(const Model& M, const double* x, const double* x0, double* dx) {
   if (M.id != TO_MODEL_QUADROTOR) { for (int i = 0; i < M.n; ++i) dx[i] = x[i] - x0[i]; return; }
   for (int i = 0; i < 3; ++i) dx[i] = x[i] - x0[i];
+  if (M.rot() != TO_ROT_QUATERNION) { /* Rodrigues vector of the relative rotation from the unnormalised quaternions */
+    double q0[4], q[4]; att_quat(M.rot(), x0 + 3, q0); att_quat(M.rot(), x + 3, q);
+    double s = q0[0] * q[0] + q0[1] * q[1] + q0[2] * q[2] + q0[3] * q[3];
+    dx[3] = (q0[0] * q[1] - q0[1] * q[0] - (q0[2] * q[3] - q0[3] * q[2])) / s;
+    dx[4] = (q0[0] * q[2] - q0[2] * q[0] - (q0[3] * q[1] - q0[1] * q[3])) / s;
+    dx[5] = (q0[0] * q[3] - q0[3] * q[0] - (q0[1] * q[2] - q0[2] * q[1])) / s;
+    for (int i = 0; i < 6; ++i) dx[6 + i] = x[6 + i] - x0[6 + i];
+    return;
+  }
   double w0 = x0[3], a0 = x0[4], b0 = x0[5], c0 = x0[6];
   double w = x[3], a = x[4], b = x[5], c = x[6];
   /* dq = conj(q0) (x) q */
@@ -432,26 +605,31 @@ inline int cone_projection_hessian(int cone, const double* x, const double* b, d
 }
 
 /* ---------------------------------------------------------------- ErrorQuadratic (src/lie_costs.jl:178-241) */
-/* dx = x (-) x_ref on the 13-state rigid body: dphi = vec(dq)/scalar(dq), dq = conj(q_ref) (x) q = [q0'q; V q]. */
+/* dx = x (-) x_ref on a rigid-body state: dphi = vec(dq)/scalar(dq), dq = conj(q_ref) (x) q = [q0'q; V q], with q, q0 the
+ * (unnormalised) quaternions of the two attitudes: the state's own 4 entries (ErrorQuadratic{QuatRotation}, n = 13), or
+ * att_quat of its 3 attitude parameters (ErrorQuadratic{MRP} / {RodriguesParam}, n = 12; rot = to_rotation, carried in C.w). */
 struct ErrQuadGeom {
-  double s, phi[3], V[3][4], q0[4];
+  double s, phi[3], V[3][4], q0[4], q[4];
+  int rot, ov; /* attitude representation; index of the first velocity entry of the state */
 };
-inline void errquad_geom(const double* x, const double* xr, ErrQuadGeom& G) {
-  const double w0 = xr[3], a0 = xr[4], b0 = xr[5], c0 = xr[6];
+inline void errquad_geom(int rot, const double* x, const double* xr, ErrQuadGeom& G) {
+  G.rot = rot; G.ov = rot == TO_ROT_QUATERNION ? 7 : 6;
+  if (rot == TO_ROT_QUATERNION) { for (int t = 0; t < 4; ++t) { G.q0[t] = xr[3 + t]; G.q[t] = x[3 + t]; } }
+  else { att_quat(rot, xr + 3, G.q0); att_quat(rot, x + 3, G.q); }
+  const double w0 = G.q0[0], a0 = G.q0[1], b0 = G.q0[2], c0 = G.q0[3];
   const double V[3][4] = {{-a0, w0, c0, -b0}, {-b0, -c0, w0, a0}, {-c0, b0, -a0, w0}};
-  G.q0[0] = w0; G.q0[1] = a0; G.q0[2] = b0; G.q0[3] = c0;
   G.s = 0.0;
-  for (int t = 0; t < 4; ++t) G.s += G.q0[t] * x[3 + t];
+  for (int t = 0; t < 4; ++t) G.s += G.q0[t] * G.q[t];
   for (int i = 0; i < 3; ++i) {
     double v = 0.0;
-    for (int t = 0; t < 4; ++t) { G.V[i][t] = V[i][t]; v += V[i][t] * x[3 + t]; }
+    for (int t = 0; t < 4; ++t) { G.V[i][t] = V[i][t]; v += V[i][t] * G.q[t]; }
     G.phi[i] = v / G.s;
   }
 }
-inline void errquad_dx(const double* x, const double* xr, double* dx) {
-  ErrQuadGeom G; errquad_geom(x, xr, G);
+inline void errquad_dx(int rot, const double* x, const double* xr, double* dx) {
+  ErrQuadGeom G; errquad_geom(rot, x, xr, G);
   for (int i = 0; i < 3; ++i) { dx[i] = x[i] - xr[i]; dx[3 + i] = G.phi[i]; }
-  for (int i = 0; i < 6; ++i) dx[6 + i] = x[7 + i] - xr[7 + i];
+  for (int i = 0; i < 6; ++i) dx[6 + i] = x[G.ov + i] - xr[G.ov + i];
 }
 
 /* ---------------------------------------------------------------- costs */
@@ -461,7 +639,7 @@ inline double cost_evaluate(const to_cost_desc& C, int n, int m, const double* x
   double J = 0.0;
   if (C.kind == TO_COST_ERROR_QUADRATIC) { /* src/lie_costs.jl:237-240 */
     double dx[12], e = 0.0;
-    errquad_dx(x, C.q, dx);
+    errquad_dx((int)C.w, x, C.q, dx);
     for (int i = 0; i < 12; ++i) e += dx[i] * C.Q[i] * dx[i];
     J = 0.5 * e + C.c;
     if (u) {
@@ -515,16 +693,33 @@ inline void cost_expansion(const to_cost_desc& C, int n, int m, const double* x,
   if (C.kind == TO_COST_ERROR_QUADRATIC) {
     /* exact derivatives of 0.5 dx'Q dx (the reference takes them with ForwardDiff): with D_i = (V_i - phi_i q0')/s,
      * grad_q = sum_i Q_i phi_i D_i',  H_qq = sum_i Q_i [D_i'D_i - phi_i (V_i'q0' + q0 V_i)/s^2 + 2 phi_i^2 q0 q0'/s^2] */
-    ErrQuadGeom G; errquad_geom(x, C.q, G);
+    ErrQuadGeom G; errquad_geom((int)C.w, x, C.q, G);
     for (int i = 0; i < 3; ++i) { grad[i] = C.Q[i] * (x[i] - C.q[i]); hess[i * nz + i] = C.Q[i]; }
-    for (int i = 0; i < 6; ++i) { grad[7 + i] = C.Q[6 + i] * (x[7 + i] - C.q[7 + i]); hess[(7 + i) * nz + 7 + i] = C.Q[6 + i]; }
+    for (int i = 0; i < 6; ++i) { grad[G.ov + i] = C.Q[6 + i] * (x[G.ov + i] - C.q[G.ov + i]); hess[(G.ov + i) * nz + G.ov + i] = C.Q[6 + i]; }
+    double gq[4] = {0, 0, 0, 0}, Hq[16] = {0}; /* derivatives with respect to the (unnormalised) quaternion */
     for (int i = 0; i < 3; ++i) {
       const double Qi = C.Q[3 + i], ph = G.phi[i];
       double D[4];
-      for (int t = 0; t < 4; ++t) { D[t] = (G.V[i][t] - ph * G.q0[t]) / G.s; grad[3 + t] += Qi * ph * D[t]; }
+      for (int t = 0; t < 4; ++t) { D[t] = (G.V[i][t] - ph * G.q0[t]) / G.s; gq[t] += Qi * ph * D[t]; }
       for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r)
-        hess[(3 + t) * nz + 3 + r] += Qi * (D[t] * D[r] - ph * (G.V[i][t] * G.q0[r] + G.q0[t] * G.V[i][r]) / (G.s * G.s)
-                                            + 2 * ph * ph * G.q0[t] * G.q0[r] / (G.s * G.s));
+        Hq[t * 4 + r] += Qi * (D[t] * D[r] - ph * (G.V[i][t] * G.q0[r] + G.q0[t] * G.V[i][r]) / (G.s * G.s)
+                               + 2 * ph * ph * G.q0[t] * G.q0[r] / (G.s * G.s));
+    }
+    if (G.rot == TO_ROT_QUATERNION) {
+      for (int t = 0; t < 4; ++t) { grad[3 + t] = gq[t]; for (int r = 0; r < 4; ++r) hess[(3 + t) * nz + 3 + r] = Hq[t * 4 + r]; }
+    } else { /* chain rule through q(p): dq/dp = [-2p'; 2I] and d2q_0/dp2 = -2I (MRP), dq/dg = [0; I] (RodriguesParam) */
+      double Jq[4][3];
+      for (int j = 0; j < 3; ++j) {
+        Jq[0][j] = G.rot == TO_ROT_MRP ? -2.0 * x[3 + j] : 0.0;
+        for (int t = 0; t < 3; ++t) Jq[1 + t][j] = (t == j) ? (G.rot == TO_ROT_MRP ? 2.0 : 1.0) : 0.0;
+      }
+      for (int j = 0; j < 3; ++j) { double g = 0.0; for (int t = 0; t < 4; ++t) g += Jq[t][j] * gq[t]; grad[3 + j] = g; }
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double h = 0.0;
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) h += Jq[t][i] * Hq[t * 4 + r] * Jq[r][j];
+        if (G.rot == TO_ROT_MRP && i == j) h += -2.0 * gq[0];
+        hess[(3 + i) * nz + 3 + j] = h;
+      }
     }
     if (!terminal) for (int i = 0; i < m; ++i) { grad[n + i] = C.R[i] * u[i] + C.r[i]; hess[(n + i) * nz + n + i] = C.R[i]; }
     return;

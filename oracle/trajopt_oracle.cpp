@@ -184,12 +184,17 @@ int validate_constraint(const Problem& P, const to_constraint_desc& d, ConInfo* 
 int validate_cost(const Problem& P, const to_cost_desc& c) {
   if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT && c.kind != TO_COST_ERROR_QUADRATIC)
     return fail(TO_ERR_UNSUPPORTED, "unknown cost kind");
-  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; q(4:7); v; w]
-    if (P.n != 13) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model (n = 13)");
-    for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
+  const int rot = P.M.rot();
+  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; attitude; v; w]
+    if (rot < 0) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model");
+    if ((int)c.w != rot || c.w != (double)rot) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic: w must name the model's attitude representation (to_rotation)");
+    if (rot == TO_ROT_QUATERNION)
+      for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
   }
-  if (c.kind == TO_COST_DIAGONAL_QUAT)
+  if (c.kind == TO_COST_DIAGONAL_QUAT) {
+    if (rot > TO_ROT_QUATERNION) return fail(TO_ERR_ARGUMENT, "DiagonalQuatCost needs a state that carries a unit quaternion");
     for (int i = 0; i < 4; ++i) if (c.q_ind[i] < 1 || c.q_ind[i] > P.n) return fail(TO_ERR_DIMENSION_MISMATCH, "quat_ind outside state");
+  }
   return TO_OK;
 }
 
@@ -422,11 +427,11 @@ void expand(const Problem& P, Traj& t) {
     const double* x = &t.X[(size_t)k * n]; const double* u = &t.U[(size_t)k * m];
     discrete_jacobian(P.M, P.integrator, x, u, P.dt[k], A.data(), Bf.data());
     errstate_jacobian(P.M, x, G0.data());
-    errstate_jacobian(P.M, &t.X[(size_t)(k + 1) * n], G1.data());
+    errstate_left_inverse(P.M, &t.X[(size_t)(k + 1) * n], G1.data()); /* E(x_{k+1}): ne x n (= G' for unit quaternions) */
     matmul(A.data(), G0.data(), T1.data(), n, n, ne); /* A G_k : n x ne */
     double* Ae = &t.A[(size_t)k * ne * ne]; double* Be = &t.Bm[(size_t)k * ne * m];
-    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[r * ne + i] * T1[r * ne + j]; Ae[i * ne + j] = s; }
-    for (int i = 0; i < ne; ++i) for (int j = 0; j < m; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[r * ne + i] * Bf[r * m + j]; Be[i * m + j] = s; }
+    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[i * n + r] * T1[r * ne + j]; Ae[i * ne + j] = s; }
+    for (int i = 0; i < ne; ++i) for (int j = 0; j < m; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[i * n + r] * Bf[r * m + j]; Be[i * m + j] = s; }
   }
   for (int k = 0; k < N; ++k) {
     const double* x = &t.X[(size_t)k * n];
@@ -439,9 +444,12 @@ void expand(const Problem& P, Traj& t) {
     /* Qxx = G' Hxx G */
     for (int r = 0; r < n; ++r) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int c = 0; c < n; ++c) s += hess[r * nz + c] * G0[c * ne + j]; T2[r * ne + j] = s; }
     for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G0[r * ne + i] * T2[r * ne + j]; Qxx[i * ne + j] = s; }
-    if (P.M.id == TO_MODEL_QUADROTOR) { /* second-order term of the attitude map: -I3 (q' dJ/dq) (Rotations ∇differential) */
+    if (P.M.id == TO_MODEL_QUADROTOR && P.M.rot() == TO_ROT_QUATERNION) { /* second-order term of the attitude map: -I3 (q' dJ/dq) (Rotations ∇differential) */
       double b1 = 0.0; for (int i = 0; i < 4; ++i) b1 += x[3 + i] * grad[3 + i];
       for (int i = 0; i < 3; ++i) Qxx[(3 + i) * ne + 3 + i] -= b1;
+    } else if (P.M.id == TO_MODEL_QUADROTOR) { /* ... of a three-parameter attitude: ∇²differential(p, dJ/dp) */
+      double H2[9]; att_differential2(P.M.rot(), x + 3, &grad[3], H2);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Qxx[(3 + i) * ne + 3 + j] += H2[3 * i + j];
     }
     for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Quu[i * m + j] = hess[(n + i) * nz + n + j];
     for (int i = 0; i < m; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int c = 0; c < n; ++c) s += hess[(n + i) * nz + c] * G0[c * ne + j]; Qux[i * ne + j] = s; }

@@ -326,6 +326,65 @@ def test_G4_quadrotor_zigzag_on_gpu(hip, oracle):
     assert_trajectories_close(T.controls(ph), T.controls(po), 1e-6, "U")
 
 
+@pytest.mark.parametrize("rot", ["mrp", "rp"])
+def test_three_parameter_attitude_quadrotor_on_gpu(rot, hip, oracle):
+    """RigidBody{MRP} / RigidBody{RodriguesParam} (src/lie_costs.jl:1-3): the Quadrotor with a three-parameter
+    attitude (n = ne = 12) and ErrorQuadratic{Rot}.  Every phase against the oracle (whose closed forms are pinned by finite
+    differences in tests/test_oracle_rotations.py; the GPU differentiates the same maps with dual numbers), then full iLQR
+    and AL solves."""
+    def build(lib, constrained=False, batch=24, N=41):
+        model = T.Quadrotor(rotation=rot)
+        n, m = model.dims()
+        th = math.radians(70.0) / 2
+        xf = model.build_state([1.0, 1.5, 0.5], [math.cos(th), 0.0, 0.0, math.sin(th)])
+        Qe = np.r_[np.ones(3), 0.5 * np.ones(3), 0.1 * np.ones(6)]
+        stage = T.ErrorQuadratic(model, Qe, np.full(m, 1e-2), xf, model.hover_control())
+        term = T.ErrorQuadratic(model, 100 * Qe, np.full(m, 1e-2), xf, model.hover_control(), terminal=True)
+        cons = T.ConstraintList(n, m, N)
+        if constrained:
+            T.add_constraint(cons, T.BoundConstraint(n, m, u_min=0.0, u_max=2.2), range(1, N))
+            T.add_constraint(cons, T.GoalConstraint(xf, [1, 2, 3, 7, 8, 9, 10, 11, 12]), N)
+        prob = T.Problem(model, T.Objective(stage, term, N), np.zeros(n), 2.0, xf=xf, constraints=cons, batch=batch, lib=lib)
+        rng = np.random.default_rng(11)
+        x0 = np.zeros((batch, n)); x0[:, :3] = rng.uniform(-0.5, 0.5, (batch, 3)); x0[:, 3:6] = 0.1 * rng.standard_normal((batch, 3))
+        prob.set_initial_state(x0)
+        T.initial_controls(prob, model.hover_control())
+        return prob
+
+    ph, po = build(hip), build(oracle)
+    perturb_controls((ph, po), 0.05)
+    T.rollout(ph); T.rollout(po)
+    np.testing.assert_allclose(T.states(ph), T.states(po), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(T.cost(ph), T.cost(po), rtol=1e-12)
+    np.testing.assert_allclose(I.discrete_jacobian(ph), I.discrete_jacobian(po), rtol=1e-9, atol=1e-11)
+    gh, Hh = I.cost_gradient_hessian(ph)
+    go, Ho = I.cost_gradient_hessian(po)
+    np.testing.assert_allclose(gh, go, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(Hh, Ho, rtol=1e-9, atol=1e-11)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    (Ah, Bh), (Ao, Bo) = I.dynamics_jacobians(ph), I.dynamics_jacobians(po)
+    np.testing.assert_allclose(Ah, Ao, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Bh, Bo, rtol=1e-9, atol=1e-11)
+    Eh, Eo = I.cost_expansion(ph), I.cost_expansion(po)
+    for k in Eh:
+        np.testing.assert_allclose(Eh[k], Eo[k], rtol=1e-9, atol=1e-10, err_msg=k)
+    kh, ko = I.gains(ph), I.gains(po)
+    np.testing.assert_array_equal(kh["rho"], ko["rho"])
+    np.testing.assert_allclose(kh["K"], ko["K"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(kh["d"], ko["d"], rtol=1e-7, atol=1e-9)
+    lh, Jh = I.forwardpass(ph)
+    lo, Jo = I.forwardpass(po)
+    np.testing.assert_array_equal(lh, lo)
+    np.testing.assert_allclose(Jh, Jo, rtol=1e-10)
+    ph, po = build(hip), build(oracle)
+    assert_solve_parity(T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve(), ph, po)
+    ph, po = build(hip, constrained=True), build(oracle, constrained=True)
+    sh, so = T.ALSolver(ph, constraint_tolerance=1e-5).solve(), T.ALSolver(po, constraint_tolerance=1e-5).solve()
+    assert_solve_parity(sh, so, ph, po)
+    assert np.all(sh.stats["c_max"] < 1e-5)
+
+
 # ---------------------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("B", [1, 63, 65, 130])
 def test_ragged_batch_sizes(B, hip, oracle):

@@ -114,17 +114,25 @@ class Cartpole(_Model):
 
 
 class Quadrotor(_Model):
-    """RobotZoo.Quadrotor / examples/Quadrotor.ipynb cells 4 and 8.  State [r, q(w,x,y,z), v, ω]."""
+    """RobotZoo.Quadrotor / examples/Quadrotor.ipynb cells 4 and 8: ``Quadrotor{R} <: RigidBody{R}``.  ``rotation`` is the
+    attitude representation R of the state (cell 5: QuatRotation, MRP or RodriguesParam; src/lie_costs.jl:1-3):
+    "quat" -> x = [r, q(w,x,y,z), v, ω], n = 13 (the default, ``Quadrotor()``); "mrp" / "rp" -> x = [r, p(3), v, ω], n = 12.
+    The error state has 12 entries either way."""
     model_id = capi.MODEL_QUADROTOR
-    n, m = 13, 4
+    m = 4
+    ROTATIONS = {"quat": 0, "QuatRotation": 0, "UnitQuaternion": 0, "mrp": 1, "MRP": 1, "rp": 2, "RodriguesParam": 2}
 
     def __init__(self, mass=0.5, J=(0.0023, 0.0023, 0.004), gravity=(0.0, 0.0, -9.81),
-                 motor_dist=0.1750, kf=1.0, km=0.0245):
+                 motor_dist=0.1750, kf=1.0, km=0.0245, rotation="quat"):
         self.mass, self.J, self.gravity = float(mass), tuple(map(float, J)), tuple(map(float, gravity))
         self.motor_dist, self.kf, self.km = float(motor_dist), float(kf), float(km)
+        if rotation not in self.ROTATIONS:
+            raise ArgumentError(f"unknown rotation {rotation!r}: one of quat, mrp, rp")
+        self.rotation = self.ROTATIONS[rotation]
+        self.n = 13 if self.rotation == 0 else 12
 
     def params(self):
-        return [self.mass, *self.J, *self.gravity, self.motor_dist, self.kf, self.km]
+        return [self.mass, *self.J, *self.gravity, self.motor_dist, self.kf, self.km, float(self.rotation)]
 
     @property
     def errstate_dim(self):
@@ -133,6 +141,14 @@ class Quadrotor(_Model):
     def hover_control(self):
         """``zeros(model)[2]``: thrust that cancels gravity, -g_z*m/4 per motor."""
         return np.full(4, -self.gravity[2] * self.mass / 4.0 / self.kf)
+
+    def build_state(self, r, q=None, v=(0.0, 0.0, 0.0), w=(0.0, 0.0, 0.0)):
+        """RobotDynamics.build_state(model, r, q, v, ω): ``q`` is a unit quaternion (w, x, y, z), stored as such or converted to
+        the model's three-parameter attitude (MRP p = q_v/(1+q_w), RodriguesParam g = q_v/q_w)."""
+        q = np.array([1.0, 0.0, 0.0, 0.0]) if q is None else _vec(q, 4, "q")
+        q = q / np.linalg.norm(q)
+        att = q if self.rotation == 0 else (q[1:] / (1.0 + q[0]) if self.rotation == 1 else q[1:] / q[0])
+        return np.concatenate([_vec(r, 3, "r"), att, _vec(v, 3, "v"), _vec(w, 3, "ω")])
 
 
 # --------------------------------------------------------------------------------------------- costs
@@ -234,30 +250,32 @@ class DiagonalQuatCost(DiagonalCost):
 
 class ErrorQuadratic(QuadraticCostFunction):
     """½ (x ⊖ x_ref)ᵀ Q (x ⊖ x_ref) + c + ½uᵀRu + rᵀu with the Cayley-map error state of a rigid body
-    (src/lie_costs.jl:178-241).  ``Q`` is the 12-vector of error-state weights, or a 13-vector / 13x13 diagonal whose
-    4th entry is dropped like the reference constructor does (:226-229); ``u_ref`` folds into r and c (:230-231)."""
+    (``ErrorQuadratic{Rot}``, src/lie_costs.jl:178-241; Rot = the model's attitude representation: QuatRotation, MRP or
+    RodriguesParam).  ``Q`` is the 12-vector of error-state weights, or — on a quaternion state — a 13-vector / 13x13
+    diagonal whose 4th entry is dropped like the reference constructor does (:226-229); ``u_ref`` folds into r and c (:230-231)."""
     kind = capi.COST_ERROR_QUADRATIC
 
     def __init__(self, model, Q, R, x_ref, u_ref=None, r=None, c=0.0, q_ind=(4, 5, 6, 7), terminal=False):
         n, m = model.dims()
-        if n != 13:
-            raise ArgumentError("ErrorQuadratic needs a rigid-body model (13 states)")
+        rot = getattr(model, "rotation", None)
+        if rot is None or n not in (12, 13):
+            raise ArgumentError("ErrorQuadratic needs a rigid-body model (13 states with a quaternion, 12 with MRP / RodriguesParam)")
         dq, Qd = _diag_or_vec(Q)
         dr, Rd = _diag_or_vec(R)
         if not (dq and dr):
             raise ArgumentError("ErrorQuadratic needs diagonal Q and R")
-        if Qd.size == 13:
+        if rot == 0 and Qd.size == 13:  # Rot <: QuatRotation && size(Q,1) == size(x_ref,1): drop the 4th entry (src/lie_costs.jl:226-229)
             Qd = np.delete(Qd, 3)
         if Qd.size != 12 or Rd.size != m:
-            raise DimensionMismatch("ErrorQuadratic: Q must have 12 (or 13) entries, R m entries")
-        self.n, self.m = n, m
+            raise DimensionMismatch("ErrorQuadratic: Q must have 12 entries (or 13 on a quaternion state), R m entries")
+        self.n, self.m, self.rotation = n, m, rot
         self.Q, self.R = Qd, Rd
         self.H = np.zeros((m, n))
         self.x_ref = _vec(x_ref, n, "x_ref")
         u_ref = np.zeros(m) if u_ref is None else _vec(u_ref, m, "u_ref")
         self.r = (np.zeros(m) if r is None else _vec(r, m, "r")) - Rd * u_ref
         self.c = float(c) + 0.5 * u_ref @ (Rd * u_ref)
-        if tuple(int(i) for i in q_ind) != (4, 5, 6, 7):
+        if rot == 0 and tuple(int(i) for i in q_ind) != (4, 5, 6, 7):
             raise ArgumentError("ErrorQuadratic: q_ind must be 4:7 (the rigid-body state layout)")
         self.q_ind = (4, 5, 6, 7)
         self.terminal = bool(terminal)
@@ -274,7 +292,7 @@ class ErrorQuadratic(QuadraticCostFunction):
         d.q[: self.n] = list(self.x_ref)
         d.r[: self.m] = list(self.r)
         d.c = self.c
-        d.w = 0.0
+        d.w = float(self.rotation)  # to_rotation of the state: ErrorQuadratic{QuatRotation} / {MRP} / {RodriguesParam}
         d.q_ref[:] = [1.0, 0.0, 0.0, 0.0]
         d.q_ind[:] = list(self.q_ind)
         return d

@@ -102,8 +102,9 @@ struct ModelOps {
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
 };
 
-// each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole, 4 Quadrotor)
-constexpr int N_MODEL_KEYS = 5;
+// each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole,
+// 4 Quadrotor, 5 Quadrotor{MRP}, 6 Quadrotor{RodriguesParam})
+constexpr int N_MODEL_KEYS = 7;
 void fill_ops_small(ModelOps* table);
 void fill_ops_small_forward(ModelOps* table);
 void fill_ops_quad_misc(ModelOps* table);
@@ -112,6 +113,11 @@ void fill_ops_quad_backward(ModelOps* table);
 void fill_ops_quad_forward_a(ModelOps* table);
 void fill_ops_quad_forward_b(ModelOps* table);
 void fill_ops_quad_forward_c(ModelOps* table);
+void fill_ops_quadatt_misc(ModelOps* table);
+void fill_ops_quadmrp_expand(ModelOps* table);
+void fill_ops_quadrp_expand(ModelOps* table);
+void fill_ops_quadmrp_forward(ModelOps* table);
+void fill_ops_quadrp_forward(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
     double t[n], col[ne];
 #pragma unroll
     for (int i = 0; i < n; ++i) t[i] = xn[i].d;
-    errstate_tmul<M>(x1, t, col);
+    errstate_invmul<M>(x1, t, col);
     if constexpr (LAY == 0) {
       double* Mc = COL_PTR(a.Mc, (N - 1) * ne);
       if (valid) {
@@ -123,10 +123,15 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   double col[ne], qxe[ne];
   errstate_tmul<M>(x, y, col);
   errstate_tmul<M>(x, gr, qxe);
-  if constexpr (M::lie) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q) on the attitude diagonal
+  if constexpr (M::att == ATT_QUAT) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q) on the attitude diagonal
     const double b1 = x[3] * gr[3] + x[4] * gr[4] + x[5] * gr[5] + x[6] * gr[6];
 #pragma unroll
     for (int i = 3; i < 6; ++i) col[i] -= (i == j) ? b1 : 0.0;
+  } else if constexpr (M::att == ATT_MRP || M::att == ATT_RP) {  // ... of a three-parameter attitude: ∇²differential(p, ∂J/∂p), a full 3x3 block
+    double H2[9];
+    att_differential2<M::att>(x + 3, gr + 3, H2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) col[3 + i] += (j == 3) ? H2[3 * i] : (j == 4) ? H2[3 * i + 1] : (j == 5) ? H2[3 * i + 2] : 0.0;
   }
   double gj = 0.0;
 #pragma unroll

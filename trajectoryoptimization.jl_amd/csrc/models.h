@@ -155,10 +155,15 @@ template <int K> __device__ __forceinline__ MDual<K> relu_t(MDual<K> x) {
 // ------------------------------------------------------------------------------------------------
 // Models.  P = model_params of the descriptor (wave-uniform, lives in SGPRs).
 // ------------------------------------------------------------------------------------------------
+// attitude representation carried by a model's state (RobotDynamics RigidBody{R}: R = QuatRotation, MRP, RodriguesParam —
+// the three src/lie_costs.jl:1-3 names); ATT_NONE: vector-space model
+enum { ATT_NONE = 0, ATT_QUAT = 1, ATT_MRP = 2, ATT_RP = 3 };
+
 template <int D>
 struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
   static constexpr int n = 2 * D, m = D, ne = 2 * D;
   static constexpr bool lie = false;
+  static constexpr int att = ATT_NONE;
   static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
   static constexpr int expand_knots = 1;
   static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
@@ -181,6 +186,7 @@ struct DoubleIntegratorModel {  // examples/quickstart.jl:15-20
 struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr int n = 4, m = 1, ne = 4;
   static constexpr bool lie = false;
+  static constexpr int att = ATT_NONE;
   static constexpr bool pin_rk4 = true;   // kernels instantiate a compile-time RK4 variant (rk_step<.., FIXED>)
   static constexpr int expand_knots = 1;
   static constexpr bool accept_write_through = true;   // the accepted step is written through to slot 0 by the next expansion (k_expand.h)
@@ -216,6 +222,7 @@ struct CartpoleModel {  // docs/src/model.md:34-50
 struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3) q(w,x,y,z) v(3) ω(3)]
   static constexpr int n = 13, m = 4, ne = 12;
   static constexpr bool lie = true;
+  static constexpr int att = ATT_QUAT;
   static constexpr bool pin_rk4 = false;  // compile-time RK4 costs registers here: measured slower than the runtime switch
 #ifndef TO_QUAD_EXPAND_KNOTS
 #define TO_QUAD_EXPAND_KNOTS 4
@@ -260,6 +267,119 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
     xd[12] = rcp_fast(J3) * (t3 - (w1 * Jw2 - w2 * Jw1));
   }
 };
+
+// The same rigid body with a THREE-parameter attitude (RigidBody{MRP} / RigidBody{RodriguesParam}; src/lie_costs.jl:1-3,
+// examples/Quadrotor.ipynb cell 5): state [r(3) p(3) v(3) ω(3)], n = ne = 12.  Kinematics (Rotations.kinematics):
+//   MRP  ṗ = ¼[(1 − |p|²) ω + 2 p×ω + 2 p (p·ω)]        RodriguesParam  ġ = ½[ω + g×ω + g (g·ω)]
+// and the body force is rotated by the unit quaternion of the attitude, q = [(1−|p|²), 2p]/(1+|p|²) resp. [1, g]/√(1+|g|²),
+// written in the rational form  q*r = M² [(w̃² − ṽ·ṽ) r + 2 ṽ (ṽ·r) + 2 w̃ (ṽ × r)],  q̃ = [w̃, ṽ] the unnormalised quaternion,
+// M² = 1/|q̃|².
+template <int ATT>
+struct QuadrotorAttModel {
+  static_assert(ATT == ATT_MRP || ATT == ATT_RP, "three-parameter attitudes");
+  static constexpr int n = 12, m = 4, ne = 12;
+  static constexpr bool lie = true;
+  static constexpr int att = ATT;
+  static constexpr bool pin_rk4 = false;
+  static constexpr int expand_knots = 4;
+  static constexpr bool accept_write_through = false;
+  static constexpr bool lds_gains = true;
+  static constexpr int ls_first_round = 16;
+  static constexpr bool mfma_backward = true, coop_backward = false;
+  static constexpr bool lane_backward = false;
+  template <class T>
+  __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
+    const double mass = P[0], J1 = P[1], J2 = P[2], J3 = P[3];
+    const double g1 = P[4], g2 = P[5], g3 = P[6], L = P[7], kf = P[8], km = P[9];
+    T p1 = x[3], p2 = x[4], p3 = x[5];
+    T w1 = x[9], w2 = x[10], w3 = x[11];
+    T F1 = relu_t(kf * u[0]), F2 = relu_t(kf * u[1]), F3 = relu_t(kf * u[2]), F4 = relu_t(kf * u[3]);
+    T Fz = F1 + F2 + F3 + F4;
+    T n2 = p1 * p1 + p2 * p2 + p3 * p3;
+    T pw = p1 * w1 + p2 * w2 + p3 * w3;
+    T c1 = p2 * w3 - p3 * w2, c2 = p3 * w1 - p1 * w3, c3 = p1 * w2 - p2 * w1;  // p × ω
+    // unnormalised quaternion of the attitude and 1/|q̃|²
+    T qw, qx, qy, qz, M2;
+    if constexpr (ATT == ATT_MRP) {
+      T s = 1.0 - n2;
+      xd[3] = 0.25 * (s * w1 + 2.0 * c1 + (2.0 * p1) * pw);
+      xd[4] = 0.25 * (s * w2 + 2.0 * c2 + (2.0 * p2) * pw);
+      xd[5] = 0.25 * (s * w3 + 2.0 * c3 + (2.0 * p3) * pw);
+      qw = s; qx = 2.0 * p1; qy = 2.0 * p2; qz = 2.0 * p3;
+      T d = 1.0 + n2;
+      M2 = recip_t(d * d);
+    } else {
+      xd[3] = 0.5 * (w1 + c1 + p1 * pw);
+      xd[4] = 0.5 * (w2 + c2 + p2 * pw);
+      xd[5] = 0.5 * (w3 + c3 + p3 * pw);
+      qw = T(1.0); qx = p1; qy = p2; qz = p3;
+      M2 = recip_t(1.0 + n2);
+    }
+    T vv = qx * qx + qy * qy + qz * qz;
+    T sc = qw * qw - vv;
+    T vr = qz * Fz;
+    T qF1 = ((2.0 * qx) * vr + (2.0 * qw) * (qy * Fz)) * M2;
+    T qF2 = ((2.0 * qy) * vr - (2.0 * qw) * (qx * Fz)) * M2;
+    T qF3 = (sc * Fz + (2.0 * qz) * vr) * M2;
+    T t1 = L * (F2 - F4), t2 = L * (F3 - F1);
+    T t3 = km * u[0] - km * u[1] + km * u[2] - km * u[3];
+    xd[0] = x[6];
+    xd[1] = x[7];
+    xd[2] = x[8];
+    const double inv_mass = rcp_fast(mass);
+    xd[6] = (mass * g1 + qF1) * inv_mass;
+    xd[7] = (mass * g2 + qF2) * inv_mass;
+    xd[8] = (mass * g3 + qF3) * inv_mass;
+    T Jw1 = J1 * w1, Jw2 = J2 * w2, Jw3 = J3 * w3;
+    xd[9] = rcp_fast(J1) * (t1 - (w2 * Jw3 - w3 * Jw2));
+    xd[10] = rcp_fast(J2) * (t2 - (w3 * Jw1 - w1 * Jw3));
+    xd[11] = rcp_fast(J3) * (t3 - (w1 * Jw2 - w2 * Jw1));
+  }
+};
+
+// 3 x 3 attitude block D(p) of the error-state Jacobian of a three-parameter attitude (Rotations ∇differential with the Cayley
+// error map: d(p ⊕ φ)/dφ at φ = 0; ṗ = D(p) ω/2):  MRP  ½[(1−|p|²) I + 2[p]× + 2pp']   RodriguesParam  I + [g]× + gg'.
+// Row-major D[3*i + j].
+template <int ATT>
+__device__ __forceinline__ void att_differential(const double* p, double* D) {
+  const double a = p[0], b = p[1], c = p[2];
+  if constexpr (ATT == ATT_MRP) {
+    const double h = 0.5 * (1.0 - (a * a + b * b + c * c));
+    D[0] = h + a * a; D[1] = -c + a * b; D[2] = b + a * c;
+    D[3] = c + b * a; D[4] = h + b * b;  D[5] = -a + b * c;
+    D[6] = -b + c * a; D[7] = a + c * b; D[8] = h + c * c;
+  } else {
+    D[0] = 1.0 + a * a; D[1] = -c + a * b;   D[2] = b + a * c;
+    D[3] = c + b * a;   D[4] = 1.0 + b * b;  D[5] = -a + b * c;
+    D[6] = -b + c * a;  D[7] = a + c * b;    D[8] = 1.0 + c * c;
+  }
+}
+// Hessian of φ -> b·(p ⊕ φ) at φ = 0 (Rotations ∇²differential; the second-order term of the error-state cost Hessian):
+//   MRP  ½[a p' + p a'] − (b·p)[(1+|p|²)/2 I − 2 pp'],  a = (1−|p|²) b + 2 b×p
+//   RP   c g' + g c' + 2 (b·g) g g',                    c = b + b×g                       (symmetric; row-major H[3*i + j])
+template <int ATT>
+__device__ __forceinline__ void att_differential2(const double* p, const double* b, double* H) {
+  const double bp = b[0] * p[0] + b[1] * p[1] + b[2] * p[2];
+  const double cx[3] = {b[1] * p[2] - b[2] * p[1], b[2] * p[0] - b[0] * p[2], b[0] * p[1] - b[1] * p[0]};  // b × p
+  if constexpr (ATT == ATT_MRP) {
+    const double n2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+    double a[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = (1.0 - n2) * b[i] + 2.0 * cx[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) H[3 * i + j] = 0.5 * (a[i] * p[j] + p[i] * a[j]) - bp * (((i == j) ? 0.5 * (1.0 + n2) : 0.0) - 2.0 * p[i] * p[j]);
+  } else {
+    double c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c[i] = b[i] + cx[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) H[3 * i + j] = c[i] * p[j] + p[i] * c[j] + 2.0 * bp * p[i] * p[j];
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Integrators: h multiplied into each stage, then combined.
@@ -310,7 +430,8 @@ __device__ __forceinline__ void rk_step(const double* P, int integrator_rt, cons
 // ------------------------------------------------------------------------------------------------
 // Error-state maps.  Identity for vector-space models.
 // ------------------------------------------------------------------------------------------------
-// v (n) = column j of G(x)   (n x ne attitude Jacobian blkdiag(I3, L(q)H, I3, I3); no 1/2: Cayley map)
+// v (n) = column j of G(x)   (n x ne attitude Jacobian blkdiag(I3, L(q)H, I3, I3); no 1/2: Cayley map; three-parameter
+// attitudes: blkdiag(I3, D(p), I3, I3), att_differential)
 template <class M>
 __device__ __forceinline__ void errstate_col(const double* x, int j, double* v) {
   constexpr int n = M::n;
@@ -319,7 +440,7 @@ __device__ __forceinline__ void errstate_col(const double* x, int j, double* v) 
   if constexpr (!M::lie) {
 #pragma unroll
     for (int i = 0; i < n; ++i) v[i] = (i == j) ? 1.0 : 0.0;
-  } else {
+  } else if constexpr (M::att == ATT_QUAT) {
     const double w = x[3], a = x[4], b = x[5], c = x[6];
     if (j < 3) {
 #pragma unroll
@@ -331,6 +452,15 @@ __device__ __forceinline__ void errstate_col(const double* x, int j, double* v) 
 #pragma unroll
       for (int i = 7; i < 13; ++i) v[i] = (i == j + 1) ? 1.0 : 0.0;
     }
+  } else {
+    double D[9];
+    att_differential<M::att>(x + 3, D);
+#pragma unroll
+    for (int i = 0; i < n; ++i) v[i] = (i == j) ? 1.0 : 0.0;
+    if (j >= 3 && j < 6) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) v[3 + i] = (j == 3) ? D[3 * i] : (j == 4) ? D[3 * i + 1] : D[3 * i + 2];
+    }
   }
 }
 
@@ -340,7 +470,7 @@ __device__ __forceinline__ void errstate_tmul(const double* x, const double* y, 
   if constexpr (!M::lie) {
 #pragma unroll
     for (int i = 0; i < M::n; ++i) out[i] = y[i];
-  } else {
+  } else if constexpr (M::att == ATT_QUAT) {
     const double w = x[3], a = x[4], b = x[5], c = x[6];
     out[0] = y[0]; out[1] = y[1]; out[2] = y[2];
     out[3] = -a * y[3] + w * y[4] + c * y[5] - b * y[6];
@@ -348,10 +478,43 @@ __device__ __forceinline__ void errstate_tmul(const double* x, const double* y, 
     out[5] = -c * y[3] + b * y[4] - a * y[5] + w * y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) out[6 + i] = y[7 + i];
+  } else {
+    double D[9];
+    att_differential<M::att>(x + 3, D);
+#pragma unroll
+    for (int i = 0; i < M::n; ++i) out[i] = y[i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[3 + j] = D[j] * y[3] + D[3 + j] * y[4] + D[6 + j] * y[5];
   }
 }
 
-// dx (ne) = x (-) x0   (RD.state_diff, Cayley map)
+// out (ne) = E(x) y (n),  E(x) = d(y' ⊖ x)/dy' at y' = x: the left inverse of G(x) that maps a change of x_{k+1} to a change of
+// its error state.  Unit quaternions: G(x)' (orthonormal columns), as the reference stack has it (A_err = G(x⁺)'AG(x)); for a
+// three-parameter attitude G'G ≠ I, so the consistent Jacobian of state_diff is used: D(p)⁻¹ in closed form,
+// MRP 4 D'/(1+|p|²)², RodriguesParam (I − [g]×)/(1+|g|²).
+template <class M>
+__device__ __forceinline__ void errstate_invmul(const double* x, const double* y, double* out) {
+  if constexpr (M::att == ATT_MRP || M::att == ATT_RP) {
+#pragma unroll
+    for (int i = 0; i < M::n; ++i) out[i] = y[i];
+    const double a = x[3], b = x[4], c = x[5];
+    const double rn = rcp_fast(1.0 + (a * a + b * b + c * c));
+    if constexpr (M::att == ATT_MRP) {
+      double D[9];
+      att_differential<ATT_MRP>(x + 3, D);
+      const double f = 4.0 * rn * rn;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) out[3 + i] = f * (D[i] * y[3] + D[3 + i] * y[4] + D[6 + i] * y[5]);  // 4 D'/(1+n)² y  (row i of D' = column i of D)
+    } else {
+      out[3] = rn * (y[3] + c * y[4] - b * y[5]);   // (I − [g]×) y / (1+n)
+      out[4] = rn * (-c * y[3] + y[4] + a * y[5]);
+      out[5] = rn * (b * y[3] - a * y[4] + y[5]);
+    }
+  } else errstate_tmul<M>(x, y, out);
+}
+
+// dx (ne) = x (-) x0   (RD.state_diff, Cayley map: the Rodrigues vector of the relative rotation, vec(q0⁻¹ ⊗ q)/scalar(q0⁻¹ ⊗ q);
+// scale-invariant, so three-parameter attitudes use their unnormalised quaternions q̃ = [1−|p|², 2p] resp. [1, g])
 template <class M>
 __device__ __forceinline__ void state_diff(const double* x, const double* x0, double* dx) {
   if constexpr (!M::lie) {
@@ -360,16 +523,26 @@ __device__ __forceinline__ void state_diff(const double* x, const double* x0, do
   } else {
 #pragma unroll
     for (int i = 0; i < 3; ++i) dx[i] = x[i] - x0[i];
-    const double w0 = x0[3], a0 = x0[4], b0 = x0[5], c0 = x0[6];
-    const double w = x[3], a = x[4], b = x[5], c = x[6];
+    double w0, a0, b0, c0, w, a, b, c;
+    if constexpr (M::att == ATT_QUAT) {
+      w0 = x0[3]; a0 = x0[4]; b0 = x0[5]; c0 = x0[6];
+      w = x[3]; a = x[4]; b = x[5]; c = x[6];
+    } else if constexpr (M::att == ATT_MRP) {
+      w0 = 1.0 - (x0[3] * x0[3] + x0[4] * x0[4] + x0[5] * x0[5]); a0 = 2.0 * x0[3]; b0 = 2.0 * x0[4]; c0 = 2.0 * x0[5];
+      w = 1.0 - (x[3] * x[3] + x[4] * x[4] + x[5] * x[5]); a = 2.0 * x[3]; b = 2.0 * x[4]; c = 2.0 * x[5];
+    } else {
+      w0 = 1.0; a0 = x0[3]; b0 = x0[4]; c0 = x0[5];
+      w = 1.0; a = x[3]; b = x[4]; c = x[5];
+    }
     const double s = w0 * w + a0 * a + b0 * b + c0 * c;
     const double v1 = w0 * a - a0 * w - (b0 * c - c0 * b);
     const double v2 = w0 * b - b0 * w - (c0 * a - a0 * c);
     const double v3 = w0 * c - c0 * w - (a0 * b - b0 * a);
     const double rs = rcp_fast(s);
     dx[3] = v1 * rs; dx[4] = v2 * rs; dx[5] = v3 * rs;
+    constexpr int o = (M::att == ATT_QUAT) ? 7 : 6;  // first velocity entry of the state
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dx[6 + i] = x[7 + i] - x0[7 + i];
+    for (int i = 0; i < 6; ++i) dx[6 + i] = x[o + i] - x0[o + i];
   }
 }
 

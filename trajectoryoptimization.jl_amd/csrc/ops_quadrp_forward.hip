@@ -1,0 +1,9 @@
+// ops_quadrp_forward.hip — Quadrotor{RodriguesParam}: the two general forward-pass variants.
+#include "ops.h"
+
+namespace to {
+void fill_ops_quadrp_forward(ModelOps* t) {
+  fill_forward<QuadrotorAttModel<ATT_RP>, 8, 9>(t[6]);
+  fill_forward<QuadrotorAttModel<ATT_RP>, 10, 11>(t[6]);
+}
+}  // namespace to

@@ -81,13 +81,30 @@ __device__ __forceinline__ double quat_dot(const double* qref, const int* qind, 
 }
 
 // ------------------------------------------------------------------------------------------------ ErrorQuadratic
-// ½ dx'Q dx with dx = x ⊖ x_ref on the 13-state rigid body (src/lie_costs.jl:178-241).  Templated on the scalar: the value
-// path runs it in double, the expansion evaluates the GRADIENT in dual numbers to get exact Hessian-vector products
-// (the reference differentiates the value twice with ForwardDiff).  xr = x_ref (13), Qe = 12 error-state weights.
-template <class T>
-__device__ __forceinline__ void errquad_phi(CostC& C, const T* x, T* phi /*3*/, T* rs_out) {
-  const double w0 = C.q[3], a0 = C.q[4], b0 = C.q[5], c0 = C.q[6];
-  const T w = x[3], a = x[4], b = x[5], c = x[6];
+// ½ dx'Q dx with dx = x ⊖ x_ref on a rigid body (src/lie_costs.jl:178-241).  Templated on the scalar: the value path runs it
+// in double, the expansion evaluates the GRADIENT in dual numbers to get exact Hessian-vector products (the reference
+// differentiates the value twice with ForwardDiff).  xr = x_ref, Qe = 12 error-state weights.  The attitude of the state is a
+// unit quaternion (n = 13; ErrorQuadratic{QuatRotation}) or three parameters (n = 12): C.w names them — 0 quaternion, 1 MRP,
+// 2 RodriguesParam (ErrorQuadratic{MRP} / {RodriguesParam}) — and the error is the Rodrigues vector of the relative rotation
+// in every case (RD.state_diff with CayleyMap, hard-coded at src/lie_costs.jl:238), computed from the (unnormalised)
+// quaternion q̃ of the attitude: q itself, [1 − |p|², 2p], or [1, g].
+template <int n> struct ErrQuadLay { static constexpr int na = (n == 13) ? 4 : 3, ov = 3 + na; };  // attitude entries, first velocity entry
+template <int n, class T>
+__device__ __forceinline__ void errquad_quat(int rot, const T* xa, T* q /*4*/) {
+  if constexpr (n == 13) { q[0] = xa[0]; q[1] = xa[1]; q[2] = xa[2]; q[3] = xa[3]; }
+  else if (rot == 1) { q[0] = 1.0 - (xa[0] * xa[0] + xa[1] * xa[1] + xa[2] * xa[2]); q[1] = 2.0 * xa[0]; q[2] = 2.0 * xa[1]; q[3] = 2.0 * xa[2]; }
+  else { q[0] = T(1.0); q[1] = xa[0]; q[2] = xa[1]; q[3] = xa[2]; }
+}
+template <int n, class T>
+__device__ __forceinline__ void errquad_phi(CostC& C, const T* x, T* phi /*3*/, T* rs_out, T* q /*4*/, double* q0 /*4*/) {
+  const int rot = (int)C.w;
+  double xr[4];
+#pragma unroll
+  for (int i = 0; i < ErrQuadLay<n>::na; ++i) xr[i] = C.q[3 + i];
+  errquad_quat<n, double>(rot, xr, q0);
+  errquad_quat<n, T>(rot, x + 3, q);
+  const double w0 = q0[0], a0 = q0[1], b0 = q0[2], c0 = q0[3];
+  const T w = q[0], a = q[1], b = q[2], c = q[3];
   const T s = w0 * w + a0 * a + b0 * b + c0 * c;
   const T rs = recip_t(s);
   phi[0] = (w0 * a - a0 * w + c0 * b - b0 * c) * rs;
@@ -95,35 +112,47 @@ __device__ __forceinline__ void errquad_phi(CostC& C, const T* x, T* phi /*3*/, 
   phi[2] = (w0 * c - c0 * w + b0 * a - a0 * b) * rs;
   *rs_out = rs;
 }
-template <class T>
+template <int n, class T>
 __device__ __forceinline__ T errquad_value(CostC& C, const T* x) {
-  T phi[3], rs;
-  errquad_phi<T>(C, x, phi, &rs);
+  constexpr int ov = ErrQuadLay<n>::ov;
+  T phi[3], rs, q[4];
+  double q0[4];
+  errquad_phi<n, T>(C, x, phi, &rs, q, q0);
   T e = T(0.0);
 #pragma unroll
   for (int i = 0; i < 3; ++i) { const T d = x[i] - C.q[i]; e = e + d * C.Q[i] * d; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) e = e + phi[i] * C.Q[3 + i] * phi[i];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { const T d = x[7 + i] - C.q[7 + i]; e = e + d * C.Q[6 + i] * d; }
+  for (int i = 0; i < 6; ++i) { const T d = x[ov + i] - C.q[ov + i]; e = e + d * C.Q[6 + i] * d; }
   return 0.5 * e;
 }
-template <class T>
-__device__ __forceinline__ void errquad_grad(CostC& C, const T* x, T* g /*13*/) {
-  const double q0[4] = {C.q[3], C.q[4], C.q[5], C.q[6]};
+template <int n, class T>
+__device__ __forceinline__ void errquad_grad(CostC& C, const T* x, T* g /*n*/) {
+  constexpr int ov = ErrQuadLay<n>::ov;
+  T phi[3], rs, q[4];
+  double q0[4];
+  errquad_phi<n, T>(C, x, phi, &rs, q, q0);
   const double V[3][4] = {{-q0[1], q0[0], q0[3], -q0[2]}, {-q0[2], -q0[3], q0[0], q0[1]}, {-q0[3], q0[2], -q0[1], q0[0]}};
-  T phi[3], rs;
-  errquad_phi<T>(C, x, phi, &rs);
 #pragma unroll
   for (int i = 0; i < 3; ++i) g[i] = C.Q[i] * (x[i] - C.q[i]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) g[7 + i] = C.Q[6 + i] * (x[7 + i] - C.q[7 + i]);
+  for (int i = 0; i < 6; ++i) g[ov + i] = C.Q[6 + i] * (x[ov + i] - C.q[ov + i]);
+  T gq[4];  // gradient with respect to the (unnormalised) quaternion
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     T acc = T(0.0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc = acc + (C.Q[3 + i] * phi[i]) * (V[i][t] - phi[i] * q0[t]);
-    g[3 + t] = acc * rs;
+    gq[t] = acc * rs;
+  }
+  if constexpr (n == 13) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[3 + t] = gq[t];
+  } else {  // chain rule through q̃(p) = [1 − |p|², 2p] (MRP) or [1, g] (RodriguesParam)
+    const bool mrp = ((int)C.w == 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) g[3 + t] = mrp ? (2.0 * gq[1 + t] - (2.0 * x[3 + t]) * gq[0]) : gq[1 + t];
   }
 }
 
@@ -132,12 +161,12 @@ __device__ __forceinline__ void errquad_grad(CostC& C, const T* x, T* g /*13*/) 
 template <int n, int m, bool DENSE = true>
 __device__ __forceinline__ double cost_eval(CostC& C, const double* x, const double* u) {
   double J;
-  if constexpr (DENSE && n == 13) {
+  if constexpr (DENSE && (n == 13 || n == 12)) {
     if (C.kind == TO_COST_ERROR_QUADRATIC) {
       double uRu = 0.0, ru = 0.0;
 #pragma unroll
       for (int i = 0; i < m; ++i) { uRu += u[i] * C.R[i] * u[i]; ru += C.r[i] * u[i]; }
-      return errquad_value<double>(C, x) + C.c + (0.5 * uRu + ru);
+      return errquad_value<n, double>(C, x) + C.c + (0.5 * uRu + ru);
     }
   }
   if (DENSE && C.kind == TO_COST_QUADRATIC) {
@@ -294,12 +323,12 @@ struct StageCostLds {
 template <int n, int m, bool DENSE = true>
 __device__ __forceinline__ void cost_grad_hvp(CostC& C, const double* x, const double* u, bool terminal,
                                               const double* v, double* g, double* y) {
-  if constexpr (DENSE && n == 13) {
+  if constexpr (DENSE && (n == 13 || n == 12)) {
     if (C.kind == TO_COST_ERROR_QUADRATIC) {
       Dual xd[n], gd[n];
 #pragma unroll
       for (int i = 0; i < n; ++i) xd[i] = Dual(x[i], v[i]);
-      errquad_grad<Dual>(C, xd, gd);
+      errquad_grad<n, Dual>(C, xd, gd);
 #pragma unroll
       for (int i = 0; i < n; ++i) { g[i] = gd[i].v; y[i] = gd[i].d; }
 #pragma unroll

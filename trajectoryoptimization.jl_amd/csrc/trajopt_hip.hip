@@ -39,6 +39,8 @@ const ModelOps* model_ops(int key) {
     fill_ops_small(g_ops); fill_ops_small_forward(g_ops);
     fill_ops_quad_misc(g_ops); fill_ops_quad_expand(g_ops); fill_ops_quad_backward(g_ops);
     fill_ops_quad_forward_a(g_ops); fill_ops_quad_forward_b(g_ops); fill_ops_quad_forward_c(g_ops);
+    fill_ops_quadatt_misc(g_ops); fill_ops_quadmrp_expand(g_ops); fill_ops_quadrp_expand(g_ops);
+    fill_ops_quadmrp_forward(g_ops); fill_ops_quadrp_forward(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
 }
@@ -81,7 +83,12 @@ int model_dims(int id, const double* params, int* n, int* m, int* ne, int* key) 
       *n = 2 * D; *m = D; *ne = 2 * D; *key = D - 1; return 0;
     }
     case TO_MODEL_CARTPOLE: *n = 4; *m = 1; *ne = 4; *key = 3; return 0;
-    case TO_MODEL_QUADROTOR: *n = 13; *m = 4; *ne = 12; *key = 4; return 0;
+    case TO_MODEL_QUADROTOR: {  // params[10]: attitude representation of the state (to_rotation)
+      const int rot = (int)params[10];
+      if (rot == TO_ROT_QUATERNION) { *n = 13; *m = 4; *ne = 12; *key = 4; return 0; }
+      if (rot == TO_ROT_MRP || rot == TO_ROT_RODRIGUES) { *n = 12; *m = 4; *ne = 12; *key = rot == TO_ROT_MRP ? 5 : 6; return 0; }
+      return -1;
+    }
   }
   return -1;
 }
@@ -187,15 +194,20 @@ int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon
   return TO_OK;
 }
 
-int validate_cost(int n, const to_cost_desc& c) {
+// rot: attitude representation of the model's state (to_rotation), -1 for vector-space models
+int validate_cost(int n, int rot, const to_cost_desc& c) {
   if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT && c.kind != TO_COST_ERROR_QUADRATIC)
     return fail(TO_ERR_UNSUPPORTED, "unknown cost kind");
-  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; q(4:7); v; w]
-    if (n != 13) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model (n = 13)");
-    for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
+  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; attitude; v; w]
+    if (rot < 0) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model");
+    if ((int)c.w != rot || c.w != (double)rot) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic: w must name the model's attitude representation (to_rotation)");
+    if (rot == TO_ROT_QUATERNION)
+      for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
   }
-  if (c.kind == TO_COST_DIAGONAL_QUAT)
+  if (c.kind == TO_COST_DIAGONAL_QUAT) {
+    if (rot > TO_ROT_QUATERNION) return fail(TO_ERR_ARGUMENT, "DiagonalQuatCost needs a state that carries a unit quaternion");
     for (int i = 0; i < 4; ++i) if (c.q_ind[i] < 1 || c.q_ind[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "quat_ind outside the state");
+  }
   return TO_OK;
 }
 
@@ -346,6 +358,7 @@ int launch_forward(to_handle* h, bool accept = true) {
   int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | ((a.P.expand_variant & 5) ? 8 : 0);
   if (!h->ops->forward[mode]) mode &= ~4;  // the model does not pin RK4
   if (a.P.unit_soc && h->ops->forward[mode | 16]) mode |= 16;
+  if (!h->ops->forward[mode]) mode = (mode | 8) & ~1 & ~16;  // the general variant (any cost kind, stage cost read per knot): a superset
   if (!h->ops->forward[mode]) return fail(TO_ERR_UNSUPPORTED, "forward-pass variant not compiled for this model");
   TRY(h->ops->forward[mode](h));
   if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
@@ -574,7 +587,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     for (int k = 0; k < N - 1; ++k) dt[k] = (desc->tf - desc->t0) / (N - 1);
   }
   if (desc->n_costs < 1 || !desc->costs) return fail(TO_ERR_ARGUMENT, "objective needs at least one cost function");
-  for (int i = 0; i < desc->n_costs; ++i) TRY(validate_cost(n, desc->costs[i]));
+  const int rot = desc->model == TO_MODEL_QUADROTOR ? (int)desc->model_params[10] : -1;
+  for (int i = 0; i < desc->n_costs; ++i) TRY(validate_cost(n, rot, desc->costs[i]));
   std::vector<int> cost_index(N);
   if (desc->cost_index) {
     for (int k = 0; k < N; ++k) {
@@ -844,7 +858,7 @@ int to_get_controls_device(to_handle* h, void* dU) {
 int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
   CHECK_H(h); CHECK_P(c); TRY(use_device(h));
   if (id < 0 || id >= (int)h->costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
-  TRY(validate_cost(h->a.P.n, *c));
+  TRY(validate_cost(h->a.P.n, h->model_key >= 4 ? (int)h->a.P.mp[10] : -1, *c));
   h->costs[id] = *c;
   return upload_tables(h);
 }
