@@ -562,8 +562,14 @@ __global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
   __shared__ double lds[L::size];
   const DevProblem& P = a.P;
   const int N = P.N;
-  const int b = blockIdx.x, hw = threadIdx.x, g = hw >> 4, c = hw & 15;
-  if (b >= P.B || !a.active[b]) return;  // wave-uniform: one trajectory per wave
+  const int hw = threadIdx.x, g = hw >> 4, c = hw & 15;
+  int b = blockIdx.x;  // one trajectory per wave: number blockIdx.x of the batch, or — active-list compaction — of this step's list
+  if (a.compact) {
+    if (blockIdx.x == 0 && hw == 0) a.acount[(a.step + 1) & 1] = 0;  // the list this step's forward pass fills starts empty
+    if ((int)blockIdx.x >= a.acount[a.step & 1]) return;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + blockIdx.x];
+  }
+  if (b >= P.B || !a.active[b]) return;  // wave-uniform
   double* Cl = lds + L::oC;
   double* Gl = lds + L::oG;
   double* Sl = lds + L::oS;

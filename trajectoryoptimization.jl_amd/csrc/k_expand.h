@@ -209,19 +209,31 @@ __global__ void __launch_bounds__(64, TO_EXPAND_WAVES) k_expand(KArgs a) {
   constexpr int R = Coop<M>::R, G = Coop<M>::G;
   const int gtile = blockIdx.x, lane = threadIdx.x;
   const int g = lane / R, j = lane % R;
-  const int b = gtile * G + g;
   const DevProblem& P = a.P;
   const int N = P.N;
   const int k0 = blockIdx.y * KC;
+  // trajectory of this lane group: position gtile*G + g of the batch, or — active-list compaction (tangent-matrix layouts,
+  // which address everything by trajectory) — of this step's list, so that the waves stay full while the batch drains
+  int b;
+  bool inrange;
+  if (LAY != 0 && LAY != 3 && a.compact) {
+    const int cnt = a.acount[a.step & 1];
+    if (gtile * G >= cnt) return;  // wave-uniform
+    inrange = (gtile * G + g) < cnt;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? gtile * G + g : cnt - 1)];
+  } else {
+    b = gtile * G + g;
+    inrange = b < P.B;
+  }
   // idle lanes (padding columns, finished trajectories) compute along with EXEC full — partially masked FP64 issues
   // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
-  const bool lane_ok = b < P.B && j < nc && a.active[b];
+  const bool lane_ok = inrange && j < nc && a.active[inrange ? b : 0];
   if (__ballot(lane_ok) == 0) return;
   // Inside a solve the step accepted by the previous forward pass still sits in its candidate slot (acc != 0): the
   // expansion reads it there and writes it through to slot 0, so the separate k_accept copy (and its re-read of every
   // candidate line that any lane of a tile accepted) disappears from the iteration.  Outside a solve acc is 0.
   // (Small models only: for the Quadrotor the gathered reads cost the expansion what k_accept costs — measured.)
-  const int c = (M::accept_write_through && b < P.B) ? a.acc[b] : 0;
+  const int c = (M::accept_write_through && inrange) ? a.acc[b] : 0;
   const int tile = b >> 6, lane64 = b & 63;
   // constraint descriptors, once per wave: up to two control-block constraints go to registers; table_cons: some other
   // constraint applies to one of this wave's knots (for the usual goal constraint: only the wave at the terminal knot)

@@ -41,7 +41,7 @@ struct FwdKnot {  // nominal state/control of one knot (+ its gains row for mode
 // instruction i belongs to trajectory GL / PCS and lands at kbuf + 16 GL, i.e. the rows sit back to back in LDS
 // (row stride RSK doubles: 416 B for the Quadrotor, so the TW rows read together fall on distinct banks).
 template <class M>
-__device__ __forceinline__ void stage_gains(const double* Kt, int b0, int bmax, int TW, int k, int N, double* kbuf, int hw) {
+__device__ __forceinline__ void stage_gains(const double* Kt, int b, int TW, int k, int N, double* kbuf, int hw) {
   constexpr int RSK = Gains<M>::RSK;
   static_assert(RSK % 2 == 0, "gains rows must be whole 16-byte pieces");
   constexpr int PCS = RSK / 2;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void stage_gains(const double* Kt, int b0, int bmax, 
     int t = gl / PCS;
     const int off = gl - t * PCS;
     t = t < TW ? t : TW - 1;  // lanes past the last row re-fetch it (their LDS pieces are never read)
-    const int bt = (b0 + t) < bmax ? b0 + t : bmax;  // the last wave of a batch may reach past it
+    const int bt = __shfl(b, t);  // trajectory of row t: lane t of the wave holds it (q = 0), whatever maps lanes to trajectories
     const char* src = (const char*)(Kt + ((size_t)bt * (N - 1) + k) * RSK) + off * 16;
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)((char*)kbuf + (size_t)i0 * 16), 16, 0, 0);
   }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
-  if constexpr (KLDS) stage_gains<M>(a.Kt, b0, P.Bp - 1, TW, 0, N, kbuf, hw);
+  if constexpr (KLDS) stage_gains<M>(a.Kt, b, TW, 0, N, kbuf, hw);
   FwdKnot<M, !KLDS> nxt;
   nxt.load(Xc, Uc, pK);
   const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + RSK;  // knot k+1 of the nominal
@@ -143,7 +143,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     // must not follow the stores), then x̄_k: nothing issued here is needed before the next wait, a whole knot away
     const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
     if (k + 1 < N - 1) {
-      if constexpr (KLDS) stage_gains<M>(a.Kt, b0, P.Bp - 1, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
+      if constexpr (KLDS) stage_gains<M>(a.Kt, b, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
       nxt.load(pXn, pUn, pKn);
       if (ncs > 0) cs0.prefetch(k + 1);
       if (ncs > 1) cs1.prefetch(k + 1);
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
         atomicAdd(&a.counter[a.step], 1);
         if (a.compact) a.alist[(size_t)((a.step + 1) & 1) * P.Bp + atomicAdd(&a.acount[(a.step + 1) & 1], 1)] = b;  // next step's list
       } else {
-        settle = a.compact && acc != 0;
+        settle = a.compact && M::accept_write_through && acc != 0;  // (models without write-through run k_accept after every forward pass)
         if (!a.al_mode) { a.status[b] = st; a.active[b] = 0; }
         else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels
           a.ost[b] = st; a.oflag[b] = 1;

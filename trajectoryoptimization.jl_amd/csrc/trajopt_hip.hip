@@ -651,10 +651,11 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   // depth is 20: further in-kernel rounds cover the rest).
   {
     int cw = std::max(1, std::min(h->ops->ls_first_round, 1024 / (P.Bp / BLOCK)));  // one forward wave per SIMD (measured: C5 0.71 M it/s with 8, 0.68 M with 16)
-    // ... but never fewer than two step sizes per round for the models that search narrowly anyway (the small ones): at
-    // B = 131 072 one candidate per round ran 29.6 M trajectory-iterations/s, two 32.5 M (a second full pass costs more than
-    // the second lane)
-    if (h->ops->ls_first_round <= 4) cw = std::max(cw, std::min(2, h->ops->ls_first_round));
+    // ... the models that search narrowly anyway (the small ones: 4 step sizes) keep their full first round at every batch size:
+    // a trajectory that rejects everything offered costs its wave a second full pass, which is worse than the extra lanes —
+    // measured at B = 131 072 (fused lane path): 25.4 / 29.6 / 37.4 M trajectory-iterations/s with 1 / 2 / 4 step sizes per
+    // round (forward pass 959 -> 582 us per batch step from 2 to 4), and 18.7 -> 21.8 M at B = 32 768
+    if (h->ops->ls_first_round <= 4) cw = h->ops->ls_first_round;
     if (const char* env = std::getenv("TRAJOPT_LS_CANDIDATES")) cw = std::max(1, std::min(16, std::atoi(env)));  // tuning knob
     int lg = 0;
     while ((2 << lg) <= cw) ++lg;
@@ -716,7 +717,10 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.accp, Bp));
   TRYB(dev_alloc(h, &a.alist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.acount, 2));
-  h->compact = h->fused_lane;  // active-list compaction goes with the fused lane path (large batches of the small models);
+  // active-list compaction: the fused lane path (large batches of the small models) and the MFMA path (Quadrotor: its expansion
+  // waves hold four trajectories each and the solves end with long straggler tails — 141 batch steps for a mean of 52
+  // iterations on C3); the cooperative small-batch path is latency-bound and keeps its fixed mapping;
+  h->compact = (h->fused_lane || a.bwd_mfma) ? 1 : 0;
   if (const char* env = std::getenv("TRAJOPT_COMPACT")) if (!std::atoi(env)) h->compact = 0;  // armed only inside a solve
   TRYB(dev_alloc(h, &a.oflag, Bp)); TRYB(dev_alloc(h, &a.ost, Bp));
   TRYB(dev_alloc(h, &a.olist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.ocount, 2));
