@@ -1,0 +1,19 @@
+// Test shim: lets g++ compile the DEVICE-side model math of csrc/models.h for the host (tests/test_device_math_on_host.py).
+// The arithmetic templates there (dynamics on double / Dual / MDual, RK steps, error-state maps) contain nothing GPU-specific
+// except two hardware estimate instructions, which are replaced by exact host equivalents: the Newton steps that follow them
+// in rcp_fast / rsqrt_fast then change nothing.  Test infrastructure only.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __global__
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
+using std::fabs;
+using std::fma;
+using std::fmax;
+using std::fmin;
+using std::rint;
+using std::sqrt;
