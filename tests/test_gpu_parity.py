@@ -713,6 +713,59 @@ def test_compaction_on_the_mfma_path_is_bit_identical(hip, monkeypatch):
             monkeypatch.delenv("TRAJOPT_BACKWARD")
 
 
+def test_fused_cooperative_pass_matches_split_kernels(hip, oracle, monkeypatch):
+    """k_expand_backward_coop (small batches of the small models, diagonal cost blocks: a second wave of the workgroup expands the
+    knots the Riccati wave is about to consume, through an LDS ring — no expansion arrays in memory) against k_expand +
+    k_backward_coop (TRAJOPT_FUSED_COOP=0) and against the oracle: gains of one pass, then full solves — Cartpole iLQR on a
+    ragged batch (the first iterations of the swing-up run into regularisation restarts, which restart the whole workgroup),
+    AL with bounds + goal, a 2-D double integrator with bounds (m = 2), and a non-uniform time grid."""
+    def di2(lib):
+        model = T.DoubleIntegrator(0.8, 2)
+        n, m = model.dims()
+        xf = np.array([1.0, -2.0, 0.0, 0.0])
+        obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 10.0 * np.ones(n), xf, 21)
+        cons = T.ConstraintList(n, m, 21)
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=-1.5, u_max=1.5), range(1, 21))
+        T.add_constraint(cons, T.GoalConstraint(xf), 21)
+        dt = np.linspace(0.05, 0.15, 20); dt *= 2.0 / dt.sum()
+        p = T.Problem(model, obj, np.zeros(n), 2.0, xf=xf, constraints=cons, batch=9, lib=lib, dt=dt,
+                      options=T.SolverOptions(lib=lib, constraint_tolerance=1e-5))
+        p.set_initial_state(np.linspace(-0.5, 0.5, 9)[:, None] * np.ones((9, n)))
+        return p
+
+    # one backward pass: gains, rho, predicted decrease — the fused kernel only runs inside solves, so compare after ONE iteration
+    cases = [(lambda lib: configs.cartpole_problem(batch=130, lib=lib), T.iLQRSolver),
+             (lambda lib: BUILDERS["cartpole_con"](lib=lib), T.ALSolver),
+             (di2, T.ALSolver)]
+    for build, Solver in cases:
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("TRAJOPT_FUSED_COOP", mode)
+            p = build(hip)
+            s = Solver(p).solve()
+            res[mode] = ({k: v.copy() for k, v in s.stats.items()}, T.states(p), T.controls(p), s.batch_steps)
+        po = build(oracle)
+        so = Solver(po).solve()
+        (s1, X1, U1, n1), (s0, X0, U0, n0) = res["1"], res["0"]
+        assert n1 == n0
+        for k in ("iterations", "iterations_outer", "status"):
+            np.testing.assert_array_equal(s1[k], s0[k], err_msg=k)
+            np.testing.assert_array_equal(s1[k], so.stats[k], err_msg=k + " vs oracle")
+        assert_trajectories_close(X1, X0, 1e-6, "X")
+        assert_trajectories_close(U1, U0, 1e-6, "U")
+        assert_trajectories_close(X1, T.states(po), 1e-6, "X vs oracle")
+        assert_trajectories_close(U1, T.controls(po), 1e-6, "U vs oracle")
+        np.testing.assert_allclose(s1["cost"], so.stats["cost"], rtol=1e-6)
+    monkeypatch.setenv("TRAJOPT_FUSED_COOP", "1")
+    # a single iteration from a rough start: rho and the line-search index are integers/exact values that depend on the restarts
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=70, **kw), hip, oracle)
+    perturb_controls((ph, po), 1.0, seed=5)
+    sh, so = T.iLQRSolver(ph, iterations=3).solve(), T.iLQRSolver(po, iterations=3).solve()
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_array_equal(gh["rho"], go["rho"])
+    assert_solve_parity(sh, so, ph, po)
+
+
 def test_mfma_backward_on_small_models(hip, oracle, monkeypatch):
     """The MFMA backward pass (one wave per trajectory, tangent-matrix expansion, compact and full cost blocks) is generic
     in the model; the small models default to the cooperative kernel, so force it: m = 1 / ne = 4 (Cartpole) and

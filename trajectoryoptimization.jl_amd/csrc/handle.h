@@ -46,6 +46,7 @@ struct to_handle_s {
   int counter_len = 0;
   int cw_base = 1, tw_base = 64;  // forward-wave shape: base, and the deep one (0: none) used once the active trajectories fit
   int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
+  int fused_coop = 0;     // solve loop, cooperative path with diagonal cost blocks: one k_expand_backward_coop launch (TRAJOPT_FUSED_COOP=0 to split)
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
   int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
   int expand_lane = 1;    // lane layout: expansion by k_expand_lane (one lane per (trajectory, knot)); 0 = column-per-lane kernel (A/B knob TRAJOPT_EXPAND_LANE)
@@ -99,6 +100,7 @@ struct ModelOps {
   int (*expand)(to_handle*) = nullptr;
   int (*backward)(to_handle*) = nullptr;
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)
+  int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
 };
 

@@ -651,4 +651,304 @@ __global__ void __launch_bounds__(64) k_expand_backward_lane(KArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused expansion + cooperative Riccati
+// Small batches of the small models (C2: B = 1024) are latency-bound: a batch step is expansion (20 us, launch-bound: all
+// knots in parallel) -> cooperative backward pass (73 us: 100 sequential knots) -> forward pass (100 us), every trajectory
+// needs ~110 of them one after the other, and the chip is nearly empty.  Here the expansion leaves the critical path: a
+// workgroup of TWO waves owns the G trajectories of one column-layout group; wave 1 expands — one lane per (trajectory, knot),
+// chunk-mode dual numbers (expand_lane_knot), KB = 64/G knots per pass, walking the horizon backwards — into a double-buffered
+// LDS ring, wave 0 runs the Riccati recursion of k_backward_coop on the chunk expanded one pass earlier (a pass of the
+// expander takes 3.3 us on the Cartpole, the 8 knots it feeds take the recursion 5.6 us).  [A B], the cost blocks and the
+// gradients never exist in memory (55 of the 71 MB a C2 batch step moved).  A Cholesky failure in any trajectory restarts the
+// whole workgroup with that trajectory's larger rho; the others redo exactly what they did (deterministic), so every
+// trajectory ends with the result of its own restart sequence, as with the split kernels.
+// Diagonal cost blocks only (KArgs::h_diag) and R <= 8 lanes per trajectory: what fits the ring.
+template <class M>
+struct FusedCoop {
+  static constexpr int ne = M::ne, m = M::m, nc = ne + m, R = Coop<M>::R, G = Coop<M>::G;
+  static constexpr int KB = 64 / G;            // knots per chunk: the expander's 64 lanes = KB knots x G trajectories
+  static constexpr int EW = ne + 2;            // per (knot, trajectory, column): the column of [A B], the cost diagonal, the gradient
+  static constexpr int chunk = KB * G * R * EW;  // doubles per ring buffer
+};
+
+// one knot of the cooperative recursion for lane (g, j) — the arithmetic of k_backward_coop's loop body, operands handed in:
+// Mj = column j of [A B], Hj = column j of the cost block, gj = gradient entry.  false: Quu + rho I is not positive definite
+// (nothing has been stored for this knot).
+template <class M>
+__device__ __forceinline__ bool coop_knot(double* S_, double* Mx, double* Hu, double* Kf, double* gl, double* sl, int j, int jx, bool glive,
+                                          const double* Mj, double* Hj, double gj, double rho, double* pKk, double& dV0, double& dV1) {
+  constexpr int m = M::m, ne = M::ne, nc = ne + m, R = Coop<M>::R;
+#pragma unroll
+  for (int i = 0; i < ne; ++i) Mx[i * R + j] = Mj[i];
+  WAVE_SYNC();
+  double Tj[ne];
+#pragma unroll
+  for (int i = 0; i < ne; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < ne; ++r) t += S_[i * ne + r] * Mj[r];
+    Tj[i] = t;
+  }
+#pragma unroll
+  for (int i = 0; i < nc; ++i) {
+    double t = Hj[i];
+#pragma unroll
+    for (int r = 0; r < ne; ++r) t += Mx[r * R + i] * Tj[r];
+    Hj[i] = t;
+  }
+#pragma unroll
+  for (int r = 0; r < ne; ++r) gj += Mj[r] * sl[r];
+#pragma unroll
+  for (int r = 0; r < m; ++r) Hu[r * R + j] = Hj[ne + r];
+  gl[j] = gj;
+  WAVE_SYNC();
+  double Quu[m][m], Lc[m][m], Qu[m];
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+#pragma unroll
+    for (int q = 0; q < m; ++q) Quu[r][q] = Hu[r * R + ne + q];
+    Qu[r] = gl[ne + r];
+  }
+  bool pd_ok = true;
+  double iL[m];
+#pragma unroll
+  for (int r = 0; r < m; ++r)
+#pragma unroll
+    for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
+#pragma unroll
+  for (int q = 0; q < m; ++q) {
+    double sj = Lc[q][q];
+#pragma unroll
+    for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
+    if (!(sj > 0.0) && glive) pd_ok = false;
+    iL[q] = rsqrt_fast(sj);
+    Lc[q][q] = sj * iL[q];
+#pragma unroll
+    for (int i = q + 1; i < m; ++i) {
+      double t = Lc[i][q];
+#pragma unroll
+      for (int r = 0; r < q; ++r) t -= Lc[i][r] * Lc[q][r];
+      Lc[i][q] = t * iL[q];
+    }
+  }
+  if (!pd_ok) return false;  // same decision in every lane of the group
+  double Kj[m], dk[m];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    double col[m];
+#pragma unroll
+    for (int i = 0; i < m; ++i) col[i] = pass ? Qu[i] : Hj[ne + i];
+#pragma unroll
+    for (int i = 0; i < m; ++i) { double t = col[i];
+#pragma unroll
+      for (int r = 0; r < i; ++r) t -= Lc[i][r] * col[r];
+      col[i] = t * iL[i]; }
+#pragma unroll
+    for (int i = m - 1; i >= 0; --i) { double t = col[i];
+#pragma unroll
+      for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
+      col[i] = t * iL[i]; }
+#pragma unroll
+    for (int i = 0; i < m; ++i) { if (pass) dk[i] = -col[i]; else Kj[i] = -col[i]; }
+  }
+  if (j < ne) {
+#pragma unroll
+    for (int r = 0; r < m; ++r) { if constexpr (m > 1) Kf[r * ne + j] = Kj[r]; if (glive) pKk[r * (ne + 1) + j] = Kj[r]; }
+  }
+  if (j == 0 && glive) {
+#pragma unroll
+    for (int r = 0; r < m; ++r) pKk[r * (ne + 1) + ne] = dk[r];
+  }
+  if constexpr (m > 1) WAVE_SYNC();
+  double Snew[ne], snew = 0.0;
+  {
+    double Wj[m], qd[m];
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+      double t = Hj[ne + r], t2 = Qu[r];
+#pragma unroll
+      for (int q = 0; q < m; ++q) { t += Quu[r][q] * Kj[q]; t2 += Quu[r][q] * dk[q]; }
+      Wj[r] = t; qd[r] = t2;
+    }
+#pragma unroll
+    for (int i = 0; i < ne; ++i) {
+      double t = Hj[i];
+#pragma unroll
+      for (int r = 0; r < m; ++r) t += ((m > 1) ? Kf[r * ne + i] : -((Hu[i] * iL[0]) * iL[0])) * Wj[r];
+#pragma unroll
+      for (int r = 0; r < m; ++r) t += Hu[r * R + i] * Kj[r];
+      Snew[i] = t;
+    }
+    snew = gj;
+#pragma unroll
+    for (int r = 0; r < m; ++r) snew += Kj[r] * qd[r];
+#pragma unroll
+    for (int r = 0; r < m; ++r) snew += Hj[ne + r] * dk[r];
+#pragma unroll
+    for (int i = 0; i < ne; ++i) Mx[i * R + j] = Snew[i];
+  }
+  double dv1 = 0.0, dv2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+    dv1 += dk[r] * Qu[r];
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
+    dv2 += dk[r] * t;
+  }
+  dV0 += dv1;
+  dV1 += 0.5 * dv2;
+  WAVE_SYNC();
+  {
+    double Ss[ne];
+#pragma unroll
+    for (int i = 0; i < ne; ++i) Ss[i] = 0.5 * (Snew[i] + Mx[jx * R + i]);
+    if (j < ne) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i) S_[i * ne + j] = Ss[i];
+      sl[j] = snew;
+    }
+  }
+  WAVE_SYNC();
+  return true;
+}
+
+template <class M, int FIXED_INTEG, int VAR>
+__global__ void __launch_bounds__(128) k_expand_backward_coop(KArgs a) {
+  static_assert(!M::lie && Coop<M>::R <= 8, "fused cooperative pass: vector-space models with at most 8 directions");
+  constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, RSK = Gains<M>::RSK;
+  using F = FusedCoop<M>;
+  using L = BwdLds<M>;
+  using LL = LaneLay<M>;
+  constexpr int R = F::R, G = F::G, KB = F::KB, EW = F::EW;
+  __shared__ double ring[2 * F::chunk];
+  __shared__ double lds[G * L::stride];
+  __shared__ int restart_flag;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gtile = blockIdx.x;
+  const int nch = (N + KB - 1) / KB;  // chunk c holds knots N-1 - c*KB - kk, kk = 0..KB-1 (the horizon backwards)
+  // ---- roles.  Backward wave: lane (g, j) as in k_backward_coop.  Expander wave: lane (kk, ge) = knot kk of the chunk, trajectory ge.
+  const int g = lane / R, j = lane % R;
+  const int b = gtile * G + g;
+  const bool glive = (b < P.B) && a.active[b < P.B ? b : 0];
+  const int kk = lane / G, ge = lane % G;
+  const int be = gtile * G + ge;
+  const bool elive = (be < P.B) && a.active[be < P.B ? be : 0];
+  {  // workgroup-uniform exit: nothing to do for any of the G trajectories
+    __shared__ int any_live;
+    if (threadIdx.x == 0) any_live = 0;
+    __syncthreads();
+    if (wave == 0 && glive && j == 0) any_live = 1;
+    __syncthreads();
+    if (!any_live) return;
+  }
+  // padding columns of the ring (j >= nc) are read by the riding-along lanes of the backward wave: keep them finite
+  for (int i = threadIdx.x; i < 2 * F::chunk; i += 128) ring[i] = 0.0;
+  const int jx = j < ne ? j : ne - 1;
+  double* S_ = lds + g * L::stride + L::oS;
+  double* Mx = lds + g * L::stride + L::oM;
+  double* Hu = lds + g * L::stride + L::oH;
+  double* Kf = lds + g * L::stride + L::oK;
+  double* gl = lds + g * L::stride + L::oG;
+  double* sl = lds + g * L::stride + L::os;
+  double* pK = a.Kt + ((size_t)(b < P.B ? b : 0) * (N - 1)) * RSK;
+  double rho = a.rho[b], drho = a.drho[b];
+  double dV0 = 0.0, dV1 = 0.0;
+  bool failed = false;
+  // expander: where this lane's trajectory lives (the step accepted by the last forward pass is written through, as in k_expand)
+  const int ce = (M::accept_write_through && be < P.B) ? a.acc[be] : 0;
+  const double* Xe = X_SLOT_PTR(a, be < P.B ? be : 0, (be < P.B) ? ce : 0);
+  const double* Ue = U_SLOT_PTR(a, be < P.B ? be : 0, (be < P.B) ? ce : 0);
+  double* X0 = X_SLOT_PTR(a, be < P.B ? be : 0, 0);
+  double* U0 = U_SLOT_PTR(a, be < P.B ? be : 0, 0);
+  const int etile = (be < P.B ? be : 0) >> 6, elane = (be < P.B ? be : 0) & 63;
+  while (true) {  // one pass over the horizon; repeated when a trajectory had to raise its regularisation
+    if (threadIdx.x == 0) restart_flag = 0;
+    __syncthreads();
+    bool gstop = failed;  // this group takes no further part in the pass (it failed for good, or it asked for the restart)
+    dV0 = 0.0; dV1 = 0.0;
+    for (int s = 0; s <= nch; ++s) {
+      if (wave == 1 && s < nch) {  // ---- expand chunk s into ring[s & 1]
+        const int k = N - 1 - s * KB - kk;
+        if (k >= 0) {  // (wave-divergent only in the last chunk)
+          const bool terminal = (k == N - 1);
+          double x[n], u[m];
+#pragma unroll
+          for (int i = 0; i < n; ++i) x[i] = EL(Xe, k * n + i);
+#pragma unroll
+          for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(Ue, k * m + i);
+          if (M::accept_write_through && ce != 0 && elive) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
+            if (!terminal) {
+#pragma unroll
+              for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
+            }
+          }
+          double Mk[ne * nc], H[LL::NS], gq[nc];
+#pragma unroll
+          for (int e = 0; e < ne * nc; ++e) Mk[e] = 0.0;
+          expand_lane_knot<M, FIXED_INTEG, VAR>(a, etile, elane, k, x, u, Mk, H, gq);
+          double* dst = ring + (size_t)(s & 1) * F::chunk + ((size_t)(kk * G + ge) * R) * EW;
+#pragma unroll
+          for (int jj = 0; jj < nc; ++jj) {
+#pragma unroll
+            for (int i = 0; i < ne; ++i) dst[jj * EW + i] = Mk[i * nc + jj];
+            dst[jj * EW + ne] = (terminal && jj >= ne) ? 0.0 : H[LL::sym(jj, jj)];
+            dst[jj * EW + ne + 1] = (terminal && jj >= ne) ? 0.0 : gq[jj];
+          }
+        }
+      }
+      if (wave == 0 && s >= 1 && !gstop) {  // ---- Riccati recursion over chunk s-1
+        const double* src = ring + (size_t)((s - 1) & 1) * F::chunk;
+        for (int q = 0; q < KB; ++q) {
+          const int k = N - 1 - (s - 1) * KB - q;
+          if (k < 0) break;
+          const double* e = src + ((size_t)(q * G + g) * R + j) * EW;
+          if (k == N - 1) {  // terminal knot: S = Qxx_N, s = qx_N
+            const double hd = e[ne], s0 = e[ne + 1];
+            if (j < ne) {
+#pragma unroll
+              for (int i = 0; i < ne; ++i) S_[i * ne + j] = (i == j) ? hd : 0.0;
+              sl[j] = s0;
+            }
+            WAVE_SYNC();
+            continue;
+          }
+          double Mj[ne], Hj[nc];
+#pragma unroll
+          for (int i = 0; i < ne; ++i) Mj[i] = e[i];
+          const double hd = e[ne];
+#pragma unroll
+          for (int i = 0; i < nc; ++i) Hj[i] = (i == j) ? hd : 0.0;
+          const double gj = e[ne + 1];
+          if (!coop_knot<M>(S_, Mx, Hu, Kf, gl, sl, j, jx, glive, Mj, Hj, gj, rho, pK + (size_t)k * RSK, dV0, dV1)) {
+            reg_increase(P.opts, rho, drho);
+            if (rho > P.opts.bp_reg_max) failed = true;
+            else restart_flag = 1;  // every lane of the group writes the same value
+            gstop = true;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (restart_flag) break;  // workgroup-uniform: read after the barrier
+    }
+    if (!restart_flag) break;
+    __syncthreads();  // everybody has seen the flag before thread 0 clears it for the next pass
+  }
+  if (wave == 0) {
+    if (!failed) reg_decrease(P.opts, rho, drho);
+    if (j == 0 && glive) {
+      a.rho[b] = rho;
+      a.drho[b] = drho;
+      a.dV[b] = dV0;
+      a.dV[(size_t)P.Bp + b] = dV1;
+      a.bpfail[b] = failed ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace to

@@ -182,6 +182,28 @@ int op_expand_backward(to_handle* h) {
   return op_expand_backward_fi<M, -1>(h);
 }
 
+// small batches of the small models with diagonal cost blocks: expansion fused into the cooperative backward pass (k_expand.h)
+template <class M, int FI>
+int op_expand_backward_coop_fi(to_handle* h) {
+  if constexpr (!M::lie && Coop<M>::R <= 8 && (!M::mfma_backward || M::coop_backward)) {
+    const DevProblem& P = h->a.P;
+    const dim3 grid((P.B + h->G - 1) / h->G);
+    if (P.expand_variant == 0) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 0>), grid, dim3(128), 0, h->stream, h->a);
+    else if (P.expand_variant == 2) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 2>), grid, dim3(128), 0, h->stream, h->a);
+    else return fail(TO_ERR_UNSUPPORTED, "fused cooperative pass needs diagonal cost blocks");
+    HIPCHECK(hipGetLastError());
+    return TO_OK;
+  }
+  return fail(TO_ERR_UNSUPPORTED, "fused expansion + cooperative backward pass not compiled for this model");
+}
+template <class M>
+int op_expand_backward_coop(to_handle* h) {
+  if constexpr (M::pin_rk4) {
+    if (h->a.P.integrator == INTEG_RK4) return op_expand_backward_coop_fi<M, INTEG_RK4>(h);
+  }
+  return op_expand_backward_coop_fi<M, -1>(h);
+}
+
 // forward pass (line search + state machine) of kernel variant MODE: grid = one wave per TW = 64 / CW trajectories
 template <class M, int MODE>
 int op_forward(to_handle* h) {

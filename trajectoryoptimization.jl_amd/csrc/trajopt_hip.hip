@@ -423,9 +423,11 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       const int step = launched + c;
       a.step = step;
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 0], h->stream));
-      if (!h->fused_lane) TRY(launch_expand(h));
+      const bool fcoop = h->fused_coop && a.h_diag && (P.expand_variant == 0 || P.expand_variant == 2);
+      if (!h->fused_lane && !fcoop) TRY(launch_expand(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
       if (h->fused_lane) TRY(h->ops->expand_backward(h));  // expansion in the registers of the lane that runs the recursion
+      else if (fcoop) TRY(h->ops->expand_backward_coop(h));  // expansion by a second wave of the workgroup, through an LDS ring
       else TRY(launch_backward(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
       // forward-wave shape of this step, from the last active count the host has seen (results do not depend on it)
@@ -700,6 +702,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     if (!std::strcmp(env, "lane") && h->ops->lane_backward) { a.bwd_mfma = 0; a.bwd_lane = 1; }
   }
   if (const char* env = std::getenv("TRAJOPT_EXPAND_LANE")) h->expand_lane = std::atoi(env) != 0;
+  h->fused_coop = (!a.bwd_lane && !a.bwd_mfma && h->ops->expand_backward_coop) ? 1 : 0;  // used while the cost blocks are diagonal (KArgs::h_diag)
+  if (const char* env = std::getenv("TRAJOPT_FUSED_COOP")) if (!std::atoi(env)) h->fused_coop = 0;
   h->fused_lane = (a.bwd_lane && h->ops->expand_backward) ? 1 : 0;
   if (const char* env = std::getenv("TRAJOPT_FUSED_LANE")) if (!std::atoi(env)) h->fused_lane = 0;
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
