@@ -34,6 +34,7 @@ struct KArgs {
   // trajectory that goes on to alist[(s+1)&1]; the kernels of step s+1 take their trajectories from that list, so the waves
   // stay full while the batch drains (a 300-step Cartpole solve averages 36 % active trajectories: tile-granular skipping
   // left most lanes of most waves idle).  Which lane processes which trajectory changes nothing in its arithmetic.
+  int coop_merge; // fused cooperative pass: symmetrise the cost-to-go Hessian where it is read (coop_knot; TRAJOPT_COOP_MERGE)
   int compact;    // 1: on
   int* alist;     // [2][Bp]
   int* acount;    // [2]

@@ -674,26 +674,33 @@ struct FusedCoop {
 // one knot of the cooperative recursion for lane (g, j) — the arithmetic of k_backward_coop's loop body, operands handed in:
 // Mj = column j of [A B], Hj = column j of the cost block, gj = gradient entry.  false: Quu + rho I is not positive definite
 // (nothing has been stored for this knot).
+// merge: S_ holds the RAW cost-to-go Hessian S' of the previous knot and is symmetrised where it is read (the same expression
+// ½(S'[i][r] + S'[r][i]), so bit-identical) — one LDS exchange round per knot less than staging S' and publishing ½(S' + S'ᵀ).
 template <class M>
 __device__ __forceinline__ bool coop_knot(double* S_, double* Mx, double* Hu, double* Kf, double* gl, double* sl, int j, int jx, bool glive,
-                                          const double* Mj, double* Hj, double gj, double rho, double* pKk, double& dV0, double& dV1) {
+                                          const double* Mj, double* Hj, double gj, double rho, double* pKk, double& dV0, double& dV1, bool merge,
+                                          const double* Mring, int EWs) {
+  // Mring (merge only): the group's [A B] of this knot as it sits in the expansion ring, M[r][i] = Mring[i*EWs + r] — the other
+  // lanes' columns are read there instead of being exchanged through Mx (one more round gone)
   constexpr int m = M::m, ne = M::ne, nc = ne + m, R = Coop<M>::R;
+  if (!merge) {
 #pragma unroll
-  for (int i = 0; i < ne; ++i) Mx[i * R + j] = Mj[i];
-  WAVE_SYNC();
+    for (int i = 0; i < ne; ++i) Mx[i * R + j] = Mj[i];
+    WAVE_SYNC();
+  }
   double Tj[ne];
 #pragma unroll
   for (int i = 0; i < ne; ++i) {
     double t = 0.0;
 #pragma unroll
-    for (int r = 0; r < ne; ++r) t += S_[i * ne + r] * Mj[r];
+    for (int r = 0; r < ne; ++r) t += (merge ? 0.5 * (S_[i * ne + r] + S_[r * ne + i]) : S_[i * ne + r]) * Mj[r];
     Tj[i] = t;
   }
 #pragma unroll
   for (int i = 0; i < nc; ++i) {
     double t = Hj[i];
 #pragma unroll
-    for (int r = 0; r < ne; ++r) t += Mx[r * R + i] * Tj[r];
+    for (int r = 0; r < ne; ++r) t += (merge ? Mring[i * EWs + r] : Mx[r * R + i]) * Tj[r];
     Hj[i] = t;
   }
 #pragma unroll
@@ -784,8 +791,10 @@ __device__ __forceinline__ bool coop_knot(double* S_, double* Mx, double* Hu, do
     for (int r = 0; r < m; ++r) snew += Kj[r] * qd[r];
 #pragma unroll
     for (int r = 0; r < m; ++r) snew += Hj[ne + r] * dk[r];
+    if (!merge) {
 #pragma unroll
-    for (int i = 0; i < ne; ++i) Mx[i * R + j] = Snew[i];
+      for (int i = 0; i < ne; ++i) Mx[i * R + j] = Snew[i];
+    }
   }
   double dv1 = 0.0, dv2 = 0.0;
 #pragma unroll
@@ -798,8 +807,14 @@ __device__ __forceinline__ bool coop_knot(double* S_, double* Mx, double* Hu, do
   }
   dV0 += dv1;
   dV1 += 0.5 * dv2;
-  WAVE_SYNC();
-  {
+  WAVE_SYNC();  // every lane has read this knot's S_, Hu, Mx
+  if (merge) {  // publish the raw column; the next knot symmetrises as it reads
+    if (j < ne) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i) S_[i * ne + j] = Snew[i];
+      sl[j] = snew;
+    }
+  } else {
     double Ss[ne];
 #pragma unroll
     for (int i = 0; i < ne; ++i) Ss[i] = 0.5 * (Snew[i] + Mx[jx * R + i]);
@@ -869,16 +884,33 @@ __global__ void __launch_bounds__(128) k_expand_backward_coop(KArgs a) {
     __syncthreads();
     bool gstop = failed;  // this group takes no further part in the pass (it failed for good, or it asked for the restart)
     dV0 = 0.0; dV1 = 0.0;
+    // the expander fetches the state / control of its NEXT knot while it works on the current one: a pass that starts with a
+    // global load round trip took 7 us instead of the 3.3 us of its arithmetic, and the lock-step made the Riccati wave wait for it
+    double xq[n], uq[m];
+    if (wave == 1) {
+      const int k = N - 1 - kk;
+#pragma unroll
+      for (int i = 0; i < n; ++i) xq[i] = (k >= 0) ? EL(Xe, k * n + i) : 0.0;
+#pragma unroll
+      for (int i = 0; i < m; ++i) uq[i] = (k >= 0 && k < N - 1) ? EL(Ue, k * m + i) : 0.0;
+    }
     for (int s = 0; s <= nch; ++s) {
       if (wave == 1 && s < nch) {  // ---- expand chunk s into ring[s & 1]
         const int k = N - 1 - s * KB - kk;
+        double x[n], u[m];
+#pragma unroll
+        for (int i = 0; i < n; ++i) x[i] = xq[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) u[i] = uq[i];
+        {
+          const int kn = k - KB;  // this lane's knot in the next chunk
+#pragma unroll
+          for (int i = 0; i < n; ++i) xq[i] = (kn >= 0) ? EL(Xe, (kn >= 0 ? kn : 0) * n + i) : 0.0;
+#pragma unroll
+          for (int i = 0; i < m; ++i) uq[i] = (kn >= 0) ? EL(Ue, (kn >= 0 ? kn : 0) * m + i) : 0.0;
+        }
         if (k >= 0) {  // (wave-divergent only in the last chunk)
           const bool terminal = (k == N - 1);
-          double x[n], u[m];
-#pragma unroll
-          for (int i = 0; i < n; ++i) x[i] = EL(Xe, k * n + i);
-#pragma unroll
-          for (int i = 0; i < m; ++i) u[i] = terminal ? 0.0 : EL(Ue, k * m + i);
           if (M::accept_write_through && ce != 0 && elive) {
 #pragma unroll
             for (int i = 0; i < n; ++i) EL(X0, k * n + i) = x[i];
@@ -924,7 +956,8 @@ __global__ void __launch_bounds__(128) k_expand_backward_coop(KArgs a) {
 #pragma unroll
           for (int i = 0; i < nc; ++i) Hj[i] = (i == j) ? hd : 0.0;
           const double gj = e[ne + 1];
-          if (!coop_knot<M>(S_, Mx, Hu, Kf, gl, sl, j, jx, glive, Mj, Hj, gj, rho, pK + (size_t)k * RSK, dV0, dV1)) {
+          if (!coop_knot<M>(S_, Mx, Hu, Kf, gl, sl, j, jx, glive, Mj, Hj, gj, rho, pK + (size_t)k * RSK, dV0, dV1, a.coop_merge != 0,
+                            src + ((size_t)(q * G + g) * R) * EW, EW)) {
             reg_increase(P.opts, rho, drho);
             if (rho > P.opts.bp_reg_max) failed = true;
             else restart_flag = 1;  // every lane of the group writes the same value

@@ -704,6 +704,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_EXPAND_LANE")) h->expand_lane = std::atoi(env) != 0;
   h->fused_coop = (!a.bwd_lane && !a.bwd_mfma && h->ops->expand_backward_coop) ? 1 : 0;  // used while the cost blocks are diagonal (KArgs::h_diag)
   if (const char* env = std::getenv("TRAJOPT_FUSED_COOP")) if (!std::atoi(env)) h->fused_coop = 0;
+  a.coop_merge = 1;
+  if (const char* env = std::getenv("TRAJOPT_COOP_MERGE")) a.coop_merge = std::atoi(env) != 0;
   h->fused_lane = (a.bwd_lane && h->ops->expand_backward) ? 1 : 0;
   if (const char* env = std::getenv("TRAJOPT_FUSED_LANE")) if (!std::atoi(env)) h->fused_lane = 0;
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
