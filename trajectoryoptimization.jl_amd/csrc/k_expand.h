@@ -676,9 +676,9 @@ struct FusedCoop {
 // (nothing has been stored for this knot).
 // merge: S_ holds the RAW cost-to-go Hessian S' of the previous knot and is symmetrised where it is read (the same expression
 // ½(S'[i][r] + S'[r][i]), so bit-identical) — one LDS exchange round per knot less than staging S' and publishing ½(S' + S'ᵀ).
-template <class M>
+template <class M, bool merge>
 __device__ __forceinline__ bool coop_knot(double* S_, double* Mx, double* Hu, double* Kf, double* gl, double* sl, int j, int jx, bool glive,
-                                          const double* Mj, double* Hj, double gj, double rho, double* pKk, double& dV0, double& dV1, bool merge,
+                                          const double* Mj, double* Hj, double gj, double rho, double* pKk, double& dV0, double& dV1,
                                           const double* Mring, int EWs) {
   // Mring (merge only): the group's [A B] of this knot as it sits in the expansion ring, M[r][i] = Mring[i*EWs + r] — the other
   // lanes' columns are read there instead of being exchanged through Mx (one more round gone)
@@ -828,7 +828,7 @@ __device__ __forceinline__ bool coop_knot(double* S_, double* Mx, double* Hu, do
   return true;
 }
 
-template <class M, int FIXED_INTEG, int VAR>
+template <class M, int FIXED_INTEG, int VAR, bool MERGE>
 __global__ void __launch_bounds__(128) k_expand_backward_coop(KArgs a) {
   static_assert(!M::lie && Coop<M>::R <= 8, "fused cooperative pass: vector-space models with at most 8 directions");
   constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, RSK = Gains<M>::RSK;
@@ -956,8 +956,8 @@ __global__ void __launch_bounds__(128) k_expand_backward_coop(KArgs a) {
 #pragma unroll
           for (int i = 0; i < nc; ++i) Hj[i] = (i == j) ? hd : 0.0;
           const double gj = e[ne + 1];
-          if (!coop_knot<M>(S_, Mx, Hu, Kf, gl, sl, j, jx, glive, Mj, Hj, gj, rho, pK + (size_t)k * RSK, dV0, dV1, a.coop_merge != 0,
-                            src + ((size_t)(q * G + g) * R) * EW, EW)) {
+          if (!coop_knot<M, MERGE>(S_, Mx, Hu, Kf, gl, sl, j, jx, glive, Mj, Hj, gj, rho, pK + (size_t)k * RSK, dV0, dV1,
+                                   src + ((size_t)(q * G + g) * R) * EW, EW)) {
             reg_increase(P.opts, rho, drho);
             if (rho > P.opts.bp_reg_max) failed = true;
             else restart_flag = 1;  // every lane of the group writes the same value

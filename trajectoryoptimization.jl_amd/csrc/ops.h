@@ -188,8 +188,11 @@ int op_expand_backward_coop_fi(to_handle* h) {
   if constexpr (!M::lie && Coop<M>::R <= 8 && (!M::mfma_backward || M::coop_backward)) {
     const DevProblem& P = h->a.P;
     const dim3 grid((P.B + h->G - 1) / h->G);
-    if (P.expand_variant == 0) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 0>), grid, dim3(128), 0, h->stream, h->a);
-    else if (P.expand_variant == 2) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 2>), grid, dim3(128), 0, h->stream, h->a);
+    const bool mg = h->a.coop_merge != 0;
+    if (P.expand_variant == 0 && mg) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 0, true>), grid, dim3(128), 0, h->stream, h->a);
+    else if (P.expand_variant == 0) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 0, false>), grid, dim3(128), 0, h->stream, h->a);
+    else if (P.expand_variant == 2 && mg) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 2, true>), grid, dim3(128), 0, h->stream, h->a);
+    else if (P.expand_variant == 2) hipLaunchKernelGGL((k_expand_backward_coop<M, FI, 2, false>), grid, dim3(128), 0, h->stream, h->a);
     else return fail(TO_ERR_UNSUPPORTED, "fused cooperative pass needs diagonal cost blocks");
     HIPCHECK(hipGetLastError());
     return TO_OK;
