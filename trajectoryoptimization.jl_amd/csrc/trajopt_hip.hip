@@ -692,9 +692,9 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     int cus = 256;
     HIPB(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const long coop_waves = ((long)B + h->G - 1) / h->G;
-    // (with the expansion fused into the lane kernel the crossover moved down: measured 14.7 vs 13.9 M it/s at B = 16 384,
-    // 7.9 vs 9.9 M at B = 8 192)
-    a.bwd_lane = (h->ops->lane_backward && coop_waves >= (h->ops->expand_backward ? 2L : 3L) * 4 * cus) ? 1 : 0;
+    // (with the expansions fused into both kernels the crossover sits at ~12 000 Cartpole trajectories: measured fused lane vs
+    // fused cooperative 10.8 vs 9.9 M it/s at B = 12 288, 7.9 vs 9.3 M at B = 8 192)
+    a.bwd_lane = (h->ops->lane_backward && coop_waves >= (h->ops->expand_backward ? 6L : 12L) * cus) ? 1 : 0;
   }
   if (const char* env = std::getenv("TRAJOPT_BACKWARD")) {
     if (!std::strcmp(env, "coop") && h->ops->coop_backward) { a.bwd_mfma = 0; a.bwd_lane = 0; }
