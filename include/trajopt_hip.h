@@ -46,7 +46,7 @@ extern "C" {
 #endif
 
 /* ABI history.  1: round 1.  2: to_solver_opts::reserved1 became al_full_newton (validated: 0 or 1), new entry points
- * to_constraint_hessians, to_comm_*, to_allgather, to_allgather_stats, to_comm_shards, to_build_id; to_cost_desc gained the
+ * to_constraint_hessians, to_comm_*, to_allgather, to_allgather_stats, to_comm_shards, to_solver_path, to_build_id; to_cost_desc gained the
  * ERROR_QUADRATIC error maps.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version. */
@@ -327,6 +327,12 @@ int to_discrete_jacobian(to_handle* h, double* F);
  * event records per batch step.
  * Tuning knob (environment, read at to_create): TRAJOPT_LS_CANDIDATES = step sizes evaluated concurrently in the first
  * line-search round (default min(16, 1024 / tiles)); results do not depend on it. */
+/* Which kernels a solve on this handle runs (chosen at to_create from the model, the batch size and the cost / constraint kinds;
+ * results never depend on it).  info[0]: backward pass 0 = cooperative (R lanes per trajectory, LDS), 1 = MFMA (one wave per
+ * trajectory), 2 = lane (one lane per trajectory); info[1]: 1 = the expansion is fused into the backward-pass kernel (profile slot
+ * 0 is then empty and slot 1 covers both); info[2]: 1 = active-list compaction; info[3]: step sizes tried concurrently in the
+ * first line-search round. */
+int to_solver_path(const to_handle* h, int32_t* info /* [4] */);
 #define TO_PROFILE_SLOTS 4
 int to_set_profiling(to_handle* h, int enable);
 int to_get_profile(to_handle* h, double* kernel_ms /* [TO_PROFILE_SLOTS] */, int64_t* launches /* [TO_PROFILE_SLOTS] */);

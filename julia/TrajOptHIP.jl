@@ -509,6 +509,13 @@ function allgather_stats(p::BatchProblem)
 end
 comm_destroy!(p::BatchProblem) = check(ccall((:to_comm_destroy, lib), Cint, (Ptr{Cvoid},), p.handle))
 
+"(backward = :coop / :mfma / :lane, fused_expansion, compaction, first_round): the kernels a solve on this handle runs."
+function solver_path(p::BatchProblem)
+    info = zeros(Int32, 4)
+    check(ccall((:to_solver_path, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), p.handle, info))
+    (backward = (:coop, :mfma, :lane)[info[1] + 1], fused_expansion = info[2] != 0, compaction = info[3] != 0, first_round = Int(info[4]))
+end
+
 # ---- measurement
 set_profiling!(p::BatchProblem, on::Bool) = check(ccall((:to_set_profiling, lib), Cint, (Ptr{Cvoid}, Cint), p.handle, on))
 reset_profile!(p::BatchProblem) = check(ccall((:to_reset_profile, lib), Cint, (Ptr{Cvoid},), p.handle))
@@ -520,6 +527,6 @@ end
 
 export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, expand!, backwardpass!, forwardpass!,
     stage_costs, al_cost, dynamics_jacobians, cost_expansion, gains, cost_gradient_hessian, discrete_jacobian, duals, set_duals!,
-    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, device_count, build_id
+    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, solver_path, device_count, build_id
 
 end # module

@@ -190,6 +190,7 @@ HIP_ONLY = {
     "comm_shards": [_H, _PI, _PI, C.POINTER(C.c_int64), _PI],
     "allgather_stats": [_H, _PI, _PI, _PD],
     "comm_destroy": [_H],
+    "solver_path": [_H, _PI],
     "set_profiling": [_H, C.c_int],
     "get_profile": [_H, _PD, C.POINTER(C.c_int64)],
     "reset_profile": [_H],

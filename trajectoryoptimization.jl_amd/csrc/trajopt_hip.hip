@@ -798,6 +798,17 @@ int to_get_options(const to_handle* h, to_solver_opts* o) { CHECK_H(h); CHECK_P(
 int to_sync(to_handle* h) { CHECK_H(h); TRY(use_device(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
 void* to_stream(to_handle* h) { return h ? (void*)h->stream : nullptr; }
 
+int to_solver_path(const to_handle* h, int32_t* info) {
+  CHECK_H(h); CHECK_P(info);
+  const KArgs& a = h->a;
+  info[0] = a.bwd_mfma ? 1 : a.bwd_lane ? 2 : 0;
+  const DevProblem& P = a.P;
+  const bool fcoop = h->fused_coop && a.h_diag && (P.expand_variant == 0 || P.expand_variant == 2);
+  info[1] = (h->fused_lane || (!a.bwd_mfma && !a.bwd_lane && fcoop)) ? 1 : 0;
+  info[2] = h->compact;
+  info[3] = h->cw_base;
+  return TO_OK;
+}
 int to_set_profiling(to_handle* h, int enable) { CHECK_H(h); h->profile = enable != 0; return TO_OK; }
 int to_reset_profile(to_handle* h) {
   CHECK_H(h);
