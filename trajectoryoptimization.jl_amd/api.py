@@ -30,10 +30,10 @@ import numpy as np
 
 from . import _capi as capi
 from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, ProblemDesc,
-                    SolverOpts, SolveStats)
+                    SolverOpts, SolveStats, UnsupportedError)
 
 __all__ = [
-    "DoubleIntegrator", "Cartpole", "Quadrotor", "RK4", "RK3", "Euler",
+    "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "dims", "RK4", "RK3", "Euler",
     "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
@@ -46,7 +46,7 @@ __all__ = [
     "get_initial_state", "get_final_state", "get_trajectory", "gettimes",
     "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "solve", "iterations", "status", "max_violation",
     "evaluate_constraints", "constraint_jacobians", "sense", "upper_bound", "lower_bound", "is_bound",
-    "DimensionMismatch", "ArgumentError",
+    "DimensionMismatch", "ArgumentError", "UnsupportedError",
 ]
 
 RK4, RK3, Euler = capi.RK4, capi.RK3, capi.EULER
@@ -85,6 +85,41 @@ class _Model:
     @property
     def errstate_dim(self):
         return self.n
+
+
+def _same_model(a, b):
+    return type(a) is type(b) and a.dims() == b.dims() and getattr(a, "params", lambda: None)() == getattr(b, "params", lambda: None)()
+
+
+class DiscreteMap(_Model):
+    """A discrete map x⁺ = g(x, u) from (n, m) to ``output_dim`` states — the jump map of a hybrid model vector
+    (test/hybrid_dynamics_model.jl:14-38).  Host-side bookkeeping only: it takes part in ``dims(models)``, ``ConstraintList(models)``
+    and the ``Problem`` validation; the library has no kernel for it."""
+
+    def __init__(self, n, m, output_dim):
+        self.n, self.m, self._ny = int(n), int(m), int(output_dim)
+
+    @property
+    def output_dim(self):
+        return self._ny
+
+    def params(self):
+        return [float(self.n), float(self.m), float(self._ny)]
+
+
+def dims(models):
+    """RD.dims(models::Vector{<:DiscreteDynamics}) (src/dynamics.jl:15-31): state / control dimension at each of the N knots of
+    an (N-1)-vector of models; the last state dimension is the last model's output dimension, the last control dimension its
+    control dimension.  Raises DimensionMismatch when consecutive models do not chain."""
+    models = list(models)
+    nx = [mod.n for mod in models] + [getattr(models[-1], "output_dim", models[-1].n)]
+    nu = [mod.m for mod in models] + [models[-1].m]
+    for k, mod in enumerate(models, start=1):
+        ny = getattr(mod, "output_dim", mod.n)
+        if nx[k] != ny:
+            raise DimensionMismatch(f"Model mismatch at time step {k}. Model {k} has an output dimension of {ny} but model {k + 1} "
+                                    f"has a state dimension of {nx[k]}.")
+    return nx, nu
 
 
 class DoubleIntegrator(_Model):
@@ -323,11 +358,7 @@ class Objective:
             self.cost = [costs] * N
         else:
             self.cost = list(costs)
-        n, m = self.cost[0].n, self.cost[0].m
-        for c in self.cost:
-            if (c.n, c.m) != (n, m):
-                raise DimensionMismatch("all cost functions must share state/control dimensions")
-        self.J = np.zeros(len(self.cost))
+        self.J = np.zeros(len(self.cost))  # (dimensions may differ from knot to knot: hybrid model vectors, src/dynamics.jl:15-31)
 
     def __len__(self):
         return len(self.cost)
@@ -337,6 +368,10 @@ class Objective:
 
     def dims(self):
         return self.cost[0].n, self.cost[0].m
+
+    def knot_dims(self):
+        """RD.dims(obj): state / control dimension of the cost function at every knot (src/objective.jl:85-87)."""
+        return [c.n for c in self.cost], [c.m for c in self.cost]
 
     def _descs(self):
         """Deduplicate by identity -> (list of CostDesc, cost_index[N])."""
@@ -787,11 +822,25 @@ def _knot_range(inds, N):
 class ConstraintList:
     """src/constraint_list.jl:35-52."""
 
-    def __init__(self, n, m, N):
-        self.n, self.m, self.N = int(n), int(m), int(N)
-        self.nx, self.nu = [self.n] * N, [self.m] * N
+    def __init__(self, n, m=None, N=None):
+        """ConstraintList(n, m, N), ConstraintList(nx, nu) with one entry per knot, or ConstraintList(models)
+        (src/constraint_list.jl:35-68)."""
+        if m is None:  # ConstraintList(models)
+            nx, nu = dims(n)
+        elif N is None:  # ConstraintList(nx, nu)
+            nx, nu = [int(v) for v in n], [int(v) for v in m]
+            if len(nx) != len(nu):
+                raise DimensionMismatch("nx and nu must have one entry per knot point")
+        else:
+            nx, nu = [int(n)] * int(N), [int(m)] * int(N)
+        self.nx, self.nu, self.N = nx, nu, len(nx)
+        self.n, self.m = max(nx), max(nu)  # the uniform dimensions when every knot has the same
         self.constraints, self.inds = [], []
-        self.p = [0] * N
+        self.p = [0] * self.N
+
+    @property
+    def uniform(self):
+        return len(set(self.nx)) == 1 and len(set(self.nu)) == 1
 
     def __len__(self):
         return len(self.constraints)
@@ -806,7 +855,7 @@ class ConstraintList:
         return list(zip(self.inds, self.constraints))
 
     def copy(self):
-        c = ConstraintList(self.n, self.m, self.N)
+        c = ConstraintList(self.nx, self.nu)
         for con, (a, b) in zip(self.constraints, self.inds):
             add_constraint(c, con, (a, b))
         return c
@@ -821,8 +870,9 @@ class ConstraintList:
 def add_constraint(cons, con, inds, idx=-1):
     """add_constraint!  (src/constraint_list.jl:103-134).  ``idx`` is 1-based like the reference."""
     k1, k2 = _knot_range(inds, cons.N)
-    if not con.check_dims(cons.n, cons.m):
-        raise DimensionMismatch(f"New constraint not consistent with n={cons.n} and m={cons.m} at time step {k1}.")
+    for k in range(k1, min(k2, cons.N) + 1):  # every knot of the range, like the reference (dimensions may change along the horizon)
+        if k >= 1 and not con.check_dims(cons.nx[k - 1], cons.nu[k - 1]):
+            raise DimensionMismatch(f"New constraint not consistent with n={cons.nx[k - 1]} and m={cons.nu[k - 1]} at time step {k}.")
     assert 1 <= k1 <= k2 <= cons.N, f"Invalid inds, inds[end] must be less than number of knotpoints, {cons.N}"
     if len(cons) == 0:
         idx = -1
@@ -901,18 +951,34 @@ class Problem:
             raise TypeError("Problem(model, obj, x0, tf; xf, constraints, t0, X0, U0, dt, integration, batch, device)")
         x0, tf = args
         self._lib = lib or capi.load_hip_library()
+        # Problem(model, ...) builds N-1 copies of the model (src/problem.jl:115); Problem(models::Vector, ...) takes one model per
+        # time step, whose dimensions may change along the horizon (src/problem.jl:36-73, src/dynamics.jl:15-31)
+        models = list(model) if isinstance(model, (list, tuple)) else [model] * (len(obj) - 1)
+        if len(models) != len(obj) - 1:
+            raise AssertionError("length(models) == N-1")  # src/problem.jl:49
+        nx, nu = dims(models)
+        if np.asarray(x0).ndim == 1 and np.asarray(x0).size != nx[0]:
+            raise AssertionError("length(x0) == nx[1]")  # src/problem.jl:46
+        self.constraints = constraints if constraints is not None else ConstraintList(nx, nu)
+        if self.constraints.nx != nx:
+            raise DimensionMismatch("Constraint state dimensions don't match model")
+        if self.constraints.nu != nu:
+            raise DimensionMismatch("Constraint control dimensions don't match model")
+        nx_obj, nu_obj = obj.knot_dims()
+        if nx_obj != nx:
+            raise DimensionMismatch("Objective state dimensions don't match model.")
+        if nu_obj != nu:
+            raise DimensionMismatch("Objective control dimensions don't match model.")
+        self.models, self.nx, self.nu = models, nx, nu
+        if not all(_same_model(mod, models[0]) for mod in models) or isinstance(models[0], DiscreteMap):
+            # every check of the reference's constructor has passed; what is missing is a kernel: the library integrates ONE
+            # compiled-in model over the whole horizon
+            raise UnsupportedError(f"hybrid model vector validated (nx = {nx}, nu = {nu}), but libtrajopt_hip only has kernels for "
+                                   "uniform model vectors (one compiled-in model on every time step)")
+        model = models[0]
         self.model, self.obj = model, obj
         n, m = model.dims()
         self.n, self.m, self.N, self.B = n, m, len(obj), int(batch)
-        self.constraints = constraints if constraints is not None else ConstraintList(n, m, self.N)
-        if (self.constraints.n, self.constraints.N) != (n, self.N):
-            raise DimensionMismatch("Constraint state dimensions don't match model")
-        if self.constraints.m != m:
-            raise DimensionMismatch("Constraint control dimensions don't match model")
-        if obj.dims()[0] != n:
-            raise DimensionMismatch("Objective state dimensions don't match model.")
-        if obj.dims()[1] != m:
-            raise DimensionMismatch("Objective control dimensions don't match model.")
         self.t0, self.tf = float(t0), float(tf)
         self.xf = np.full(n, np.nan) if xf is None else _vec(xf, n, "xf")
         self.integration = integration
