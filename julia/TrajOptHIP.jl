@@ -171,8 +171,12 @@ costdesc(c::TO.QuadraticCost) = CostDesc(1, c.terminal, pad(vec(Matrix(c.Q)), MA
     pad(vec(Matrix(c.H)), MAXM * MAXN), pad(c.q, MAXN), pad(c.r, MAXM), c.c, 0.0, NOQUAT...)
 costdesc(c::TO.DiagonalQuatCost) = CostDesc(2, c.terminal, pad(diag(c.Q), MAXN * MAXN), pad(diag(c.R), MAXM * MAXM),
     pad(Float64[], MAXM * MAXN), pad(c.q, MAXN), pad(c.r, MAXM), c.c, c.w, Tuple(Float64.(c.q_ref)), Int32.(Tuple(c.q_ind)))
-costdesc(c::TO.ErrorQuadratic) = CostDesc(3, false, pad(diag(c.Q), MAXN * MAXN), pad(diag(c.R), MAXM * MAXM),
-    pad(Float64[], MAXM * MAXN), pad(c.x_ref, MAXN), pad(c.r, MAXM), c.c, 0.0, (1.0, 0.0, 0.0, 0.0), Int32.(Tuple(c.q_ind)))
+# ErrorQuadratic{Rot}: w carries to_rotation of the model's state (0 QuatRotation, 1 MRP, 2 RodriguesParam; src/lie_costs.jl:1-3,178-241)
+rotationcode(::Type{<:Rotations.QuatRotation}) = 0.0
+rotationcode(::Type{<:Rotations.MRP}) = 1.0
+rotationcode(::Type{<:Rotations.RodriguesParam}) = 2.0
+costdesc(c::TO.ErrorQuadratic{Rot}) where {Rot} = CostDesc(3, false, pad(diag(c.Q), MAXN * MAXN), pad(diag(c.R), MAXM * MAXM),
+    pad(Float64[], MAXM * MAXN), pad(c.x_ref, MAXN), pad(c.r, MAXM), c.c, rotationcode(Rot), (1.0, 0.0, 0.0, 0.0), Int32.(Tuple(c.q_ind)))
 
 # constraints (src/constraints.jl); sense codes = to_cone
 sensecode(::TO.Equality) = Int32(0)
@@ -226,7 +230,8 @@ modelid(::RobotZoo.Cartpole) = Int32(1)
 modelid(::RobotZoo.Quadrotor) = Int32(2)
 modelid(::RobotZoo.DoubleIntegrator) = Int32(0)
 modelparams(c::RobotZoo.Cartpole) = pad([c.mc, c.mp, c.l, c.g], 16)
-modelparams(q::RobotZoo.Quadrotor) = pad([q.mass, q.J[1, 1], q.J[2, 2], q.J[3, 3], q.gravity..., q.motor_dist, q.kf, q.km], 16)
+modelparams(q::RobotZoo.Quadrotor{R}) where {R} = pad([q.mass, q.J[1, 1], q.J[2, 2], q.J[3, 3], q.gravity..., q.motor_dist, q.kf, q.km,
+    rotationcode(R)], 16)   # params[10] = attitude representation of the state: Quadrotor{QuatRotation} n = 13, {MRP} / {RodriguesParam} n = 12
 modelparams(d::RobotZoo.DoubleIntegrator{N,M}) where {N,M} = pad([1.0, M], 16)
 continuous(model::RD.DiscretizedDynamics) = model.continuous_dynamics
 integratorid(::RD.DiscretizedDynamics{<:Any,<:RD.RK4}) = Int32(0)

@@ -16,5 +16,8 @@ cd "$repo"
 bid=$(python -c "import trajopt_amd as T; print(T.load_hip_library().build_id())")
 python tools/pmc_traffic.py "$out/hbm_traffic_pmc.json" "$bid" $(find "$out/fetch" "$out/write" "$out/valu" -name '*counter_collection.csv')
 cp $(find "$out/kt" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
-python bench.py "$@" --no-extra > "$out/bench.json" 2> "$out/bench.log"
+# the plain bench line quotes the traffic just measured: bench.py reads profiles/*_<workload>_b<batch>_hbm_traffic_pmc.json and
+# only accepts a file stamped with the build id of the library it loaded (PROFILE_COPY = that file name, e.g. r03_cartpole_b1024)
+if [ -n "${PROFILE_COPY:-}" ]; then cp "$out/hbm_traffic_pmc.json" "profiles/${PROFILE_COPY}_hbm_traffic_pmc.json"; fi
+python bench.py "$@" --no-extra --no-probe-sweep --throughput-probe 0 > "$out/bench.json" 2> "$out/bench.log"
 tail -c 600 "$out/bench.json"

@@ -30,11 +30,13 @@ struct KArgs {
   int* acc;       // [Bp] slot of the candidate accepted in this forward pass (0 = none): copied onto slot 0 by k_accept, or
                   //      written through by the next k_expand (M::accept_write_through)
   int* accp;      // [Bp] where that candidate sits: forward wave * 64 + hardware lane (slot_ptr)
-  // Active-list compaction (lane path of the small models, large batches): the forward pass of batch step s appends every
-  // trajectory that goes on to alist[(s+1)&1]; the kernels of step s+1 take their trajectories from that list, so the waves
-  // stay full while the batch drains (a 300-step Cartpole solve averages 36 % active trajectories: tile-granular skipping
-  // left most lanes of most waves idle).  Which lane processes which trajectory changes nothing in its arithmetic.
-  int coop_merge; // fused cooperative pass: symmetrise the cost-to-go Hessian where it is read (coop_knot; TRAJOPT_COOP_MERGE)
+  // Active-list compaction (fused lane path of the small models at large batches, MFMA path of the Quadrotor): after batch step s
+  // k_compact lists the trajectories that go on, IN INDEX ORDER, in alist[(s+1)&1]; the kernels of step s+1 take their
+  // trajectories from that list, so the waves stay full while the batch drains (tile-granular skipping left most lanes of
+  // most waves idle: C3 runs 141 batch steps for a mean of 52 iterations).  Which lane works on which trajectory changes
+  // nothing in its arithmetic.  Index order keeps neighbouring lanes on neighbouring trajectories: the nominal arrays are
+  // batch-fastest, and an arbitrary order (atomic appends) turned every nominal load into one 64-byte sector per lane (C5:
+  // forward fetch traffic x2.5).
   int compact;    // 1: on
   int* alist;     // [2][Bp]
   int* acount;    // [2]

@@ -565,7 +565,6 @@ __global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
   const int hw = threadIdx.x, g = hw >> 4, c = hw & 15;
   int b = blockIdx.x;  // one trajectory per wave: number blockIdx.x of the batch, or — active-list compaction — of this step's list
   if (a.compact) {
-    if (blockIdx.x == 0 && hw == 0) a.acount[(a.step + 1) & 1] = 0;  // the list this step's forward pass fills starts empty
     if ((int)blockIdx.x >= a.acount[a.step & 1]) return;
     b = a.alist[(size_t)(a.step & 1) * P.Bp + blockIdx.x];
   }

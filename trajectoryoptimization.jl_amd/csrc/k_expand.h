@@ -420,7 +420,6 @@ __global__ void __launch_bounds__(64) k_expand_backward_lane(KArgs a) {
   int b, inrange;
   if (a.compact) {
     const int cnt = a.acount[a.step & 1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.acount[(a.step + 1) & 1] = 0;  // the list this step's forward pass fills starts empty
     if ((int)blockIdx.x * 64 >= cnt) return;  // wave-uniform
     const int li = blockIdx.x * 64 + threadIdx.x;
     inrange = li < cnt;

@@ -332,8 +332,7 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
       }
       a.rho[b] = rho; a.drho[b] = drho;
       if (!inner_done) {
-        atomicAdd(&a.counter[a.step], 1);
-        if (a.compact) a.alist[(size_t)((a.step + 1) & 1) * P.Bp + atomicAdd(&a.acount[(a.step + 1) & 1], 1)] = b;  // next step's list
+        atomicAdd(&a.counter[a.step], 1);  // (with compaction k_compact rebuilds the list of active trajectories after this step)
       } else {
         settle = a.compact && M::accept_write_through && acc != 0;  // (models without write-through run k_accept after every forward pass)
         if (!a.al_mode) { a.status[b] = st; a.active[b] = 0; }

@@ -64,6 +64,35 @@ __global__ void k_solve_init(KArgs a, int reset_duals) {
   }
 }
 
+// Stable compaction of the active flags into alist[(step+1)&1] (ascending trajectory index) and acount[(step+1)&1].
+// ONE workgroup of 1024 threads: wave w owns the contiguous segment [w*seg, (w+1)*seg) of the batch, seg a multiple of 64;
+// pass 1 counts (ballot + popcount), a 16-entry scan in LDS gives every wave its offset, pass 2 writes the indices.
+__global__ void __launch_bounds__(1024) k_compact(KArgs a) {
+  __shared__ int wcount[16];
+  const int Bp = a.P.Bp, B = a.P.B;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seg = (((Bp + 15) / 16) + 63) / 64 * 64;
+  const int lo = wave * seg, hi = min(Bp, lo + seg);
+  int cnt = 0;
+  for (int i = lo; i < hi; i += 64) {
+    const int b = i + lane;
+    cnt += __popcll(__ballot(b < B && a.active[b] != 0));
+  }
+  if (lane == 0) wcount[wave] = cnt;
+  __syncthreads();
+  int off = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { off += (w < wave) ? wcount[w] : 0; total += wcount[w]; }
+  int* out = a.alist + (size_t)((a.step + 1) & 1) * Bp;
+  for (int i = lo; i < hi; i += 64) {
+    const int b = i + lane;
+    const bool on = b < B && a.active[b] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) out[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    off += __popcll(m);
+  }
+  if (threadIdx.x == 0) a.acount[(a.step + 1) & 1] = total;
+}
+
 __global__ void k_set_active(KArgs a, int value, int clear_bpfail) {
   TILE_LANE();
   if (b >= a.P.Bp) return;

@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(64) k_outer_finish(KArgs a) {
   a.status[b] = TO_UNSOLVED;
   a.oflag[b] = 0;
   atomicAdd(&a.counter[a.step], 1);
-  if (a.compact) a.alist[(size_t)((a.step + 1) & 1) * P.Bp + atomicAdd(&a.acount[(a.step + 1) & 1], 1)] = b;  // goes on with the next step
 }
 #undef OUTER_LANE
 

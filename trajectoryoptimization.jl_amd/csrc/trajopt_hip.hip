@@ -435,6 +435,10 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       a.CW = deep ? h->cw_deep : h->cw_base; a.TW = deep ? h->tw_deep : h->tw_base;
       TRY(launch_forward(h, !h->ops->write_through));
       if (al_mode) TRY(launch_outer(h));
+      if (a.compact) {  // the list of the trajectories that go on, for the next step's kernels
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
+        HIPCHECK(hipGetLastError());
+      }
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
     }
     HIPCHECK(hipMemcpyAsync(&h->counter_host[launched], &a.counter[launched], sizeof(int) * chunk, hipMemcpyDeviceToHost, h->stream));
