@@ -41,7 +41,8 @@ WORKLOADS = {
     "quadrotor": dict(batch=4096, N=201, solver="ilqr",
                       desc="C3 Quadrotor point-to-point iLQR (n=13,m=4,ne=12), N=201, batch=4096 per GPU"),
     "quadrotor_al": dict(batch=8192, N=201, solver="al",
-                         desc="C5 Quadrotor + GoalConstraint + NormConstraint(SOC) AL-iLQR, N=201, batch=8192 per GPU"),
+                         desc="C5 Quadrotor + GoalConstraint(xf, inds=[1,2,3,8..13]: position + velocities) + NormConstraint(SOC, |u|<=6) "
+                              "AL-iLQR, N=201, batch=8192 per GPU"),
 }
 
 
