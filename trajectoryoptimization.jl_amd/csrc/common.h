@@ -37,6 +37,7 @@ struct KArgs {
   // nothing in its arithmetic.  Index order keeps neighbouring lanes on neighbouring trajectories: the nominal arrays are
   // batch-fastest, and an arbitrary order (atomic appends) turned every nominal load into one 64-byte sector per lane (C5:
   // forward fetch traffic x2.5).
+  int coop_merge; // fused cooperative pass: symmetrise the cost-to-go Hessian where it is read (coop_knot; TRAJOPT_COOP_MERGE)
   int compact;    // 1: on
   int* alist;     // [2][Bp]
   int* acount;    // [2]
