@@ -766,6 +766,25 @@ def test_fused_cooperative_pass_matches_split_kernels(hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+def test_large_batch_compaction_two_launch_path(hip, monkeypatch):
+    """Batches beyond 16 384 trajectories build their active lists with the two-launch compaction (k_compact_count /
+    k_compact_write, index order): 20 000 Cartpole trajectories (ragged: 313 tiles, the last one partly empty) on the fused lane
+    path, 40 iterations so that part of the batch has converged and the lists have holes — bit-identical to the same solve
+    without compaction."""
+    out = []
+    for compact in ("1", "0"):
+        monkeypatch.setenv("TRAJOPT_COMPACT", compact)
+        p = configs.cartpole_problem(batch=20000, N=41, tf=2.0, lib=hip)
+        s = T.iLQRSolver(p, iterations=40).solve()
+        out.append(({k: v.copy() for k, v in s.stats.items()}, T.states(p), T.controls(p), s.batch_steps))
+    (s1, X1, U1, n1), (s0, X0, U0, n0) = out
+    assert n1 == n0 and 0 < np.mean(s1["status"] == T.capi.SOLVE_SUCCEEDED) < 1 or len(set(s1["iterations"])) > 5
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s0[k], err_msg=k)
+    np.testing.assert_array_equal(X1, X0)
+    np.testing.assert_array_equal(U1, U0)
+
+
 def test_mfma_backward_on_small_models(hip, oracle, monkeypatch):
     """The MFMA backward pass (one wave per trajectory, tangent-matrix expansion, compact and full cost blocks) is generic
     in the model; the small models default to the cooperative kernel, so force it: m = 1 / ne = 4 (Cartpole) and

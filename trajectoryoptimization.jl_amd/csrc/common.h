@@ -41,6 +41,7 @@ struct KArgs {
   int compact;    // 1: on
   int* alist;     // [2][Bp]
   int* acount;    // [2]
+  int* ccount;    // [256] per-workgroup counts of the two-launch compaction (large batches)
   double *Mc, *Hc, *gc;               // column layout (see "column layout" below): [Ā B̄], Q-function cost blocks, gradient
   double* Kt;                         // gains, trajectory-major rows: Kt[(b*(N-1) + k)*RSK + r*(ne+1) + i] = K_k[r][i], i = ne: d_k[r]
   double *Mt, *Ht, *gt;               // tangent-matrix layout of the expansion for the MFMA backward pass (k_backward.h)

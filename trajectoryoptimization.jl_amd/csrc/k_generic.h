@@ -93,6 +93,55 @@ __global__ void __launch_bounds__(1024) k_compact(KArgs a) {
   if (threadIdx.x == 0) a.acount[(a.step + 1) & 1] = total;
 }
 
+// The same for large batches, in two launches of NB workgroups (the single workgroup takes 87 us for 131 072 flags, 9 % of a
+// batch step of the large-batch sweep): k_compact_count leaves every workgroup's number of active trajectories in ccount[],
+// k_compact_write sums the counts of the workgroups before it and writes its indices.  Workgroup g owns the flags
+// [g*per, (g+1)*per), per a multiple of 1024; wave w of it the 64-aligned slices w*64 + i*1024.
+__global__ void __launch_bounds__(1024) k_compact_count(KArgs a, int per) {
+  __shared__ int wcount[16];
+  const int B = a.P.B, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = blockIdx.x * per;
+  int cnt = 0;
+  for (int i = lo + wave * 64; i < lo + per; i += 1024) {
+    const int b = i + lane;
+    cnt += __popcll(__ballot(b < B && a.active[b] != 0));
+  }
+  if (lane == 0) wcount[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wcount[w];
+    a.ccount[blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(1024) k_compact_write(KArgs a, int per) {
+  __shared__ int scount[16 * 64];  // active trajectories of slice (i, w) of this workgroup, i < per/1024 <= 64
+  __shared__ int base_s;
+  const int B = a.P.B, Bp = a.P.Bp, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = blockIdx.x * per, nsl = per / 1024;
+  for (int i = 0; i < nsl; ++i) {
+    const int b = lo + i * 1024 + wave * 64 + lane;
+    const int c = __popcll(__ballot(b < B && a.active[b] != 0));
+    if (lane == 0) scount[i * 16 + wave] = c;
+  }
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int g = 0; g < (int)blockIdx.x; ++g) t += a.ccount[g];
+    base_s = t;
+    if (blockIdx.x == gridDim.x - 1) a.acount[(a.step + 1) & 1] = t + a.ccount[blockIdx.x];
+  }
+  __syncthreads();
+  int* out = a.alist + (size_t)((a.step + 1) & 1) * Bp;
+  for (int i = 0; i < nsl; ++i) {
+    int off = base_s;  // slices are numbered (i, wave) in index order: i*16 + wave
+    for (int q = 0; q < i * 16 + wave; ++q) off += scount[q];
+    const int b = lo + i * 1024 + wave * 64 + lane;
+    const bool on = b < B && a.active[b] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) out[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+  }
+}
+
 __global__ void k_set_active(KArgs a, int value, int clear_bpfail) {
   TILE_LANE();
   if (b >= a.P.Bp) return;

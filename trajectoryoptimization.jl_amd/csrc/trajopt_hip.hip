@@ -436,7 +436,15 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       TRY(launch_forward(h, !h->ops->write_through));
       if (al_mode) TRY(launch_outer(h));
       if (a.compact) {  // the list of the trajectories that go on, for the next step's kernels
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
+        if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
+        else {  // two launches of up to 256 workgroups, each owning `per` flags (a multiple of 1024, at most 64 slices of 1024)
+          int per = ((P.Bp + 255) / 256 + 1023) / 1024 * 1024;
+          if (per > 65536) per = 65536;
+          const int nb = (P.Bp + per - 1) / per;
+          if (nb > 256) return fail(TO_ERR_UNSUPPORTED, "batch too large for the compaction kernels (16 777 216 trajectories)");
+          hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(1024), 0, h->stream, a, per);
+          hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(1024), 0, h->stream, a, per);
+        }
         HIPCHECK(hipGetLastError());
       }
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
@@ -726,7 +734,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.accp, Bp));
-  TRYB(dev_alloc(h, &a.alist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.acount, 2));
+  TRYB(dev_alloc(h, &a.alist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.acount, 2)); TRYB(dev_alloc(h, &a.ccount, 256));
   // active-list compaction: the fused lane path (large batches of the small models) and the MFMA path (Quadrotor: its expansion
   // waves hold four trajectories each and the solves end with long straggler tails — 141 batch steps for a mean of 52
   // iterations on C3); the cooperative small-batch path is latency-bound and keeps its fixed mapping;
