@@ -409,8 +409,11 @@ __global__ void __launch_bounds__(64) k_expand_lane(KArgs a) {
 // registers right before it consumes it — [A B], the cost block and the gradient never exist in memory.  What is left per
 // knot: x, u (read), the accepted step written through (5 doubles) and the gains row (5 doubles).
 // Same arithmetic, same order as k_expand_lane followed by k_backward_lane (bit-identical gains).
+#ifndef TO_FUSED_LANE_WAVES
+#define TO_FUSED_LANE_WAVES 1  // minimum waves per SIMD the fused lane kernel is compiled for (register cap 512 / waves)
+#endif
 template <class M, int FIXED_INTEG, int VAR>
-__global__ void __launch_bounds__(64) k_expand_backward_lane(KArgs a) {
+__global__ void __launch_bounds__(64, TO_FUSED_LANE_WAVES) k_expand_backward_lane(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, RSK = Gains<M>::RSK;
   using L = LaneLay<M>;
   constexpr int NS = L::NS;
