@@ -289,7 +289,7 @@ def main():
     ap.add_argument("--throughput-probe", type=int, default=-1,
                     help="also solve a batch of this size once (reported separately; default 32768 for the cartpole workload at N=1, 0 = off)")
     ap.add_argument("--no-probe-sweep", dest="probe_sweep", action="store_false",
-                    help="skip the batch sweep (2x ... 32x the probe batch) that locates the throughput plateau")
+                    help="skip the batch sweep (2x ... 64x the probe batch) that locates the throughput plateau")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate hipEvent-profiled pass (no roofline object)")
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     args = ap.parse_args()
@@ -353,7 +353,7 @@ def main():
             out["throughput_probe"] = probe_once(probe)
             if args.probe_sweep and name == "cartpole":  # where does the throughput plateau?
                 sweep = [out["throughput_probe"]]
-                for pbatch in (2 * probe, 4 * probe, 8 * probe, 16 * probe, 32 * probe):
+                for pbatch in (2 * probe, 4 * probe, 8 * probe, 16 * probe, 32 * probe, 64 * probe):
                     try:
                         sweep.append(probe_once(pbatch))
                     except Exception as e:
