@@ -252,14 +252,20 @@ end
 
 function BatchProblem(prob::TO.Problem, B::Integer; device::Integer = 0, opts::Union{Nothing,SolverOpts} = nothing)
     n, m, N = RD.dims(prob)
-    costs = unique(prob.obj.cost)
-    descs = [costdesc(c) for c in costs]
+    # distinct cost OBJECTS (identity, not value: set_LQR_goal! mutates them in place), in order of first appearance, and for
+    # every knot the 0-based position of its cost in that list (to_problem_desc.cost_index; Objective.cost src/objective.jl:28)
+    costs = Any[]
+    for c in prob.obj.cost
+        any(x -> x === c, costs) || push!(costs, c)
+    end
+    descs = CostDesc[costdesc(c) for c in costs]
     index = Int32[findfirst(c -> c === prob.obj.cost[k], costs) - 1 for k in 1:N]
-    cons = ConstraintDesc[condesc(con, inds) for (inds, con) in zip(prob.constraints)]
-    dts = Float64[z.dt for z in prob.Z[1:N-1]]
+    cons = ConstraintDesc[condesc(con, inds) for (inds, con) in zip(prob.constraints)]   # Base.zip(::ConstraintList) = zip(inds, constraints), src/constraint_list.jl:147
+    dts = Float64[prob.Z[k].dt for k in 1:N-1]
     model = prob.model[1]
     desc = ProblemDesc(TO_ABI_VERSION, modelid(continuous(model)), integratorid(model), n, m, N, B,
-        modelparams(continuous(model)), prob.Z[1].t, prob.tf, pointer(dts), length(descs), pointer(descs), pointer(index),
+        modelparams(continuous(model)), TO.get_initial_time(prob), TO.get_final_time(prob),   # src/problem.jl:186-196 (Problem has no tf field)
+        pointer(dts), length(descs), pointer(descs), pointer(index),
         length(cons), isempty(cons) ? Ptr{ConstraintDesc}(C_NULL) : pointer(cons))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve descs index cons dts begin
