@@ -212,10 +212,10 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     u0 = initial_controls_value(T, prob, name)
     n, m, N = prob.dims()
     dims = (n, m, prob.errstate_dim, N, sum(prob.constraints.p))
-    info = (C.c_int32 * 4)()
+    info = (C.c_int32 * 8)()
     prob._call("solver_path", info)
     path = {"backward": ("coop", "mfma", "lane")[info[0]], "fused_expansion": bool(info[1]), "compaction": bool(info[2]),
-            "first_round_step_sizes": int(info[3])}
+            "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4])}
     gather = None
     if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
         from trajectoryoptimization_jl_amd.distributed import TrajectoryGather

@@ -47,10 +47,11 @@ extern "C" {
 
 /* ABI history.  1: round 1.  2: to_solver_opts::reserved1 became al_full_newton (validated: 0 or 1), new entry points
  * to_constraint_hessians, to_comm_*, to_allgather, to_allgather_stats, to_comm_shards, to_solver_path, to_build_id; to_cost_desc gained the
- * ERROR_QUADRATIC error maps.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
+ * ERROR_QUADRATIC error maps.  3: TO_MODEL_HYBRID_DOUBLE_INTEGRATOR and to_knot_dims (model vectors whose dimensions change
+ * along the horizon), to_solver_path reports 8 values.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version. */
-#define TO_ABI_VERSION 2
+#define TO_ABI_VERSION 3
 
 #define TO_MAX_N 16       /* max state dimension            */
 #define TO_MAX_M 8        /* max control dimension          */
@@ -89,9 +90,16 @@ typedef enum {
 typedef enum {
   TO_MODEL_DOUBLE_INTEGRATOR = 0, /* examples/quickstart.jl:11-23; n=2D, m=D; params[0]=mass, params[1]=D (1,2,3) */
   TO_MODEL_CARTPOLE = 1,          /* docs/src/model.md:20-51; params = mc, mp, l, g                               */
-  TO_MODEL_QUADROTOR = 2          /* examples/Quadrotor.ipynb cells 4,8; params = mass, Jx,Jy,Jz, gx,gy,gz,
+  TO_MODEL_QUADROTOR = 2,         /* examples/Quadrotor.ipynb cells 4,8; params = mass, Jx,Jy,Jz, gx,gy,gz,
                                      motor_dist, kf, km, rotation (to_rotation, params[10]; 0 = the notebook's
                                      Quadrotor{QuatRotation}: n = 13)                                            */
+  TO_MODEL_HYBRID_DOUBLE_INTEGRATOR = 3 /* the model VECTOR of test/hybrid_dynamics_model.jl:14-52 (src/dynamics.jl:15-31): a 2-D double
+                                     integrator (4, 2) for the first S = params[1] time steps, a jump map (4, 2) -> 2,
+                                     x+ = [(x3 + x4)/2, (u1 + u2)/2], on step S + 1, then a 1-D double integrator (2, 1);
+                                     params[0] = mass; needs 1 <= S <= N - 2.  Stored at the largest dimensions (n = 4, m = 2):
+                                     states / controls of the narrower knots are zero-padded, costs and constraints of
+                                     those knots are given at (4, 2) with nothing on the padding (a padded control needs a
+                                     positive R entry: it then stays exactly 0).  to_knot_dims reports the live dimensions. */
 } to_model_id;
 
 /* Attitude representation R of a RigidBody{R} state (examples/Quadrotor.ipynb cell 5: "typically one of QuatRotation{T},
@@ -331,8 +339,11 @@ int to_discrete_jacobian(to_handle* h, double* F);
  * results never depend on it).  info[0]: backward pass 0 = cooperative (R lanes per trajectory, LDS), 1 = MFMA (one wave per
  * trajectory), 2 = lane (one lane per trajectory); info[1]: 1 = the expansion is fused into the backward-pass kernel (profile slot
  * 0 is then empty and slot 1 covers both); info[2]: 1 = active-list compaction; info[3]: step sizes tried concurrently in the
- * first line-search round. */
-int to_solver_path(const to_handle* h, int32_t* info /* [4] */);
+ * first line-search round; info[4]: waves per forward-pass workgroup (2: roller + accountant, k_forward2); info[5..7]: 0. */
+int to_solver_path(const to_handle* h, int32_t* info /* [8] */);
+/* Live state / control dimensions per knot, nx[N], nu[N] (RD.dims(models), src/dynamics.jl:15-31: the terminal knot carries the
+ * last model's control dimension).  (n, m) on every knot unless the model is a hybrid model vector. */
+int to_knot_dims(const to_handle* h, int32_t* nx, int32_t* nu);
 #define TO_PROFILE_SLOTS 4
 int to_set_profiling(to_handle* h, int enable);
 int to_get_profile(to_handle* h, double* kernel_ms /* [TO_PROFILE_SLOTS] */, int64_t* launches /* [TO_PROFILE_SLOTS] */);

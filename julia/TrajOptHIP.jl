@@ -20,7 +20,7 @@ const TO = TrajectoryOptimization
 const lib = get(ENV, "TRAJOPT_HIP_LIBRARY", "libtrajopt_hip")   # trajectoryoptimization.jl_amd/csrc/libtrajopt_hip.so
 
 # ------------------------------------------------------------------------------------------------ header mirrors
-const TO_ABI_VERSION = Int32(2)
+const TO_ABI_VERSION = Int32(3)
 const MAXN, MAXM, MAXP, MAXPAR, MAXIND = 16, 8, 40, 400, 48
 const PROFILE_SLOTS = 4
 
@@ -520,11 +520,27 @@ function allgather_stats(p::BatchProblem)
 end
 comm_destroy!(p::BatchProblem) = check(ccall((:to_comm_destroy, lib), Cint, (Ptr{Cvoid},), p.handle))
 
-"(backward = :coop / :mfma / :lane, fused_expansion, compaction, first_round): the kernels a solve on this handle runs."
+"(backward = :coop / :mfma / :lane, fused_expansion, compaction, first_round, forward_waves): the kernels a solve on this handle runs."
 function solver_path(p::BatchProblem)
-    info = zeros(Int32, 4)
+    info = zeros(Int32, 8)
     check(ccall((:to_solver_path, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), p.handle, info))
-    (backward = (:coop, :mfma, :lane)[info[1] + 1], fused_expansion = info[2] != 0, compaction = info[3] != 0, first_round = Int(info[4]))
+    (backward = (:coop, :mfma, :lane)[info[1] + 1], fused_expansion = info[2] != 0, compaction = info[3] != 0, first_round = Int(info[4]),
+     forward_waves = Int(info[5]))
+end
+
+"""
+    knot_dims(p) -> (nx, nu)
+
+Live state / control dimension at each of the N knots (`RD.dims(models)`, src/dynamics.jl:15-31).  `(n, m)` everywhere unless the
+handle was created for a hybrid model vector (`TO_MODEL_HYBRID_DOUBLE_INTEGRATOR`, whose states / controls are stored zero-padded at
+the largest dimensions).  A Julia host builds such a handle from the descriptor directly: model id 3, `model_params = [mass, S]`
+(S = time steps of the first model), costs / constraints of the narrower knots given at the storage dimensions with nothing on
+the padding (the Python package's `pad_cost` / `IndexedConstraint` lowering, trajectoryoptimization.jl_amd/api.py, is the recipe).
+"""
+function knot_dims(p::BatchProblem)
+    nx, nu = zeros(Int32, p.N), zeros(Int32, p.N)
+    check(ccall((:to_knot_dims, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), p.handle, nx, nu))
+    (Int.(nx), Int.(nu))
 end
 
 # ---- measurement
@@ -538,6 +554,6 @@ end
 
 export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, expand!, backwardpass!, forwardpass!,
     stage_costs, al_cost, dynamics_jacobians, cost_expansion, gains, cost_gradient_hessian, discrete_jacobian, duals, set_duals!,
-    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, solver_path, device_count, build_id
+    reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, solver_path, knot_dims, device_count, build_id
 
 end # module

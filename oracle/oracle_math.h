@@ -49,6 +49,7 @@ inline int model_dims(int id, const double* params, int* n, int* m, int* ne) {
       if (rot < TO_ROT_QUATERNION || rot > TO_ROT_RODRIGUES) return -1;
       *n = rot == TO_ROT_QUATERNION ? 13 : 12; *m = 4; *ne = 12; return 0;
     }
+    case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; return 0; /* stored at the largest (n, m) of its phases */
   }
   return -1;
 }
@@ -430,6 +431,40 @@ inline void discrete_jacobian(const Model& M, int integrator, const double* x, c
   for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
     A[i * n + j] = (i == j ? 1.0 : 0.0) + (D1x[i * n + j] + 2.0 * D2x[i * n + j] + 2.0 * D3x[i * n + j] + D4x[i * n + j]) / 6.0;
   for (int i = 0; i < n * m; ++i) Bm[i] = (D1u[i] + 2.0 * D2u[i] + 2.0 * D3u[i] + D4u[i]) / 6.0;
+}
+
+/* ---------------------------------------------------------------- model vectors (src/dynamics.jl:15-31)
+ * One time step of whatever model governs step k, and its Jacobian.  For every compiled-in model but the hybrid one this is the
+ * RK step above.  TO_MODEL_HYBRID_DOUBLE_INTEGRATOR (test/hybrid_dynamics_model.jl:14-52) stores its states / controls zero-padded
+ * at (4, 2): steps 0 .. S-1 (S = p[1]) a 2-D double integrator, step S the jump map x+ = [(x3 + x4)/2, (u1 + u2)/2] (:31-33),
+ * later steps a 1-D double integrator on (x1, x2, u1). */
+inline Model hybrid_phase(const Model& M, int D) {
+  Model S; S.id = TO_MODEL_DOUBLE_INTEGRATOR; S.n = 2 * D; S.m = D; S.ne = 2 * D;
+  std::memset(S.p, 0, sizeof(S.p)); S.p[0] = M.p[0]; S.p[1] = D;
+  return S;
+}
+inline void knot_dims(const Model& M, int k, int* nx, int* nu) { /* knot k = 0 .. N-1; RD.dims(models): the terminal knot carries the last model's control dimension */
+  *nx = M.n; *nu = M.m;
+  if (M.id == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { const int S = (int)M.p[1]; *nx = k <= S ? 4 : 2; *nu = k <= S ? 2 : 1; }
+}
+inline void knot_step(const Model& M, int integrator, int k, const double* x, const double* u, double h, double* xn) {
+  if (M.id != TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { discrete_dynamics(M, integrator, x, u, h, xn); return; }
+  const int S = (int)M.p[1];
+  if (k < S) { discrete_dynamics(hybrid_phase(M, 2), integrator, x, u, h, xn); return; }
+  xn[2] = 0.0; xn[3] = 0.0;
+  if (k == S) { xn[0] = (x[2] + x[3]) * 0.5; xn[1] = (u[0] + u[1]) * 0.5; return; }
+  discrete_dynamics(hybrid_phase(M, 1), integrator, x, u, h, xn); /* reads x[0..1], u[0]; writes xn[0..1] */
+}
+inline void knot_step_jacobian(const Model& M, int integrator, int k, const double* x, const double* u, double h, double* A, double* Bm) {
+  if (M.id != TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { discrete_jacobian(M, integrator, x, u, h, A, Bm); return; }
+  const int S = (int)M.p[1];
+  if (k < S) { discrete_jacobian(hybrid_phase(M, 2), integrator, x, u, h, A, Bm); return; }
+  std::memset(A, 0, sizeof(double) * 16); std::memset(Bm, 0, sizeof(double) * 8);
+  if (k == S) { A[0 * 4 + 2] = 0.5; A[0 * 4 + 3] = 0.5; Bm[1 * 2 + 0] = 0.5; Bm[1 * 2 + 1] = 0.5; return; }
+  double a[4], b[2];
+  discrete_jacobian(hybrid_phase(M, 1), integrator, x, u, h, a, b);
+  A[0] = a[0]; A[1] = a[1]; A[4] = a[2]; A[5] = a[3];
+  Bm[0] = b[0]; Bm[2] = b[1];
 }
 
 /* ---------------------------------------------------------------- error state */

@@ -209,6 +209,11 @@ int build_problem(const to_problem_desc* desc, const to_solver_opts* opts, Probl
   if (desc->B < 1) return fail(TO_ERR_ARGUMENT, "batch must be positive");
   if (!(desc->tf > desc->t0)) return fail(TO_ERR_ASSERTION, "Final time must be greater than initial time"); /* src/problem.jl:50 */
   if (desc->integrator < TO_RK4 || desc->integrator > TO_EULER) return fail(TO_ERR_UNSUPPORTED, "unknown integrator");
+  if (desc->model == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) {
+    const double S = desc->model_params[1];
+    if (!(S >= 1.0) || !(S <= (double)(desc->N - 2)) || S != std::floor(S))
+      return fail(TO_ERR_ARGUMENT, "hybrid double integrator: params[1] (time steps of the first model) must be an integer in 1 .. N-2");
+  }
   P->M.id = desc->model; P->M.n = n; P->M.m = m; P->M.ne = ne;
   std::memcpy(P->M.p, desc->model_params, sizeof(P->M.p));
   P->integrator = desc->integrator; P->n = n; P->m = m; P->ne = ne; P->N = desc->N; P->B = desc->B;
@@ -265,7 +270,7 @@ void rollout(const Problem& P, Traj& t) { /* src/problem.jl:334-340 */
   const int n = P.n, m = P.m;
   for (int i = 0; i < n; ++i) t.X[i] = t.x0[i];
   for (int k = 0; k < P.N - 1; ++k)
-    discrete_dynamics(P.M, P.integrator, &t.X[(size_t)k * n], &t.U[(size_t)k * m], P.dt[k], &t.X[(size_t)(k + 1) * n]);
+    knot_step(P.M, P.integrator, k, &t.X[(size_t)k * n], &t.U[(size_t)k * m], P.dt[k], &t.X[(size_t)(k + 1) * n]);
 }
 
 inline void knot_z(const Problem& P, const double* X, const double* U, int k, double* z) {
@@ -425,7 +430,7 @@ void expand(const Problem& P, Traj& t) {
   A.resize(n * n); Bf.resize(n * m); G0.resize(n * ne); G1.resize(n * ne); T1.resize(n * ne); grad.resize(nz); hess.resize(nz * nz); T2.resize(n * ne);
   for (int k = 0; k < N - 1; ++k) {
     const double* x = &t.X[(size_t)k * n]; const double* u = &t.U[(size_t)k * m];
-    discrete_jacobian(P.M, P.integrator, x, u, P.dt[k], A.data(), Bf.data());
+    knot_step_jacobian(P.M, P.integrator, k, x, u, P.dt[k], A.data(), Bf.data());
     errstate_jacobian(P.M, x, G0.data());
     errstate_left_inverse(P.M, &t.X[(size_t)(k + 1) * n], G1.data()); /* E(x_{k+1}): ne x n (= G' for unit quaternions) */
     matmul(A.data(), G0.data(), T1.data(), n, n, ne); /* A G_k : n x ne */
@@ -572,7 +577,7 @@ bool rollout_closed_loop(const Problem& P, Traj& t, double alpha) {
       ub[j] = t.U[(size_t)k * m + j] + du;
     }
     double* xn = &t.Xb[(size_t)(k + 1) * n];
-    discrete_dynamics(P.M, P.integrator, xb, ub, P.dt[k], xn);
+    knot_step(P.M, P.integrator, k, xb, ub, P.dt[k], xn);
     double mx = 0.0, mu = 0.0;
     for (int i = 0; i < n; ++i) { double a = std::fabs(xn[i]); if (!(a <= mx)) mx = a; }
     for (int j = 0; j < m; ++j) { double a = std::fabs(ub[j]); if (!(a <= mu)) mu = a; }
@@ -906,7 +911,7 @@ int oracle_discrete_jacobian(oracle_handle* h, double* F) {
   std::vector<double> A(n * n), Bf(n * m);
   for (int b = 0; b < h->P.B; ++b) for (int k = 0; k < N - 1; ++k) {
     const Traj& t = h->T[b];
-    discrete_jacobian(h->P.M, h->P.integrator, &t.X[(size_t)k * n], &t.U[(size_t)k * m], h->P.dt[k], A.data(), Bf.data());
+    knot_step_jacobian(h->P.M, h->P.integrator, k, &t.X[(size_t)k * n], &t.U[(size_t)k * m], h->P.dt[k], A.data(), Bf.data());
     size_t kb = k + (size_t)(N - 1) * b;
     for (int i = 0; i < n; ++i) {
       for (int j = 0; j < n; ++j) F[i + n * (j + nz * kb)] = A[i * n + j];
@@ -916,6 +921,11 @@ int oracle_discrete_jacobian(oracle_handle* h, double* F) {
   return TO_OK;
 }
 
+int oracle_knot_dims(const oracle_handle* h, int32_t* nx, int32_t* nu) {
+  CHECK_H(h);
+  for (int k = 0; k < h->P.N; ++k) { int a, b; knot_dims(h->P.M, k, &a, &b); nx[k] = a; nu[k] = b; }
+  return TO_OK;
+}
 int oracle_constraint_info(const oracle_handle* h, int32_t id, int32_t* p, int32_t* width, int32_t* nk, int32_t* sense) {
   CHECK_H(h);
   if (id < 0 || id >= (int)h->P.cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
@@ -1030,11 +1040,13 @@ int oracle_cone_projection_hessian(int /*device*/, int32_t cone, int32_t dim, in
 int oracle_dynamics(int32_t model, const double* params, const double* x, const double* u, double* xdot) {
   Model M; M.id = model; std::memcpy(M.p, params, sizeof(M.p));
   if (model_dims(model, params, &M.n, &M.m, &M.ne)) return fail(TO_ERR_UNSUPPORTED, "unknown model");
+  if (model == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) return fail(TO_ERR_UNSUPPORTED, "a model vector has no single continuous dynamics");
   dynamics(M, x, u, xdot); return TO_OK;
 }
 int oracle_discrete_dynamics(int32_t model, const double* params, int32_t integrator, const double* x, const double* u, double h, double* xn) {
   Model M; M.id = model; std::memcpy(M.p, params, sizeof(M.p));
   if (model_dims(model, params, &M.n, &M.m, &M.ne)) return fail(TO_ERR_UNSUPPORTED, "unknown model");
+  if (model == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) return fail(TO_ERR_UNSUPPORTED, "a model vector steps per knot (rollout)");
   discrete_dynamics(M, integrator, x, u, h, xn); return TO_OK;
 }
 int oracle_state_diff(int32_t model, const double* params, const double* x, const double* x0, double* dx) {

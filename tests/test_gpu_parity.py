@@ -1106,3 +1106,126 @@ def test_indexed_constraints_solve(hip, oracle):
     sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
     assert_solve_parity(sh, so, ph, po, rtol=1e-5)
     assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+
+
+@pytest.mark.parametrize("width", [16, 4])
+def test_two_wave_forward_pass(width, hip, oracle, monkeypatch):
+    """k_forward2 (a roller wave and an accountant wave per workgroup, an LDS ring between them) against k_forward: the same
+    expressions in the same order — equal up to the FMA contraction the compiler picks per kernel (1e-13 per pass; step indices,
+    iteration counts and statuses identical).  Constrained Quadrotor batch through the phase API (several line-search rounds with
+    the narrow shape), then full iLQR / AL solves (compaction, deep shape) against the one-wave kernel and the oracle."""
+    monkeypatch.setenv("TRAJOPT_LS_DEEP", "0")
+    monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", str(width))
+    probs = []
+    for two in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_FWD2", two)
+        o = T.SolverOptions(lib=hip, constraint_tolerance=1e-4)
+        p = configs.quadrotor_problem(batch=24, N=101, tf=5.0, constrained=True, lib=hip, options=o)
+        T.rollout(p)
+        probs.append(p)
+    later_rounds = 0
+    for it in range(36):
+        out = []
+        for p in probs:
+            if it % 15 == 14:
+                I.dual_update(p)
+            I.expand(p); I.backwardpass(p)
+            ls, J = I.forwardpass(p)
+            out.append((ls, J, T.states(p), T.controls(p)))
+        (l0, J0, X0, U0), (l1, J1, X1, U1) = out
+        np.testing.assert_array_equal(l0, l1, err_msg=f"iteration {it}")
+        np.testing.assert_allclose(J1, J0, rtol=1e-11, err_msg=f"iteration {it}")
+        np.testing.assert_allclose(X1, X0, rtol=1e-9, atol=1e-10, err_msg=f"iteration {it}")
+        np.testing.assert_allclose(U1, U0, rtol=1e-9, atol=1e-10, err_msg=f"iteration {it}")
+        later_rounds += int((l0 >= width).sum())
+    assert width == 16 or later_rounds > 20
+    monkeypatch.delenv("TRAJOPT_LS_DEEP")
+    monkeypatch.delenv("TRAJOPT_LS_CANDIDATES")
+    sols = []
+    for two in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_FWD2", two)
+        p = configs.quadrotor_problem(batch=37, N=61, tf=1.5, lib=hip)
+        s = T.iLQRSolver(p, iterations=40).solve()
+        o = T.SolverOptions(lib=hip, constraint_tolerance=1e-4)
+        pc = configs.quadrotor_problem(batch=24, N=101, tf=5.0, constrained=True, lib=hip, options=o)
+        sc = T.ALSolver(pc).solve()
+        sols.append((s.stats["iterations"], s.stats["status"], sc.stats["iterations"], sc.stats["status"],
+                     s.stats["cost"], T.states(p), T.controls(p), sc.stats["cost"], T.states(pc), T.controls(pc)))
+    for i, (x0, x1) in enumerate(zip(*sols)):
+        if i < 4:
+            np.testing.assert_array_equal(x0, x1)
+        else:
+            np.testing.assert_allclose(x1, x0, rtol=1e-6, atol=1e-7)
+    monkeypatch.setenv("TRAJOPT_FWD2", "1")
+    ph, po = pair(lambda **kw: configs.quadrotor_problem(batch=37, N=61, tf=1.5, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph, iterations=40).solve(), T.iLQRSolver(po, iterations=40).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
+@pytest.mark.parametrize("path", ["default", "lane", "split"])
+def test_hybrid_model_vector_on_gpu(path, hip, oracle, monkeypatch):
+    """SURVEY §8(f)4, test/hybrid_dynamics_model.jl: the model vector 2-D double integrator x 5 -> jump map -> 1-D double
+    integrator x 4 (TO_MODEL_HYBRID_DOUBLE_INTEGRATOR, states / controls zero-padded at (4, 2)) on every small-model kernel path:
+    fused cooperative (default), one lane per trajectory with chunk-mode duals (fused lane), and the split expansion + backward
+    kernels.  Each phase against the oracle (whose solve is pinned against a Riccati recursion at the true per-knot dimensions in
+    tests/test_hybrid_dims.py), then iLQR and AL solves; the padding must stay exactly zero."""
+    from test_hybrid_dims import hybrid_problem
+    if path == "lane":
+        monkeypatch.setenv("TRAJOPT_BACKWARD", "lane")
+    elif path == "split":
+        monkeypatch.setenv("TRAJOPT_FUSED_COOP", "0")
+    batch = 70
+    (ph, costs, x0, hyb), (po, _, _, _) = hybrid_problem(hip, batch=batch), hybrid_problem(oracle, batch=batch)
+    assert ph.knot_dims() == po.knot_dims() == (ph.nx, ph.nu)
+    rng = np.random.default_rng(2)
+    x0b = np.zeros((batch, 4)); x0b[:] = x0; x0b += 0.3 * rng.standard_normal((batch, 4))
+    U0 = 0.2 * rng.standard_normal((batch, ph.N - 1, 2)); U0[:, 6:, 1] = 0.0   # the padded control of the 1-D steps is zero by contract
+    for p in (ph, po):
+        p.set_initial_state(x0b); T.initial_controls(p, U0); T.rollout(p)
+    np.testing.assert_allclose(T.states(ph), T.states(po), rtol=1e-13, atol=1e-14)
+    np.testing.assert_array_equal(T.states(ph)[:, 6:, 2:], 0.0)
+    np.testing.assert_allclose(T.cost(ph), T.cost(po), rtol=1e-13)
+    np.testing.assert_allclose(I.discrete_jacobian(ph), I.discrete_jacobian(po), rtol=1e-12, atol=1e-14)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    (Ah, Bh), (Ao, Bo) = I.dynamics_jacobians(ph), I.dynamics_jacobians(po)
+    np.testing.assert_allclose(Ah, Ao, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(Bh, Bo, rtol=1e-12, atol=1e-14)
+    kh, ko = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(kh["K"], ko["K"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(kh["d"], ko["d"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(kh["K"][:, 6:, 1, :], 0.0)    # no feedback onto a padded control
+    np.testing.assert_array_equal(kh["d"][:, 6:, 1], 0.0)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+    np.testing.assert_array_equal(T.states(ph)[:, 6:, 2:], 0.0)
+    np.testing.assert_array_equal(T.controls(ph)[:, 6:, 1], 0.0)
+    (ph, _, _, _), (po, _, _, _) = hybrid_problem(hip, batch=batch, constrained=True), hybrid_problem(oracle, batch=batch, constrained=True)
+    for p in (ph, po):
+        p.set_initial_state(x0b)
+    assert T.num_constraints(ph) == [4, 4, 4, 4, 4, 0, 3, 3, 3, 3, 2]
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED) and np.all(sh.stats["c_max"] < 1e-6)
+    np.testing.assert_array_equal(T.controls(ph)[:, 6:, 1], 0.0)
+
+
+def test_hybrid_model_vector_large_batch_on_gpu(hip, oracle):
+    """The same model vector at a batch that takes the fused lane kernel and active-list compaction by default (B >= 12 288):
+    a sample of trajectories against the oracle."""
+    from test_hybrid_dims import hybrid_problem
+    batch = 12288 + 37
+    (ph, _, x0, _) = hybrid_problem(hip, batch=batch)
+    rng = np.random.default_rng(4)
+    x0b = np.zeros((batch, 4)); x0b[:] = x0; x0b += 0.3 * rng.standard_normal((batch, 4))
+    ph.set_initial_state(x0b)
+    sh = T.iLQRSolver(ph).solve()
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+    idx = rng.choice(batch, 64, replace=False)
+    (po, _, _, _) = hybrid_problem(oracle, batch=64)
+    po.set_initial_state(x0b[idx])
+    so = T.iLQRSolver(po).solve()
+    np.testing.assert_array_equal(sh.stats["iterations"][idx], so.stats["iterations"])
+    np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=1e-9)
+    np.testing.assert_allclose(T.states(ph)[idx], T.states(po), rtol=1e-7, atol=1e-9)

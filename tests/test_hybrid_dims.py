@@ -4,9 +4,11 @@ a jump map (4, 2) -> 2, a 1-D double integrator (2, 1) for four steps.
 
 What is built: every check the reference's constructors make — RD.dims(models) with its DimensionMismatch text,
 ConstraintList(models) / ConstraintList(nx, nu), add_constraint! against the dimensions of every knot of the range,
-num_constraints, Problem's constraint / objective / initial-state checks.  What is not: kernels.  The library integrates one
-compiled-in model over the whole horizon, so a model vector that passes all checks but is not uniform ends in UnsupportedError
-(TO_ERR_UNSUPPORTED) — stated, not silently accepted."""
+num_constraints, Problem's constraint / objective / initial-state checks — and the solve: the model vector of the reference's test
+is the per-step view of the compiled-in TO_MODEL_HYBRID_DOUBLE_INTEGRATOR (states / controls zero-padded at (4, 2), per-knot
+costs / constraints lowered by pad_cost / IndexedConstraint).  The oracle's solve is pinned here against an independent numpy
+Riccati recursion written at the TRUE per-knot dimensions (no padding anywhere); the GPU against the oracle in test_gpu_parity.py.
+A model vector that passes all checks but belongs to no compiled-in hybrid model ends in UnsupportedError, not silently."""
 import numpy as np
 import pytest
 
@@ -14,8 +16,61 @@ import trajopt_amd as T
 
 
 def hybrid_models():
+    """The reference test's vector as bare per-step models (the jump map is bookkeeping only: no compiled-in model owns it)."""
     model1, jump, model2 = T.DoubleIntegrator(1.0, 2), T.DiscreteMap(4, 2, 2), T.DoubleIntegrator(1.0, 1)
     return [model1] * 5 + [jump] + [model2] * 4, model1, model2
+
+
+def lqr_reference(steps_2d, N, dt, mass, costs, x0):
+    """Time-varying LQR at the true per-knot dimensions: exact discrete maps x+ = A_k x + B_k u (RK4 of a double integrator is its
+    exact Taylor series: A = [I hI; 0 I], B = [h²/2m I; h/m I]; the jump map is linear), backward Riccati with the linear cost
+    terms, forward rollout.  Returns the optimal X (list of arrays), U and the total cost."""
+    def di(D):
+        A = np.eye(2 * D); A[:D, D:] = dt * np.eye(D)
+        B = np.vstack([dt * dt / (2 * mass) * np.eye(D), dt / mass * np.eye(D)])
+        return A, B
+    maps = []
+    for k in range(N - 1):
+        if k < steps_2d:
+            maps.append(di(2))
+        elif k == steps_2d:
+            maps.append((np.array([[0, 0, .5, .5], [0, 0, 0, 0.]]), np.array([[0, 0], [.5, .5]])))
+        else:
+            maps.append(di(1))
+    Q = [np.diag(c.Q) for c in costs]; R = [np.diag(c.R) for c in costs]; q = [c.q for c in costs]; r = [c.r for c in costs]
+    S, s = Q[-1], q[-1]
+    K, d = [None] * (N - 1), [None] * (N - 1)
+    for k in range(N - 2, -1, -1):
+        A, B = maps[k]
+        Quu = R[k] + B.T @ S @ B; Qux = B.T @ S @ A; Qu = r[k] + B.T @ s
+        K[k] = -np.linalg.solve(Quu, Qux); d[k] = -np.linalg.solve(Quu, Qu)
+        Qxx = Q[k] + A.T @ S @ A; Qx = q[k] + A.T @ s
+        S = Qxx + K[k].T @ Quu @ K[k] + K[k].T @ Qux + Qux.T @ K[k]
+        s = Qx + K[k].T @ Quu @ d[k] + K[k].T @ Qu + Qux.T @ d[k]
+    X, U, J = [np.asarray(x0, float)], [], 0.0
+    for k in range(N - 1):
+        u = K[k] @ X[k] + d[k]
+        J += 0.5 * X[k] @ Q[k] @ X[k] + q[k] @ X[k] + 0.5 * u @ R[k] @ u + r[k] @ u + costs[k].c
+        U.append(u); X.append(maps[k][0] @ X[k] + maps[k][1] @ u)
+    J += 0.5 * X[-1] @ Q[-1] @ X[-1] + q[-1] @ X[-1] + costs[-1].c
+    return X, U, J
+
+
+def hybrid_problem(lib, batch=3, constrained=False, steps_2d=5, N=11, tf=2.0, mass=1.3):
+    hyb = T.HybridDoubleIntegrator(mass, steps_2d)
+    models = hyb.models(N)
+    nx, nu = T.dims(models)
+    rng = np.random.default_rng(5)
+    costs = [T.LQRCost(rng.uniform(0.5, 2.0, n), rng.uniform(0.05, 0.3, m), rng.uniform(-1, 1, n), rng.uniform(-0.2, 0.2, m))
+             for n, m in zip(nx, nu)]
+    cons = T.ConstraintList(models)
+    if constrained:
+        T.add_constraint(cons, T.BoundConstraint(4, 2, u_max=0.8, u_min=-0.8), range(1, steps_2d + 1))
+        T.add_constraint(cons, T.BoundConstraint(2, 1, u_max=0.6, u_min=-0.6, x_max=[10, np.inf]), range(steps_2d + 2, N))
+        T.add_constraint(cons, T.GoalConstraint(np.array([0.3, -0.2])), N)
+    x0 = np.array([0.5, -0.4, 0.2, 0.1])
+    prob = T.Problem(models, T.Objective(costs), x0, tf, constraints=cons, batch=batch, lib=lib)
+    return prob, costs, x0, hyb
 
 
 def test_dims_of_a_model_vector():
@@ -56,7 +111,7 @@ def test_problem_validation_over_a_model_vector(oracle):
     obj = T.Objective(costs)
     assert obj.knot_dims() == (nx, nu)
     x0, tf = np.zeros(4), 2.0
-    # every check passes; the missing piece is a kernel for non-uniform vectors, and the error says so
+    # every check passes; this vector's jump map belongs to no compiled-in hybrid model, and the error says so
     with pytest.raises(T.UnsupportedError, match="hybrid model vector validated"):
         T.Problem(models, obj, x0, tf, lib=oracle)
     cons = T.ConstraintList(models)
@@ -97,3 +152,65 @@ def test_a_uniform_model_vector_is_the_ordinary_problem(oracle):
     np.testing.assert_array_equal(sa.stats["iterations"], sb.stats["iterations"])
     with pytest.raises(AssertionError):                          # length(models) == N-1 (src/problem.jl:49)
         T.Problem([model] * 5, obj, np.zeros(n), 1.0, lib=oracle)
+
+
+def test_hybrid_model_vector_is_recognised():
+    hyb = T.HybridDoubleIntegrator(1.0, 5)
+    models = hyb.models(11)
+    assert T.dims(models) == ([4, 4, 4, 4, 4, 4, 2, 2, 2, 2, 2], [2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1])   # test/hybrid_dynamics_model.jl:52-54
+    assert T.HybridDoubleIntegrator.match(models) is hyb
+    assert T.HybridDoubleIntegrator.match(models[:5] + models[6:] + [models[-1]]) is None            # no jump map
+    assert T.HybridDoubleIntegrator.match(models[1:] + [models[-1]]) is None                           # jump one step early
+    other = T.HybridDoubleIntegrator(2.0, 5)
+    assert T.HybridDoubleIntegrator.match(other.models(11)[:5] + models[5:]) is None                  # another mass before the jump
+    c = T.pad_cost(T.LQRCost(np.array([2.0, 3.0]), np.array([0.5]), np.array([1.0, -1.0])), 4, 2)
+    assert list(c.Q) == [2, 3, 0, 0] and list(c.R) == [0.5, 1.0] and list(c.q) == [-2, 3, 0, 0] and list(c.r) == [0, 0]
+
+
+def test_hybrid_solve_on_the_oracle_equals_per_knot_riccati(oracle):
+    """Unconstrained: the problem is linear-quadratic, so iLQR lands on the LQR optimum in one full step.  The oracle runs on the
+    zero-padded (4, 2) vectors; the reference solution is computed at the true dimensions (4, 2) -> jump -> (2, 1)."""
+    prob, costs, x0, hyb = hybrid_problem(oracle)
+    assert prob.hybrid and prob.knot_dims() == (prob.nx, prob.nu)
+    assert T.num_constraints(prob) == [0] * 11
+    sol = T.iLQRSolver(prob).solve()
+    assert np.all(sol.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+    Xr, Ur, Jr = lqr_reference(hyb.steps_2d, prob.N, prob.tf / (prob.N - 1), hyb.mass, costs, x0)
+    X, U = T.states(prob), T.controls(prob)
+    for k in range(prob.N):
+        nk = prob.nx[k]
+        np.testing.assert_allclose(X[0, k, :nk], Xr[k], rtol=1e-9, atol=1e-11, err_msg=f"knot {k + 1}")
+        np.testing.assert_array_equal(X[:, k, nk:], 0.0)          # padding stays exactly zero
+    for k in range(prob.N - 1):
+        mk = prob.nu[k]
+        np.testing.assert_allclose(U[0, k, :mk], Ur[k], rtol=1e-9, atol=1e-11, err_msg=f"step {k + 1}")
+        np.testing.assert_array_equal(U[:, k, mk:], 0.0)
+    # padded controls carry R = 1 and stay at 0, so the padded objective equals the true one
+    np.testing.assert_allclose(sol.stats["cost"], Jr, rtol=1e-11)
+    # dynamics Jacobians at the jump: A = [0 0 .5 .5; 0...], B = [0 0; .5 .5] in the padded layout
+    from trajopt_amd import internal as I
+    I.expand(prob)
+    A, B = I.dynamics_jacobians(prob)
+    np.testing.assert_array_equal(A[0, 5], np.array([[0, 0, .5, .5], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]]))
+    np.testing.assert_array_equal(B[0, 5], np.array([[0, 0], [.5, .5], [0, 0], [0, 0]]))
+    np.testing.assert_array_equal(A[0, 7][2:], 0.0)
+    np.testing.assert_array_equal(B[0, 7][:, 1], 0.0)
+
+
+def test_hybrid_al_solve_on_the_oracle(oracle):
+    """Bounds on both sides of the jump and a terminal goal at the reduced dimension (test/hybrid_dynamics_model.jl:84-94):
+    num_constraints as in the reference, the AL solve converges, active bounds hold, padding stays zero."""
+    prob, costs, x0, hyb = hybrid_problem(oracle, constrained=True)
+    assert T.num_constraints(prob) == [4, 4, 4, 4, 4, 0, 3, 3, 3, 3, 2]                                # :94
+    sol = T.ALSolver(prob).solve()
+    assert np.all(sol.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+    assert np.all(sol.stats["c_max"] < 1e-6)
+    X, U = T.states(prob), T.controls(prob)
+    np.testing.assert_allclose(X[:, -1, :2], [[0.3, -0.2]] * prob.B, atol=1e-6)
+    assert np.all(np.abs(U[:, :5]) <= 0.8 + 1e-6) and np.all(np.abs(U[:, 6:, 0]) <= 0.6 + 1e-6)
+    assert np.any(np.abs(U[:, :5]) > 0.8 - 1e-4)          # a bound is active: the unconstrained optimum violates it
+    np.testing.assert_array_equal(X[:, 6:, 2:], 0.0)
+    np.testing.assert_array_equal(U[:, 6:, 1], 0.0)
+    # evaluate_constraints on the reduced-dimension bound: rows [x1 max; u1 max; u1 min]
+    vals = T.evaluate_constraints(prob, 1)
+    np.testing.assert_allclose(vals[0, 0], [X[0, 6, 0] - 10.0, U[0, 6, 0] - 0.6, -0.6 - U[0, 6, 0]], rtol=1e-12, atol=1e-14)

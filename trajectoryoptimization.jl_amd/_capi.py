@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-TO_ABI_VERSION = 2
+TO_ABI_VERSION = 3
 TO_MAX_N, TO_MAX_M, TO_MAX_P = 16, 8, 40
 TO_MAX_CON_PARAMS, TO_MAX_CON_INDS = 400, 48
 
@@ -26,7 +26,7 @@ TO_ERR_HIP, TO_ERR_UNSUPPORTED, TO_ERR_NULL, TO_ERR_CONE = -4, -5, -6, -7
 (UNSOLVED, LINESEARCH_FAIL, SOLVE_SUCCEEDED, MAX_ITERATIONS, MAX_ITERATIONS_OUTER, MAXIMUM_COST,
  STATE_LIMIT, CONTROL_LIMIT, NO_PROGRESS, COST_INCREASE, REGULARIZATION_MAX) = range(11)
 
-MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR = 0, 1, 2
+MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_HYBRID_DOUBLE_INTEGRATOR = 0, 1, 2, 3
 RK4, RK3, EULER = 0, 1, 2
 COST_DIAGONAL, COST_QUADRATIC, COST_DIAGONAL_QUAT, COST_ERROR_QUADRATIC = 0, 1, 2, 3
 CONE_ZERO, CONE_NEGATIVE_ORTHANT, CONE_SECOND_ORDER, CONE_POSITIVE_ORTHANT, CONE_IDENTITY = range(5)
@@ -170,6 +170,7 @@ SIGNATURES = {
     "constraint_jacobians": [_H, C.c_int32, _PD],
     "constraint_hessians": [_H, C.c_int32, _PD, _PD],
     "constraint_info": [_H, C.c_int32, _PI, _PI, _PI, _PI],
+    "knot_dims": [_H, _PI, _PI],
     "max_violation": [_H, _PD],
     "get_duals": [_H, C.c_int32, _PD, _PD],
     "set_duals": [_H, C.c_int32, _PD, _PD],

@@ -33,7 +33,7 @@ from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, 
                     SolverOpts, SolveStats, UnsupportedError)
 
 __all__ = [
-    "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "dims", "RK4", "RK3", "Euler",
+    "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "HybridDoubleIntegrator", "pad_cost", "dims", "RK4", "RK3", "Euler",
     "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
@@ -93,11 +93,13 @@ def _same_model(a, b):
 
 class DiscreteMap(_Model):
     """A discrete map x⁺ = g(x, u) from (n, m) to ``output_dim`` states — the jump map of a hybrid model vector
-    (test/hybrid_dynamics_model.jl:14-38).  Host-side bookkeeping only: it takes part in ``dims(models)``, ``ConstraintList(models)``
-    and the ``Problem`` validation; the library has no kernel for it."""
+    (test/hybrid_dynamics_model.jl:14-38).  On its own it is host-side bookkeeping (``dims(models)``, ``ConstraintList(models)``,
+    the ``Problem`` validation); the map itself is compiled into the library as part of a hybrid model (``HybridDoubleIntegrator``),
+    which hands out its jump map through ``.models(N)``."""
 
-    def __init__(self, n, m, output_dim):
+    def __init__(self, n, m, output_dim, hybrid=None):
         self.n, self.m, self._ny = int(n), int(m), int(output_dim)
+        self.hybrid = hybrid  # the compiled-in hybrid model this map belongs to (None: bookkeeping only)
 
     @property
     def output_dim(self):
@@ -134,6 +136,64 @@ class DoubleIntegrator(_Model):
 
     def params(self):
         return [self.mass, float(self.D)]
+
+
+class HybridDoubleIntegrator(_Model):
+    """The model vector of test/hybrid_dynamics_model.jl:14-52 as ONE compiled-in model (TO_MODEL_HYBRID_DOUBLE_INTEGRATOR): a 2-D
+    double integrator (4, 2) for ``steps_2d`` time steps, the jump map (4, 2) -> 2, x⁺ = [(x₃ + x₄)/2, (u₁ + u₂)/2], then a 1-D
+    double integrator (2, 1).  ``models(N)`` is the reference-shaped (N-1)-vector of per-step models to build ``ConstraintList``,
+    ``Objective`` and ``Problem`` from; ``Problem`` recognises it, stores states / controls zero-padded at (4, 2) and lowers the
+    per-knot costs and constraints onto the padded vectors (``pad_cost``, ``IndexedConstraint``)."""
+    model_id = capi.MODEL_HYBRID_DOUBLE_INTEGRATOR
+    n, m = 4, 2
+
+    def __init__(self, mass=1.0, steps_2d=5):
+        self.mass, self.steps_2d = float(mass), int(steps_2d)
+        if self.steps_2d < 1:
+            raise ArgumentError("HybridDoubleIntegrator needs at least one 2-D time step")
+        self._first, self._second = DoubleIntegrator(self.mass, 2), DoubleIntegrator(self.mass, 1)
+        self.jump = DiscreteMap(4, 2, 2, hybrid=self)
+
+    def params(self):
+        return [self.mass, float(self.steps_2d)]
+
+    def models(self, N):
+        """One model per time step for an N-knot horizon (N - 1 entries)."""
+        rest = N - 2 - self.steps_2d
+        if rest < 0:
+            raise ArgumentError("horizon too short for the jump map: N >= steps_2d + 2")
+        return [self._first] * self.steps_2d + [self.jump] + [self._second] * rest
+
+    @staticmethod
+    def match(models):
+        """The HybridDoubleIntegrator whose ``models(N)`` equals this model vector, or None."""
+        jumps = [k for k, mod in enumerate(models) if isinstance(mod, DiscreteMap)]
+        if len(jumps) != 1 or not isinstance(models[jumps[0]].hybrid, HybridDoubleIntegrator):
+            return None
+        hyb = models[jumps[0]].hybrid
+        want = hyb.models(len(models) + 1) if len(models) >= hyb.steps_2d + 1 else None
+        if want is None or jumps[0] != hyb.steps_2d:
+            return None
+        return hyb if all(_same_model(a, b) for a, b in zip(models, want)) else None
+
+
+def pad_cost(cost, n, m):
+    """The cost function of a knot with live dimensions (cost.n, cost.m) on the zero-padded (n, m) vectors of a hybrid model:
+    nothing on padded states; a padded control gets R = 1 and no linear term, so its feedforward and feedback gains are exactly
+    zero and it stays at 0 (a zero R entry would make Quu singular)."""
+    n0, m0 = cost.n, cost.m
+    if (n0, m0) == (n, m):
+        return cost
+    if n0 > n or m0 > m:
+        raise DimensionMismatch("cost dimensions exceed the padded model dimensions")
+    if cost.kind not in (capi.COST_DIAGONAL, capi.COST_QUADRATIC):
+        raise UnsupportedError("only DiagonalCost / QuadraticCost can be padded onto a hybrid model's storage dimensions")
+    q, r = np.r_[cost.q, np.zeros(n - n0)], np.r_[cost.r, np.zeros(m - m0)]
+    if cost.kind == capi.COST_DIAGONAL:
+        return DiagonalCost(np.r_[cost.Q, np.zeros(n - n0)], np.r_[cost.R, np.ones(m - m0)], q, r, cost.c, terminal=cost.terminal)
+    Q, R, H = np.zeros((n, n)), np.eye(m), np.zeros((m, n))
+    Q[:n0, :n0], R[:m0, :m0], H[:m0, :n0] = cost.Q, cost.R, cost.H
+    return QuadraticCost(Q, R, H, q, r, cost.c, terminal=cost.terminal)
 
 
 class Cartpole(_Model):
@@ -970,12 +1030,30 @@ class Problem:
         if nu_obj != nu:
             raise DimensionMismatch("Objective control dimensions don't match model.")
         self.models, self.nx, self.nu = models, nx, nu
+        self.hybrid = False
         if not all(_same_model(mod, models[0]) for mod in models) or isinstance(models[0], DiscreteMap):
-            # every check of the reference's constructor has passed; what is missing is a kernel: the library integrates ONE
-            # compiled-in model over the whole horizon
-            raise UnsupportedError(f"hybrid model vector validated (nx = {nx}, nu = {nu}), but libtrajopt_hip only has kernels for "
-                                   "uniform model vectors (one compiled-in model on every time step)")
-        model = models[0]
+            # every check of the reference's constructor has passed.  The library integrates ONE compiled-in model over the whole
+            # horizon; a model vector runs when it is the per-step view of a compiled-in HYBRID model (models.h, model_step)
+            model = HybridDoubleIntegrator.match(models)
+            if model is None:
+                raise UnsupportedError(f"hybrid model vector validated (nx = {nx}, nu = {nu}), but libtrajopt_hip has no compiled-in "
+                                       "hybrid model with these per-step models (HybridDoubleIntegrator.models(N) is one)")
+            self.hybrid = True
+            n, m = model.dims()
+            # costs and constraints of the narrower knots onto the zero-padded storage vectors
+            padded = {}
+            obj_lowered = Objective([padded.setdefault(id(c), pad_cost(c, n, m)) for c in obj.cost])
+            cons_lowered = ConstraintList(n, m, len(obj))
+            for inds, con in self.constraints.zip():
+                k1 = _knot_range(inds, len(obj))[0]
+                n0, m0 = nx[k1 - 1], nu[k1 - 1]
+                if (n0, m0) != (n, m) and not (isinstance(con, GoalConstraint) and n0 == n):
+                    con = IndexedConstraint(n, m, con, ix=(1, n0), iu=(1, m0))
+                add_constraint(cons_lowered, con, inds)
+            x0 = np.asarray(x0, dtype=np.float64)
+            x0 = np.concatenate([x0, np.zeros(x0.shape[:-1] + (n - nx[0],))], axis=-1) if nx[0] < n else x0
+        else:
+            model, obj_lowered, cons_lowered = models[0], obj, self.constraints
         self.model, self.obj = model, obj
         n, m = model.dims()
         self.n, self.m, self.N, self.B = n, m, len(obj), int(batch)
@@ -984,11 +1062,12 @@ class Problem:
         self.integration = integration
         self._dt = None if dt is None else np.ascontiguousarray(_vec(dt, self.N - 1, "dt"))
 
-        uniq, index = obj._descs()
+        uniq, index = obj_lowered._descs()
+        self._obj_lowered, self._cons_lowered = obj_lowered, cons_lowered
         self._cost_objs = uniq
         self._costs = (CostDesc * len(uniq))(*[c._desc() for c in uniq])
         self._cost_index = (C.c_int32 * self.N)(*index)
-        self._cons = self.constraints._descs()
+        self._cons = cons_lowered._descs()
         d = ProblemDesc()
         d.abi_version, d.model, d.integrator = capi.TO_ABI_VERSION, model.model_id, integration
         d.n, d.m, d.N, d.B = n, m, self.N, self.B
@@ -997,17 +1076,26 @@ class Problem:
         d.t0, d.tf = self.t0, self.tf
         d.dt = self._dt.ctypes.data_as(C.POINTER(C.c_double)) if self._dt is not None else None
         d.n_costs, d.costs, d.cost_index = len(uniq), self._costs, self._cost_index
-        d.n_constraints = len(self.constraints)
+        d.n_constraints = len(cons_lowered)
         d.constraints = self._cons
         self._desc = d
         self._h = C.c_void_p()
         opts = options._o if isinstance(options, SolverOptions) else options
         self._lib.call("create", C.byref(d), C.byref(opts) if opts is not None else None, int(device), C.byref(self._h))
+        knx, knu = self.knot_dims()
+        if (knx, knu) != (nx, nu):  # the library's own view of the model vector (to_knot_dims) against RD.dims(models)
+            raise DimensionMismatch(f"library knot dimensions {knx}, {knu} differ from dims(models) = {nx}, {nu}")
         self.set_initial_state(x0)
         if U0 is not None:
             initial_controls(self, U0)
         if X0 is not None:
             initial_states(self, X0)
+
+    def knot_dims(self):
+        """Live (state, control) dimension at each knot as the library sees them (to_knot_dims; RD.dims(models))."""
+        nx, nu = (C.c_int32 * self.N)(), (C.c_int32 * self.N)()
+        self._call("knot_dims", nx, nu)
+        return list(nx), list(nu)
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -46,6 +46,7 @@ struct to_handle_s {
   int counter_len = 0;
   int cw_base = 1, tw_base = 64;  // forward-wave shape: base, and the deep one (0: none) used once the active trajectories fit
   int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
+  int fwd2 = 0;           // forward pass as two-wave workgroups (roller + accountant, k_forward2; TRAJOPT_FWD2=0/1)
   int fused_coop = 0;     // solve loop, cooperative path with diagonal cost blocks: one k_expand_backward_coop launch (TRAJOPT_FUSED_COOP=0 to split)
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
   int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
@@ -102,11 +103,12 @@ struct ModelOps {
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)
   int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
+  int (*forward2[32])(to_handle*) = {};  // the same variants as two-wave workgroups (k_forward2; models with LDS-staged gains)
 };
 
 // each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole,
-// 4 Quadrotor, 5 Quadrotor{MRP}, 6 Quadrotor{RodriguesParam})
-constexpr int N_MODEL_KEYS = 7;
+// 4 Quadrotor, 5 Quadrotor{MRP}, 6 Quadrotor{RodriguesParam}, 7 hybrid double integrator)
+constexpr int N_MODEL_KEYS = 8;
 void fill_ops_small(ModelOps* table);
 void fill_ops_small_forward(ModelOps* table);
 void fill_ops_quad_misc(ModelOps* table);
@@ -115,11 +117,15 @@ void fill_ops_quad_backward(ModelOps* table);
 void fill_ops_quad_forward_a(ModelOps* table);
 void fill_ops_quad_forward_b(ModelOps* table);
 void fill_ops_quad_forward_c(ModelOps* table);
+void fill_ops_quad_forward2_a(ModelOps* table);
+void fill_ops_quad_forward2_b(ModelOps* table);
+void fill_ops_quad_forward2_c(ModelOps* table);
 void fill_ops_quadatt_misc(ModelOps* table);
 void fill_ops_quadmrp_expand(ModelOps* table);
 void fill_ops_quadrp_expand(ModelOps* table);
 void fill_ops_quadmrp_forward(ModelOps* table);
 void fill_ops_quadrp_forward(ModelOps* table);
+void fill_ops_hybrid(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

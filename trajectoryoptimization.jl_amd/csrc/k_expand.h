@@ -63,7 +63,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
     for (int i = 0; i < n; ++i) xd[i] = Dual(x[i], v[i]);
 #pragma unroll
     for (int i = 0; i < m; ++i) ud[i] = Dual(u[i], v[n + i]);
-    rk_step<M, Dual, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+    model_step<M, Dual, FIXED_INTEG>(P.mp, P.integrator, k, xd, ud, P.dt[k], xn);
     double t[n], col[ne];
 #pragma unroll
     for (int i = 0; i < n; ++i) t[i] = xn[i].d;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int l
     for (int i = 0; i < n; ++i) { xd[i].v = x[i]; xd[i].d[i] = 1.0; }
 #pragma unroll
     for (int i = 0; i < m; ++i) { ud[i].v = u[i]; ud[i].d[ne + i] = 1.0; }
-    rk_step<M, MDual<nc>, FIXED_INTEG>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+    model_step<M, MDual<nc>, FIXED_INTEG>(P.mp, P.integrator, k, xd, ud, P.dt[k], xn);
 #pragma unroll
     for (int i = 0; i < ne; ++i)
 #pragma unroll

@@ -183,7 +183,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
       } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1);
     }
     J += Jk;
-    rk_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, xb, ub, h, xn);
+    model_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, k, xb, ub, h, xn);
     double mx = 0.0, mu_ = 0.0;
 #pragma unroll
     for (int i = 0; i < n; ++i) { xb[i] = xn[i]; const double v = fabs(xn[i]); if (!(v <= mx)) mx = v; }
@@ -225,70 +225,13 @@ __device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int
   return gs / (N - 1);
 }
 
-// Forward pass of one iLQR iteration.  grid = Bp / TW waves.  Line search: round r evaluates step sizes r*CW .. r*CW+CW-1
-// concurrently (one per lane group) and takes the FIRST accepted one — identical to sequential backtracking
-// (SURVEY.md row S2); then — when a.control — the per-trajectory solver state machine runs: convergence test (row S3)
-// and the hand-over to the AL outer update (row S4, k_outer_*).
-template <class M, int MODE>
-__global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
-  extern __shared__ double kbuf[];  // M::lds_gains: two buffers of gains_lds_doubles(TW)
+// End of a forward pass, one lane per trajectory (q == 0): failed-search regularisation, the solver state machine (rows S3, S4)
+// and — with active-list compaction — the settling of accepted steps of trajectories that leave the plain iteration path.
+template <class M>
+__device__ __forceinline__ void forward_finish(const KArgs& a, int tile, int lane, int b, int hw, int q, int t, int TW, bool act, bool bpfail,
+                                               bool zero_step, int accepted, int acc, double Jprev, double Jnew, double grad) {
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
-  const int hw = threadIdx.x;
-  const int CW = a.CW, TW = a.TW;
-  const int q = hw / TW, t = hw - q * TW;      // lanes with q >= CW (64 is not a multiple of TW) ride along without a candidate
-  const int b0 = blockIdx.x * TW;
-  // trajectory of this lane: position b0 + t of the batch, or — with active-list compaction — of this step's list
-  int b, inrange;
-  if (a.compact) {
-    const int cnt = a.acount[a.step & 1];
-    if (b0 >= cnt) return;  // wave-uniform
-    inrange = (b0 + t) < cnt;
-    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? b0 + t : cnt - 1)];
-  } else {
-    inrange = (b0 + t) < P.B;
-    b = (b0 + t) < P.Bp ? b0 + t : P.Bp - 1;  // clamped: the last wave may reach past the batch
-  }
-  const int tile = b >> 6, lane = b & 63;
-  // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
-  // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
-  // predicated.  The wave leaves only when no lane needs anything.
-  const bool act = inrange && a.active[b] != 0;
-  if (__ballot(act) == 0) return;
-  const bool bpfail = act && a.bpfail[b] != 0;
-  const int total = o.iterations_linesearch;
-  const double Jprev = a.J[b];
-  const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
-  // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
-  const bool zero_step = act && !bpfail && (-(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev)));
-  bool need = act && !bpfail && !zero_step;
-  int accepted = zero_step ? 0 : -1, acc = 0;
-  double Jnew = Jprev, grad = 0.0;
-  const double f = o.line_search_decrease_factor;
-  double alpha = 1.0, fCW = 1.0;
-  for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }  // same products the sequential search forms
-  const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
-  const int krow = t * Gains<M>::RSK;
-  for (int c0 = 0; c0 < total; c0 += CW) {
-    if (__ballot(need) == 0) break;
-    const bool cand = need && q < CW && (c0 + q) < total;
-    double J, gm;
-    bool ok;
-    forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, q + 1, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
-    bool accept = false;
-    if (cand && ok) {
-      const double expected = -alpha * (dV0 + alpha * dV1);
-      const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
-      accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
-    }
-    const unsigned long long am = __ballot(accept);
-    int qs = -1;  // first accepted candidate of this lane's trajectory (bits qq*TW + t)
-    for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
-    const int src = (qs >= 0 ? qs : 0) * TW + t;
-    const double Js = __shfl(J, src), gs = __shfl(gm, src);
-    if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
-    alpha *= fCW;
-  }
   // one lane per trajectory finishes the iteration; `settle`: the trajectory leaves the plain next-iteration path (it is done, or
   // its inner solve ended and the AL outer update takes over) while its accepted step still only exists as a candidate
   bool settle = false;
@@ -364,6 +307,359 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
       if (hw == src) a.acc[bs] = 0;
     }
   }
+}
+
+// Forward pass of one iLQR iteration.  grid = Bp / TW waves.  Line search: round r evaluates step sizes r*CW .. r*CW+CW-1
+// concurrently (one per lane group) and takes the FIRST accepted one — identical to sequential backtracking
+// (SURVEY.md row S2); then — when a.control — the per-trajectory solver state machine runs: convergence test (row S3)
+// and the hand-over to the AL outer update (row S4, k_outer_*).
+template <class M, int MODE>
+__global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
+  extern __shared__ double kbuf[];  // M::lds_gains: two buffers of gains_lds_doubles(TW)
+  const DevProblem& P = a.P;
+  const to_solver_opts& o = P.opts;
+  const int hw = threadIdx.x;
+  const int CW = a.CW, TW = a.TW;
+  const int q = hw / TW, t = hw - q * TW;      // lanes with q >= CW (64 is not a multiple of TW) ride along without a candidate
+  const int b0 = blockIdx.x * TW;
+  // trajectory of this lane: position b0 + t of the batch, or — with active-list compaction — of this step's list
+  int b, inrange;
+  if (a.compact) {
+    const int cnt = a.acount[a.step & 1];
+    if (b0 >= cnt) return;  // wave-uniform
+    inrange = (b0 + t) < cnt;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? b0 + t : cnt - 1)];
+  } else {
+    inrange = (b0 + t) < P.B;
+    b = (b0 + t) < P.Bp ? b0 + t : P.Bp - 1;  // clamped: the last wave may reach past the batch
+  }
+  const int tile = b >> 6, lane = b & 63;
+  // gfx950 issues FP64 VALU ~1.3x slower whenever EXEC is not all ones (tools/fp64_issue_probe.hip), so lanes that have
+  // nothing to do are NOT masked off: they roll out their own (valid) trajectory as well and only their stores are
+  // predicated.  The wave leaves only when no lane needs anything.
+  const bool act = inrange && a.active[b] != 0;
+  if (__ballot(act) == 0) return;
+  const bool bpfail = act && a.bpfail[b] != 0;
+  const int total = o.iterations_linesearch;
+  const double Jprev = a.J[b];
+  const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
+  // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
+  const bool zero_step = act && !bpfail && (-(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev)));
+  bool need = act && !bpfail && !zero_step;
+  int accepted = zero_step ? 0 : -1, acc = 0;
+  double Jnew = Jprev, grad = 0.0;
+  const double f = o.line_search_decrease_factor;
+  double alpha = 1.0, fCW = 1.0;
+  for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }  // same products the sequential search forms
+  const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
+  const int krow = t * Gains<M>::RSK;
+  for (int c0 = 0; c0 < total; c0 += CW) {
+    if (__ballot(need) == 0) break;
+    const bool cand = need && q < CW && (c0 + q) < total;
+    double J, gm;
+    bool ok;
+    forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, q + 1, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
+    bool accept = false;
+    if (cand && ok) {
+      const double expected = -alpha * (dV0 + alpha * dV1);
+      const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+      accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
+    }
+    const unsigned long long am = __ballot(accept);
+    int qs = -1;  // first accepted candidate of this lane's trajectory (bits qq*TW + t)
+    for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
+    const int src = (qs >= 0 ? qs : 0) * TW + t;
+    const double Js = __shfl(J, src), gs = __shfl(gm, src);
+    if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
+    alpha *= fCW;
+  }
+  forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, Jprev, Jnew, grad);
+}
+
+// ------------------------------------------------------------------------------------------------ two-wave forward pass
+// The Quadrotor-class rollout is a latency chain: ~1 000 instructions per knot on ONE wave, and for most batch steps of a solve
+// the chip holds fewer forward waves than SIMDs (the batch has drained), so the step takes exactly as long as that chain.  Only
+// about two thirds of it IS the recurrence (state difference, gains, RK stages); the rest — candidate stores, stage cost, AL
+// terms, admissibility limits, gradient metric — merely consumes (x_k, u_k).  k_forward2 gives a workgroup TWO waves with the
+// same lane -> (candidate, trajectory) map:
+//   wave 0, the roller: nominal + gains (LDS-DMA) -> δx, u_k, RK step; publishes (x_k, u_k, d_k) in an LDS ring slot per knot;
+//   wave 1, the accountant: one knot behind, stores the candidate, accumulates J / gradient metric / limits from the slot, and
+//           after the rollout runs the acceptance test and the state machine exactly as k_forward does.
+// One workgroup barrier per knot orders the two-slot ring (the roller refills slot k&1 two knots later, i.e. after the barrier
+// the accountant reaches only when it has read it).  Every expression and every summation order is k_forward's: results are
+// bit-identical (tests/test_gpu_parity.py).  The early exit of a wave whose candidates have all left the admissible box is not
+// replicated (it only saves time in a case that is rejected anyway).
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the accountant's candidate stores and dual
+// prefetches (vmcnt) at every knot.  Both waves sit on one CU; nothing but LDS is exchanged between them.
+#define FWD2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <class M>
+struct Fwd2Ring {
+  static constexpr int n = M::n, m = M::m;
+  static constexpr int NV = n + 2 * m, PAIRS = (NV + 1) / 2, SLOT = PAIRS * 128;  // doubles per slot: 64 lanes x PAIRS 16-byte pieces
+};
+
+template <class M, int MODE>
+__device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, int b, double alpha, double* kbuf, int kbuf_len, int krow,
+                                          int TW, int hw, double* ring) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
+  constexpr bool SIMPLE = (MODE & 1) != 0;
+  using R = Fwd2Ring<M>;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const double* Xc = TILE_PTR(a.Xs, N * n);
+  const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
+  const double* px0 = TILE_PTR(a.x0, n);
+  double mp[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mp[i] = in_vgpr(P.mp[i]);
+  const int integrator = P.integrator;
+  const double h0 = SIMPLE ? P.dt[0] : 0.0;
+  double xb[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
+  stage_gains<M>(a.Kt, b, TW, 0, N, kbuf, hw);
+  FwdKnot<M, false> nxt;
+  nxt.load(Xc, Uc, nullptr);
+  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64;
+  for (int k = 0; k < N - 1; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const FwdKnot<M, false> cur = nxt;
+    const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
+    double vals[2 * R::PAIRS];  // [x_k | u_k | d_k | pad]
+#pragma unroll
+    for (int i = 0; i < n; ++i) vals[i] = xb[i];
+    double dx[ne], ub[m], xn[n];
+    state_diff<M>(xb, cur.x, dx);
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      double kr[ne + 1];
+#pragma unroll
+      for (int i = 0; i <= ne; ++i) kr[i] = kcur[j * (ne + 1) + i];
+      __builtin_amdgcn_sched_barrier(0);
+      const double dj = kr[ne];
+      double du = dj * alpha;
+#pragma unroll
+      for (int i = 0; i < ne; ++i) du += kr[i] * dx[i];
+      ub[j] = cur.u[j] + du;
+      vals[n + j] = ub[j];
+      vals[n + m + j] = dj;
+    }
+    if (2 * R::PAIRS > R::NV) vals[2 * R::PAIRS - 1] = 0.0;
+    double2* slot = (double2*)(ring + (size_t)(k & 1) * R::SLOT) + hw;
+#pragma unroll
+    for (int pr = 0; pr < R::PAIRS; ++pr) slot[pr * 64] = make_double2(vals[2 * pr], vals[2 * pr + 1]);
+    // The next knot's DMA / loads go out only NOW: hipcc orders every LDS write of a wave behind its outstanding LDS-DMAs (it
+    // cannot tell the ring from the gains buffers) and a vmcnt wait drains the nominal loads with them — issued at the top of the
+    // knot, as in k_forward, the ring writes above stalled for a full memory round trip per knot.  They land during the RK stages.
+    if (k + 1 < N - 1) {
+      stage_gains<M>(a.Kt, b, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
+      nxt.load(pXn, pUn, nullptr);
+    }
+    pXn += n * 64; pUn += m * 64;
+    const double h = SIMPLE ? h0 : P.dt[k];
+    model_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, k, xb, ub, h, xn);
+#pragma unroll
+    for (int i = 0; i < n; ++i) xb[i] = xn[i];
+    FWD2_BARRIER();
+  }
+  {  // terminal state
+    double2* slot = (double2*)(ring + (size_t)((N - 1) & 1) * R::SLOT) + hw;
+#pragma unroll
+    for (int pr = 0; pr < (n + 1) / 2; ++pr) slot[pr * 64] = make_double2(xb[2 * pr], (2 * pr + 1 < n) ? xb[2 * pr + 1] : 0.0);
+    FWD2_BARRIER();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <class M, int MODE>
+__device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane, int b, bool live, double* ctab, int hw, const double* ring,
+                                             double& J_out, double& g_out, bool& ok_out) {
+  constexpr int n = M::n, m = M::m;
+  constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0;
+  using R = Fwd2Ring<M>;
+  const DevProblem& P = a.P;
+  const to_solver_opts& o = P.opts;
+  const int N = P.N;
+  const size_t cblock = live ? (size_t)blockIdx.x : (size_t)a.dump_wave;
+  double* pXo = a.Xc + (cblock * (size_t)(N * n)) * 64 + hw;
+  double* pUo = a.Uc + (cblock * (size_t)((N - 1) * m)) * 64 + hw;
+  const double* lam0 = TILE_PTR(a.lam, P.n_duals);
+  const double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  const bool dt_scaling = P.opts.cost_dt_scaling != 0;
+  const double max_x = o.max_state_value, max_u = o.max_control_value;
+  StageCostLds<n, m> sc;
+  double h0 = 0.0;
+  if constexpr (SIMPLE) {
+    sc.load(P.costs[P.cost_index[0]], ctab, hw);
+    WAVE_SYNC();
+    h0 = P.dt[0];
+  }
+  ConStage<n, m, (MODE & 16) != 0> cs0, cs1;
+  int ncs = 0, uncached = 0;
+  cs0.ci = -1; cs1.ci = -1;
+  if constexpr (CONS) {
+    for (int ci = 0; ci < P.n_cons; ++ci) {
+      ConC& K = P.cons[ci];
+      if (K.fast == 2 && K.k1 == 0 && K.k2 >= N - 2 && K.p <= m + 1 && ncs < 2) {
+        if (ncs == 0) cs0.load(K, ci, lam0, mu0); else cs1.load(K, ci, lam0, mu0);
+        ++ncs;
+      } else if (K.k1 <= N - 2) ++uncached;
+    }
+  }
+  const bool all_cached = CONS && uncached == 0;
+  if (ncs > 0) cs0.prefetch(0);
+  if (ncs > 1) cs1.prefetch(0);
+  double J = 0.0, gsum = 0.0;
+  bool ok = true;
+  for (int k = 0; k < N - 1; ++k) {
+    FWD2_BARRIER();  // the roller has published knot k
+    if (ncs > 0) cs0.advance();
+    if (ncs > 1) cs1.advance();
+    if (k + 1 < N - 1) {
+      if (ncs > 0) cs0.prefetch(k + 1);
+      if (ncs > 1) cs1.prefetch(k + 1);
+    }
+    double vals[2 * R::PAIRS];
+    const double2* slot = (const double2*)(ring + (size_t)(k & 1) * R::SLOT) + hw;
+#pragma unroll
+    for (int pr = 0; pr < R::PAIRS; ++pr) { const double2 v = slot[pr * 64]; vals[2 * pr] = v.x; vals[2 * pr + 1] = v.y; }
+    const double* xb = vals;
+    const double* ub = vals + n;
+    const double* dk = vals + n + m;
+#pragma unroll
+    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
+    pXo += n * 64;
+#pragma unroll
+    for (int j = 0; j < m; ++j) EL(pUo, j) = ub[j];
+    pUo += m * 64;
+    double gk = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(dk[j]) * rcp_fast(fabs(ub[j]) + 1.0));
+    gsum += gk;
+    const double h = SIMPLE ? h0 : P.dt[k];
+    double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], xb, ub);
+    if (dt_scaling) Jk *= h;
+    if constexpr (CONS) {
+      if (all_cached) {
+        double Ja = 0.0;
+        if (ncs > 0) Ja += cs0.term(ub);
+        if (ncs > 1) Ja += cs1.term(ub);
+        Jk += Ja;
+      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1);
+    }
+    J += Jk;
+    // admissibility (k_forward checks x_{k+1} and u_k in iteration k: the same set of values, seen one knot later here)
+    double mx = 0.0, mu_ = 0.0;
+    if (k > 0) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) { const double v = fabs(xb[i]); if (!(v <= mx)) mx = v; }
+    }
+#pragma unroll
+    for (int j = 0; j < m; ++j) { const double v = fabs(ub[j]); if (!(v <= mu_)) mu_ = v; }
+    if (!(mx <= max_x) || !(mu_ <= max_u)) ok = false;
+  }
+  FWD2_BARRIER();  // terminal state
+  {
+    double xb[n + 1];
+    const double2* slot = (const double2*)(ring + (size_t)((N - 1) & 1) * R::SLOT) + hw;
+#pragma unroll
+    for (int pr = 0; pr < (n + 1) / 2; ++pr) { const double2 v = slot[pr * 64]; xb[2 * pr] = v.x; if (2 * pr + 1 < n + 1) xb[2 * pr + 1] = v.y; }
+    double mx = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) { const double v = fabs(xb[i]); if (!(v <= mx)) mx = v; }
+    if (!(mx <= max_x)) ok = false;
+#pragma unroll
+    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
+    double u0[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) u0[j] = 0.0;
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true);
+  }
+  J_out = J; g_out = gsum / (N - 1); ok_out = ok;
+}
+
+#ifndef TO_FWD2_WAVES
+#define TO_FWD2_WAVES 1
+#endif
+// dynamic LDS: [gains buffer 0 | gains buffer 1 | stage-cost table | ring slot 0 | ring slot 1 | need mask]
+template <class M>
+__host__ __device__ inline size_t fwd2_lds_doubles(int TW) {
+  return 2 * (size_t)gains_lds_doubles<M>(TW) + StageCostLds<M::n, M::m>::size + 2 * (size_t)Fwd2Ring<M>::SLOT + 2;
+}
+template <class M, int MODE>
+__global__ void __launch_bounds__(128, TO_FWD2_WAVES) k_forward2(KArgs a) {
+  static_assert(M::lds_gains, "the two-wave forward pass stages its gains through LDS");
+  extern __shared__ double kbuf[];
+  const DevProblem& P = a.P;
+  const to_solver_opts& o = P.opts;
+  const int hw = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0: roller, 1: accountant (wave-uniform, a scalar branch)
+  const int CW = a.CW, TW = a.TW;
+  const int q = hw / TW, t = hw - q * TW;
+  const int b0 = blockIdx.x * TW;
+  int b, inrange;
+  if (a.compact) {
+    const int cnt = a.acount[a.step & 1];
+    if (b0 >= cnt) return;  // both waves of the workgroup
+    inrange = (b0 + t) < cnt;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? b0 + t : cnt - 1)];
+  } else {
+    inrange = (b0 + t) < P.B;
+    b = (b0 + t) < P.Bp ? b0 + t : P.Bp - 1;
+  }
+  const int tile = b >> 6, lane = b & 63;
+  const bool act = inrange && a.active[b] != 0;
+  if (__ballot(act) == 0) return;  // nothing of this workgroup's state changes before its last barrier: both waves decide alike
+  const bool bpfail = act && a.bpfail[b] != 0;
+  const int total = o.iterations_linesearch;
+  const double Jprev = a.J[b];
+  const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
+  const bool zero_step = act && !bpfail && (-(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev)));
+  bool need = act && !bpfail && !zero_step;
+  int accepted = zero_step ? 0 : -1, acc = 0;
+  double Jnew = Jprev, grad = 0.0;
+  const double f = o.line_search_decrease_factor;
+  double alpha = 1.0, fCW = 1.0;
+  for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }
+  const int kbuf_len = gains_lds_doubles<M>(TW);
+  const int krow = t * Gains<M>::RSK;
+  double* ctab = kbuf + 2 * (size_t)kbuf_len;
+  double* ring = ctab + StageCostLds<M::n, M::m>::size;
+  unsigned long long* needmask = (unsigned long long*)(ring + 2 * (size_t)Fwd2Ring<M>::SLOT);
+  unsigned long long nm = __ballot(need);  // identical in both waves here; afterwards the accountant's word
+  for (int c0 = 0; c0 < total; c0 += CW) {
+    if (nm == 0) break;
+    if (role == 0) {
+      fwd2_roll<M, MODE>(a, tile, lane, b, alpha, kbuf, kbuf_len, krow, TW, hw, ring);
+    } else {
+      const bool cand = need && q < CW && (c0 + q) < total;
+      double J, gm;
+      bool ok;
+      fwd2_account<M, MODE>(a, tile, lane, b, cand, ctab, hw, ring, J, gm, ok);
+      bool accept = false;
+      if (cand && ok) {
+        const double expected = -alpha * (dV0 + alpha * dV1);
+        const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+        accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
+      }
+      const unsigned long long am = __ballot(accept);
+      int qs = -1;
+      for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
+      const int src = (qs >= 0 ? qs : 0) * TW + t;
+      const double Js = __shfl(J, src), gs = __shfl(gm, src);
+      if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
+      const unsigned long long left = __ballot(need);
+      if (hw == 0) *needmask = left;
+    }
+    FWD2_BARRIER();
+    {  // (the word is rewritten a whole rollout — N barriers — later)
+      const unsigned long long w = *needmask;
+      nm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+    }
+    alpha *= fCW;
+  }
+  if (role == 0) return;
+  forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, Jprev, Jnew, grad);
 }
 
 }  // namespace to

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:33
   for (int k = 0; k < P.N - 1; ++k) {
 #pragma unroll
     for (int i = 0; i < m; ++i) u[i] = EL(U, k * m + i);
-    rk_step<M, double, FIXED_INTEG>(P.mp, P.integrator, x, u, P.dt[k], xn);
+    model_step<M, double, FIXED_INTEG>(P.mp, P.integrator, k, x, u, P.dt[k], xn);
 #pragma unroll
     for (int i = 0; i < n; ++i) { x[i] = xn[i]; EL(X, (k + 1) * n + i) = x[i]; }
   }
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64) k_discrete_jacobian(KArgs a, double* F) {
   for (int i = 0; i < n; ++i) xd[i] = Dual(EL(X, k * n + i), (i == j) ? 1.0 : 0.0);
 #pragma unroll
   for (int i = 0; i < m; ++i) ud[i] = Dual(EL(U, k * m + i), (n + i == j) ? 1.0 : 0.0);
-  rk_step<M, Dual>(P.mp, P.integrator, xd, ud, P.dt[k], xn);
+  model_step<M, Dual>(P.mp, P.integrator, k, xd, ud, P.dt[k], xn);
   const size_t kb = (size_t)k + (size_t)(N - 1) * b;
 #pragma unroll
   for (int i = 0; i < n; ++i) F[(size_t)i + n * ((size_t)j + nz * kb)] = xn[i].d;

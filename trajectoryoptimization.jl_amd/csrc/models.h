@@ -428,6 +428,74 @@ __device__ __forceinline__ void rk_step(const double* P, int integrator_rt, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hybrid model vectors (src/dynamics.jl:15-31, test/hybrid_dynamics_model.jl): the model — and with it the LIVE state / control
+// dimension — changes along the horizon.  A hybrid model is compiled in like any other, at the largest (n, m) of its phases;
+// states and controls of the narrower phases are stored zero-padded, and the model itself maps time step k to a phase:
+//   static constexpr bool hybrid = true;
+//   step<T, FIXED>(P, integrator, k, x, u, h, xn)   one time step of whatever model governs step k (padded in, padded out)
+//   knot_dims(P, N, k, &nx, &nu)                      live dimensions at knot k (host side: to_knot_dims, validation)
+// Every kernel takes its time step through model_step, which hands the knot index to such a model and is rk_step otherwise.
+template <class M, class = void>
+struct is_hybrid { static constexpr bool value = false; };
+template <class M>
+struct is_hybrid<M, decltype((void)M::hybrid)> { static constexpr bool value = M::hybrid; };
+
+template <class M, class T, int FIXED = -1>
+__device__ __forceinline__ void model_step(const double* P, int integrator_rt, int k, const T* x, const T* u, double h, T* xn) {
+  if constexpr (is_hybrid<M>::value) M::template step<T, FIXED>(P, integrator_rt, k, x, u, h, xn);
+  else rk_step<M, T, FIXED>(P, integrator_rt, x, u, h, xn);
+}
+
+// component-wise select (a select between two dual-number objects went through scratch memory in the larger kernels)
+__device__ __forceinline__ double select_t(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ Dual select_t(bool c, Dual a, Dual b) { return Dual(c ? a.v : b.v, c ? a.d : b.d); }
+template <int K> __device__ __forceinline__ MDual<K> select_t(bool c, MDual<K> a, MDual<K> b) {
+  MDual<K> r; r.v = c ? a.v : b.v;
+#pragma unroll
+  for (int i = 0; i < K; ++i) r.d[i] = c ? a.d[i] : b.d[i];
+  return r;
+}
+
+// The model vector of test/hybrid_dynamics_model.jl:14-52: a 2-D double integrator (4, 2) for the first S = P[1] time steps, a
+// jump map (4, 2) -> 2, x+ = [(x3 + x4)/2, (u1 + u2)/2] (test :31-33; a discrete map here), then a 1-D double integrator (2, 1).
+// Stored at (4, 2); P[0] = mass.  Branch-free: all three maps are evaluated and selected by the (per-lane) knot index, so the
+// kernels whose lanes sit on different knots keep their EXEC mask full.
+struct HybridDoubleIntegratorModel {
+  static constexpr int n = 4, m = 2, ne = 4;
+  static constexpr bool lie = false;
+  static constexpr int att = ATT_NONE;
+  static constexpr bool hybrid = true;
+  static constexpr bool pin_rk4 = true;
+  static constexpr int expand_knots = 1;
+  static constexpr bool accept_write_through = true;
+  static constexpr bool lds_gains = false;
+  static constexpr int ls_first_round = 4;
+  static constexpr bool mfma_backward = false, coop_backward = true;
+  static constexpr bool lane_backward = true;
+  template <class T>
+  __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) { DoubleIntegratorModel<2>::f(P, x, u, xd); }
+  template <class T, int FIXED>
+  __device__ __forceinline__ static void step(const double* P, int integrator_rt, int k, const T* x, const T* u, double h, T* xn) {
+    const int S = (int)P[1];
+    T ya[4], yc[2];
+    rk_step<DoubleIntegratorModel<2>, T, FIXED>(P, integrator_rt, x, u, h, ya);
+    rk_step<DoubleIntegratorModel<1>, T, FIXED>(P, integrator_rt, x, u, h, yc);  // reads x[0..1], u[0]
+    const T j0 = (x[2] + x[3]) * 0.5, j1 = (u[0] + u[1]) * 0.5;
+    const T zero(0.0);
+    const bool first = k < S, jump = k == S;
+    xn[0] = select_t(first, ya[0], select_t(jump, j0, yc[0]));
+    xn[1] = select_t(first, ya[1], select_t(jump, j1, yc[1]));
+    xn[2] = select_t(first, ya[2], zero);
+    xn[3] = select_t(first, ya[3], zero);
+  }
+  __host__ __device__ static void knot_dims(const double* P, int N, int k, int* nx, int* nu) {  // knot k = 0 .. N-1
+    const int S = (int)P[1];
+    *nx = k <= S ? 4 : 2;          // knots 0..S carry the 2-D state (the jump map's input included)
+    *nu = k <= S ? 2 : 1;          // the terminal knot reports the control dimension of the last model (RD.dims)
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Error-state maps.  Identity for vector-space models.
 // ------------------------------------------------------------------------------------------------
 // v (n) = column j of G(x)   (n x ne attitude Jacobian blkdiag(I3, L(q)H, I3, I3); no 1/2: Cayley map; three-parameter

@@ -218,6 +218,22 @@ int op_forward(to_handle* h) {
   return TO_OK;
 }
 
+template <class M, int MODE>
+int op_forward2(to_handle* h) {
+  const KArgs& a = h->a;
+  const int TW = a.TW;
+  hipLaunchKernelGGL((k_forward2<M, MODE>), dim3((a.P.Bp + TW - 1) / TW), dim3(128), sizeof(double) * fwd2_lds_doubles<M>(TW), h->stream, a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+template <class M, int LO, int HI>
+void fill_forward2(ModelOps& o) {
+  if constexpr (LO < HI) {
+    if constexpr (M::pin_rk4 || (LO & 4) == 0) o.forward2[LO] = op_forward2<M, LO>;
+    fill_forward2<M, LO + 1, HI>(o);
+  }
+}
+
 template <class M>
 void fill_misc(ModelOps& o) {
   fill_traits<M>(o);

@@ -1,0 +1,15 @@
+// ops_hybrid.hip — the hybrid double integrator (model vector with a dimension change, test/hybrid_dynamics_model.jl): every kernel of
+// the small-model paths, taking its time step through model_step.
+#include "ops.h"
+
+namespace to {
+void fill_ops_hybrid(ModelOps* t) {
+  using M = HybridDoubleIntegratorModel;
+  fill_misc<M>(t[7]);
+  t[7].expand = op_expand<M>;
+  t[7].backward = op_backward<M>;
+  t[7].expand_backward = op_expand_backward<M>;
+  t[7].expand_backward_coop = op_expand_backward_coop<M>;
+  fill_forward<M, 0, 16>(t[7]);
+}
+}  // namespace to

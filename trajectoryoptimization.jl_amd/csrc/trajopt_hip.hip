@@ -39,8 +39,10 @@ const ModelOps* model_ops(int key) {
     fill_ops_small(g_ops); fill_ops_small_forward(g_ops);
     fill_ops_quad_misc(g_ops); fill_ops_quad_expand(g_ops); fill_ops_quad_backward(g_ops);
     fill_ops_quad_forward_a(g_ops); fill_ops_quad_forward_b(g_ops); fill_ops_quad_forward_c(g_ops);
+    fill_ops_quad_forward2_a(g_ops); fill_ops_quad_forward2_b(g_ops); fill_ops_quad_forward2_c(g_ops);
     fill_ops_quadatt_misc(g_ops); fill_ops_quadmrp_expand(g_ops); fill_ops_quadrp_expand(g_ops);
     fill_ops_quadmrp_forward(g_ops); fill_ops_quadrp_forward(g_ops);
+    fill_ops_hybrid(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
 }
@@ -89,6 +91,7 @@ int model_dims(int id, const double* params, int* n, int* m, int* ne, int* key) 
       if (rot == TO_ROT_MRP || rot == TO_ROT_RODRIGUES) { *n = 12; *m = 4; *ne = 12; *key = rot == TO_ROT_MRP ? 5 : 6; return 0; }
       return -1;
     }
+    case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; *key = 7; return 0;
   }
   return -1;
 }
@@ -360,7 +363,8 @@ int launch_forward(to_handle* h, bool accept = true) {
   if (a.P.unit_soc && h->ops->forward[mode | 16]) mode |= 16;
   if (!h->ops->forward[mode]) mode = (mode | 8) & ~1 & ~16;  // the general variant (any cost kind, stage cost read per knot): a superset
   if (!h->ops->forward[mode]) return fail(TO_ERR_UNSUPPORTED, "forward-pass variant not compiled for this model");
-  TRY(h->ops->forward[mode](h));
+  if (h->fwd2 && h->ops->forward2[mode]) TRY(h->ops->forward2[mode](h));
+  else TRY(h->ops->forward[mode](h));
   if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
   return TO_OK;
 }
@@ -603,6 +607,11 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (desc->n_costs < 1 || !desc->costs) return fail(TO_ERR_ARGUMENT, "objective needs at least one cost function");
   const int rot = desc->model == TO_MODEL_QUADROTOR ? (int)desc->model_params[10] : -1;
   for (int i = 0; i < desc->n_costs; ++i) TRY(validate_cost(n, rot, desc->costs[i]));
+  if (desc->model == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) {
+    const double S = desc->model_params[1];
+    if (!(S >= 1.0) || !(S <= (double)(N - 2)) || S != std::floor(S))
+      return fail(TO_ERR_ARGUMENT, "hybrid double integrator: params[1] (time steps of the first model) must be an integer in 1 .. N-2");
+  }
   std::vector<int> cost_index(N);
   if (desc->cost_index) {
     for (int k = 0; k < N; ++k) {
@@ -716,6 +725,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_EXPAND_LANE")) h->expand_lane = std::atoi(env) != 0;
   h->fused_coop = (!a.bwd_lane && !a.bwd_mfma && h->ops->expand_backward_coop) ? 1 : 0;  // used while the cost blocks are diagonal (KArgs::h_diag)
   if (const char* env = std::getenv("TRAJOPT_FUSED_COOP")) if (!std::atoi(env)) h->fused_coop = 0;
+  h->fwd2 = 0;
+  if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env) != 0;
   a.coop_merge = 1;
   if (const char* env = std::getenv("TRAJOPT_COOP_MERGE")) a.coop_merge = std::atoi(env) != 0;
   h->fused_lane = (a.bwd_lane && h->ops->expand_backward) ? 1 : 0;
@@ -819,6 +830,18 @@ int to_solver_path(const to_handle* h, int32_t* info) {
   info[1] = (h->fused_lane || (!a.bwd_mfma && !a.bwd_lane && fcoop)) ? 1 : 0;
   info[2] = h->compact;
   info[3] = h->cw_base;
+  info[4] = h->fwd2 ? 2 : 1;
+  info[5] = info[6] = info[7] = 0;
+  return TO_OK;
+}
+int to_knot_dims(const to_handle* h, int32_t* nx, int32_t* nu) {
+  CHECK_H(h); CHECK_P(nx); CHECK_P(nu);
+  const DevProblem& P = h->a.P;
+  for (int k = 0; k < P.N; ++k) {
+    int a = P.n, b = P.m;
+    if (h->model_key == 7) HybridDoubleIntegratorModel::knot_dims(P.mp, P.N, k, &a, &b);
+    nx[k] = a; nu[k] = b;
+  }
   return TO_OK;
 }
 int to_set_profiling(to_handle* h, int enable) { CHECK_H(h); h->profile = enable != 0; return TO_OK; }
