@@ -298,13 +298,19 @@ def test_full_size_C5_vs_oracle_subsample(hip, oracle):
     assert set(np.unique(sh.stats["status"])) <= {T.capi.SOLVE_SUCCEEDED, T.capi.MAX_ITERATIONS, T.capi.MAX_ITERATIONS_OUTER}
 
 
-def test_G4_quadrotor_zigzag_on_gpu(hip, oracle):
+@pytest.mark.parametrize("forward_waves", ["one", "auto"])
+def test_G4_quadrotor_zigzag_on_gpu(forward_waves, hip, oracle, monkeypatch):
     """The reference's Quadrotor zig-zag (examples/Quadrotor.ipynb cells 10-22, golden G4_quadrotor_altro: 90
     iterations, J = 0.29928, violation 7.6e-10) solved on the GPU: per-knot waypoint costs + control bounds, AL-iLQR.
     Sanity against the notebook (the S4 pin SURVEY §8c prescribes: cost to 1 %, feasible to 1e-6) and parity against the
     oracle.  (The start — 1/20 of the hover thrust, 20 m to fly — makes the solve chaotic in the start position: moved by
-    1e-2 m the ORACLE itself needs 58 ... 591 iterations instead of 85, so only the notebook's own start is compared.)"""
+    1e-2 m the ORACLE itself needs 58 ... 591 iterations instead of 85, so only the notebook's own start is compared.)
+    The same chaos shows between the two forward kernels: k_forward ("one") follows the oracle's path step for step (85
+    iterations); k_forward2 (the default for a batch this small) sums the same cost terms with another FMA contraction — 2e-14
+    relative in J — and arrives after 68 iterations at the same optimum: notebook pins for both, step-for-step parity for "one"."""
     g = G["G4_quadrotor_altro"]
+    if forward_waves == "one":
+        monkeypatch.setenv("TRAJOPT_FWD2", "0")
 
     def build(lib):  # the notebook's single start, in every lane of a small batch
         return configs.quadrotor_zigzag_problem(lib=lib, batch=5)
@@ -319,11 +325,15 @@ def test_G4_quadrotor_zigzag_on_gpu(hip, oracle):
     for r, k in zip(wpts[:2], times[:2]):
         assert np.linalg.norm(Xh[0, k - 1, :3] - r) < 0.6
     assert np.linalg.norm(Xh[0, -1, :3] - wpts[2]) < 5e-3
-    for k in ("iterations", "iterations_outer", "status"):
-        np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
-    np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6)
-    assert_trajectories_close(Xh, T.states(po), 1e-6, "X")
-    assert_trajectories_close(T.controls(ph), T.controls(po), 1e-6, "U")
+    np.testing.assert_array_equal(sh.stats["iterations"], sh.stats["iterations"][0])   # identical lanes stay identical
+    if forward_waves == "one":
+        for k in ("iterations", "iterations_outer", "status"):
+            np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
+        np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6)
+        assert_trajectories_close(Xh, T.states(po), 1e-6, "X")
+        assert_trajectories_close(T.controls(ph), T.controls(po), 1e-6, "U")
+    else:
+        np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-2)
 
 
 @pytest.mark.parametrize("rot", ["mrp", "rp"])
@@ -1162,6 +1172,29 @@ def test_two_wave_forward_pass(width, hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_two_wave_forward_pass_small_models(two, hip, oracle, monkeypatch):
+    """The small models' forward pass (gains row in registers, accepted steps written through by the next expansion) with one
+    wave per candidate group (TRAJOPT_FWD2=0) and as roller + accountant workgroups (=1; the default picks per batch step):
+    both against the oracle — Cartpole iLQR and AL (C2 shapes), a line search that goes into later rounds, and the quickstart
+    problem (2-D double integrator, bounds, obstacles, goal)."""
+    monkeypatch.setenv("TRAJOPT_FWD2", two)
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=96, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=40, constrained=True, **kw), hip, oracle)
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", "1")
+    ph, po = pair(lambda **kw: configs.cartpole_problem(batch=33, **kw), hip, oracle)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    monkeypatch.delenv("TRAJOPT_LS_CANDIDATES")
+    ph, po = pair(BUILDERS["quickstart"], hip, oracle)   # 2-D double integrator, bounds + circle obstacles + goal
+    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+
+
 @pytest.mark.parametrize("path", ["default", "lane", "split"])
 def test_hybrid_model_vector_on_gpu(path, hip, oracle, monkeypatch):
     """SURVEY §8(f)4, test/hybrid_dynamics_model.jl: the model vector 2-D double integrator x 5 -> jump map -> 1-D double
@@ -1207,7 +1240,8 @@ def test_hybrid_model_vector_on_gpu(path, hip, oracle, monkeypatch):
     assert T.num_constraints(ph) == [4, 4, 4, 4, 4, 0, 3, 3, 3, 3, 2]
     sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
     assert_solve_parity(sh, so, ph, po)
-    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED) and np.all(sh.stats["c_max"] < 1e-6)
+    done = sh.stats["status"] == T.capi.SOLVE_SUCCEEDED   # (a few of the perturbed starts run into the iteration limit, on the oracle alike)
+    assert done.mean() > 0.9 and np.all(sh.stats["c_max"][done] < 1e-6)
     np.testing.assert_array_equal(T.controls(ph)[:, 6:, 1], 0.0)
 
 

@@ -46,7 +46,8 @@ struct to_handle_s {
   int counter_len = 0;
   int cw_base = 1, tw_base = 64;  // forward-wave shape: base, and the deep one (0: none) used once the active trajectories fit
   int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
-  int fwd2 = 0;           // forward pass as two-wave workgroups (roller + accountant, k_forward2; TRAJOPT_FWD2=0/1)
+  int fwd2 = 2;           // forward pass as two-wave workgroups (roller + accountant, k_forward2): 0 never, 1 always, 2 per step (TRAJOPT_FWD2)
+  int simds = 1024;       // SIMDs of the device (4 per CU)
   int fused_coop = 0;     // solve loop, cooperative path with diagonal cost blocks: one k_expand_backward_coop launch (TRAJOPT_FUSED_COOP=0 to split)
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
   int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
@@ -126,6 +127,7 @@ void fill_ops_quadrp_expand(ModelOps* table);
 void fill_ops_quadmrp_forward(ModelOps* table);
 void fill_ops_quadrp_forward(ModelOps* table);
 void fill_ops_hybrid(ModelOps* table);
+void fill_ops_small_forward2(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

@@ -403,11 +403,13 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
                                           int TW, int hw, double* ring) {
   constexpr int n = M::n, m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
   constexpr bool SIMPLE = (MODE & 1) != 0;
+  constexpr bool KLDS = M::lds_gains;
   using R = Fwd2Ring<M>;
   const DevProblem& P = a.P;
   const int N = P.N;
   const double* Xc = TILE_PTR(a.Xs, N * n);
   const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const double* px0 = TILE_PTR(a.x0, n);
   double mp[16];
 #pragma unroll
@@ -417,14 +419,18 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
   double xb[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
-  stage_gains<M>(a.Kt, b, TW, 0, N, kbuf, hw);
-  FwdKnot<M, false> nxt;
-  nxt.load(Xc, Uc, nullptr);
-  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64;
+  if constexpr (KLDS) stage_gains<M>(a.Kt, b, TW, 0, N, kbuf, hw);
+  FwdKnot<M, !KLDS> nxt;
+  nxt.load(Xc, Uc, pK);
+  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + RSK;
   for (int k = 0; k < N - 1; ++k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const FwdKnot<M, false> cur = nxt;
+    if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const FwdKnot<M, !KLDS> cur = nxt;
     const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
+    if constexpr (!KLDS) {  // gains row in registers: plain loads, the compiler waits for exactly what it uses — issue them first
+      if (k + 1 < N - 1) nxt.load(pXn, pUn, pKn);
+      pXn += n * 64; pUn += m * 64; pKn += RSK;
+    }
     double vals[2 * R::PAIRS];  // [x_k | u_k | d_k | pad]
 #pragma unroll
     for (int i = 0; i < n; ++i) vals[i] = xb[i];
@@ -434,8 +440,8 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
     for (int j = 0; j < m; ++j) {
       double kr[ne + 1];
 #pragma unroll
-      for (int i = 0; i <= ne; ++i) kr[i] = kcur[j * (ne + 1) + i];
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i <= ne; ++i) kr[i] = KLDS ? kcur[j * (ne + 1) + i] : cur.kd[KLDS ? 0 : j * (ne + 1) + i];
+      if constexpr (KLDS) __builtin_amdgcn_sched_barrier(0);
       const double dj = kr[ne];
       double du = dj * alpha;
 #pragma unroll
@@ -448,14 +454,17 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
     double2* slot = (double2*)(ring + (size_t)(k & 1) * R::SLOT) + hw;
 #pragma unroll
     for (int pr = 0; pr < R::PAIRS; ++pr) slot[pr * 64] = make_double2(vals[2 * pr], vals[2 * pr + 1]);
-    // The next knot's DMA / loads go out only NOW: hipcc orders every LDS write of a wave behind its outstanding LDS-DMAs (it
-    // cannot tell the ring from the gains buffers) and a vmcnt wait drains the nominal loads with them — issued at the top of the
-    // knot, as in k_forward, the ring writes above stalled for a full memory round trip per knot.  They land during the RK stages.
-    if (k + 1 < N - 1) {
-      stage_gains<M>(a.Kt, b, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
-      nxt.load(pXn, pUn, nullptr);
+    // LDS-staged gains: the next knot's DMA / loads go out only NOW.  hipcc orders every LDS write of a wave behind its
+    // outstanding LDS-DMAs (it cannot tell the ring from the gains buffers) and a vmcnt wait drains the nominal loads with
+    // them — issued at the top of the knot, as in k_forward, the ring writes above stalled for a full memory round trip per
+    // knot.  They land during the RK stages.
+    if constexpr (KLDS) {
+      if (k + 1 < N - 1) {
+        stage_gains<M>(a.Kt, b, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
+        nxt.load(pXn, pUn, pKn);
+      }
+      pXn += n * 64; pUn += m * 64; pKn += RSK;
     }
-    pXn += n * 64; pUn += m * 64;
     const double h = SIMPLE ? h0 : P.dt[k];
     model_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, k, xb, ub, h, xn);
 #pragma unroll
@@ -468,7 +477,7 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
     for (int pr = 0; pr < (n + 1) / 2; ++pr) slot[pr * 64] = make_double2(xb[2 * pr], (2 * pr + 1 < n) ? xb[2 * pr + 1] : 0.0);
     FWD2_BARRIER();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <class M, int MODE>
@@ -487,11 +496,11 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
   const bool dt_scaling = P.opts.cost_dt_scaling != 0;
   const double max_x = o.max_state_value, max_u = o.max_control_value;
-  StageCostLds<n, m> sc;
+  typename std::conditional<M::lds_gains, StageCostLds<n, m>, StageCostDiag<n, m>>::type sc;
   double h0 = 0.0;
   if constexpr (SIMPLE) {
-    sc.load(P.costs[P.cost_index[0]], ctab, hw);
-    WAVE_SYNC();
+    if constexpr (M::lds_gains) { sc.load(P.costs[P.cost_index[0]], ctab, hw); WAVE_SYNC(); }
+    else sc.load(P.costs[P.cost_index[0]]);
     h0 = P.dt[0];
   }
   ConStage<n, m, (MODE & 16) != 0> cs0, cs1;
@@ -584,11 +593,10 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
 // dynamic LDS: [gains buffer 0 | gains buffer 1 | stage-cost table | ring slot 0 | ring slot 1 | need mask]
 template <class M>
 __host__ __device__ inline size_t fwd2_lds_doubles(int TW) {
-  return 2 * (size_t)gains_lds_doubles<M>(TW) + StageCostLds<M::n, M::m>::size + 2 * (size_t)Fwd2Ring<M>::SLOT + 2;
+  return (M::lds_gains ? 2 * (size_t)gains_lds_doubles<M>(TW) + StageCostLds<M::n, M::m>::size : 0) + 2 * (size_t)Fwd2Ring<M>::SLOT + 2;
 }
 template <class M, int MODE>
 __global__ void __launch_bounds__(128, TO_FWD2_WAVES) k_forward2(KArgs a) {
-  static_assert(M::lds_gains, "the two-wave forward pass stages its gains through LDS");
   extern __shared__ double kbuf[];
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
@@ -621,10 +629,10 @@ __global__ void __launch_bounds__(128, TO_FWD2_WAVES) k_forward2(KArgs a) {
   const double f = o.line_search_decrease_factor;
   double alpha = 1.0, fCW = 1.0;
   for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }
-  const int kbuf_len = gains_lds_doubles<M>(TW);
+  const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
   const int krow = t * Gains<M>::RSK;
   double* ctab = kbuf + 2 * (size_t)kbuf_len;
-  double* ring = ctab + StageCostLds<M::n, M::m>::size;
+  double* ring = ctab + (M::lds_gains ? StageCostLds<M::n, M::m>::size : 0);
   unsigned long long* needmask = (unsigned long long*)(ring + 2 * (size_t)Fwd2Ring<M>::SLOT);
   unsigned long long nm = __ballot(need);  // identical in both waves here; afterwards the accountant's word
   for (int c0 = 0; c0 < total; c0 += CW) {

@@ -42,7 +42,7 @@ const ModelOps* model_ops(int key) {
     fill_ops_quad_forward2_a(g_ops); fill_ops_quad_forward2_b(g_ops); fill_ops_quad_forward2_c(g_ops);
     fill_ops_quadatt_misc(g_ops); fill_ops_quadmrp_expand(g_ops); fill_ops_quadrp_expand(g_ops);
     fill_ops_quadmrp_forward(g_ops); fill_ops_quadrp_forward(g_ops);
-    fill_ops_hybrid(g_ops);
+    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
 }
@@ -356,14 +356,14 @@ int launch_accept(to_handle* h) {  // materialise accepted candidate slots on sl
 // forward pass: ONE launch runs the whole line search (CW step sizes per round, concurrently, inside each wave) and the
 // per-trajectory state machine (k_forward.h).  Kernel variants: bit0 simple stage cost, bit1 constraints, bit2
 // compile-time RK4 (models that pin it), bit3 dense costs / generic constraints.
-int launch_forward(to_handle* h, bool accept = true) {
+int launch_forward(to_handle* h, bool accept = true, bool two_wave = false) {
   const KArgs& a = h->a;
   int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | ((a.P.expand_variant & 5) ? 8 : 0);
   if (!h->ops->forward[mode]) mode &= ~4;  // the model does not pin RK4
   if (a.P.unit_soc && h->ops->forward[mode | 16]) mode |= 16;
   if (!h->ops->forward[mode]) mode = (mode | 8) & ~1 & ~16;  // the general variant (any cost kind, stage cost read per knot): a superset
   if (!h->ops->forward[mode]) return fail(TO_ERR_UNSUPPORTED, "forward-pass variant not compiled for this model");
-  if (h->fwd2 && h->ops->forward2[mode]) TRY(h->ops->forward2[mode](h));
+  if ((two_wave || h->fwd2 == 1) && h->ops->forward2[mode]) TRY(h->ops->forward2[mode](h));
   else TRY(h->ops->forward[mode](h));
   if (accept) TRY(launch_accept(h));  // inside a solve the next expansion writes the accepted step through instead
   return TO_OK;
@@ -437,7 +437,11 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       // forward-wave shape of this step, from the last active count the host has seen (results do not depend on it)
       const bool deep = h->cw_deep && last_active <= h->deep_max_active;
       a.CW = deep ? h->cw_deep : h->cw_base; a.TW = deep ? h->tw_deep : h->tw_base;
-      TRY(launch_forward(h, !h->ops->write_through));
+      // ... and its workgroup shape: two waves per candidate group (roller + accountant, k_forward2) shorten the rollout's latency
+      // chain by a third, but need twice the wave slots — taken once both waves of every workgroup get a SIMD of their own
+      // (C3: 610 vs 812 us per step with the chip full, 480 vs 320 us once the batch has drained)
+      const bool two = h->fwd2 == 2 && (long long)2 * ((last_active + a.TW - 1) / a.TW) <= (long long)h->simds;
+      TRY(launch_forward(h, !h->ops->write_through, two));
       if (al_mode) TRY(launch_outer(h));
       if (a.compact) {  // the list of the trajectories that go on, for the next step's kernels
         if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
@@ -712,6 +716,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   {
     int cus = 256;
     HIPB(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    h->simds = 4 * cus;
     const long coop_waves = ((long)B + h->G - 1) / h->G;
     // (with the expansions fused into both kernels the crossover sits at ~12 000 Cartpole trajectories: measured fused lane vs
     // fused cooperative 10.8 vs 9.9 M it/s at B = 12 288, 7.9 vs 9.3 M at B = 8 192)
@@ -725,8 +730,9 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_EXPAND_LANE")) h->expand_lane = std::atoi(env) != 0;
   h->fused_coop = (!a.bwd_lane && !a.bwd_mfma && h->ops->expand_backward_coop) ? 1 : 0;  // used while the cost blocks are diagonal (KArgs::h_diag)
   if (const char* env = std::getenv("TRAJOPT_FUSED_COOP")) if (!std::atoi(env)) h->fused_coop = 0;
-  h->fwd2 = 0;
-  if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env) != 0;
+  h->fwd2 = 2;  // 0: one-wave forward pass only; 1: two-wave always (phase API included); 2: per batch step, by the active count
+  if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env);
+  if (h->fwd2 < 0 || h->fwd2 > 2) h->fwd2 = 2;
   a.coop_merge = 1;
   if (const char* env = std::getenv("TRAJOPT_COOP_MERGE")) a.coop_merge = std::atoi(env) != 0;
   h->fused_lane = (a.bwd_lane && h->ops->expand_backward) ? 1 : 0;
@@ -830,7 +836,7 @@ int to_solver_path(const to_handle* h, int32_t* info) {
   info[1] = (h->fused_lane || (!a.bwd_mfma && !a.bwd_lane && fcoop)) ? 1 : 0;
   info[2] = h->compact;
   info[3] = h->cw_base;
-  info[4] = h->fwd2 ? 2 : 1;
+  info[4] = (h->fwd2 && h->ops->forward2[1]) ? 2 : 1;  // (two-wave workgroups are used while the active trajectories leave room for them)
   info[5] = info[6] = info[7] = 0;
   return TO_OK;
 }
