@@ -339,7 +339,8 @@ int to_discrete_jacobian(to_handle* h, double* F);
  * results never depend on it).  info[0]: backward pass 0 = cooperative (R lanes per trajectory, LDS), 1 = MFMA (one wave per
  * trajectory), 2 = lane (one lane per trajectory); info[1]: 1 = the expansion is fused into the backward-pass kernel (profile slot
  * 0 is then empty and slot 1 covers both); info[2]: 1 = active-list compaction; info[3]: step sizes tried concurrently in the
- * first line-search round; info[4]: waves per forward-pass workgroup (2: roller + accountant, k_forward2); info[5..7]: 0. */
+ * first line-search round; info[4]: waves per forward-pass workgroup (2: roller + accountant, k_forward2); info[5]: 1 = the backward pass runs as a scan over the
+ * horizon (one wave per trajectory, k_scan.h) while few trajectories are active; info[6..7]: 0. */
 int to_solver_path(const to_handle* h, int32_t* info /* [8] */);
 /* Live state / control dimensions per knot, nx[N], nu[N] (RD.dims(models), src/dynamics.jl:15-31: the terminal knot carries the
  * last model's control dimension).  (n, m) on every knot unless the model is a hybrid model vector. */

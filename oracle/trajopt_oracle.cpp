@@ -561,6 +561,180 @@ bool backward(const Problem& P, Traj& t) {
   return true;
 }
 
+/* ---- Arithmetic model of the GPU's scan backward pass (csrc/k_scan.h), for tests/test_oracle_sensitivity.py only -------------
+ * NOT a restatement of the reference: the reference (Altro) runs the sequential recursion above.  The GPU's k_expand_backward_scan
+ * computes the cost-to-go at every second knot with an associative scan (Särkkä & García-Fernández 2023, Lemma 10) and walks the
+ * two knots of each block with the sequential expressions; this function does the same on the CPU — same element definitions,
+ * same Hillis-Steele order, same block size — so that the effect of the scan's rounding on whole solves can be measured
+ * oracle-against-oracle (env ORACLE_RICCATI_SCAN=1 switches every backward pass of this library to it). */
+namespace scanexp {
+struct El { double A[16], b[4], C[16], eta[4], J[16]; };
+/* solve M X = R for X (n x r), M n x n row-major general, partial pivoting-free LU (M = I + PSD*PSD: well conditioned) */
+static void lu_solve(int n, double* M, double* R, int r) {
+  for (int c = 0; c < n; ++c) {
+    double piv = 1.0 / M[c * n + c];
+    for (int i = c + 1; i < n; ++i) {
+      double f = M[i * n + c] * piv;
+      for (int j = c + 1; j < n; ++j) M[i * n + j] -= f * M[c * n + j];
+      for (int j = 0; j < r; ++j) R[i * r + j] -= f * R[c * r + j];
+    }
+  }
+  for (int c = n - 1; c >= 0; --c) {
+    double piv = 1.0 / M[c * n + c];
+    for (int j = 0; j < r; ++j) {
+      double v = R[c * r + j];
+      for (int i = c + 1; i < n; ++i) v -= M[c * n + i] * R[i * r + j];
+      R[c * r + j] = v * piv;
+    }
+  }
+}
+static void combine(int n, const El& e1, const El& e2, El& o) {
+  double M[16], R[4 * 9];
+  const int r = 2 * n + 1;
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double v = (i == j) ? 1.0 : 0.0; for (int t = 0; t < n; ++t) v += e1.C[i * n + t] * e2.J[t * n + j]; M[i * n + j] = v; }
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) R[i * r + j] = e1.A[i * n + j];
+    double v = e1.b[i]; for (int t = 0; t < n; ++t) v -= e1.C[i * n + t] * e2.eta[t]; R[i * r + n] = v;
+    for (int j = 0; j < n; ++j) R[i * r + n + 1 + j] = e1.C[i * n + j];
+  }
+  double Mc[16]; for (int i = 0; i < n * n; ++i) Mc[i] = M[i];
+  lu_solve(n, Mc, R, r);
+  double XC[16];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) { double v = 0; for (int t = 0; t < n; ++t) v += e2.A[i * n + t] * R[t * r + j]; o.A[i * n + j] = v; }
+    { double v = e2.b[i]; for (int t = 0; t < n; ++t) v += e2.A[i * n + t] * R[t * r + n]; o.b[i] = v; }
+    for (int j = 0; j < n; ++j) { double v = 0; for (int t = 0; t < n; ++t) v += e2.A[i * n + t] * R[t * r + n + 1 + j]; XC[i * n + j] = v; }
+  }
+  double Cn[16];
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double v = e2.C[i * n + j]; for (int t = 0; t < n; ++t) v += XC[i * n + t] * e2.A[j * n + t]; Cn[i * n + j] = v; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) o.C[i * n + j] = 0.5 * (Cn[i * n + j] + Cn[j * n + i]);
+  /* (I + J2 C1) = M^T */
+  double Mt[16], Y[4 * 5];
+  const int r2 = n + 1;
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Mt[i * n + j] = M[j * n + i];
+  for (int i = 0; i < n; ++i) {
+    double v = e2.eta[i]; for (int t = 0; t < n; ++t) v += e2.J[i * n + t] * e1.b[t]; Y[i * r2 + 0] = v;
+    for (int j = 0; j < n; ++j) { double w = 0; for (int t = 0; t < n; ++t) w += e2.J[i * n + t] * e1.A[t * n + j]; Y[i * r2 + 1 + j] = w; }
+  }
+  lu_solve(n, Mt, Y, r2);
+  double Jn[16];
+  for (int i = 0; i < n; ++i) {
+    { double v = e1.eta[i]; for (int t = 0; t < n; ++t) v += e1.A[t * n + i] * Y[t * r2 + 0]; o.eta[i] = v; }
+    for (int j = 0; j < n; ++j) { double v = e1.J[i * n + j]; for (int t = 0; t < n; ++t) v += e1.A[t * n + i] * Y[t * r2 + 1 + j]; Jn[i * n + j] = v; }
+  }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) o.J[i * n + j] = 0.5 * (Jn[i * n + j] + Jn[j * n + i]);
+}
+}  // namespace scanexp
+
+bool backward(const Problem& P, Traj& t);
+bool backward_scan(const Problem& P, Traj& t) {
+  using namespace scanexp;
+  const int m = P.m, ne = P.ne, N = P.N, n = ne;
+  if (t.rho != 0.0 || ne > 4 || m > 2 || N > 126 || !P.cons.empty()) return backward(P, t);  /* the GPU kernel's scope */
+  for (int k = 0; k < N; ++k) { /* ... diagonal cost blocks only */
+    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) if (i != j && t.Qxx[(size_t)k * ne * ne + i * ne + j] != 0.0) return backward(P, t);
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) if (i != j && t.Quu[(size_t)k * m * m + i * m + j] != 0.0) return backward(P, t);
+    for (int i = 0; i < m * ne; ++i) if (t.Qux[(size_t)k * m * ne + i] != 0.0) return backward(P, t);
+  }
+  std::vector<El> el(N);
+  for (int k = 0; k < N - 1; ++k) {
+    const double* A = &t.A[(size_t)k * ne * ne]; const double* Bm = &t.Bm[(size_t)k * ne * m];
+    const double* Q = &t.Qxx[(size_t)k * ne * ne]; const double* R = &t.Quu[(size_t)k * m * m];
+    const double* H = &t.Qux[(size_t)k * m * ne]; const double* q = &t.qx[(size_t)k * ne]; const double* r = &t.qu[(size_t)k * m];
+    double L[4]; for (int i = 0; i < m * m; ++i) L[i] = R[i];
+    if (!cholesky(L, m)) return backward(P, t);
+    /* RiH = R^-1 H (m x ne), Rir = R^-1 r */
+    double RiH[8], Rir[2], col[2];
+    for (int j = 0; j < ne; ++j) { for (int i = 0; i < m; ++i) col[i] = H[i * ne + j]; chol_solve(L, m, col); for (int i = 0; i < m; ++i) RiH[i * ne + j] = col[i]; }
+    for (int i = 0; i < m; ++i) col[i] = r[i]; chol_solve(L, m, col); for (int i = 0; i < m; ++i) Rir[i] = col[i];
+    double RiBt[8]; /* R^-1 B^T (m x ne) */
+    for (int j = 0; j < ne; ++j) { for (int i = 0; i < m; ++i) col[i] = Bm[j * m + i]; chol_solve(L, m, col); for (int i = 0; i < m; ++i) RiBt[i * ne + j] = col[i]; }
+    El& e = el[k];
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) {
+        double a = A[i * n + j]; for (int c = 0; c < m; ++c) a -= Bm[i * m + c] * RiH[c * n + j]; e.A[i * n + j] = a;
+        double qq = Q[i * n + j]; for (int c = 0; c < m; ++c) qq -= H[c * n + i] * RiH[c * n + j]; e.J[i * n + j] = qq;
+        double cc = 0; for (int c = 0; c < m; ++c) cc += Bm[i * m + c] * RiBt[c * n + j]; e.C[i * n + j] = cc;
+      }
+      double bb = 0; for (int c = 0; c < m; ++c) bb -= Bm[i * m + c] * Rir[c]; e.b[i] = bb;
+      double ee = q[i]; for (int c = 0; c < m; ++c) ee -= H[c * n + i] * Rir[c]; e.eta[i] = ee;
+    }
+  }
+  { El& e = el[N - 1]; std::memset(&e, 0, sizeof(e));
+    for (int i = 0; i < n * n; ++i) e.J[i] = t.Qxx[(size_t)(N - 1) * ne * ne + i];
+    for (int i = 0; i < n; ++i) e.eta[i] = t.qx[(size_t)(N - 1) * ne + i]; }
+  const int BL = 2, L = (N + BL - 1) / BL;
+  std::vector<El> cur(L), nxt(L);
+  for (int l = 0; l < L; ++l) {
+    int k0 = l * BL;
+    cur[l] = el[k0];
+    for (int k = k0 + 1; k < std::min(N, k0 + BL); ++k) { El o; combine(n, cur[l], el[k], o); cur[l] = o; }
+  }
+  for (int d = 1; d < L; d *= 2) {
+    for (int l = 0; l < L; ++l) { if (l + d < L) combine(n, cur[l], cur[l + d], nxt[l]); else nxt[l] = cur[l]; }
+    std::swap(cur, nxt);
+  }
+  /* per block: sequential Riccati steps from the next block's suffix value */
+  static thread_local std::vector<double> S, s, SA, SB, Qxx, Quu, Qux, Qx, Qu, Lc, col, KtQuu, Snew, snew;
+  S.resize(ne * ne); s.resize(ne); SA.resize(ne * ne); SB.resize(ne * m); Qxx.resize(ne * ne); Quu.resize(m * m); Qux.resize(m * ne);
+  Qx.resize(ne); Qu.resize(m); Lc.resize(m * m); col.resize(m); KtQuu.resize(ne * m); Snew.resize(ne * ne); snew.resize(ne);
+  t.dV[0] = t.dV[1] = 0.0;
+  std::vector<double> dv1s(N - 1), dv2s(N - 1);
+  for (int l = L - 1; l >= 0; --l) {
+    int k0 = l * BL, kend = std::min(N, k0 + BL);  /* knots k0 .. kend-1 */
+    if (kend == N) { /* block holds the terminal knot */
+      for (int i = 0; i < ne * ne; ++i) S[i] = t.Qxx[(size_t)(N - 1) * ne * ne + i];
+      for (int i = 0; i < ne; ++i) s[i] = t.qx[(size_t)(N - 1) * ne + i];
+      kend = N - 1;
+    } else {
+      for (int i = 0; i < ne * ne; ++i) S[i] = cur[l + 1].J[i];
+      for (int i = 0; i < ne; ++i) s[i] = cur[l + 1].eta[i];
+    }
+    for (int k = kend - 1; k >= k0; --k) {
+      const double* A = &t.A[(size_t)k * ne * ne]; const double* Bm = &t.Bm[(size_t)k * ne * m];
+      const double* cQxx = &t.Qxx[(size_t)k * ne * ne]; const double* cQuu = &t.Quu[(size_t)k * m * m];
+      const double* cQux = &t.Qux[(size_t)k * m * ne]; const double* cqx = &t.qx[(size_t)k * ne]; const double* cqu = &t.qu[(size_t)k * m];
+      matmul(S.data(), A, SA.data(), ne, ne, ne);
+      matmul(S.data(), Bm, SB.data(), ne, ne, m);
+      for (int i = 0; i < ne; ++i) { double v = cqx[i]; for (int r = 0; r < ne; ++r) v += A[r * ne + i] * s[r]; Qx[i] = v; }
+      for (int j = 0; j < m; ++j) { double v = cqu[j]; for (int r = 0; r < ne; ++r) v += Bm[r * m + j] * s[r]; Qu[j] = v; }
+      for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double v = cQxx[i * ne + j]; for (int r = 0; r < ne; ++r) v += A[r * ne + i] * SA[r * ne + j]; Qxx[i * ne + j] = v; }
+      for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { double v = cQuu[i * m + j]; for (int r = 0; r < ne; ++r) v += Bm[r * m + i] * SB[r * m + j]; Quu[i * m + j] = v; }
+      for (int i = 0; i < m; ++i) for (int j = 0; j < ne; ++j) { double v = cQux[i * ne + j]; for (int r = 0; r < ne; ++r) v += Bm[r * m + i] * SA[r * ne + j]; Qux[i * ne + j] = v; }
+      for (int i = 0; i < m * m; ++i) Lc[i] = Quu[i];
+      if (!cholesky(Lc.data(), m)) return backward(P, t);
+      double* K = &t.K[(size_t)k * m * ne]; double* d = &t.d[(size_t)k * m];
+      for (int j = 0; j < ne; ++j) { for (int i = 0; i < m; ++i) col[i] = Qux[i * ne + j]; chol_solve(Lc.data(), m, col.data()); for (int i = 0; i < m; ++i) K[i * ne + j] = -col[i]; }
+      for (int i = 0; i < m; ++i) col[i] = Qu[i];
+      chol_solve(Lc.data(), m, col.data());
+      for (int i = 0; i < m; ++i) d[i] = -col[i];
+      for (int i = 0; i < ne; ++i) for (int j = 0; j < m; ++j) { double v = 0.0; for (int r = 0; r < m; ++r) v += K[r * ne + i] * Quu[r * m + j]; KtQuu[i * m + j] = v; }
+      for (int i = 0; i < ne; ++i) {
+        double v = Qx[i];
+        for (int j = 0; j < m; ++j) v += KtQuu[i * m + j] * d[j];
+        for (int j = 0; j < m; ++j) v += K[j * ne + i] * Qu[j];
+        for (int j = 0; j < m; ++j) v += Qux[j * ne + i] * d[j];
+        snew[i] = v;
+      }
+      for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) {
+        double v = Qxx[i * ne + j];
+        for (int r = 0; r < m; ++r) v += KtQuu[i * m + r] * K[r * ne + j];
+        for (int r = 0; r < m; ++r) v += K[r * ne + i] * Qux[r * ne + j];
+        for (int r = 0; r < m; ++r) v += Qux[r * ne + i] * K[r * ne + j];
+        Snew[i * ne + j] = v;
+      }
+      for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) S[i * ne + j] = 0.5 * (Snew[i * ne + j] + Snew[j * ne + i]);
+      for (int i = 0; i < ne; ++i) s[i] = snew[i];
+      double dv1 = 0.0, dv2 = 0.0;
+      for (int i = 0; i < m; ++i) { dv1 += d[i] * Qu[i]; double v = 0.0; for (int j = 0; j < m; ++j) v += Quu[i * m + j] * d[j]; dv2 += d[i] * v; }
+      dv1s[k] = dv1; dv2s[k] = 0.5 * dv2;
+    }
+  }
+  for (int k = N - 2; k >= 0; --k) { t.dV[0] += dv1s[k]; t.dV[1] += dv2s[k]; }
+  reg_decrease(P, t);
+  return true;
+}
+
 /* closed-loop rollout with step alpha into (Xb,Ub); false if a state/control limit or NaN is hit */
 bool rollout_closed_loop(const Problem& P, Traj& t, double alpha) {
   const int n = P.n, m = P.m, ne = P.ne, N = P.N;
@@ -627,7 +801,7 @@ double gradient_metric(const Problem& P, const Traj& t) {
 /* one iLQR iteration; returns true when the inner solve is finished (status set) */
 bool ilqr_step(const Problem& P, Traj& t, double cost_tol, int max_iters, double& J_prev) {
   expand(P, t);
-  if (!backward(P, t)) { t.status = TO_REGULARIZATION_MAX; return true; }
+  if (!(std::getenv("ORACLE_RICCATI_SCAN") ? backward_scan(P, t) : backward(P, t))) { t.status = TO_REGULARIZATION_MAX; return true; }
   double J = forward(P, t, J_prev);
   t.dJ = J_prev - J;
   /* a zero step (stationary point) makes no progress either: with a gradient tolerance it cannot meet, the solve ends
@@ -822,7 +996,7 @@ int oracle_stage_costs(oracle_handle* h, double* Jk) {
 int oracle_expand(oracle_handle* h) { CHECK_H(h); for_batch(h, [&](Traj& t, int) { expand(h->P, t); }); return TO_OK; }
 int oracle_backward(oracle_handle* h) {
   CHECK_H(h);
-  for_batch(h, [&](Traj& t, int) { if (!backward(h->P, t)) t.status = TO_REGULARIZATION_MAX; });
+  for_batch(h, [&](Traj& t, int) { if (!(std::getenv("ORACLE_RICCATI_SCAN") ? backward_scan(h->P, t) : backward(h->P, t))) t.status = TO_REGULARIZATION_MAX; });
   return TO_OK;
 }
 int oracle_forward(oracle_handle* h, int32_t* ls_index, double* J_new) {

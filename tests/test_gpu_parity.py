@@ -1263,3 +1263,52 @@ def test_hybrid_model_vector_large_batch_on_gpu(hip, oracle):
     np.testing.assert_array_equal(sh.stats["iterations"][idx], so.stats["iterations"])
     np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=1e-9)
     np.testing.assert_allclose(T.states(ph)[idx], T.states(po), rtol=1e-7, atol=1e-9)
+
+
+def test_scan_backward_pass(hip, oracle, monkeypatch):
+    """k_expand_backward_scan (k_scan.h): the Riccati recursion as an associative scan over the horizon — one wave per trajectory,
+    two knots per lane — against the oracle's sequential recursion.  Gains and expected improvement through the phase API
+    (TRAJOPT_SCAN=2 routes to_backward through the solve loop's kernel pair), on the initial guess and on iterates of the solve;
+    a trajectory with pending regularisation (rho > 0) must come out of the cooperative kernel exactly as without the scan; then
+    full solves with the scan on (default) and off: identical integers, results within the band."""
+    monkeypatch.setenv("TRAJOPT_SCAN", "2")
+    for name, batch in (("cartpole", 70), ("di", 5)):
+        def build(lib):
+            if name == "cartpole":
+                return configs.cartpole_problem(batch=batch, lib=lib)
+            model = T.DoubleIntegrator(1.0, 2)
+            N = 21
+            obj = T.LQRObjective(np.ones(4), 0.1 * np.ones(2), 10 * np.ones(4), np.array([1.0, 2.0, 0, 0]), N)
+            p = T.Problem(model, obj, np.zeros(4), 3.0, batch=batch, lib=lib)
+            T.initial_controls(p, np.array([0.1, 0.0]))
+            return p
+        ph, po = build(hip), build(oracle)
+        for it in range(6):
+            for p in (ph, po):
+                if it == 0:
+                    T.rollout(p)
+                I.expand(p); I.backwardpass(p)
+            kh, ko = I.gains(ph), I.gains(po)
+            np.testing.assert_array_equal(kh["rho"], ko["rho"])
+            # iteration 0: the same inputs to the last bit — the scan's own rounding (2e-15 of the largest gain in the numpy
+            # prototype); later iterates have drifted apart by what the solve amplifies (1e8 on this problem: DESIGN.md §2)
+            tolK, told = (1e-13, 1e-12) if it == 0 else (1e-9, 1e-8)
+            scale = np.abs(ko["K"]).max(axis=(1, 2, 3), keepdims=True)
+            assert np.max(np.abs(kh["K"] - ko["K"]) / scale) < tolK, f"{name} iteration {it}"
+            dscale = np.maximum(np.abs(ko["d"]).max(axis=(1, 2), keepdims=True), 1e-6)   # (an exactly solved LQ problem leaves d = rounding noise)
+            assert np.max(np.abs(kh["d"] - ko["d"]) / dscale) < told, f"{name} iteration {it}"
+            np.testing.assert_allclose(kh["dV"], ko["dV"], rtol=1e-12 if it == 0 else 1e-8, atol=1e-18)
+            for p in (ph, po):
+                I.forwardpass(p)
+    # full solves: scan on / off / oracle
+    sols = {}
+    for scan in ("1", "0"):
+        monkeypatch.setenv("TRAJOPT_SCAN", scan)
+        p = configs.cartpole_problem(batch=200, lib=hip)
+        s = T.iLQRSolver(p).solve()
+        sols[scan] = (s, p)
+    po = configs.cartpole_problem(batch=200, lib=oracle)
+    so = T.iLQRSolver(po).solve()
+    for scan in ("1", "0"):
+        s, p = sols[scan]
+        assert_solve_parity(s, so, p, po)

@@ -71,3 +71,45 @@ def test_c5_oracle_vs_oracle_ulp_perturbations(oracle):
         np.testing.assert_allclose(base[0]["cost"], b[0]["cost"], rtol=2e-3)
     # the perturbations are 1e-16 relative: anything above 1e-9 on an identical path is amplification by the solve itself
     assert worst > 1e-9, "the C5 solve no longer amplifies a 1-ulp perturbation: re-derive the GPU thresholds"
+
+
+def test_c2_scan_riccati_arithmetic_leaves_the_solves_in_place(oracle, monkeypatch):
+    """The GPU's scan backward pass (csrc/k_scan.h) computes the cost-to-go at every second knot with an associative scan, so its
+    gains carry another rounding than the sequential recursion's (2e-15 of the largest gain).  The Cartpole iLQR solve amplifies
+    backward-pass perturbations by ~1e8 (a relative 1e-14 noise on S moves 0.6 % of the C2 batch past 1e-6, 1e-13 moves 5 %), so
+    "close gains" proves nothing by itself.  This test does: the oracle runs the C2 solve with the sequential recursion and with
+    the arithmetic model of the scan (oracle/trajopt_oracle.cpp backward_scan: same elements, same Hillis-Steele order, same
+    blocks of two knots — env ORACLE_RICCATI_SCAN) on a sub-batch.  Measured on the whole C2 batch of 1024: every iteration count
+    and status identical, converged states within 2.8e-7, costs within 2.4e-9 (relative)."""
+    from oracle_binding import set_threads
+    cnt = 192
+
+    def solve(scan):
+        if scan:
+            monkeypatch.setenv("ORACLE_RICCATI_SCAN", "1")
+        else:
+            monkeypatch.delenv("ORACLE_RICCATI_SCAN", raising=False)
+        p = configs.cartpole_problem(batch=cnt, lib=oracle)
+        set_threads(p, oracle.max_threads())
+        s = T.iLQRSolver(p).solve()
+        return {k: v.copy() for k, v in s.stats.items()}, T.states(p), T.controls(p), p
+
+    (sa, Xa, Ua, pa), (sb, Xb, Ub, pb) = solve(False), solve(True)
+    np.testing.assert_array_equal(sa["iterations"], sb["iterations"])
+    np.testing.assert_array_equal(sa["status"], sb["status"])
+    assert relerr(Xa, Xb).max() < 1e-6 and relerr(Ua, Ub).max() < 1e-6
+    np.testing.assert_allclose(sa["cost"], sb["cost"], rtol=1e-7)
+    # and the scan really ran: its gains differ from the sequential ones in the last bits on the same iterate
+    from trajopt_amd import internal as I
+    gains = []
+    for scan in (False, True):
+        if scan:
+            monkeypatch.setenv("ORACLE_RICCATI_SCAN", "1")
+        else:
+            monkeypatch.delenv("ORACLE_RICCATI_SCAN", raising=False)
+        p = configs.cartpole_problem(batch=4, lib=oracle)
+        T.rollout(p); I.expand(p); I.backwardpass(p)
+        gains.append(I.gains(p))
+    dK = np.abs(gains[0]["K"] - gains[1]["K"]).max() / np.abs(gains[0]["K"]).max()
+    assert 0.0 < dK < 1e-13
+    np.testing.assert_allclose(gains[0]["dV"], gains[1]["dV"], rtol=1e-12)

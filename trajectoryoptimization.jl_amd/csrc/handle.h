@@ -48,6 +48,8 @@ struct to_handle_s {
   int cw_deep = 0, tw_deep = 0, deep_max_active = 0;
   int fwd2 = 2;           // forward pass as two-wave workgroups (roller + accountant, k_forward2): 0 never, 1 always, 2 per step (TRAJOPT_FWD2)
   int simds = 1024;       // SIMDs of the device (4 per CU)
+  int scan = 0;           // solve loop: scan backward pass (k_scan.h) ahead of the fused cooperative kernel while the active trajectories are few (TRAJOPT_SCAN=0/1)
+  int scan_max_active = 0;
   int fused_coop = 0;     // solve loop, cooperative path with diagonal cost blocks: one k_expand_backward_coop launch (TRAJOPT_FUSED_COOP=0 to split)
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
   int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
@@ -102,6 +104,7 @@ struct ModelOps {
   int (*expand)(to_handle*) = nullptr;
   int (*backward)(to_handle*) = nullptr;
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)
+  int (*expand_backward_scan)(to_handle*) = nullptr;  // fused expansion + scan Riccati, one wave per trajectory (k_scan.h)
   int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
   int (*forward2[32])(to_handle*) = {};  // the same variants as two-wave workgroups (k_forward2; models with LDS-staged gains)
@@ -128,6 +131,7 @@ void fill_ops_quadmrp_forward(ModelOps* table);
 void fill_ops_quadrp_forward(ModelOps* table);
 void fill_ops_hybrid(ModelOps* table);
 void fill_ops_small_forward2(ModelOps* table);
+void fill_ops_small_scan(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

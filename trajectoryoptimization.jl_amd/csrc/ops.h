@@ -4,6 +4,7 @@
 #include "k_backward.h"
 #include "k_expand.h"
 #include "k_forward.h"
+#include "k_scan.h"
 #include "k_misc.h"
 
 namespace to {
@@ -205,6 +206,22 @@ int op_expand_backward_coop(to_handle* h) {
     if (h->a.P.integrator == INTEG_RK4) return op_expand_backward_coop_fi<M, INTEG_RK4>(h);
   }
   return op_expand_backward_coop_fi<M, -1>(h);
+}
+
+// fused expansion + scan backward pass (k_scan.h): unconstrained problems with diagonal cost blocks, one wave per trajectory
+template <class M>
+int op_expand_backward_scan(to_handle* h) {
+  if constexpr (!M::lie && M::ne <= 4 && M::m <= 2) {
+    const DevProblem& P = h->a.P;
+    if (P.expand_variant != 0 || !h->a.h_diag || P.N > 126) return fail(TO_ERR_UNSUPPORTED, "scan backward pass: outside its scope");
+    const dim3 grid(P.B);
+    if (M::pin_rk4 && P.integrator == INTEG_RK4) {
+      if constexpr (M::pin_rk4) hipLaunchKernelGGL((k_expand_backward_scan<M, INTEG_RK4, 0>), grid, dim3(64), 0, h->stream, h->a);
+    } else hipLaunchKernelGGL((k_expand_backward_scan<M, -1, 0>), grid, dim3(64), 0, h->stream, h->a);
+    HIPCHECK(hipGetLastError());
+    return TO_OK;
+  }
+  return fail(TO_ERR_UNSUPPORTED, "scan backward pass not compiled for this model");
 }
 
 // forward pass (line search + state machine) of kernel variant MODE: grid = one wave per TW = 64 / CW trajectories
