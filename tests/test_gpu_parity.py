@@ -780,7 +780,8 @@ def test_large_batch_compaction_two_launch_path(hip, monkeypatch):
     """Batches beyond 16 384 trajectories build their active lists with the two-launch compaction (k_compact_count /
     k_compact_write, index order): 20 000 Cartpole trajectories (ragged: 313 tiles, the last one partly empty) on the fused lane
     path, 40 iterations so that part of the batch has converged and the lists have holes — bit-identical to the same solve
-    without compaction."""
+    without compaction.  (Unconstrained batches below ~20 000 default to the scan + cooperative kernels: the lane path is forced.)"""
+    monkeypatch.setenv("TRAJOPT_BACKWARD", "lane")
     out = []
     for compact in ("1", "0"):
         monkeypatch.setenv("TRAJOPT_COMPACT", compact)
@@ -1245,10 +1246,11 @@ def test_hybrid_model_vector_on_gpu(path, hip, oracle, monkeypatch):
     np.testing.assert_array_equal(T.controls(ph)[:, 6:, 1], 0.0)
 
 
-def test_hybrid_model_vector_large_batch_on_gpu(hip, oracle):
-    """The same model vector at a batch that takes the fused lane kernel and active-list compaction by default (B >= 12 288):
-    a sample of trajectories against the oracle."""
+def test_hybrid_model_vector_large_batch_on_gpu(hip, oracle, monkeypatch):
+    """The same model vector on the throughput path — fused lane kernel + active-list compaction (the default from ~20 000
+    unconstrained trajectories on; forced here at 12 325): a sample of trajectories against the oracle."""
     from test_hybrid_dims import hybrid_problem
+    monkeypatch.setenv("TRAJOPT_BACKWARD", "lane")
     batch = 12288 + 37
     (ph, _, x0, _) = hybrid_problem(hip, batch=batch)
     rng = np.random.default_rng(4)

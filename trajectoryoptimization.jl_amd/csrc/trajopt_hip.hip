@@ -727,7 +727,12 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     const long coop_waves = ((long)B + h->G - 1) / h->G;
     // (with the expansions fused into both kernels the crossover sits at ~12 000 Cartpole trajectories: measured fused lane vs
     // fused cooperative 10.8 vs 9.9 M it/s at B = 12 288, 7.9 vs 9.3 M at B = 8 192)
-    a.bwd_lane = (h->ops->lane_backward && coop_waves >= (h->ops->expand_backward ? 6L : 12L) * cus) ? 1 : 0;
+    // (and where the scan kernel runs ahead of the cooperative one — unconstrained problems with diagonal cost blocks — at
+    // ~20 000: scan + cooperative vs fused lane 15.2 vs 11.2 M it/s at B = 12 288, 17.1 vs 14.4 at 16 384, 19.4 vs 20.4 at 24 576)
+    const bool scan_path = h->ops->expand_backward_scan && h->cons.empty() && N <= 126 && diagonal_cost_blocks(h) &&
+                           !(std::getenv("TRAJOPT_SCAN") && !std::atoi(std::getenv("TRAJOPT_SCAN")));
+    const long lane_from = scan_path ? 10L : (h->ops->expand_backward ? 6L : 12L);
+    a.bwd_lane = (h->ops->lane_backward && coop_waves >= lane_from * cus) ? 1 : 0;
   }
   if (const char* env = std::getenv("TRAJOPT_BACKWARD")) {
     if (!std::strcmp(env, "coop") && h->ops->coop_backward) { a.bwd_mfma = 0; a.bwd_lane = 0; }
