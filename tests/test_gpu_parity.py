@@ -1270,9 +1270,10 @@ def test_hybrid_model_vector_large_batch_on_gpu(hip, oracle, monkeypatch):
 def test_scan_backward_pass(hip, oracle, monkeypatch):
     """k_expand_backward_scan (k_scan.h): the Riccati recursion as an associative scan over the horizon — one wave per trajectory,
     two knots per lane — against the oracle's sequential recursion.  Gains and expected improvement through the phase API
-    (TRAJOPT_SCAN=2 routes to_backward through the solve loop's kernel pair), on the initial guess and on iterates of the solve;
-    a trajectory with pending regularisation (rho > 0) must come out of the cooperative kernel exactly as without the scan; then
-    full solves with the scan on (default) and off: identical integers, results within the band."""
+    (TRAJOPT_SCAN=2 routes to_backward through the solve loop's kernel), on the initial guess and on iterates of the solve; a
+    trajectory with pending regularisation (rho > 0: no Riccati recursion, no scan) takes the sequential pass inside the same
+    kernel and must match the oracle's sequential pass to the last digits; then full solves with the scan on (default) and off:
+    identical integers, results within the band."""
     monkeypatch.setenv("TRAJOPT_SCAN", "2")
     for name, batch in (("cartpole", 70), ("di", 5)):
         def build(lib):
@@ -1302,6 +1303,20 @@ def test_scan_backward_pass(hip, oracle, monkeypatch):
             np.testing.assert_allclose(kh["dV"], ko["dV"], rtol=1e-12 if it == 0 else 1e-8, atol=1e-18)
             for p in (ph, po):
                 I.forwardpass(p)
+    # regularisation pending from the start (bp_reg_initial > 0): the in-kernel sequential pass, phase API and full solve
+    def build_reg(lib):
+        return configs.cartpole_problem(batch=33, lib=lib, options=T.SolverOptions(lib=lib, bp_reg_initial=5.0))
+    ph, po = build_reg(hip), build_reg(oracle)
+    for p in (ph, po):
+        T.rollout(p); I.expand(p); I.backwardpass(p)
+    kh, ko = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(kh["K"], ko["K"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(kh["d"], ko["d"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(kh["dV"], ko["dV"], rtol=1e-12)
+    np.testing.assert_array_equal(kh["rho"], ko["rho"])
+    ph, po = build_reg(hip), build_reg(oracle)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
     # full solves: scan on / off / oracle
     sols = {}
     for scan in ("1", "0"):

@@ -37,8 +37,6 @@ struct KArgs {
   // nothing in its arithmetic.  Index order keeps neighbouring lanes on neighbouring trajectories: the nominal arrays are
   // batch-fastest, and an arbitrary order (atomic appends) turned every nominal load into one 64-byte sector per lane (C5:
   // forward fetch traffic x2.5).
-  int* bwd_done;  // [Bp] scan backward pass (k_scan.h): 1 = this step's gains of the trajectory are done, the cooperative kernel skips it
-  int scan_step;  // 1: k_expand_backward_scan ran in this batch step (bwd_done is current)
   int coop_merge; // fused cooperative pass: symmetrise the cost-to-go Hessian where it is read (coop_knot; TRAJOPT_COOP_MERGE)
   int compact;    // 1: on
   int* alist;     // [2][Bp]

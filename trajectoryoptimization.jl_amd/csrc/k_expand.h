@@ -849,11 +849,10 @@ __global__ void __launch_bounds__(128) k_expand_backward_coop(KArgs a) {
   // ---- roles.  Backward wave: lane (g, j) as in k_backward_coop.  Expander wave: lane (kk, ge) = knot kk of the chunk, trajectory ge.
   const int g = lane / R, j = lane % R;
   const int b = gtile * G + g;
-  // (a trajectory whose gains the scan kernel produced in this batch step — k_scan.h — takes no part)
-  const bool glive = (b < P.B) && a.active[b < P.B ? b : 0] && !(a.scan_step && a.bwd_done[b < P.B ? b : 0]);
+  const bool glive = (b < P.B) && a.active[b < P.B ? b : 0];
   const int kk = lane / G, ge = lane % G;
   const int be = gtile * G + ge;
-  const bool elive = (be < P.B) && a.active[be < P.B ? be : 0] && !(a.scan_step && a.bwd_done[be < P.B ? be : 0]);
+  const bool elive = (be < P.B) && a.active[be < P.B ? be : 0];
   {  // workgroup-uniform exit: nothing to do for any of the G trajectories
     __shared__ int any_live;
     if (threadIdx.x == 0) any_live = 0;

@@ -16,14 +16,15 @@
 //      whose (J, eta) IS the cost-to-go (S, s) at knot 2l;
 //   4. takes (S, s) of the NEXT block from lane l+1 and walks its own two knots with the sequential recursion — the very
 //      expressions of k_backward_lane — which yields the gains, the expected improvement and nothing else.
-// 7 combines + 2 expansions + 2 Riccati steps per lane instead of 100 dependent knots: ~25 us instead of 94 us per C2 step.
+// 7 combines + 2 expansions + 2 Riccati steps per lane instead of 100 dependent knots: 30 us instead of 88 us per C2 step.
 // The cost-to-go at the block boundaries carries the scan's rounding instead of the sequential recursion's: gains agree to
 // 2e-15 (max-norm, relative); solving the C2 batch of 1024 with this arithmetic on the CPU leaves every iteration count and
 // status unchanged and moves the converged states by <= 2.8e-7 — inside the 1e-6 band.
 // Scope: rho == 0 on entry (no control regularisation: with rho > 0 the recursion S = Qxx + K'QuuK + ... uses the UNregularised
 // Quu with gains of the regularised one and is no Riccati recursion any more), diagonal cost blocks, unconstrained problems,
-// N <= 126, ne <= 4, m <= 2.  A trajectory outside the scope, or whose Quu turns out not positive definite, is left to
-// the cooperative kernel, which runs right after this one for exactly those (KArgs::bwd_done).
+// N <= 126, ne <= 4, m <= 2.  A trajectory with rho > 0, or whose Quu turns out not positive definite, takes the sequential pass
+// in this same wave (every knot's expansion is parked in LDS; all lanes walk the horizon on broadcast operands): the arithmetic
+// and the restart rule of k_backward_lane, no second launch.
 #pragma once
 #include "common.h"
 #include "k_backward.h"
@@ -209,11 +210,11 @@ __device__ __forceinline__ bool scan_element(const double* Mk, const double* Hd,
   return ok || beyond;
 }
 
-// One sequential Riccati step (k_backward_lane's knot with rho = 0, verbatim) from (S, s) = cost-to-go at knot k+1: gains row to
-// pKk, expected-improvement terms, (S, s) <- cost-to-go at knot k.  false: Quu is not positive definite.
+// One sequential Riccati step (k_backward_lane's knot, verbatim) from (S, s) = cost-to-go at knot k+1: gains row to pKk,
+// expected-improvement terms, (S, s) <- cost-to-go at knot k.  false: Quu + rho I is not positive definite.
 template <class M>
 __device__ __forceinline__ bool scan_riccati_step(const double* Me, const double* Hd, const double* g, double (&S)[M::ne][M::ne], double (&s)[M::ne],
-                                                  double* pKk, bool store, double& dv1o, double& dv2o) {
+                                                  double rho, double* pKk, bool store, double& dv1o, double& dv2o) {
   constexpr int m = M::m, ne = M::ne, nc = ne + m;
   double Mk[ne][nc];
 #pragma unroll
@@ -262,7 +263,7 @@ __device__ __forceinline__ bool scan_riccati_step(const double* Me, const double
 #pragma unroll
   for (int r = 0; r < m; ++r)
 #pragma unroll
-    for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q];
+    for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
 #pragma unroll
   for (int q = 0; q < m; ++q) {
     double sj = Lc[q][q];
@@ -373,10 +374,8 @@ __global__ void __launch_bounds__(64, 1) k_expand_backward_scan(KArgs a) {
   const int N = P.N;
   const int b = blockIdx.x, l = threadIdx.x;
   const int tile = b >> 6, lane = b & 63;
-  // scope (wave-uniform): active, no regularisation pending
   double rho = a.rho[b], drho = a.drho[b];
   if (!a.active[b]) return;
-  if (rho != 0.0) { if (l == 0) a.bwd_done[b] = 0; return; }
   const int c = M::accept_write_through ? a.acc[b] : 0;
   const double* X = X_SLOT_PTR(a, b, c);
   const double* U = U_SLOT_PTR(a, b, c);
@@ -423,95 +422,137 @@ __global__ void __launch_bounds__(64, 1) k_expand_backward_scan(KArgs a) {
     }
     scan_combine<ne>(e0, e1, el);
   }
-  // ---- 3: suffix scan across the lanes: after round d lane l holds the element of blocks l .. l + 2d - 1
-  const int NB = (N + 1) / 2;  // blocks on the horizon
-#pragma unroll 1
-  for (int d = 1; d < NB; d <<= 1) {
-    E pe;
-    const int src = l + d;
-    const bool has = src < 64;
-    const int sl = has ? src : 63;
-    {
-      const double* pv = (const double*)&el;
-      double* po = (double*)&pe;
-#pragma unroll
-      for (int i = 0; i < E::NV; ++i) po[i] = scan_shfl(pv[i], sl);
-    }
-    if (!has) pe.identity();
-    E out;
-    scan_combine<ne>(el, pe, out);
-    el = out;
-  }
-  // ---- 4: cost-to-go behind this lane's block, then its own knots sequentially
-  double S[ne][ne], s[ne];
-  {
-    const int src = (l + 1 < 64) ? l + 1 : 63;
-    double Jn[E::NSY], en[ne];
-#pragma unroll
-    for (int i = 0; i < E::NSY; ++i) Jn[i] = scan_shfl(el.J[i], src);
-#pragma unroll
-    for (int i = 0; i < ne; ++i) en[i] = scan_shfl(el.eta[i], src);
-#pragma unroll
-    for (int i = 0; i < ne; ++i) {
-#pragma unroll
-      for (int j = 0; j < ne; ++j) S[i][j] = Jn[E::sy(i, j)];
-      s[i] = en[i];
-    }
-  }
+  // ---- the scan path proper: no regularisation pending (wave-uniform)
   double dV0 = 0.0, dV1 = 0.0;
   double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
-#pragma unroll
-  for (int kk = 1; kk >= 0; --kk) {
-    const int k = 2 * l + kk;
-    double Mk[ne * nc], Hd[nc], g[nc];
-    const double* pk = park + (size_t)kk * PK * 64 + l;
-#pragma unroll
-    for (int i = 0; i < ne * nc; ++i) Mk[i] = pk[i * 64];
-#pragma unroll
-    for (int j = 0; j < nc; ++j) { Hd[j] = pk[(ne * nc + j) * 64]; g[j] = pk[(ne * nc + nc + j) * 64]; }
-    if (k == N - 1) {  // the terminal knot opens the recursion of its block: S = Q_N, s = q_N
-#pragma unroll
+  bool done = false, failed = false;
+  // (a control cost entry that is not positive admits no element — C = B R⁻¹ B' — but the sequential pass may still find
+  // Quu = R + B'SB positive definite: such a trajectory walks sequentially with its rho untouched)
+  const bool elements_ok = __ballot(!ok) == 0;
+  if (rho == 0.0 && elements_ok) {
+    // ---- 3: suffix scan across the lanes: after round d lane l holds the element of blocks l .. l + 2d - 1
+    const int NB = (N + 1) / 2;  // blocks on the horizon
+  #pragma unroll 1
+    for (int d = 1; d < NB; d <<= 1) {
+      E pe;
+      const int src = l + d;
+      const bool has = src < 64;
+      const int sl = has ? src : 63;
+      {
+        const double* pv = (const double*)&el;
+        double* po = (double*)&pe;
+  #pragma unroll
+        for (int i = 0; i < E::NV; ++i) po[i] = scan_shfl(pv[i], sl);
+      }
+      if (!has) pe.identity();
+      E out;
+      scan_combine<ne>(el, pe, out);
+      el = out;
+    }
+    // ---- 4: cost-to-go behind this lane's block, then its own knots sequentially
+    double S[ne][ne], s[ne];
+    {
+      const int src = (l + 1 < 64) ? l + 1 : 63;
+      double Jn[E::NSY], en[ne];
+  #pragma unroll
+      for (int i = 0; i < E::NSY; ++i) Jn[i] = scan_shfl(el.J[i], src);
+  #pragma unroll
+      for (int i = 0; i < ne; ++i) en[i] = scan_shfl(el.eta[i], src);
+  #pragma unroll
       for (int i = 0; i < ne; ++i) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) S[i][j] = (i == j) ? Hd[i] : 0.0;
-        s[i] = g[i];
+  #pragma unroll
+        for (int j = 0; j < ne; ++j) S[i][j] = Jn[E::sy(i, j)];
+        s[i] = en[i];
       }
     }
-    const bool stage = k < N - 1;  // (lanes / knots past the horizon compute along on finite data and store nothing)
-    double dv1, dv2;
-    double St[ne][ne], st[ne];
-#pragma unroll
-    for (int i = 0; i < ne; ++i) {
-#pragma unroll
-      for (int j = 0; j < ne; ++j) St[i][j] = S[i][j];
-      st[i] = s[i];
-    }
-    const bool pd = scan_riccati_step<M>(Mk, Hd, g, St, st, pK + (size_t)(stage ? k : 0) * RSK, stage, dv1, dv2);
-    if (stage) {
-      if (!pd) ok = false;
-      dV0 += dv1; dV1 += dv2;
-#pragma unroll
-      for (int i = 0; i < ne; ++i) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) S[i][j] = St[i][j];
-        s[i] = st[i];
+  #pragma unroll
+    for (int kk = 1; kk >= 0; --kk) {
+      const int k = 2 * l + kk;
+      double Mk[ne * nc], Hd[nc], g[nc];
+      const double* pk = park + (size_t)kk * PK * 64 + l;
+  #pragma unroll
+      for (int i = 0; i < ne * nc; ++i) Mk[i] = pk[i * 64];
+  #pragma unroll
+      for (int j = 0; j < nc; ++j) { Hd[j] = pk[(ne * nc + j) * 64]; g[j] = pk[(ne * nc + nc + j) * 64]; }
+      if (k == N - 1) {  // the terminal knot opens the recursion of its block: S = Q_N, s = q_N
+  #pragma unroll
+        for (int i = 0; i < ne; ++i) {
+  #pragma unroll
+          for (int j = 0; j < ne; ++j) S[i][j] = (i == j) ? Hd[i] : 0.0;
+          s[i] = g[i];
+        }
       }
+      const bool stage = k < N - 1;  // (lanes / knots past the horizon compute along on finite data and store nothing)
+      double dv1, dv2;
+      double St[ne][ne], st[ne];
+  #pragma unroll
+      for (int i = 0; i < ne; ++i) {
+  #pragma unroll
+        for (int j = 0; j < ne; ++j) St[i][j] = S[i][j];
+        st[i] = s[i];
+      }
+      const bool pd = scan_riccati_step<M>(Mk, Hd, g, St, st, 0.0, pK + (size_t)(stage ? k : 0) * RSK, stage, dv1, dv2);
+      if (stage) {
+        if (!pd) ok = false;
+        dV0 += dv1; dV1 += dv2;
+  #pragma unroll
+        for (int i = 0; i < ne; ++i) {
+  #pragma unroll
+          for (int j = 0; j < ne; ++j) S[i][j] = St[i][j];
+          s[i] = st[i];
+        }
+      }
+    }
+    // expected improvement: sum over the knots (fixed butterfly order)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { dV0 += __shfl_xor(dV0, o); dV1 += __shfl_xor(dV1, o); }
+    if (__ballot(!ok) == 0) done = true;
+    else {  // some Quu is not positive definite: what the sequential pass does at its first failure, then its restart below
+      reg_increase(P.opts, rho, drho);
+      if (rho > P.opts.bp_reg_max) failed = true;
     }
   }
-  // expected improvement: sum over the knots (fixed butterfly order)
+  // ---- regularisation pending (rho > 0: the regularised recursion is no Riccati recursion, no scan) or raised just now: the
+  // sequential pass, in this same wave.  Every knot's expansion is parked in LDS; ALL lanes walk the horizon together on the same
+  // (broadcast) operands — identical values in every lane, EXEC full, no exchange — lane 0 stores.  k_backward_lane's loop,
+  // restarts included; ~95 us for 100 knots, on a path the C2 solve never takes.
+  WAVE_SYNC();  // the parked expansions of every lane, visible to every lane
+  while (!done && !failed) {
+    double S[ne][ne], s[ne];
+    bool restart = false;
+    dV0 = 0.0; dV1 = 0.0;
+    for (int k = N - 1; k >= 0; --k) {
+      double Mk[ne * nc], Hd[nc], g[nc];
+      const double* pk = park + (size_t)(k & 1) * PK * 64 + (k >> 1);
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { dV0 += __shfl_xor(dV0, o); dV1 += __shfl_xor(dV1, o); }
-  const bool all_ok = __ballot(!ok) == 0;
-  if (l == 0) {
-    if (all_ok) {
-      reg_decrease(P.opts, rho, drho);
-      a.rho[b] = rho; a.drho[b] = drho;
-      a.dV[b] = dV0; a.dV[(size_t)P.Bp + b] = dV1;
-      a.bpfail[b] = 0;
-      a.bwd_done[b] = 1;
-    } else {
-      a.bwd_done[b] = 0;  // the cooperative kernel takes this trajectory (it raises rho and restarts as the sequential pass does)
+      for (int i = 0; i < ne * nc; ++i) Mk[i] = pk[i * 64];
+#pragma unroll
+      for (int j = 0; j < nc; ++j) { Hd[j] = pk[(ne * nc + j) * 64]; g[j] = pk[(ne * nc + nc + j) * 64]; }
+      if (k == N - 1) {
+#pragma unroll
+        for (int i = 0; i < ne; ++i) {
+#pragma unroll
+          for (int j = 0; j < ne; ++j) S[i][j] = (i == j) ? Hd[i] : 0.0;
+          s[i] = g[i];
+        }
+        continue;
+      }
+      double dv1, dv2;
+      const bool pd = scan_riccati_step<M>(Mk, Hd, g, S, s, rho, pK + (size_t)k * RSK, l == 0, dv1, dv2);
+      if (!pd) {  // (wave-uniform: every lane holds the same numbers)
+        reg_increase(P.opts, rho, drho);
+        if (rho > P.opts.bp_reg_max) failed = true; else restart = true;
+        break;
+      }
+      dV0 += dv1; dV1 += dv2;
     }
+    if (!restart) done = !failed;
+  }
+  if (!failed) reg_decrease(P.opts, rho, drho);
+  if (l == 0) {
+    a.rho[b] = rho; a.drho[b] = drho;
+    a.dV[b] = dV0; a.dV[(size_t)P.Bp + b] = dV1;
+    a.bpfail[b] = failed ? 1 : 0;
   }
 }
 

@@ -5,5 +5,7 @@ namespace to {
 void fill_ops_quadrp_forward(ModelOps* t) {
   fill_forward<QuadrotorAttModel<ATT_RP>, 8, 9>(t[6]);
   fill_forward<QuadrotorAttModel<ATT_RP>, 10, 11>(t[6]);
+  fill_forward2<QuadrotorAttModel<ATT_RP>, 8, 9>(t[6]);
+  fill_forward2<QuadrotorAttModel<ATT_RP>, 10, 11>(t[6]);
 }
 }  // namespace to

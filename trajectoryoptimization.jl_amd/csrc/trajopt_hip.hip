@@ -431,14 +431,9 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       if (!h->fused_lane && !fcoop) TRY(launch_expand(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 1], h->stream));
       if (h->fused_lane) TRY(h->ops->expand_backward(h));  // expansion in the registers of the lane that runs the recursion
-      else if (fcoop) {
-        // unconstrained problems with few active trajectories: the scan kernel first (every trajectory without pending
-        // regularisation: k_scan.h), the cooperative kernel for whatever it left
-        a.scan_step = (h->scan && P.expand_variant == 0 && last_active <= h->scan_max_active) ? 1 : 0;
-        if (a.scan_step) TRY(h->ops->expand_backward_scan(h));
-        TRY(h->ops->expand_backward_coop(h));  // expansion by a second wave of the workgroup, through an LDS ring
-        a.scan_step = 0;
-      }
+      else if (fcoop && h->scan && P.expand_variant == 0 && last_active <= h->scan_max_active)
+        TRY(h->ops->expand_backward_scan(h));  // unconstrained, diagonal cost blocks: the recursion as a scan over the horizon (k_scan.h)
+      else if (fcoop) TRY(h->ops->expand_backward_coop(h));  // expansion by a second wave of the workgroup, through an LDS ring
       else TRY(launch_backward(h));
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 2], h->stream));
       // forward-wave shape of this step, from the last active count the host has seen (results do not depend on it)
@@ -753,7 +748,6 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_SCAN")) { if (!std::atoi(env)) h->scan = 0; else if (h->scan && std::atoi(env) == 2) h->scan = 2; }
   h->scan_max_active = 1 << 30;
   if (const char* env = std::getenv("TRAJOPT_SCAN_MAX")) h->scan_max_active = std::atoi(env);
-  a.scan_step = 0;
   h->fused_lane = (a.bwd_lane && h->ops->expand_backward) ? 1 : 0;
   if (const char* env = std::getenv("TRAJOPT_FUSED_LANE")) if (!std::atoi(env)) h->fused_lane = 0;
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
@@ -771,7 +765,6 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.accp, Bp));
   TRYB(dev_alloc(h, &a.alist, 2 * (size_t)Bp)); TRYB(dev_alloc(h, &a.acount, 2)); TRYB(dev_alloc(h, &a.ccount, 256));
-  TRYB(dev_alloc(h, &a.bwd_done, (size_t)Bp));
   // active-list compaction: the fused lane path (large batches of the small models) and the MFMA path (Quadrotor: its expansion
   // waves hold four trajectories each and the solves end with long straggler tails — 141 batch steps for a mean of 52
   // iterations on C3); the cooperative small-batch path is latency-bound and keeps its fixed mapping;
@@ -814,6 +807,11 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     std::vector<double> nanv((size_t)N * n * Bp, std::nan(""));
     HIPB(hipMemcpyAsync(a.Xs, nanv.data(), nanv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPB(hipStreamSynchronize(h->stream));
+    {  // the regularisation a phase-API backward pass starts from (a solve resets it the same way: k_solve_init)
+      std::vector<double> rho0((size_t)Bp, P.opts.bp_reg_initial);
+      HIPB(hipMemcpyAsync(a.rho, rho0.data(), rho0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIPB(hipStreamSynchronize(h->stream));
+    }
     if (!cons.empty()) {
       std::vector<double> mu(cons.size() * Bp, P.opts.penalty_initial);
       HIPB(hipMemcpyAsync(a.mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -856,7 +854,9 @@ int to_solver_path(const to_handle* h, int32_t* info) {
   info[1] = (h->fused_lane || (!a.bwd_mfma && !a.bwd_lane && fcoop)) ? 1 : 0;
   info[2] = h->compact;
   info[3] = h->cw_base;
-  info[4] = (h->fwd2 && h->ops->forward2[1]) ? 2 : 1;  // (two-wave workgroups are used while the active trajectories leave room for them)
+  bool has2 = false;
+  for (int i = 0; i < 32; ++i) has2 = has2 || h->ops->forward2[i] != nullptr;
+  info[4] = (h->fwd2 && has2) ? 2 : 1;  // (two-wave workgroups are used while the active trajectories leave room for them)
   info[5] = (h->scan && fcoop && P.expand_variant == 0 && !a.bwd_mfma && !a.bwd_lane) ? 1 : 0;
   info[6] = info[7] = 0;
   return TO_OK;
@@ -993,12 +993,9 @@ int to_backward(to_handle* h) {
   TRY(launch_set_active(h, 1));
   const DevProblem& P = h->a.P;
   if (h->scan == 2 && h->a.h_diag && P.expand_variant == 0) {
-    // TRAJOPT_SCAN=2 (tests): the phase API runs the solve loop's fused pair — scan kernel, then the cooperative kernel for what
-    // it left — so that its gains can be read back and compared; both expand on their own (to_expand's arrays are not used)
-    h->a.scan_step = 1;
+    // TRAJOPT_SCAN=2 (tests): the phase API runs the solve loop's scan kernel so that its gains can be read back and compared
+    // (it expands on its own: to_expand's arrays are not used)
     TRY(h->ops->expand_backward_scan(h));
-    TRY(h->ops->expand_backward_coop(h));
-    h->a.scan_step = 0;
   } else TRY(launch_backward(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
