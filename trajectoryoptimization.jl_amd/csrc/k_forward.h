@@ -436,19 +436,25 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
     for (int i = 0; i < n; ++i) vals[i] = xb[i];
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
+    {
+      // the roller has registers to spare (the accountant holds the cost / AL state): the whole gains block of the knot is
+      // requested in one go — one LDS round trip per knot instead of one per row (C3 forward phase 604.8 -> 599.5 us per step)
+      double kr[m][ne + 1];
 #pragma unroll
-    for (int j = 0; j < m; ++j) {
-      double kr[ne + 1];
+      for (int j = 0; j < m; ++j)
 #pragma unroll
-      for (int i = 0; i <= ne; ++i) kr[i] = KLDS ? kcur[j * (ne + 1) + i] : cur.kd[KLDS ? 0 : j * (ne + 1) + i];
+        for (int i = 0; i <= ne; ++i) kr[j][i] = KLDS ? kcur[j * (ne + 1) + i] : cur.kd[KLDS ? 0 : j * (ne + 1) + i];
       if constexpr (KLDS) __builtin_amdgcn_sched_barrier(0);
-      const double dj = kr[ne];
-      double du = dj * alpha;
 #pragma unroll
-      for (int i = 0; i < ne; ++i) du += kr[i] * dx[i];
-      ub[j] = cur.u[j] + du;
-      vals[n + j] = ub[j];
-      vals[n + m + j] = dj;
+      for (int j = 0; j < m; ++j) {
+        const double dj = kr[j][ne];
+        double du = dj * alpha;
+#pragma unroll
+        for (int i = 0; i < ne; ++i) du += kr[j][i] * dx[i];
+        ub[j] = cur.u[j] + du;
+        vals[n + j] = ub[j];
+        vals[n + m + j] = dj;
+      }
     }
     if (2 * R::PAIRS > R::NV) vals[2 * R::PAIRS - 1] = 0.0;
     double2* slot = (double2*)(ring + (size_t)(k & 1) * R::SLOT) + hw;
