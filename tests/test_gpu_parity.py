@@ -1329,3 +1329,34 @@ def test_scan_backward_pass(hip, oracle, monkeypatch):
     for scan in ("1", "0"):
         s, p = sols[scan]
         assert_solve_parity(s, so, p, po)
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 21, 64, 65, 126, 127])
+def test_scan_backward_pass_horizons(N, hip, oracle, monkeypatch):
+    """The scan kernel's block / lane bookkeeping over horizons from the degenerate (N = 2: one stage knot and the terminal one in the
+    same block) to the largest it takes (N = 126: 63 blocks; 127 falls back to the cooperative kernel), odd and even: gains on the
+    initial guess and full solves against the oracle, for the 2-D double integrator (m = 2) and the Cartpole (m = 1)."""
+    monkeypatch.setenv("TRAJOPT_SCAN", "2")
+
+    def build_di(lib):
+        model = T.DoubleIntegrator(1.0, 2)
+        obj = T.LQRObjective(np.array([1.0, 2.0, 0.5, 0.3]), np.array([0.1, 0.2]), 10 * np.ones(4), np.array([1.0, 2.0, 0, 0]), N)
+        p = T.Problem(model, obj, np.array([0.2, -0.1, 0.0, 0.3]), 0.1 * (N - 1), batch=9, lib=lib)
+        T.initial_controls(p, np.array([0.1, -0.05]))
+        return p
+
+    def build_cp(lib):
+        return configs.cartpole_problem(batch=9, N=N, tf=0.05 * (N - 1), lib=lib)
+
+    for build in (build_di, build_cp):
+        ph, po = build(hip), build(oracle)
+        for p in (ph, po):
+            T.rollout(p); I.expand(p); I.backwardpass(p)
+        kh, ko = I.gains(ph), I.gains(po)
+        scale = max(np.abs(ko["K"]).max(), 1e-30)
+        assert np.abs(kh["K"] - ko["K"]).max() / scale < 1e-12
+        assert np.abs(kh["d"] - ko["d"]).max() / max(np.abs(ko["d"]).max(), 1e-9) < 1e-11
+        np.testing.assert_allclose(kh["dV"], ko["dV"], rtol=1e-11, atol=1e-20)
+        ph, po = build(hip), build(oracle)
+        sh, so = T.iLQRSolver(ph, iterations=25).solve(), T.iLQRSolver(po, iterations=25).solve()
+        assert_solve_parity(sh, so, ph, po, unconverged_rtol=1e-4)
