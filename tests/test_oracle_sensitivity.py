@@ -113,3 +113,40 @@ def test_c2_scan_riccati_arithmetic_leaves_the_solves_in_place(oracle, monkeypat
     dK = np.abs(gains[0]["K"] - gains[1]["K"]).max() / np.abs(gains[0]["K"]).max()
     assert 0.0 < dK < 1e-13
     np.testing.assert_allclose(gains[0]["dV"], gains[1]["dV"], rtol=1e-12)
+
+
+def test_scan_riccati_model_on_two_control_models(oracle, monkeypatch):
+    """The scan arithmetic model on the models with m = 2 (general 2x2 R in the element construction, C = B R⁻¹ B' of rank 2): the
+    2-D double integrator and the hybrid model vector (a jump map and a dimension change inside the scan) — gains against the
+    sequential recursion on the same iterate, and the solves end on the same iterations / trajectories."""
+    from trajopt_amd import internal as I
+    from test_hybrid_dims import hybrid_problem
+
+    def build_di(lib):
+        model = T.DoubleIntegrator(1.0, 2)
+        N = 31
+        obj = T.LQRObjective(np.array([1.0, 2.0, 0.5, 0.3]), np.array([0.1, 0.2]), 10 * np.ones(4), np.array([1.0, 2.0, 0, 0]), N)
+        p = T.Problem(model, obj, np.array([0.2, -0.1, 0.0, 0.3]), 3.0, batch=3, lib=lib)
+        T.initial_controls(p, np.array([0.1, -0.05]))
+        return p
+
+    for build in (build_di, lambda lib: hybrid_problem(lib)[0]):
+        out = []
+        for scan in (False, True):
+            if scan:
+                monkeypatch.setenv("ORACLE_RICCATI_SCAN", "1")
+            else:
+                monkeypatch.delenv("ORACLE_RICCATI_SCAN", raising=False)
+            p = build(oracle)
+            T.rollout(p); I.expand(p); I.backwardpass(p)
+            g = I.gains(p)
+            p2 = build(oracle)
+            s = T.iLQRSolver(p2).solve()
+            out.append((g, s.stats["iterations"].copy(), T.states(p2), s.stats["cost"].copy()))
+        (g0, it0, X0, J0), (g1, it1, X1, J1) = out
+        scale = np.abs(g0["K"]).max()
+        assert 0.0 < np.abs(g0["K"] - g1["K"]).max() / scale < 1e-13      # the scan ran, and agrees to rounding
+        np.testing.assert_allclose(g1["d"], g0["d"], rtol=1e-10, atol=1e-13 * max(np.abs(g0["d"]).max(), 1.0))
+        np.testing.assert_array_equal(it0, it1)
+        np.testing.assert_allclose(X1, X0, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(J1, J0, rtol=1e-11)
