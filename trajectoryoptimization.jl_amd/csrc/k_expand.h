@@ -120,6 +120,44 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
       }
     }
   }
+  if constexpr (LAY == 2 && M::lie) {
+    // Compact cost block (diagonal + 3x3 attitude block, KArgs::h_compact): a lane needs its column's DIAGONAL entry, the
+    // attitude lanes rows 3..5, the control lanes the control rows — and entry j of the projected gradient.  With v = column j of
+    // G(x) (or e_{n+r}) already in registers these are dot products, (G'y)[j] = v·y and (G'g)[j] = v·g: the zeros of v add
+    // exactly nothing, so the values are those of picking entry j out of G'y / G'g — without the 16-deep select chains per
+    // picked entry that were half of this kernel's non-FP64 instructions (profiles/r03: 49 % of its VALU instructions).
+    double gj = 0.0, dj = 0.0;
+#pragma unroll
+    for (int i = 0; i < nz; ++i) gj += v[i] * gr[i];
+#pragma unroll
+    for (int i = 0; i < n; ++i) dj += v[i] * y[i];
+    double col[ne];
+    errstate_tmul<M>(x, y, col);  // (only the attitude rows 3..5 are used below)
+    if constexpr (M::att == ATT_QUAT) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q) on the attitude diagonal
+      const double b1 = x[3] * gr[3] + x[4] * gr[4] + x[5] * gr[5] + x[6] * gr[6];
+#pragma unroll
+      for (int i = 3; i < 6; ++i) col[i] -= (i == j) ? b1 : 0.0;
+    } else if constexpr (M::att == ATT_MRP || M::att == ATT_RP) {  // ... of a three-parameter attitude: ∇²differential(p, ∂J/∂p)
+      double H2[9];
+      att_differential2<M::att>(x + 3, gr + 3, H2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) col[3 + i] += (j == 3) ? H2[3 * i] : (j == 4) ? H2[3 * i + 1] : (j == 5) ? H2[3 * i + 2] : 0.0;
+    }
+    if (!valid) return;
+    const bool isctl = ct >= NEP, isatt = (ct >= 3 && ct < 6);
+    double* Ht = a.Ht + ((size_t)b * N + k) * 64 + ct;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // compact_row(g, ct), by lane class
+      constexpr int arow[4] = {4, 5, 3, 3};  // attitude lanes: g = 0 -> row 4, 1 -> 5, 3 -> 3 (g = 2: none)
+      const double yc = (g < m && !terminal) ? y[n + (g < m ? g : 0)] : 0.0;
+      const double va = col[arow[g]];
+      const double val = isctl ? yc : isatt ? va : dj;
+      const bool ok = isctl ? (g < m) : isatt ? (g != 2) : ((ct & 3) == g);
+      if (ok) Ht[g * 16] = val;
+    }
+    a.gt[((size_t)b * N + k) * 16 + ct] = gj;
+    return;
+  }
   double col[ne], qxe[ne];
   errstate_tmul<M>(x, y, col);
   errstate_tmul<M>(x, gr, qxe);
