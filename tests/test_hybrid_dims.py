@@ -185,6 +185,9 @@ def test_hybrid_solve_on_the_oracle_equals_per_knot_riccati(oracle):
         mk = prob.nu[k]
         np.testing.assert_allclose(U[0, k, :mk], Ur[k], rtol=1e-9, atol=1e-11, err_msg=f"step {k + 1}")
         np.testing.assert_array_equal(U[:, k, mk:], 0.0)
+    for fn in (lambda: T.set_goal_state(prob, np.zeros(4)), lambda: T.update_trajectory(prob, np.zeros((4, 11)), np.zeros((2, 10)))):
+        with pytest.raises(T.UnsupportedError, match="hybrid model vector"):
+            fn()
     # padded controls carry R = 1 and stay at 0, so the padded objective equals the true one
     np.testing.assert_allclose(sol.stats["cost"], Jr, rtol=1e-11)
     # dynamics Jacobians at the jump: A = [0 0 .5 .5; 0...], B = [0 0; .5 .5] in the padded layout

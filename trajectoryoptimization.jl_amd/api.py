@@ -1245,6 +1245,8 @@ def gettimes(prob):
 
 def set_goal_state(prob, xf, objective=True, constraint=True):
     """set_goal_state!  (src/problem.jl:294-310): set_LQR_goal! on every cost, update GoalConstraints."""
+    if getattr(prob, "hybrid", False):  # (the reference's set_goal_state! needs one state dimension for all knots as well)
+        raise UnsupportedError("set_goal_state on a hybrid model vector: the knots have different state dimensions; rebuild the problem")
     xf = _vec(xf, prob.n, "xf")
     if objective:
         for i, c in enumerate(prob._cost_objs):
@@ -1269,6 +1271,8 @@ def update_trajectory(prob, X, U, start=1):
     """update_trajectory!(obj, Z, start)  (src/objective.jl:198-212): retarget a tracking objective (one cost per knot,
     see TrackingObjective) to knots start..start+N-1 of the reference (X [n, Nref], U [m, >=Nref-1]); like
     set_LQR_goal! it changes only q and r, never the constant c (src/cost_functions.jl:249-258)."""
+    if getattr(prob, "hybrid", False):
+        raise UnsupportedError("update_trajectory on a hybrid model vector: the knots have different dimensions; rebuild the problem")
     X = np.asarray(X, dtype=np.float64)
     U = np.asarray(U, dtype=np.float64)
     costs = prob.obj.cost
