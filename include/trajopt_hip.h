@@ -48,10 +48,12 @@ extern "C" {
 /* ABI history.  1: round 1.  2: to_solver_opts::reserved1 became al_full_newton (validated: 0 or 1), new entry points
  * to_constraint_hessians, to_comm_*, to_allgather, to_allgather_stats, to_comm_shards, to_solver_path, to_build_id; to_cost_desc gained the
  * ERROR_QUADRATIC error maps.  3: TO_MODEL_HYBRID_DOUBLE_INTEGRATOR and to_knot_dims (model vectors whose dimensions change
- * along the horizon), to_solver_path reports 8 values.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
+ * along the horizon), to_solver_path reports 8 values.  4: projected-Newton polish — to_solver_opts gained the Altro
+ * ProjectedNewtonSolver options (appended), to_solve_stats gained iterations_pn, new status TO_PROJECTION_FAIL, new entry
+ * points to_pn_solve, to_altro_solve, to_dynamics_defect and the asynchronous to_*_solve_async / to_solve_wait.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version. */
-#define TO_ABI_VERSION 3
+#define TO_ABI_VERSION 4
 
 #define TO_MAX_N 16       /* max state dimension            */
 #define TO_MAX_M 8        /* max control dimension          */
@@ -83,7 +85,9 @@ typedef enum {
   TO_CONTROL_LIMIT = 7, /* |u| <= max_control_value is rejected as a line-search candidate, not reported as a status */
   TO_NO_PROGRESS = 8,
   TO_COST_INCREASE = 9,
-  TO_REGULARIZATION_MAX = 10
+  TO_REGULARIZATION_MAX = 10,
+  TO_PROJECTION_FAIL = 11 /* to_pn_solve / to_altro_solve: the projected-Newton polish ended above constraint_tolerance (Altro keeps
+                             SOLVE_SUCCEEDED there and only warns; here the status tells) */
 } to_solver_status;
 
 /* ---- models (RobotZoo.jl / examples, restated; SURVEY.md §8a R2,R3) ----------------------- */
@@ -225,6 +229,16 @@ typedef struct {
   int32_t al_full_newton;             /* 0: Gauss-Newton AL Hessian (Altro's default).  1: the expansion adds the constraint curvature
                                          sum_r ybar_r * d2c_r/dz2, ybar = the multiplier estimate lambda + I_mu c, with the closed forms of
                                          to_constraint_hessians (src/abstract_constraint.jl:255-280: the nabla-jacobian! term) */
+  /* projected-Newton polish (Altro.jl ProjectedNewtonSolver, the last stage of ALTRO: examples/Cartpole.ipynb cells 17-19,
+   * examples/Quadrotor.ipynb cell 20; names follow Altro's SolverOptions).  to_altro_solve runs the AL stage until the violation
+   * is below projected_newton_tolerance and hands the trajectory to the polish, which ends at constraint_tolerance. */
+  double projected_newton_tolerance;  /* 1e-3 */
+  double active_set_tolerance_pn;     /* 1e-3: an inequality row takes part in the projection when c >= -tol */
+  double rho_chol;                    /* 1e-8 (Altro: 1e-2): regularisation of S = D H^-1 D' before its Cholesky factorisation */
+  double rho_primal;                  /* 1e-8: added to the diagonal cost Hessian H (the metric of the projection) */
+  double r_threshold;                 /* 1.1: stop refining on one linearisation once log10(viol)/log10(viol_prev) drops below */
+  int32_t n_steps;                    /* 2: the polish runs at most n_steps + 1 linearisations (Altro: `while count <= n_steps`) */
+  int32_t projected_newton;           /* 1: to_altro_solve polishes; 0: to_altro_solve == to_al_solve */
 } to_solver_opts;
 
 /* caller-allocated outputs of a solve; any pointer may be NULL */
@@ -235,8 +249,10 @@ typedef struct {
   double* cost;               /* [B] objective cost J at the solution (cost(prob), no AL terms) */
   double* dJ;                 /* [B] last accepted cost decrease */
   double* gradient;           /* [B] last iLQR gradient metric */
-  double* c_max;              /* [B] max constraint violation (0 without constraints) */
+  double* c_max;              /* [B] max constraint violation (0 without constraints); to_pn_solve / to_altro_solve: the dynamics and
+                                 initial-condition defects count too (a polished trajectory is no longer an exact rollout) */
   double* penalty_max;        /* [B] largest penalty used */
+  int32_t* iterations_pn;     /* [B] projection solves (linearisations) of the projected-Newton polish; 0 where it did not run */
   /* aggregates written by the library */
   int64_t total_iterations;   /* sum_b iterations[b] (the numerator of the headline metric) */
   int32_t batch_steps;        /* batch-synchronous device iterations executed */
@@ -315,6 +331,24 @@ int to_backward(to_handle* h);   /* Riccati recursion -> K, d, dV; regularises p
 int to_forward(to_handle* h, int32_t* ls_index /* [B], -1 = failed */, double* J_new /* [B] */);
 int to_ilqr_solve(to_handle* h, to_solve_stats* stats);
 int to_al_solve(to_handle* h, to_solve_stats* stats);
+/* Altro's ProjectedNewtonSolver on the CURRENT trajectory (X, U) of every trajectory of the batch: Newton steps on the active
+ * constraints — dynamics defects x_{k+1} (-) f(x_k, u_k), the initial condition, equality rows, inequality rows within
+ * active_set_tolerance_pn of their bound, second-order cones through the scalar row |v| - s — in the metric of the diagonal
+ * cost Hessian: dZ = -H^-1 D'(D H^-1 D' + rho I)^-1 d in error-state coordinates, the block-tridiagonal S factorised knot by
+ * knot, with Altro's refinement / line-search / convergence-rate loops.  Status: TO_SOLVE_SUCCEEDED when the violation
+ * (defects included) ends <= constraint_tolerance, TO_PROJECTION_FAIL otherwise.  stats->iterations stay 0. */
+int to_pn_solve(to_handle* h, to_solve_stats* stats);
+/* ALTRO (Altro.jl solve!(::ALTROSolver)): AL-iLQR with constraint_tolerance := projected_newton_tolerance, then the polish on
+ * every trajectory the AL stage left SOLVE_SUCCEEDED with c_max > constraint_tolerance.  With projected_newton = 0 or no
+ * constraints: to_al_solve. */
+int to_altro_solve(to_handle* h, to_solve_stats* stats);
+/* Asynchronous variants: enqueue the solve on the handle's stream from a worker thread owned by the handle and
+ * return at once; to_solve_wait blocks until it is done and returns its code (stats are valid after that).  One solve in flight
+ * per handle; any other call on the handle while one is in flight fails with TO_ERR_ARGUMENT. */
+int to_ilqr_solve_async(to_handle* h, to_solve_stats* stats);
+int to_al_solve_async(to_handle* h, to_solve_stats* stats);
+int to_altro_solve_async(to_handle* h, to_solve_stats* stats);
+int to_solve_wait(to_handle* h);
 
 /* expansion / gain getters (parity + solver introspection); host layouts column-major:
  *   A[ne,ne,N-1,B]  Bm[ne,m,N-1,B]  Qxx[ne,ne,N,B] Quu[m,m,N,B] Qux[m,ne,N,B] qx[ne,N,B] qu[m,N,B]
@@ -363,6 +397,9 @@ int to_constraint_jacobians(to_handle* h, int32_t con_id, double* jac);
 int to_constraint_hessians(to_handle* h, int32_t con_id, const double* lambda, double* H);
 int to_constraint_info(const to_handle* h, int32_t con_id, int32_t* p, int32_t* width, int32_t* nk, int32_t* sense);
 int to_max_violation(to_handle* h, double* c_max /* [B] */);
+/* max |x_1 (-) x0|, |x_{k+1} (-) f(x_k, u_k)| over the horizon, per trajectory: exactly 0 for a rollout, the dynamics
+ * infeasibility a projected-Newton polish leaves otherwise */
+int to_dynamics_defect(to_handle* h, double* defect /* [B] */);
 int to_get_duals(to_handle* h, int32_t con_id, double* lambda /* [p,nk,B] */, double* mu /* [B] */);
 int to_set_duals(to_handle* h, int32_t con_id, const double* lambda, const double* mu);
 int to_reset_duals(to_handle* h);            /* lambda = 0, mu = penalty_initial */

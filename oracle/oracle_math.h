@@ -531,6 +531,37 @@ inline void state_diff(const Model& M, const double* x, const double* x0, double
   for (int i = 0; i < 6; ++i) dx[6 + i] = x[7 + i] - x0[7 + i];
 }
 
+/* xo = x (+) dx: the inverse of state_diff (RD's state_diff with the Cayley map: state_diff(x (+) dx, x) = dx).  The projected-Newton
+ * polish (Altro ProjectedNewtonSolver; out of tree) moves states along error-state steps.  Attitude: q (x) [1, phi] / sqrt(1 + |phi|^2)
+ * keeps |q|; three-parameter attitudes compose through their unnormalised quaternion and map back (MRP p = v / (|q| + w),
+ * RodriguesParam g = v / w). */
+inline void state_add(const Model& M, const double* x, const double* dx, double* xo) {
+  if (M.id != TO_MODEL_QUADROTOR) { for (int i = 0; i < M.n; ++i) xo[i] = x[i] + dx[i]; return; }
+  for (int i = 0; i < 3; ++i) xo[i] = x[i] + dx[i];
+  const int rot = M.rot();
+  const int o = rot == TO_ROT_QUATERNION ? 7 : 6;
+  for (int i = 0; i < 6; ++i) xo[o + i] = x[o + i] + dx[6 + i];
+  double q[4];
+  if (rot == TO_ROT_QUATERNION) { for (int i = 0; i < 4; ++i) q[i] = x[3 + i]; } else att_quat(rot, x + 3, q);
+  const double f1 = dx[3], f2 = dx[4], f3 = dx[5];
+  /* q (x) [1, phi] */
+  double r[4] = {q[0] - q[1] * f1 - q[2] * f2 - q[3] * f3,
+                 q[1] + q[0] * f1 + q[2] * f3 - q[3] * f2,
+                 q[2] + q[0] * f2 + q[3] * f1 - q[1] * f3,
+                 q[3] + q[0] * f3 + q[1] * f2 - q[2] * f1};
+  if (rot == TO_ROT_QUATERNION) {
+    const double s = 1.0 / std::sqrt(1.0 + (f1 * f1 + f2 * f2 + f3 * f3));
+    for (int i = 0; i < 4; ++i) xo[3 + i] = r[i] * s;
+  } else if (rot == TO_ROT_MRP) {
+    const double nr = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    const double s = 1.0 / (nr + r[0]);
+    for (int i = 0; i < 3; ++i) xo[3 + i] = r[1 + i] * s;
+  } else {
+    const double s = 1.0 / r[0];
+    for (int i = 0; i < 3; ++i) xo[3 + i] = r[1 + i] * s;
+  }
+}
+
 /* ---------------------------------------------------------------- cones (src/cones.jl) */
 /* returns SOC branch: 0 below, 1 in, 2 outside, -1 invalid (NaN) */
 inline int soc_status(const double* x, int dim) {

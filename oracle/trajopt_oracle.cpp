@@ -70,7 +70,7 @@ struct Traj {
   double dV[2] = {0, 0};
   double rho = 0, drho = 0;
   double J = 0, dJ = 0, grad = 0, c_max = 0;
-  int iterations = 0, iterations_outer = 0, status = TO_UNSOLVED, ls_index = -1;
+  int iterations = 0, iterations_outer = 0, iterations_pn = 0, status = TO_UNSOLVED, ls_index = -1;
   int dJ_zero_counter = 0;
   bool ls_failed = false, zero_step = false;
 };
@@ -95,6 +95,8 @@ void default_opts(to_solver_opts* o) {
   o->cost_tolerance_intermediate = 1e-4; o->penalty_initial = 1.0; o->penalty_scaling = 10.0;
   o->penalty_max = 1e8; o->dual_max = 1e8; o->iterations_outer = 30; o->cost_dt_scaling = 0;
   o->iterations_total = 1000;
+  o->projected_newton_tolerance = 1e-3; o->active_set_tolerance_pn = 1e-3; o->rho_chol = 1e-8; o->rho_primal = 1e-8;
+  o->r_threshold = 1.1; o->n_steps = 2; o->projected_newton = 1;
 }
 
 /* ------------------------------------------------------------------ descriptor validation */
@@ -112,6 +114,9 @@ int validate_opts(const to_solver_opts& o) {
   if (!(o.max_cost_value > 0.0) || !(o.max_state_value > 0.0) || !(o.max_control_value > 0.0)) return bad("max_*_value must be > 0");
   if (o.cost_dt_scaling != 0 && o.cost_dt_scaling != 1) return bad("cost_dt_scaling must be 0 or 1");
   if (o.al_full_newton != 0 && o.al_full_newton != 1) return bad("al_full_newton must be 0 or 1");
+  if (!(o.projected_newton_tolerance >= 0) || !(o.active_set_tolerance_pn >= 0)) return bad("projected-Newton tolerances must be >= 0");
+  if (!(o.rho_chol >= 0) || !(o.rho_primal > 0) || !(o.r_threshold > 0)) return bad("rho_chol >= 0, rho_primal > 0, r_threshold > 0");
+  if (o.n_steps < 0 || (o.projected_newton != 0 && o.projected_newton != 1)) return bad("n_steps must be >= 0, projected_newton 0 or 1");
   return TO_OK;
 }
 
@@ -372,17 +377,17 @@ void dual_update(const Problem& P, Traj& t) {
 }
 
 /* full-state cost (+AL) expansion at knot k: grad (nz), hess (nz*nz row-major) */
-void knot_expansion_full(const Problem& P, const Traj& t, int k, double* grad, double* hess) {
+void knot_expansion_full(const Problem& P, const Traj& t, const double* X, const double* U, bool with_al, int k, double* grad, double* hess) {
   const int n = P.n, m = P.m, nz = n + m;
   const bool terminal = (k == P.N - 1);
-  double z[MAXZ]; knot_z(P, t.X.data(), t.U.data(), k, z);
+  double z[MAXZ]; knot_z(P, X, U, k, z);
   cost_expansion(P.costs[P.cost_index[k]], n, m, z, z + n, terminal, grad, hess);
   if (P.opts.cost_dt_scaling && !terminal) {
     for (int i = 0; i < nz; ++i) grad[i] *= P.dt[k];
     for (int i = 0; i < nz * nz; ++i) hess[i] *= P.dt[k];
   }
   double c[TO_MAX_P], jac[TO_MAX_P * MAXZ], y[TO_MAX_P], W[TO_MAX_P * TO_MAX_P];
-  for (size_t i = 0; i < P.cons.size(); ++i) {
+  for (size_t i = 0; with_al && i < P.cons.size(); ++i) {
     const ConInfo& ci = P.cons[i];
     if (k < ci.k1 || k > ci.k2) continue;
     const int p = ci.p; const double mu = t.mu[i];
@@ -424,41 +429,52 @@ void knot_expansion_full(const Problem& P, const Traj& t, int k, double* grad, d
   }
 }
 
+/* error-state dynamics Jacobians of step k at (X, U): Ae (ne x ne), Be (ne x m), row-major */
+void dynamics_blocks(const Problem& P, const double* X, const double* U, int k, double* Ae, double* Be) {
+  const int n = P.n, m = P.m, ne = P.ne;
+  static thread_local std::vector<double> A, Bf, G0, G1, T1;
+  A.resize(n * n); Bf.resize(n * m); G0.resize(n * ne); G1.resize(n * ne); T1.resize(n * ne);
+  const double* x = &X[(size_t)k * n]; const double* u = &U[(size_t)k * m];
+  knot_step_jacobian(P.M, P.integrator, k, x, u, P.dt[k], A.data(), Bf.data());
+  errstate_jacobian(P.M, x, G0.data());
+  errstate_left_inverse(P.M, &X[(size_t)(k + 1) * n], G1.data()); /* E(x_{k+1}): ne x n (= G' for unit quaternions) */
+  matmul(A.data(), G0.data(), T1.data(), n, n, ne); /* A G_k : n x ne */
+  for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[i * n + r] * T1[r * ne + j]; Ae[i * ne + j] = s; }
+  for (int i = 0; i < ne; ++i) for (int j = 0; j < m; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[i * n + r] * Bf[r * m + j]; Be[i * m + j] = s; }
+}
+
+/* error-state cost (+AL when with_al) blocks of knot k at (X, U) */
+void cost_blocks(const Problem& P, const Traj& t, const double* X, const double* U, bool with_al, int k,
+                 double* Qxx, double* Quu, double* Qux, double* qx, double* qu) {
+  const int n = P.n, m = P.m, ne = P.ne, nz = n + m;
+  static thread_local std::vector<double> G0, grad, hess, T2;
+  G0.resize(n * ne); grad.resize(nz); hess.resize(nz * nz); T2.resize(n * ne);
+  const double* x = &X[(size_t)k * n];
+  knot_expansion_full(P, t, X, U, with_al, k, grad.data(), hess.data());
+  errstate_jacobian(P.M, x, G0.data());
+  for (int i = 0; i < ne; ++i) { double s = 0.0; for (int r = 0; r < n; ++r) s += G0[r * ne + i] * grad[r]; qx[i] = s; }
+  for (int j = 0; j < m; ++j) qu[j] = grad[n + j];
+  /* Qxx = G' Hxx G */
+  for (int r = 0; r < n; ++r) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int c = 0; c < n; ++c) s += hess[r * nz + c] * G0[c * ne + j]; T2[r * ne + j] = s; }
+  for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G0[r * ne + i] * T2[r * ne + j]; Qxx[i * ne + j] = s; }
+  if (P.M.id == TO_MODEL_QUADROTOR && P.M.rot() == TO_ROT_QUATERNION) { /* second-order term of the attitude map: -I3 (q' dJ/dq) (Rotations ∇differential) */
+    double b1 = 0.0; for (int i = 0; i < 4; ++i) b1 += x[3 + i] * grad[3 + i];
+    for (int i = 0; i < 3; ++i) Qxx[(3 + i) * ne + 3 + i] -= b1;
+  } else if (P.M.id == TO_MODEL_QUADROTOR) { /* ... of a three-parameter attitude: ∇²differential(p, dJ/dp) */
+    double H2[9]; att_differential2(P.M.rot(), x + 3, &grad[3], H2);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Qxx[(3 + i) * ne + 3 + j] += H2[3 * i + j];
+  }
+  for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Quu[i * m + j] = hess[(n + i) * nz + n + j];
+  for (int i = 0; i < m; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int c = 0; c < n; ++c) s += hess[(n + i) * nz + c] * G0[c * ne + j]; Qux[i * ne + j] = s; }
+}
+
 void expand(const Problem& P, Traj& t) {
-  const int n = P.n, m = P.m, ne = P.ne, nz = n + m, N = P.N;
-  static thread_local std::vector<double> A, Bf, G0, G1, T1, grad, hess, T2;
-  A.resize(n * n); Bf.resize(n * m); G0.resize(n * ne); G1.resize(n * ne); T1.resize(n * ne); grad.resize(nz); hess.resize(nz * nz); T2.resize(n * ne);
-  for (int k = 0; k < N - 1; ++k) {
-    const double* x = &t.X[(size_t)k * n]; const double* u = &t.U[(size_t)k * m];
-    knot_step_jacobian(P.M, P.integrator, k, x, u, P.dt[k], A.data(), Bf.data());
-    errstate_jacobian(P.M, x, G0.data());
-    errstate_left_inverse(P.M, &t.X[(size_t)(k + 1) * n], G1.data()); /* E(x_{k+1}): ne x n (= G' for unit quaternions) */
-    matmul(A.data(), G0.data(), T1.data(), n, n, ne); /* A G_k : n x ne */
-    double* Ae = &t.A[(size_t)k * ne * ne]; double* Be = &t.Bm[(size_t)k * ne * m];
-    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[i * n + r] * T1[r * ne + j]; Ae[i * ne + j] = s; }
-    for (int i = 0; i < ne; ++i) for (int j = 0; j < m; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G1[i * n + r] * Bf[r * m + j]; Be[i * m + j] = s; }
-  }
-  for (int k = 0; k < N; ++k) {
-    const double* x = &t.X[(size_t)k * n];
-    knot_expansion_full(P, t, k, grad.data(), hess.data());
-    errstate_jacobian(P.M, x, G0.data());
-    double* Qxx = &t.Qxx[(size_t)k * ne * ne]; double* Quu = &t.Quu[(size_t)k * m * m]; double* Qux = &t.Qux[(size_t)k * m * ne];
-    double* qx = &t.qx[(size_t)k * ne]; double* qu = &t.qu[(size_t)k * m];
-    for (int i = 0; i < ne; ++i) { double s = 0.0; for (int r = 0; r < n; ++r) s += G0[r * ne + i] * grad[r]; qx[i] = s; }
-    for (int j = 0; j < m; ++j) qu[j] = grad[n + j];
-    /* Qxx = G' Hxx G */
-    for (int r = 0; r < n; ++r) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int c = 0; c < n; ++c) s += hess[r * nz + c] * G0[c * ne + j]; T2[r * ne + j] = s; }
-    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int r = 0; r < n; ++r) s += G0[r * ne + i] * T2[r * ne + j]; Qxx[i * ne + j] = s; }
-    if (P.M.id == TO_MODEL_QUADROTOR && P.M.rot() == TO_ROT_QUATERNION) { /* second-order term of the attitude map: -I3 (q' dJ/dq) (Rotations ∇differential) */
-      double b1 = 0.0; for (int i = 0; i < 4; ++i) b1 += x[3 + i] * grad[3 + i];
-      for (int i = 0; i < 3; ++i) Qxx[(3 + i) * ne + 3 + i] -= b1;
-    } else if (P.M.id == TO_MODEL_QUADROTOR) { /* ... of a three-parameter attitude: ∇²differential(p, dJ/dp) */
-      double H2[9]; att_differential2(P.M.rot(), x + 3, &grad[3], H2);
-      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Qxx[(3 + i) * ne + 3 + j] += H2[3 * i + j];
-    }
-    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Quu[i * m + j] = hess[(n + i) * nz + n + j];
-    for (int i = 0; i < m; ++i) for (int j = 0; j < ne; ++j) { double s = 0.0; for (int c = 0; c < n; ++c) s += hess[(n + i) * nz + c] * G0[c * ne + j]; Qux[i * ne + j] = s; }
-  }
+  const int m = P.m, ne = P.ne, N = P.N;
+  for (int k = 0; k < N - 1; ++k)
+    dynamics_blocks(P, t.X.data(), t.U.data(), k, &t.A[(size_t)k * ne * ne], &t.Bm[(size_t)k * ne * m]);
+  for (int k = 0; k < N; ++k)
+    cost_blocks(P, t, t.X.data(), t.U.data(), true, k, &t.Qxx[(size_t)k * ne * ne], &t.Quu[(size_t)k * m * m], &t.Qux[(size_t)k * m * ne],
+                &t.qx[(size_t)k * ne], &t.qu[(size_t)k * m]);
 }
 
 void reg_increase(const Problem& P, Traj& t) {
@@ -831,21 +847,31 @@ void ilqr_solve(const Problem& P, Traj& t, double cost_tol, int max_iters) {
   }
 }
 
-void al_solve(const Problem& P, Traj& t) {
+void al_solve(const Problem& P, Traj& t, double constraint_tolerance) {
   std::fill(t.lambda.begin(), t.lambda.end(), 0.0);
   std::fill(t.mu.begin(), t.mu.end(), P.opts.penalty_initial);
-  t.iterations = 0; t.iterations_outer = 0;
+  t.iterations = 0; t.iterations_outer = 0; t.iterations_pn = 0;
   for (int outer = 1; outer <= P.opts.iterations_outer; ++outer) {
     int budget = std::min(P.opts.iterations, P.opts.iterations_total - t.iterations);
     ilqr_solve(P, t, P.opts.cost_tolerance_intermediate, budget);
     t.iterations_outer = outer;
     t.c_max = max_violation(P, t);
     if (t.status != TO_SOLVE_SUCCEEDED && t.status != TO_MAX_ITERATIONS && t.status != TO_NO_PROGRESS) break;
-    if (t.c_max < P.opts.constraint_tolerance) { t.status = TO_SOLVE_SUCCEEDED; break; }
+    if (t.c_max < constraint_tolerance) { t.status = TO_SOLVE_SUCCEEDED; break; }
     if (t.iterations >= P.opts.iterations_total) { t.status = TO_MAX_ITERATIONS; break; }
     if (outer == P.opts.iterations_outer) { t.status = TO_MAX_ITERATIONS_OUTER; break; }
     dual_update(P, t);
   }
+}
+
+#include "oracle_pn.h"
+
+/* Altro solve!(::ALTROSolver): the AL stage runs to projected_newton_tolerance, the polish takes the trajectories it left
+ * SOLVE_SUCCEEDED above constraint_tolerance */
+void altro_solve(const Problem& P, Traj& t) {
+  const bool pn = P.opts.projected_newton && !P.cons.empty();
+  al_solve(P, t, pn ? P.opts.projected_newton_tolerance : P.opts.constraint_tolerance);
+  if (pn && t.status == TO_SOLVE_SUCCEEDED && t.c_max > P.opts.constraint_tolerance) pn_solve(P, t);
 }
 
 template <class F>
@@ -857,7 +883,7 @@ void for_batch(oracle_handle* h, F f) {
   for (int b = 0; b < B; ++b) f(h->T[b], b);
 }
 
-void fill_stats(oracle_handle* h, to_solve_stats* st, double ms) {
+void fill_stats(oracle_handle* h, to_solve_stats* st, double ms, bool with_defect = false) {
   if (!st) return;
   const Problem& P = h->P;
   int64_t tot = 0;
@@ -870,7 +896,11 @@ void fill_stats(oracle_handle* h, to_solve_stats* st, double ms) {
     if (st->cost) st->cost[b] = total_cost(P, t, t.X.data(), t.U.data(), false);
     if (st->dJ) st->dJ[b] = t.dJ;
     if (st->gradient) st->gradient[b] = t.grad;
-    if (st->c_max) st->c_max[b] = P.cons.empty() ? 0.0 : max_violation(P, t);
+    if (st->c_max) {
+      st->c_max[b] = P.cons.empty() ? 0.0 : max_violation(P, t);
+      if (with_defect) { const double df = dynamics_defect(P, t); if (df > st->c_max[b] || std::isnan(df)) st->c_max[b] = df; }
+    }
+    if (st->iterations_pn) st->iterations_pn[b] = t.iterations_pn;
     if (st->penalty_max) { double mx = 0.0; for (double v : t.mu) mx = std::fmax(mx, v); st->penalty_max[b] = mx; }
   }
   st->total_iterations = tot; st->batch_steps = 0; st->solve_ms = ms;
@@ -1020,9 +1050,30 @@ int oracle_ilqr_solve(oracle_handle* h, to_solve_stats* st) {
 int oracle_al_solve(oracle_handle* h, to_solve_stats* st) {
   CHECK_H(h);
   auto t0 = std::chrono::steady_clock::now();
-  for_batch(h, [&](Traj& t, int) { al_solve(h->P, t); });
+  for_batch(h, [&](Traj& t, int) { al_solve(h->P, t, h->P.opts.constraint_tolerance); });
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   fill_stats(h, st, ms);
+  return TO_OK;
+}
+int oracle_pn_solve(oracle_handle* h, to_solve_stats* st) {
+  CHECK_H(h);
+  auto t0 = std::chrono::steady_clock::now();
+  for_batch(h, [&](Traj& t, int) { t.iterations = 0; t.iterations_outer = 0; pn_solve(h->P, t); });
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  fill_stats(h, st, ms, true);
+  return TO_OK;
+}
+int oracle_altro_solve(oracle_handle* h, to_solve_stats* st) {
+  CHECK_H(h);
+  auto t0 = std::chrono::steady_clock::now();
+  for_batch(h, [&](Traj& t, int) { altro_solve(h->P, t); });
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  fill_stats(h, st, ms, true);
+  return TO_OK;
+}
+int oracle_dynamics_defect(oracle_handle* h, double* out) {
+  CHECK_H(h); CHECK_P(out);
+  for_batch(h, [&](Traj& t, int b) { out[b] = dynamics_defect(h->P, t); });
   return TO_OK;
 }
 
@@ -1068,11 +1119,9 @@ int oracle_get_gains(oracle_handle* h, double* K, double* d, double* dV, double*
 int oracle_cost_expansion(oracle_handle* h, double* grad, double* hess) {
   CHECK_H(h);
   const int n = h->P.n, m = h->P.m, nz = n + m, N = h->P.N;
-  /* objective only (no AL): temporarily evaluate with an empty constraint list */
-  Problem P2 = h->P; P2.cons.clear();
   std::vector<double> g(nz), H(nz * nz);
   for (int b = 0; b < h->P.B; ++b) for (int k = 0; k < N; ++k) {
-    knot_expansion_full(P2, h->T[b], k, g.data(), H.data());
+    knot_expansion_full(h->P, h->T[b], h->T[b].X.data(), h->T[b].U.data(), /*with_al (objective only)*/ false, k, g.data(), H.data());
     size_t kb = k + (size_t)N * b;
     if (grad) for (int i = 0; i < nz; ++i) grad[i + nz * kb] = g[i];
     if (hess) for (int i = 0; i < nz; ++i) for (int j = 0; j < nz; ++j) hess[i + nz * (j + nz * kb)] = H[i * nz + j];
@@ -1227,6 +1276,11 @@ int oracle_state_diff(int32_t model, const double* params, const double* x, cons
   Model M; M.id = model; std::memcpy(M.p, params, sizeof(M.p));
   if (model_dims(model, params, &M.n, &M.m, &M.ne)) return fail(TO_ERR_UNSUPPORTED, "unknown model");
   state_diff(M, x, x0, dx); return TO_OK;
+}
+int oracle_state_add(int32_t model, const double* params, const double* x, const double* dx, double* xo) {
+  Model M; M.id = model; std::memcpy(M.p, params, sizeof(M.p));
+  if (model_dims(model, params, &M.n, &M.m, &M.ne)) return fail(TO_ERR_UNSUPPORTED, "unknown model");
+  state_add(M, x, dx, xo); return TO_OK;
 }
 
 }  // extern "C"

@@ -14,7 +14,8 @@ _native = None
 
 
 def build_oracle(force=False):
-    srcs = [ROOT / "oracle" / "trajopt_oracle.cpp", ROOT / "oracle" / "oracle_math.h", ROOT / "include" / "trajopt_hip.h"]
+    srcs = [ROOT / "oracle" / "trajopt_oracle.cpp", ROOT / "oracle" / "oracle_math.h", ROOT / "oracle" / "oracle_pn.h",
+            ROOT / "include" / "trajopt_hip.h"]
     stale = (not ORACLE_SO.exists()) or any(s.stat().st_mtime > ORACLE_SO.stat().st_mtime for s in srcs)
     if force or stale:
         subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
@@ -28,6 +29,7 @@ def _bind(path):
         "dynamics": [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "discrete_dynamics": [C.c_int32, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)],
         "state_diff": [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "state_add": [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     }.items():
         f = getattr(lib.dll, "oracle_" + name)
         f.argtypes, f.restype = argtypes, C.c_int

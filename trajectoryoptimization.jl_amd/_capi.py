@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-TO_ABI_VERSION = 3
+TO_ABI_VERSION = 4
 TO_MAX_N, TO_MAX_M, TO_MAX_P = 16, 8, 40
 TO_MAX_CON_PARAMS, TO_MAX_CON_INDS = 400, 48
 
@@ -24,7 +24,7 @@ TO_ERR_HIP, TO_ERR_UNSUPPORTED, TO_ERR_NULL, TO_ERR_CONE = -4, -5, -6, -7
 
 # solver status (to_solver_status, Altro.jl TerminationStatus order)
 (UNSOLVED, LINESEARCH_FAIL, SOLVE_SUCCEEDED, MAX_ITERATIONS, MAX_ITERATIONS_OUTER, MAXIMUM_COST,
- STATE_LIMIT, CONTROL_LIMIT, NO_PROGRESS, COST_INCREASE, REGULARIZATION_MAX) = range(11)
+ STATE_LIMIT, CONTROL_LIMIT, NO_PROGRESS, COST_INCREASE, REGULARIZATION_MAX, PROJECTION_FAIL) = range(12)
 
 MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_HYBRID_DOUBLE_INTEGRATOR = 0, 1, 2, 3
 RK4, RK3, EULER = 0, 1, 2
@@ -114,6 +114,10 @@ class SolverOpts(C.Structure):
         ("dual_max", C.c_double),
         ("iterations_outer", C.c_int32), ("cost_dt_scaling", C.c_int32),
         ("iterations_total", C.c_int32), ("al_full_newton", C.c_int32),
+        # projected-Newton polish (Altro ProjectedNewtonSolver options)
+        ("projected_newton_tolerance", C.c_double), ("active_set_tolerance_pn", C.c_double),
+        ("rho_chol", C.c_double), ("rho_primal", C.c_double), ("r_threshold", C.c_double),
+        ("n_steps", C.c_int32), ("projected_newton", C.c_int32),
     ]
 
 
@@ -123,6 +127,7 @@ class SolveStats(C.Structure):
         ("status", C.POINTER(C.c_int32)),
         ("cost", C.POINTER(C.c_double)), ("dJ", C.POINTER(C.c_double)), ("gradient", C.POINTER(C.c_double)),
         ("c_max", C.POINTER(C.c_double)), ("penalty_max", C.POINTER(C.c_double)),
+        ("iterations_pn", C.POINTER(C.c_int32)),
         ("total_iterations", C.c_int64), ("batch_steps", C.c_int32), ("reserved", C.c_int32),
         ("solve_ms", C.c_double),
     ]
@@ -161,6 +166,9 @@ SIGNATURES = {
     "forward": [_H, _PI, _PD],
     "ilqr_solve": [_H, C.POINTER(SolveStats)],
     "al_solve": [_H, C.POINTER(SolveStats)],
+    "pn_solve": [_H, C.POINTER(SolveStats)],
+    "altro_solve": [_H, C.POINTER(SolveStats)],
+    "dynamics_defect": [_H, _PD],
     "get_dynamics_jacobians": [_H, _PD, _PD],
     "get_cost_expansion": [_H, _PD, _PD, _PD, _PD, _PD],
     "get_gains": [_H, _PD, _PD, _PD, _PD],
@@ -195,6 +203,10 @@ HIP_ONLY = {
     "set_profiling": [_H, C.c_int],
     "get_profile": [_H, _PD, C.POINTER(C.c_int64)],
     "reset_profile": [_H],
+    "ilqr_solve_async": [_H, C.POINTER(SolveStats)],
+    "al_solve_async": [_H, C.POINTER(SolveStats)],
+    "altro_solve_async": [_H, C.POINTER(SolveStats)],
+    "solve_wait": [_H],
 }
 
 

@@ -44,7 +44,7 @@ __all__ = [
     "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
     "set_initial_state", "set_goal_state", "update_trajectory", "get_constraints", "get_objective", "get_model",
     "get_initial_state", "get_final_state", "get_trajectory", "gettimes",
-    "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "solve", "iterations", "status", "max_violation",
+    "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "ProjectedNewtonSolver", "dynamics_defect", "solve", "iterations", "status", "max_violation",
     "evaluate_constraints", "constraint_jacobians", "sense", "upper_bound", "lower_bound", "is_bound",
     "DimensionMismatch", "ArgumentError", "UnsupportedError",
 ]
@@ -1365,7 +1365,8 @@ class _Solver:
         B = prob.B
         self.stats = dict(
             iterations=np.zeros(B, np.int32), iterations_outer=np.zeros(B, np.int32), status=np.zeros(B, np.int32),
-            cost=np.zeros(B), dJ=np.zeros(B), gradient=np.zeros(B), c_max=np.zeros(B), penalty_max=np.zeros(B))
+            cost=np.zeros(B), dJ=np.zeros(B), gradient=np.zeros(B), c_max=np.zeros(B), penalty_max=np.zeros(B),
+            iterations_pn=np.zeros(B, np.int32))
         self.total_iterations = 0
         self.batch_steps = 0
         self.solve_ms = 0.0
@@ -1388,11 +1389,21 @@ class iLQRSolver(_Solver):
 
 
 class ALSolver(_Solver):
-    """Altro's augmented-Lagrangian iLQR (the AL stage of ALTROSolver; projected-Newton polish is out of scope)."""
+    """Altro's augmented-Lagrangian iLQR (Altro.ALSolver: the AL stage of ALTROSolver, run to ``constraint_tolerance``)."""
     _entry = "al_solve"
 
 
-ALTROSolver = ALSolver
+class ProjectedNewtonSolver(_Solver):
+    """Altro.ProjectedNewtonSolver: Newton steps on the active constraints (dynamics defects included) from the problem's
+    CURRENT trajectory; ``stats["iterations_pn"]`` counts the linearisations, ``stats["c_max"]`` includes the defects."""
+    _entry = "pn_solve"
+
+
+class ALTROSolver(_Solver):
+    """Altro.ALTROSolver (examples/Cartpole.ipynb cell 17, examples/Quadrotor.ipynb cell 20): AL-iLQR down to
+    ``projected_newton_tolerance``, then the projected-Newton polish down to ``constraint_tolerance``
+    (``projected_newton=0``: the AL stage alone, like Altro's option of the same name)."""
+    _entry = "altro_solve"
 
 
 def solve(solver):
@@ -1406,6 +1417,15 @@ def iterations(solver):
 
 def status(solver):
     return solver.stats["status"]
+
+
+def dynamics_defect(obj):
+    """max |x_1 (-) x0|, |x_{k+1} (-) f(x_k, u_k)| per trajectory -> [B]: exactly 0 for a rollout, the dynamics infeasibility
+    a projected-Newton polish leaves (it treats the dynamics as constraints) otherwise."""
+    prob = obj.prob if isinstance(obj, _Solver) else obj
+    d = np.empty(prob.B)
+    prob._call("dynamics_defect", prob._pd(d))
+    return d
 
 
 def max_violation(obj):
