@@ -40,10 +40,20 @@ WORKLOADS = {
                      desc="C2 Cartpole swing-up iLQR (n=4,m=1), N=101, batch=1024 per GPU"),
     "quadrotor": dict(batch=4096, N=201, solver="ilqr",
                       desc="C3 Quadrotor point-to-point iLQR (n=13,m=4,ne=12), N=201, batch=4096 per GPU"),
-    "quadrotor_al": dict(batch=8192, N=201, solver="al",
-                         desc="C5 Quadrotor + GoalConstraint(xf, inds=[1,2,3,8..13]: position + velocities) + NormConstraint(SOC, |u|<=6) "
-                              "AL-iLQR, N=201, batch=8192 per GPU"),
+    "quadrotor_al": dict(batch=8192, N=201, solver="altro", opts={"n_steps": "C5_PN_STEPS"},
+                         desc="C5 Quadrotor + GoalConstraint(xf, inds=[1,2,3,8..13]: position + velocities) + NormConstraint(SOC, |u|<=6), "
+                              "solved as the reference's stack solves constrained problems: ALTRO = AL-iLQR to 1e-3 + projected-Newton "
+                              "polish to constraint_tolerance 1e-6 (n_steps = 8); N=201, batch=8192 per GPU; the metric counts the "
+                              "inner iLQR iterations, the time includes the polish"),
+    "quadrotor_al_nopn": dict(batch=8192, N=201, solver="al",
+                              desc="C5 without the polish (AL-iLQR run to 1e-6 on its own; round-3 definition, kept for comparison)"),
 }
+
+
+def make_solver(T, configs, name, prob):
+    W = WORKLOADS[name]
+    kw = {k: (getattr(configs, v) if isinstance(v, str) else v) for k, v in W.get("opts", {}).items()}
+    return {"ilqr": T.iLQRSolver, "al": T.ALSolver, "altro": T.ALTROSolver}[W["solver"]](prob, **kw)
 
 
 def build_problem(T, configs, name, batch, b_offset, device, lib):
@@ -51,7 +61,7 @@ def build_problem(T, configs, name, batch, b_offset, device, lib):
         return configs.cartpole_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
     if name == "quadrotor":
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
-    if name == "quadrotor_al":
+    if name in ("quadrotor_al", "quadrotor_al_nopn"):
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib, constrained=True,
                                          goal_inds=configs.C5_GOAL_INDS)
     raise ValueError(name)
@@ -103,7 +113,7 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     o, flags = load_oracle_native()
     threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
     sample = min(batch, 1024 if name == "cartpole" else 256 if name == "quadrotor" else 128)
-    Solver = T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver
+    Solver = lambda pr: make_solver(T, configs, name, pr)
     prob = build_problem(T, configs, name, sample, 0, 0, o)
     set_threads(prob, threads)
     u0 = initial_controls_value(T, prob, name)
@@ -208,7 +218,7 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings."""
     W = WORKLOADS[name]
     prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
-    solver = (T.ALSolver if W["solver"] == "al" else T.iLQRSolver)(prob)
+    solver = make_solver(T, configs, name, prob)
     u0 = initial_controls_value(T, prob, name)
     n, m, N = prob.dims()
     dims = (n, m, prob.errstate_dim, N, sum(prob.constraints.p))
@@ -247,6 +257,7 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     barrier()
     dt = time.perf_counter() - t0
     status = solver.stats["status"].copy()
+    it_pn = solver.stats["iterations_pn"].copy()
     kms, kln = (C.c_double * 4)(), (C.c_int64 * 4)()
     iters_prof = 0
     if profile:  # the per-phase launch counts AND the iteration count of the roofline block both come from this pass
@@ -271,6 +282,10 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
            "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
                       "trajectory_iterations_per_step": iters_all / steps, "batch_steps_per_solve": bsteps / steps,
                       "converged_fraction": float(np.mean(status == T.capi.SOLVE_SUCCEEDED)), "solver_path": path,
+                      "projected_newton": None if W["solver"] != "altro" else {
+                          "polished_fraction": float(np.mean(it_pn > 0)), "linearisations_histogram": np.bincount(it_pn).tolist(),
+                          "projection_failed_fraction": float(np.mean(status == T.capi.PROJECTION_FAIL)),
+                          "ms_per_solve": (kms[3] / kln[3]) if (profile and kln[3] > 0) else None},
                       "collective": ("RCCL all_gather of converged (X,U) once per solve + stats gather (to_allgather / to_allgather_stats); "
                                      "ranks the RCCL communicator saw: %d, shards %s" % (len(gather.counts), gather.counts))
                       if gather is not None else "none"},
@@ -340,7 +355,7 @@ def main():
 
             def probe_once(pbatch):
                 pb = build_problem(T, configs, name, pbatch, 0, local_rank, lib)
-                ps = (T.ALSolver if WORKLOADS[name]["solver"] == "al" else T.iLQRSolver)(pb)
+                ps = make_solver(T, configs, name, pb)
                 ps.solve()
                 T.initial_controls(pb, u0)
                 t1 = time.perf_counter(); ps.solve(); d1 = time.perf_counter() - t1

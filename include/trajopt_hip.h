@@ -365,7 +365,7 @@ int to_discrete_jacobian(to_handle* h, double* F);
 
 /* ---- measurement: per-kernel device time of the solve loop, from hipEvents recorded on the handle's stream ----
  * slots: 0 expansion, 1 backward pass, 2 forward pass (line-search rounds, selection / state machine, accept copy, AL
- * outer update), 3 unused.  A "launch" is one batch step.  Accumulates over solves until reset.  Enabling it adds four
+ * outer update), 3 projected-Newton polish (to_altro_solve; one "launch" = all its kernels of one solve).  A "launch" is one batch step.  Accumulates over solves until reset.  Enabling it adds four
  * event records per batch step.
  * Tuning knob (environment, read at to_create): TRAJOPT_LS_CANDIDATES = step sizes evaluated concurrently in the first
  * line-search round (default min(16, 1024 / tiles)); results do not depend on it. */

@@ -9,6 +9,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __global__
+#define TO_CONST_AS   // descriptor tables: plain pointers on the host (problem_dev.h)
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 using std::fabs;
@@ -17,3 +18,4 @@ using std::fmax;
 using std::fmin;
 using std::rint;
 using std::sqrt;
+using std::log10;

@@ -1382,6 +1382,26 @@ class _Solver:
         self.total_iterations, self.batch_steps, self.solve_ms = st.total_iterations, st.batch_steps, st.solve_ms
         return self
 
+    def solve_async(self):
+        """Enqueue the solve and return at once (to_*_solve_async); ``wait()`` blocks until it is done.  One solve in flight per
+        Problem; the stats arrays are valid after ``wait()``."""
+        if self._entry == "pn_solve":
+            raise UnsupportedError("no asynchronous entry point for the projected-Newton solver alone")
+        p = self.prob
+        p._call("set_options", C.byref(self.opts._o))
+        self._st = st = SolveStats()
+        for k, a in self.stats.items():
+            ptr = a.ctypes.data_as(C.POINTER(C.c_int32 if a.dtype == np.int32 else C.c_double))
+            setattr(st, k, ptr)
+        p._call(self._entry + "_async", C.byref(st))
+        return self
+
+    def wait(self):
+        self.prob._call("solve_wait")
+        st = self._st
+        self.total_iterations, self.batch_steps, self.solve_ms = st.total_iterations, st.batch_steps, st.solve_ms
+        return self
+
 
 class iLQRSolver(_Solver):
     """Altro.iLQRSolver(prob, opts): unconstrained iLQR on the batch (examples/Cartpole.ipynb cell 25)."""

@@ -70,6 +70,11 @@ def quadrotor_x0(batch, b_offset=0, seed=2):
 # C5's GoalConstraint acts on position and both velocities (SURVEY.md §8d "optionally inds=[1,2,3,8..13]"): the full
 # 13-state goal also pins the quaternion, which RK4 does not keep on the unit sphere, so it is infeasible at 1e-6.
 C5_GOAL_INDS = [1, 2, 3, 8, 9, 10, 11, 12, 13]
+# C5 solved as ALTRO (AL-iLQR + projected-Newton polish): the polish may linearise up to C5_PN_STEPS + 1 times (Altro's default
+# n_steps = 2 allows 3).  The rotor-force clamp max(0, kf u) is a kink of the dynamics; the AL stage parks some controls at
+# u ~ 0, where each Newton step can cross the kink for a few of them and the Jacobian has to be rebuilt on the other side:
+# 98.4 % of the batch is done within 3 linearisations, the rest needs 4 or 5.
+C5_PN_STEPS = 8
 
 
 def quadrotor_problem(batch=4096, N=201, tf=5.0, b_offset=0, constrained=False, goal_inds=None, u_norm_max=6.0,

@@ -59,6 +59,8 @@ struct KArgs {
                         // consumed by the k_outer_* kernels of the same step, which also clear the other parity's count)
   double* knotbuf;    // tiled, L = N: per-knot scratch of the outer update (violations, then AL cost terms)
   double* mu_next;    // tiled, L = n_cons: penalties after the pending outer update
+  int* it_pn;         // [Bp] projection solves of the projected-Newton polish (k_pn.h)
+  double* pn_cmax;    // [Bp] violation the polish ended with (dynamics defects included)
   int al_mode;    // 0: iLQR, 1: AL-iLQR
   int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
   int step;

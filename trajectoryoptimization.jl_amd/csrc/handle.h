@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -69,6 +70,20 @@ struct to_handle_s {
   std::vector<int32_t> comm_counts;  // shard size of every rank (exchanged at to_comm_init_rank)
   long long comm_offset = 0, comm_total = 0;  // global index of this rank's first trajectory; sum of the shards
   bool comm_equal = true;            // all shards equal: one in-place all-gather, else grouped broadcasts
+  // projected-Newton polish (k_pn.h): workspace and tables, allocated on first use
+  double* pn_ws = nullptr;
+  size_t pn_ws_bytes = 0;
+  int* pn_pak = nullptr;
+  long long* pn_koff = nullptr;
+  int* pn_list = nullptr;
+  int pn_tab_len = 0, pn_list_len = 0;
+  // asynchronous solves (to_*_solve_async / to_solve_wait)
+  std::thread worker;
+  bool inflight = false;
+  int async_rc = 0;
+  std::string async_err;
+  int last_steps = 0;     // batch steps and device time of the last solve (fill_stats)
+  double last_ms = 0.0;
   // measurement
   bool profile = false;
   std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
@@ -106,6 +121,8 @@ struct ModelOps {
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)
   int (*expand_backward_scan)(to_handle*) = nullptr;  // fused expansion + scan Riccati, one wave per trajectory (k_scan.h)
   int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
+  int (*pn)(to_handle*, const int* list, int count) = nullptr;  // projected-Newton polish of the listed trajectories (k_pn.h)
+  int (*defect)(to_handle*, double* out) = nullptr;             // max dynamics / initial-condition defect of the nominal trajectory
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
   int (*forward2[32])(to_handle*) = {};  // the same variants as two-wave workgroups (k_forward2; models with LDS-staged gains)
 };
@@ -132,6 +149,7 @@ void fill_ops_quadrp_forward(ModelOps* table);
 void fill_ops_hybrid(ModelOps* table);
 void fill_ops_small_forward2(ModelOps* table);
 void fill_ops_small_scan(ModelOps* table);
+void fill_ops_pn(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

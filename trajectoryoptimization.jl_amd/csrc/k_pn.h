@@ -1,0 +1,699 @@
+// k_pn.h — projected-Newton polish (Altro.jl ProjectedNewtonSolver, the last stage of ALTRO): ONE WAVE per trajectory.
+//
+// What it computes is defined by oracle/oracle_pn.h (Altro is out of tree): Newton steps onto the active
+// constraints — initial condition, dynamics defects f(x_k, u_k) (-) x_{k+1}, equality rows, inequality rows within
+// active_set_tolerance_pn, second-order cones through the row |v| - s — in the metric of the diagonal objective Hessian,
+//   dZ = -W D'(D W D' + rho I)^-1 d,  W = 1 / (max(diag H, 0) + rho_primal),
+// in error-state coordinates, with Altro's reg_solve refinement, backtracking on |d|_inf and convergence-rate loops.
+//
+// Mapping to the hardware.  Rows grouped by knot — group k = [defect arriving at knot k (ne rows); active constraint rows of
+// knot k] — make S = D W D' BLOCK-TRIDIAGONAL with blocks of nb_k = ne + pa_k <= 12 + 9 rows (C5), so its Cholesky factor is one
+// sweep over the horizon: L_k,k-1 = S_k,k-1 L_k-1^-T (only the ne defect rows couple backwards), L_k = chol(S_kk + rho I -
+// L_k,k-1 L_k,k-1').  That sweep — like the Riccati recursion — is sequential in k and far too small per knot for more than
+// one wave, while the batch supplies the parallelism: a workgroup of one wave owns one trajectory, keeps the two live diagonal
+// blocks, the coupling block and the knot's Jacobian rows in LDS (14 KB for C5), and its 64 lanes own ENTRIES of those blocks.
+// Residuals, the step and the line search in between are parallel over the knots or over (knot, column) pairs of the same
+// wave.  Per-trajectory state lives in a trajectory-major workspace (a header and one contiguous record per knot: the sweeps
+// stream it in order), sized on the host from the constraint list.  One projection round of the batch is three launches:
+//   k_pn_begin    (wave per trajectory)  fresh active set + violation; done / budget spent -> write the trajectory back, status
+//   k_pn_lin_col / k_pn_lin_knot  (wave per 64 (knot, column) pairs / knots)  Jacobian columns of the dynamics by forward-mode dual numbers through the
+//                 RK stages, active constraint rows, the metric — the register-hungry part (Quadrotor duals), fully parallel
+//   k_pn_project  (wave per trajectory)  factorisation, reg_solve refinement, line search, convergence-rate loop
+// and the host enqueues n_steps + 2 rounds back to back (a trajectory that is done costs its waves one header load).
+//
+// The kernel is written as a sequence of PHASES: `PN_FOR(i, n) { ... }` runs its body for i = 0..n-1 with the iterations
+// spread over the lanes, `PN_SYNC()` separates phases; no iteration of a phase reads what another iteration of the same phase
+// writes, and everything a later phase needs goes through LDS or the workspace.  Values computed outside PN_FOR are
+// wave-uniform (every lane computes them from the same memory).  With TO_PN_HOST defined the same source compiles with g++ —
+// PN_FOR becomes a plain loop — and the CPU test-suite runs THIS code against the oracle (tests/test_pn_host.py) before a GPU
+// is involved; on the GPU the -m gpu tests compare it with the oracle again.
+#pragma once
+#include "common.h"
+
+namespace to {
+
+constexpr int PN_MAX_ROWS = 64;      // candidate constraint rows of one knot (one bit each in the active mask)
+constexpr int PN_NB_LIMIT = 44;      // largest block: ne + active rows of a knot (LDS: 2 NB^2 + ... doubles)
+constexpr int PN_REFINEMENTS = 10;   // Altro _projection_solve!: max_refinements
+constexpr int PN_LS_TRIALS = 10;     // Altro _projection_linesearch!
+constexpr int PN_REG_SOLVE_ITERS = 25;
+constexpr double PN_REG_SOLVE_TOL = 1e-8;
+
+struct PnArgs {
+  KArgs a;
+  const int* pak;         // [N] candidate rows of knot k (upper bound of its active rows; host table)
+  const long long* koff;  // [N+1] offset of knot k's record in a trajectory's workspace, koff[N] = doubles per trajectory
+  double* ws;             // workspace of the trajectories of this launch
+  const int* list;        // trajectories to polish
+  int base;               // this launch polishes list[base + workgroup]
+  int nbmax;              // max_k (ne + pak[k])
+  int* it_pn;             // [Bp] projection solves
+  double* cmax_out;       // [Bp] violation at the end (defects included)
+};
+
+#ifdef TO_PN_HOST
+#define PN_FOR(i, n) for (int i = 0; i < (n); ++i)
+#define PN_SYNC() do { } while (0)
+#define PN_FN inline
+#define PN_HD inline
+#else
+// The trip count depends on n only and EVERY lane runs every pass: a lane beyond the end repeats the last item (same loads, same
+// arithmetic, the same values stored to the same addresses, read-modify-writes included: the lanes of a wave read before any of
+// them writes).  A wave whose EXEC mask stays full has no divergent regions for the register allocator to place spills around
+// (hipcc may put a VGPR->AGPR spill ahead of the exec restore of a join block), and FP64 instructions issue faster.
+#define PN_FOR(i, n)                                                             \
+  for (int i##_b = 0, i##_n = (n); i##_b < i##_n; i##_b += 64)                   \
+    for (int i = (i##_b + lane < i##_n ? i##_b + lane : i##_n - 1), i##_1 = 1; i##_1; i##_1 = 0)
+#define PN_SYNC() __syncthreads()   // the workgroup IS the wave: LDS and workspace writes of a phase become visible to the next
+#define PN_FN __device__ inline
+#define PN_HD __host__ __device__ inline
+#endif
+
+PN_FN void pn_upd_max(double& m, double v) { if (v > m || v != v) m = v; }  // NaN sticks (v > NaN is false)
+PN_FN int pn_popc(unsigned long long m) { int c = 0; while (m) { m &= m - 1; ++c; } return c; }
+
+// vectors of a knot record: d (rhs on the active set), dn (candidate's), dl (multiplier step), r (residual), t (scratch)
+enum { PN_VD = 0, PN_VDN = 1, PN_VDL = 2, PN_VR = 3, PN_VT = 4, PN_NVEC = 5 };
+
+template <class M>
+struct PnRec {
+  double *Z, *Zb, *dZ, *W, *F, *C, *vec, *Ld, *Lo, *loc;
+  unsigned long long* mask;
+  int nbm;  // ne + pak[k]: stride of the record's vectors
+  PN_FN double* v(int which) const { return vec + which * nbm; }
+};
+// doubles of knot k's record (host: workspace sizing; must match pn_rec)
+template <class M>
+PN_HD long long pn_rec_size(int pa, int pa_prev, bool first) {
+  constexpr int ne = M::ne, nc = M::ne + M::m, nz = M::n + M::m;
+  const int nb = ne + pa, nbp = first ? 0 : ne + pa_prev;
+  return 2 * nz + 2 * nc + ne * nc + (long long)pa * nc + PN_NVEC * nb + (long long)nb * nb + (long long)ne * nbp + 4;
+}
+template <class M>
+PN_FN PnRec<M> pn_rec(const PnArgs& q, double* w, int k) {
+  constexpr int ne = M::ne, nc = M::ne + M::m, nz = M::n + M::m;
+  const int pa = q.pak[k], nb = ne + pa, nbp = k > 0 ? ne + q.pak[k - 1] : 0;
+  PnRec<M> r;
+  double* p = w + q.koff[k];
+  r.Z = p; p += nz; r.Zb = p; p += nz; r.dZ = p; p += nc; r.W = p; p += nc; r.F = p; p += ne * nc; r.C = p; p += pa * nc;
+  r.vec = p; p += PN_NVEC * nb; r.Ld = p; p += nb * nb; r.Lo = p; p += ne * nbp;
+  r.mask = reinterpret_cast<unsigned long long*>(p); r.loc = p + 1;
+  r.nbm = nb;
+  return r;
+}
+
+// LDS of one wave (doubles): two diagonal blocks, the coupling block, the knot's Jacobian rows and metric, two vectors, a
+// 64-entry reduction buffer
+struct PnLds {
+  double *LA, *LB, *Lo, *F, *Ca, *Cb, *Wa, *Wb, *va, *vb, *red;
+  int NB;
+};
+template <class M>
+PN_HD long long pn_lds_doubles(int NB) {
+  constexpr int ne = M::ne, nc = M::ne + M::m;
+  return 2LL * NB * NB + (long long)ne * NB + ne * nc + 2LL * (NB - ne) * nc + 2 * nc + 2 * NB + 64;
+}
+template <class M>
+PN_FN PnLds pn_lds(double* p, int NB) {
+  constexpr int ne = M::ne, nc = M::ne + M::m;
+  PnLds l; l.NB = NB;
+  l.LA = p; p += NB * NB; l.LB = p; p += NB * NB; l.Lo = p; p += ne * NB; l.F = p; p += ne * nc;
+  l.Ca = p; p += (NB - ne) * nc; l.Cb = p; p += (NB - ne) * nc; l.Wa = p; p += nc; l.Wb = p; p += nc;
+  l.va = p; p += NB; l.vb = p; p += NB; l.red = p;
+  return l;
+}
+
+// ---- candidate rows of a knot: f(q, value, gradient over z = [x; u] (nz), equality?) for every row that may take part.
+// A second-order cone [v; s] contributes the ONE row |v| - s.
+template <class M, bool GRAD, class Fn>
+PN_FN void pn_for_candidates(const DevProblem& P, int k, const double* z, Fn&& f) {
+  constexpr int nz = M::n + M::m;
+  int qi = 0;
+  double gz[nz], coef[nz];
+  for (int ci = 0; ci < P.n_cons; ++ci) {
+    ConC& K = P.cons[ci];
+    if (k < K.k1 || k > K.k2) continue;
+    const int p = K.p;
+    if (K.d.sense == TO_CONE_SECOND_ORDER) {
+      double a2 = 0.0;
+      for (int r = 0; r < p - 1; ++r) { const double c = sel_row<nz>(K, z, r); a2 += c * c; }
+      const double a = sqrt(a2), s = sel_row<nz>(K, z, p - 1);
+      if (GRAD) {
+        for (int j = 0; j < nz; ++j) gz[j] = 0.0;
+        if (a > 0.0)
+          for (int r = 0; r < p - 1; ++r) { const int j = K.sidx[r]; if (j >= 0) gz[j] += (sel_row<nz>(K, z, r) / a) * K.ssgn[r]; }
+        const int js = K.sidx[p - 1];
+        if (js >= 0) gz[js] -= K.ssgn[p - 1];
+      }
+      f(qi, a - s, gz, false);
+      ++qi;
+    } else if (K.selector) {
+      for (int r = 0; r < p; ++r) {
+        if (GRAD) { for (int j = 0; j < nz; ++j) gz[j] = 0.0; const int j = K.sidx[r]; if (j >= 0) gz[j] = K.ssgn[r]; }
+        f(qi, sel_row<nz>(K, z, r), gz, K.d.sense == TO_CONE_ZERO);
+        ++qi;
+      }
+    } else {
+      for (int r = 0; r < p; ++r) {
+        for (int j = 0; j < nz; ++j) coef[j] = 0.0;
+        const double c = con_row<nz>(K, z, r, coef);
+        if (GRAD) {
+          for (int j = 0; j < nz; ++j) gz[j] = 0.0;
+          for (int t = 0; t < K.d.n_inds && t < nz; ++t) gz[K.d.inds[t] - 1] += coef[t];
+        }
+        f(qi, c, gz, K.d.sense == TO_CONE_ZERO);
+        ++qi;
+      }
+    }
+  }
+}
+
+// gradient of a row in the coordinates the step moves in: [G(x)' g_x; g_u] (no control at the terminal knot)
+template <class M>
+PN_FN void pn_project_row(const double* x, const double* gz, bool terminal, double* ge) {
+  constexpr int n = M::n, m = M::m, ne = M::ne;
+  errstate_tmul<M>(x, gz, ge);
+  for (int j = 0; j < m; ++j) ge[ne + j] = terminal ? 0.0 : gz[n + j];
+}
+
+// defect arriving at knot k (ne): the initial condition at k = 0, f(x_{k-1}, u_{k-1}) (-) x_k otherwise
+template <class M>
+PN_FN void pn_defect(const DevProblem& P, int k, const double* zprev, const double* z, const double* x0, double* e) {
+  constexpr int n = M::n;
+  // branch-free in k (the lanes of a wave sit on different knots): the step is always taken, the operands selected
+  const int kp = k > 0 ? k - 1 : 0;
+  double f[n], a[n], b[n];
+  model_step<M, double>(P.mp, P.integrator, kp, zprev, zprev + n, P.dt[kp], f);
+  for (int i = 0; i < n; ++i) { a[i] = (k == 0) ? z[i] : f[i]; b[i] = (k == 0) ? x0[i] : z[i]; }
+  state_diff<M>(a, b, e);
+}
+
+#ifdef TO_PN_HOST
+#define PN_LANE_PARAM
+#define PN_LANE_ARG
+#else
+#define PN_LANE_PARAM , int lane
+#define PN_LANE_ARG , lane
+#endif
+
+// max over the knots of loc[0] (NaN-aware): wave-uniform result
+template <class M>
+PN_FN double pn_reduce_max(const PnArgs& q, double* w, const PnLds& L PN_LANE_PARAM) {
+  const int N = q.a.P.N;
+  PN_FOR(j, 64) {
+    double mx = 0.0;
+    for (int k = j; k < N; k += 64) pn_upd_max(mx, pn_rec<M>(q, w, k).loc[0]);
+    L.red[j] = mx;
+  }
+  PN_SYNC();
+  double mx = 0.0;
+  for (int j = 0; j < 64; ++j) pn_upd_max(mx, L.red[j]);
+  PN_SYNC();
+  return mx;
+}
+
+// d on the active set of the point Z (cand = false) or Zb (true), into d or dn.  refresh: choose the active set from the values
+// first.  Returns |d|_inf.
+template <class M>
+PN_FN double pn_eval(const PnArgs& q, double* w, const PnLds& L, const double* x0, bool cand, bool refresh, int dst_vec PN_LANE_PARAM) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  const DevProblem& P = q.a.P;
+  const int N = P.N;
+  const double tol_a = P.opts.active_set_tolerance_pn;
+  PN_FOR(k, N) {
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const double* z = cand ? R.Zb : R.Z;
+    const double* zp = z;
+    if (k > 0) { const PnRec<M> Rp = pn_rec<M>(q, w, k - 1); zp = cand ? Rp.Zb : Rp.Z; }
+    double* dst = R.v(dst_vec);
+    double e[ne], mx = 0.0;
+    pn_defect<M>(P, k, zp, z, x0, e);
+    for (int i = 0; i < ne; ++i) { dst[i] = e[i]; pn_upd_max(mx, fabs(e[i])); }
+    unsigned long long mask = refresh ? 0ull : *R.mask;
+    int na = 0;
+    const bool terminal = (k == N - 1);
+    if (refresh) {
+      pn_for_candidates<M, true>(P, k, z, [&](int qi, double val, const double* gz, bool eq) {
+        if (!(eq || val >= -tol_a)) return;
+        double ge[nc], g2 = 0.0;
+        pn_project_row<M>(z, gz, terminal, ge);
+        for (int j = 0; j < nc; ++j) g2 += ge[j] * ge[j];
+        if (!(g2 > 0.0)) return;
+        mask |= 1ull << qi;
+        dst[ne + na++] = val; pn_upd_max(mx, fabs(val));
+      });
+      *R.mask = mask;
+    } else {
+      pn_for_candidates<M, false>(P, k, z, [&](int qi, double val, const double*, bool) {
+        if (!(mask >> qi & 1ull)) return;
+        dst[ne + na++] = val; pn_upd_max(mx, fabs(val));
+      });
+    }
+    R.loc[0] = mx;
+  }
+  PN_SYNC();
+  return pn_reduce_max<M>(q, w, L PN_LANE_ARG);
+}
+
+// inverse metric of knot k: 1 / (max(diag of the error-state OBJECTIVE Hessian, 0) + rho_primal)
+template <class M>
+PN_FN void pn_metric(const DevProblem& P, int k, const double* z, bool terminal, double* W) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m;
+  CostC& C = P.costs[P.cost_index[k]];
+  const double sc = (P.opts.cost_dt_scaling && !terminal) ? P.dt[k] : 1.0;
+  double v[nz], g[nz], y[nz];
+  for (int j = 0; j < ne; ++j) {
+    errstate_col<M>(z, j, v);
+    for (int i = n; i < nz; ++i) v[i] = 0.0;
+    cost_grad_hvp<n, m, true>(C, z, z + n, terminal, v, g, y);
+    double dj = 0.0;
+    for (int i = 0; i < n; ++i) dj += v[i] * y[i];
+    if constexpr (M::att == ATT_QUAT) {  // second-order term of the attitude map: -I3 (q' dJ/dq)
+      if (j >= 3 && j < 6) { double b1 = 0.0; for (int i = 0; i < 4; ++i) b1 += z[3 + i] * g[3 + i]; dj -= b1; }
+    } else if constexpr (M::att == ATT_MRP || M::att == ATT_RP) {
+      if (j >= 3 && j < 6) { double H2[9]; att_differential2<M::att>(z + 3, g + 3, H2); dj += H2[4 * (j - 3)]; }
+    }
+    W[j] = 1.0 / (fmax(dj * sc, 0.0) + P.opts.rho_primal);
+  }
+  for (int j = 0; j < m; ++j) {
+    for (int i = 0; i < nz; ++i) v[i] = (i == n + j) ? 1.0 : 0.0;
+    cost_grad_hvp<n, m, true>(C, z, z + n, terminal, v, g, y);
+    W[ne + j] = terminal ? 0.0 : 1.0 / (fmax(y[n + j] * sc, 0.0) + P.opts.rho_primal);
+  }
+}
+
+// Linearisation, item by item (one lane per item).  k_pn_lin_col, items [0, (N-1) nc): column j of the error-state Jacobian [A B]
+// of step k by a dual number through the RK stages (ForwardDiff-equivalent, like k_expand), stored in the record of the knot the
+// defect arrives at.  k_pn_lin_knot, items [0, N): metric and active constraint rows of a knot.
+template <class M>
+PN_FN void pn_lin_column(const PnArgs& q, double* w, int it) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  const DevProblem& P = q.a.P;
+  const int k = it / nc, j = it % nc;
+  const PnRec<M> R = pn_rec<M>(q, w, k), Rn = pn_rec<M>(q, w, k + 1);
+  double v[nz];
+  errstate_col<M>(R.Z, j < ne ? j : 0, v);
+  for (int i = 0; i < n; ++i) v[i] = (j < ne) ? v[i] : 0.0;
+  for (int i = n; i < nz; ++i) v[i] = (i == n + j - ne) ? 1.0 : 0.0;
+  Dual xd[n], ud[m], xn[n];
+  for (int i = 0; i < n; ++i) xd[i] = Dual(R.Z[i], v[i]);
+  for (int i = 0; i < m; ++i) ud[i] = Dual(R.Z[n + i], v[n + i]);
+  model_step<M, Dual>(P.mp, P.integrator, k, xd, ud, P.dt[k], xn);
+  double y[n], col[ne];
+  for (int i = 0; i < n; ++i) y[i] = xn[i].d;
+  errstate_invmul<M>(Rn.Z, y, col);
+  for (int i = 0; i < ne; ++i) Rn.F[i * nc + j] = col[i];
+}
+template <class M>
+PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
+  constexpr int nc = M::ne + M::m;
+  const DevProblem& P = q.a.P;
+  const PnRec<M> R = pn_rec<M>(q, w, k);
+  const bool terminal = (k == P.N - 1);
+  pn_metric<M>(P, k, R.Z, terminal, R.W);
+  const unsigned long long mask = *R.mask;
+  int na = 0;
+  pn_for_candidates<M, true>(P, k, R.Z, [&](int qi, double, const double* gz, bool) {
+    if (!(mask >> qi & 1ull)) return;
+    pn_project_row<M>(R.Z, gz, terminal, R.C + (size_t)na * nc);
+    ++na;
+  });
+}
+
+// block-tridiagonal Cholesky factor of S + rho I, S = D W D', into the records (Ld, Lo).  false: a pivot was not positive.
+template <class M>
+PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_LANE_PARAM) {
+  constexpr int ne = M::ne, nc = M::ne + M::m;
+  const int N = q.a.P.N, NB = L.NB;
+  double *Lc = L.LA, *Lp = L.LB, *Cc = L.Ca, *Cp = L.Cb, *Wc = L.Wa, *Wp = L.Wb;
+  int nbp = 0;
+  for (int k = 0; k < N; ++k) {
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const int pa = pn_popc(*R.mask), nb = ne + pa;
+    PN_FOR(e, ne * nc) L.F[e] = (k > 0) ? R.F[e] : 0.0;
+    PN_FOR(e, pa * nc) Cc[e] = R.C[e];
+    PN_FOR(e, nc) Wc[e] = R.W[e];
+    PN_SYNC();
+    const double sg = (k == 0) ? 1.0 : -1.0, sgp = (k == 1) ? 1.0 : -1.0;  // coefficient of dx_k in its own arriving-defect row
+    PN_FOR(e, nb * nb) {
+      const int i = e / nb, j = e % nb;
+      if (j <= i) {
+        double v = 0.0;
+        if (i < ne) {
+          if (k > 0) for (int c = 0; c < nc; ++c) v += L.F[i * nc + c] * Wp[c] * L.F[j * nc + c];
+          if (i == j) v += Wc[i];
+        } else if (j < ne) v = sg * Wc[j] * Cc[(i - ne) * nc + j];
+        else for (int c = 0; c < nc; ++c) v += Cc[(i - ne) * nc + c] * Wc[c] * Cc[(j - ne) * nc + c];
+        Lc[i * NB + j] = v + (i == j ? rho : 0.0);
+      }
+    }
+    if (k > 0) {
+      PN_FOR(e, ne * nbp) {
+        const int i = e / nbp, j = e % nbp;
+        double v = 0.0;
+        if (j < ne) v = sgp * L.F[i * nc + j] * Wp[j];
+        else for (int c = 0; c < nc; ++c) v += L.F[i * nc + c] * Wp[c] * Cp[(j - ne) * nc + c];
+        L.Lo[i * NB + j] = v;
+      }
+    }
+    PN_SYNC();
+    if (k > 0) {
+      PN_FOR(i, ne) {  // L_k,k-1 = S_k,k-1 L_k-1^-T, one row per lane
+        for (int j = 0; j < nbp; ++j) {
+          double v = L.Lo[i * NB + j];
+          for (int t = 0; t < j; ++t) v -= L.Lo[i * NB + t] * Lp[j * NB + t];
+          L.Lo[i * NB + j] = v / Lp[j * NB + j];
+        }
+      }
+      PN_SYNC();
+      PN_FOR(e, ne * ne) {
+        const int i = e / ne, j = e % ne;
+        if (j <= i) { double v = 0.0; for (int t = 0; t < nbp; ++t) v += L.Lo[i * NB + t] * L.Lo[j * NB + t]; Lc[i * NB + j] -= v; }
+      }
+      PN_SYNC();
+    }
+    for (int j = 0; j < nb; ++j) {  // right-looking Cholesky of the block
+      const double pj = Lc[j * NB + j];
+      if (!(pj > 0.0)) return false;
+      const double lj = sqrt(pj);
+      PN_FOR(i, nb - j) { const int ii = j + i; Lc[ii * NB + j] = (i == 0) ? lj : Lc[ii * NB + j] / lj; }
+      PN_SYNC();
+      const int cnt = nb - j - 1;
+      PN_FOR(e, cnt * cnt) {
+        const int i = j + 1 + e / cnt, c = j + 1 + e % cnt;
+        if (c <= i) Lc[i * NB + c] -= Lc[i * NB + j] * Lc[c * NB + j];
+      }
+      PN_SYNC();
+    }
+    PN_FOR(e, nb * nb) { const int i = e / nb, j = e % nb; R.Ld[e] = (j <= i) ? Lc[i * NB + j] : 0.0; }
+    if (k > 0) PN_FOR(e, ne * nbp) R.Lo[e] = L.Lo[(e / nbp) * NB + e % nbp];
+    PN_SYNC();
+    double* t;
+    t = Lc; Lc = Lp; Lp = t; t = Cc; Cc = Cp; Cp = t; t = Wc; Wc = Wp; Wp = t;
+    nbp = nb;
+  }
+  return true;
+}
+
+// (L L') x = b in place on vector `which` of the records
+template <class M>
+PN_FN void pn_chol_solve(const PnArgs& q, double* w, const PnLds& L, int which PN_LANE_PARAM) {
+  constexpr int ne = M::ne;
+  const int N = q.a.P.N, NB = L.NB;
+  double *yc = L.va, *yp = L.vb, *Lc = L.LA;
+  int nbp = 0;
+  for (int k = 0; k < N; ++k) {  // forward: L y = b
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const int nb = ne + pn_popc(*R.mask);
+    double* v = R.v(which);
+    PN_FOR(e, nb * nb) Lc[(e / nb) * NB + e % nb] = R.Ld[e];
+    if (k > 0) PN_FOR(e, ne * nbp) L.Lo[(e / nbp) * NB + e % nbp] = R.Lo[e];
+    PN_FOR(i, nb) yc[i] = v[i];
+    PN_SYNC();
+    if (k > 0) {
+      PN_FOR(i, ne) { double s = 0.0; for (int t = 0; t < nbp; ++t) s += L.Lo[i * NB + t] * yp[t]; yc[i] -= s; }
+      PN_SYNC();
+    }
+    for (int j = 0; j < nb; ++j) {
+      const double yj = yc[j] / Lc[j * NB + j];
+      PN_FOR(i, nb - j) { if (i == 0) yc[j] = yj; else yc[j + i] -= Lc[(j + i) * NB + j] * yj; }
+      PN_SYNC();
+    }
+    PN_FOR(i, nb) v[i] = yc[i];
+    PN_SYNC();
+    double* t = yc; yc = yp; yp = t;
+    nbp = nb;
+  }
+  for (int k = N - 1; k >= 0; --k) {  // backward: L' x = y
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const int nb = ne + pn_popc(*R.mask);
+    double* v = R.v(which);
+    PN_FOR(e, nb * nb) Lc[(e / nb) * NB + e % nb] = R.Ld[e];
+    if (k < N - 1) { const PnRec<M> Rn = pn_rec<M>(q, w, k + 1); PN_FOR(e, ne * nb) L.Lo[(e / nb) * NB + e % nb] = Rn.Lo[e]; }
+    PN_FOR(i, nb) yc[i] = v[i];
+    PN_SYNC();
+    if (k < N - 1) {
+      PN_FOR(j, nb) { double s = 0.0; for (int i = 0; i < ne; ++i) s += L.Lo[i * NB + j] * yp[i]; yc[j] -= s; }
+      PN_SYNC();
+    }
+    for (int j = nb - 1; j >= 0; --j) {
+      const double xj = yc[j] / Lc[j * NB + j];
+      PN_FOR(i, j + 1) { if (i == j) yc[j] = xj; else yc[i] -= Lc[j * NB + i] * xj; }
+      PN_SYNC();
+    }
+    PN_FOR(i, nb) v[i] = yc[i];
+    PN_SYNC();
+    double* t = yc; yc = yp; yp = t;
+  }
+}
+
+// dZ = -W D' lambda (lambda = vector `which`)
+template <class M>
+PN_FN void pn_step(const PnArgs& q, double* w, int which PN_LANE_PARAM) {
+  constexpr int ne = M::ne, nc = M::ne + M::m;
+  const int N = q.a.P.N;
+  PN_FOR(it, N * nc) {
+    const int k = it / nc, c = it % nc;
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const double* lam = R.v(which);
+    const int pa = pn_popc(*R.mask);
+    double s = 0.0;
+    if (k < N - 1) {
+      const PnRec<M> Rn = pn_rec<M>(q, w, k + 1);
+      const double* ln = Rn.v(which);
+      for (int i = 0; i < ne; ++i) s += Rn.F[i * nc + c] * ln[i];
+    }
+    if (c < ne) s += (k == 0 ? 1.0 : -1.0) * lam[c];
+    for (int a = 0; a < pa; ++a) s += R.C[a * nc + c] * lam[ne + a];
+    R.dZ[c] = -(R.W[c] * s);
+  }
+  PN_SYNC();
+}
+
+// r = b + D dZ  (= b - S lambda for the lambda dZ was formed from); returns |r|_2
+template <class M>
+PN_FN double pn_residual(const PnArgs& q, double* w, const PnLds& L, int vb, int vr PN_LANE_PARAM) {
+  constexpr int ne = M::ne, nc = M::ne + M::m;
+  const int N = q.a.P.N, NB = L.NB;
+  PN_FOR(it, N * NB) {
+    const int k = it / NB, i = it % NB;
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const int nb = ne + pn_popc(*R.mask);
+    if (i < nb) {
+      double s = 0.0;
+      if (i < ne) {
+        if (k > 0) { const PnRec<M> Rp = pn_rec<M>(q, w, k - 1); for (int c = 0; c < nc; ++c) s += R.F[i * nc + c] * Rp.dZ[c]; }
+        s += (k == 0 ? 1.0 : -1.0) * R.dZ[i];
+      } else for (int c = 0; c < nc; ++c) s += R.C[(i - ne) * nc + c] * R.dZ[c];
+      R.v(vr)[i] = R.v(vb)[i] + s;
+    }
+  }
+  PN_SYNC();
+  PN_FOR(j, 64) {
+    double s = 0.0;
+    for (int k = j; k < N; k += 64) {
+      const PnRec<M> R = pn_rec<M>(q, w, k);
+      const int nb = ne + pn_popc(*R.mask);
+      const double* r = R.v(vr);
+      for (int i = 0; i < nb; ++i) s += r[i] * r[i];
+    }
+    L.red[j] = s;
+  }
+  PN_SYNC();
+  double s = 0.0;
+  for (int j = 0; j < 64; ++j) s += L.red[j];
+  PN_SYNC();
+  return sqrt(s);
+}
+
+// Altro reg_solve: dl = (S + rho I)^-1 d refined against the unregularised S; leaves dZ = -W D' dl
+template <class M>
+PN_FN void pn_reg_solve(const PnArgs& q, double* w, const PnLds& L PN_LANE_PARAM) {
+  constexpr int ne = M::ne;
+  const int N = q.a.P.N, NB = L.NB;
+  PN_FOR(it, N * NB) { const int k = it / NB, i = it % NB; const PnRec<M> R = pn_rec<M>(q, w, k); if (i < R.nbm) R.v(PN_VDL)[i] = R.v(PN_VD)[i]; }
+  PN_SYNC();
+  pn_chol_solve<M>(q, w, L, PN_VDL PN_LANE_ARG);
+  for (int it = 0;; ++it) {
+    pn_step<M>(q, w, PN_VDL PN_LANE_ARG);
+    if (it >= PN_REG_SOLVE_ITERS) break;
+    const double nr = pn_residual<M>(q, w, L, PN_VD, PN_VR PN_LANE_ARG);
+    if (nr < PN_REG_SOLVE_TOL) break;
+    pn_chol_solve<M>(q, w, L, PN_VR PN_LANE_ARG);
+    PN_FOR(e, N * NB) { const int k = e / NB, i = e % NB; const PnRec<M> R = pn_rec<M>(q, w, k); if (i < ne + pn_popc(*R.mask)) R.v(PN_VDL)[i] += R.v(PN_VR)[i]; }
+    PN_SYNC();
+  }
+}
+
+// header of a trajectory's workspace
+enum { PN_H_STATE = 0, PN_H_STEPS = 1, PN_H_VIOL = 2, PN_H_FAILED = 3, PN_HEADER = 8 };
+enum { PN_FRESH = 0, PN_ACTIVE = 1, PN_DONE = 2 };
+
+// Round `round` of the polish of trajectory b, first part: (round 0: fetch the trajectory;) fresh active set and its violation; if
+// that is within constraint_tolerance, the budget of n_steps + 1 linearisations is spent (Altro projection_solve!: while count
+// <= n_steps) or the last factorisation failed: evaluate what the trajectory violates now (constraints as max_violation reports
+// them, and defects), write it back, set the status.  Otherwise the trajectory is ACTIVE for k_pn_lin / k_pn_project.
+template <class M>
+PN_FN void pn_begin(const PnArgs& q, int b, double* w, double* lds_mem, int round PN_LANE_PARAM) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m;
+  const KArgs& a = q.a;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const to_solver_opts& o = P.opts;
+  if (round > 0 && w[PN_H_STATE] == (double)PN_DONE) return;
+  const PnLds L = pn_lds<M>(lds_mem, q.nbmax);
+  const int tile = b >> 6, tl = b & 63;
+  double* Xn = a.Xs + ((size_t)tile * (size_t)(N * n)) * 64 + tl;
+  double* Un = a.Us + ((size_t)tile * (size_t)((N - 1) * m)) * 64 + tl;
+  const double* x0t = a.x0 + ((size_t)tile * (size_t)n) * 64 + tl;
+  double x0[n];
+  for (int i = 0; i < n; ++i) x0[i] = EL(x0t, i);
+  if (round == 0) {
+    PN_FOR(e, N * nz) {
+      const int k = e / nz, i = e % nz;
+      pn_rec<M>(q, w, k).Z[i] = i < n ? EL(Xn, k * n + i) : (k < N - 1 ? EL(Un, k * m + (i - n)) : 0.0);
+    }
+    PN_FOR(j, 1) { w[PN_H_STEPS] = 0.0; w[PN_H_FAILED] = 0.0; }
+    PN_SYNC();
+  }
+  const bool failed = w[PN_H_FAILED] != 0.0;
+  const double viol = pn_eval<M>(q, w, L, x0, false, true, PN_VD PN_LANE_ARG);
+  if (!(viol <= o.constraint_tolerance || round > o.n_steps || failed)) {
+    PN_FOR(j, 1) { w[PN_H_STATE] = (double)PN_ACTIVE; w[PN_H_VIOL] = viol; }
+    PN_SYNC();
+    return;
+  }
+  PN_FOR(k, N) {
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const double* zp = pn_rec<M>(q, w, k > 0 ? k - 1 : 0).Z;
+    double e[ne], mx = 0.0;
+    pn_defect<M>(P, k, zp, R.Z, x0, e);
+    for (int i = 0; i < ne; ++i) pn_upd_max(mx, fabs(e[i]));
+    if (P.n_cons > 0) pn_upd_max(mx, knot_violation<M>(P, k, R.Z, R.Z + n));
+    R.loc[0] = mx;
+  }
+  PN_SYNC();
+  const double cmax = pn_reduce_max<M>(q, w, L PN_LANE_ARG);
+  PN_FOR(e, N * nz) {
+    const int k = e / nz, i = e % nz;
+    const double v = pn_rec<M>(q, w, k).Z[i];
+    if (i < n) EL(Xn, k * n + i) = v; else if (k < N - 1) EL(Un, k * m + (i - n)) = v;
+  }
+  PN_FOR(j, 1) {
+    q.it_pn[b] = (int)w[PN_H_STEPS];
+    q.cmax_out[b] = cmax;
+    a.status[b] = (cmax <= o.constraint_tolerance) ? TO_SOLVE_SUCCEEDED : TO_PROJECTION_FAIL;
+    w[PN_H_STATE] = (double)PN_DONE;
+  }
+  PN_SYNC();
+}
+
+// ... second part, after the linearisation: Altro _projection_solve! on the frozen active set
+template <class M>
+PN_FN void pn_project(const PnArgs& q, int b, double* w, double* lds_mem PN_LANE_PARAM) {
+  constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m;
+  const KArgs& a = q.a;
+  const DevProblem& P = a.P;
+  const int N = P.N;
+  const to_solver_opts& o = P.opts;
+  if (w[PN_H_STATE] != (double)PN_ACTIVE) return;
+  const PnLds L = pn_lds<M>(lds_mem, q.nbmax);
+  const int NB = L.NB;
+  const int tile = b >> 6, tl = b & 63;
+  const double* x0t = a.x0 + ((size_t)tile * (size_t)n) * 64 + tl;
+  double x0[n];
+  for (int i = 0; i < n; ++i) x0[i] = EL(x0t, i);
+  const double viol = w[PN_H_VIOL];
+  PN_SYNC();  // every lane has read the header before lane 0 rewrites it
+  PN_FOR(j, 1) w[PN_H_STEPS] += 1.0;
+  if (!pn_factor<M>(q, w, L, o.rho_chol PN_LANE_ARG)) {
+    PN_FOR(j, 1) w[PN_H_FAILED] = 1.0;
+    PN_SYNC();
+    return;
+  }
+  double viol_prev = viol;
+  for (int count = 0; count < PN_REFINEMENTS; ++count) {
+    pn_reg_solve<M>(q, w, L PN_LANE_ARG);
+    double alpha = 1.0, v = 0.0;
+    bool accepted = false;
+    for (int ls = 0; ls < PN_LS_TRIALS; ++ls) {
+      PN_FOR(k, N) {
+        const PnRec<M> R = pn_rec<M>(q, w, k);
+        double stp[ne];
+        for (int i = 0; i < ne; ++i) stp[i] = alpha * R.dZ[i];
+        state_add<M>(R.Z, stp, R.Zb);
+        for (int j = 0; j < m; ++j) R.Zb[n + j] = (k < N - 1) ? R.Z[n + j] + alpha * R.dZ[ne + j] : 0.0;
+      }
+      PN_SYNC();
+      v = pn_eval<M>(q, w, L, x0, true, false, PN_VDN PN_LANE_ARG);
+      if (v < viol_prev) { accepted = true; break; }
+      alpha *= 0.5;
+    }
+    if (!accepted) break;
+    PN_FOR(e, N * nz) { const PnRec<M> R = pn_rec<M>(q, w, e / nz); R.Z[e % nz] = R.Zb[e % nz]; }
+    PN_FOR(e, N * NB) { const int k = e / NB, i = e % NB; const PnRec<M> R = pn_rec<M>(q, w, k); if (i < R.nbm) R.v(PN_VD)[i] = R.v(PN_VDN)[i]; }
+    PN_SYNC();
+    const double before = viol_prev;
+    viol_prev = v;
+    if (v < o.constraint_tolerance) break;
+    if (before < 1.0) { if (log10(v) / log10(before) < o.r_threshold) break; }
+    else if (!(v < 0.5 * before)) break;
+  }
+}
+
+#ifndef TO_PN_HOST
+template <class M>
+__global__ void __launch_bounds__(64) k_pn_begin(PnArgs q, int round) {
+  extern __shared__ double pn_lds_mem[];
+  const int b = q.list[q.base + blockIdx.x];
+  pn_begin<M>(q, b, q.ws + (size_t)blockIdx.x * (size_t)q.koff[q.a.P.N], pn_lds_mem, round, (int)threadIdx.x);
+}
+template <class M>
+__global__ void __launch_bounds__(64) k_pn_project(PnArgs q) {
+  extern __shared__ double pn_lds_mem[];
+  const int b = q.list[q.base + blockIdx.x];
+  pn_project<M>(q, b, q.ws + (size_t)blockIdx.x * (size_t)q.koff[q.a.P.N], pn_lds_mem, (int)threadIdx.x);
+}
+// grid (trajectories of the launch, ceil(items / 64)), EXEC full (a lane beyond the end repeats the last item).  Two kernels:
+// the dual-number RK step of the Quadrotor takes every register there is, the knot items (cost / constraint descriptors that
+// differ between the lanes' knots: lane-divergent branches) must not share its allocation (spill placement).
+template <class M>
+__global__ void __launch_bounds__(64) k_pn_lin_col(PnArgs q) {
+  constexpr int nc = M::ne + M::m;
+  double* w = q.ws + (size_t)blockIdx.x * (size_t)q.koff[q.a.P.N];
+  if (w[PN_H_STATE] != (double)PN_ACTIVE) return;
+  pn_lin_column<M>(q, w, min((int)(blockIdx.y * 64 + threadIdx.x), (q.a.P.N - 1) * nc - 1));
+}
+template <class M>
+__global__ void __launch_bounds__(64) k_pn_lin_knot(PnArgs q) {
+  double* w = q.ws + (size_t)blockIdx.x * (size_t)q.koff[q.a.P.N];
+  if (w[PN_H_STATE] != (double)PN_ACTIVE) return;
+  pn_lin_knot<M>(q, w, min((int)(blockIdx.y * 64 + threadIdx.x), q.a.P.N - 1));
+}
+
+// max |x_1 (-) x0|, |f(x_k, u_k) (-) x_{k+1}| of the nominal trajectory (to_dynamics_defect): one lane per trajectory
+template <class M>
+__global__ void __launch_bounds__(64) k_defect(KArgs a, double* out) {
+  constexpr int n = M::n, m = M::m, ne = M::ne;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  if (b >= P.B) return;
+  const double* X = TILE_PTR(a.Xs, P.N * n);
+  const double* U = TILE_PTR(a.Us, (P.N - 1) * m);
+  const double* x0t = TILE_PTR(a.x0, n);
+  double zp[n + m], z[n + m], x0[n], e[ne], mx = 0.0;
+  for (int i = 0; i < n; ++i) { x0[i] = EL(x0t, i); z[i] = EL(X, i); }
+  pn_defect<M>(P, 0, z, z, x0, e);
+  for (int i = 0; i < ne; ++i) pn_upd_max(mx, fabs(e[i]));
+  for (int k = 1; k < P.N; ++k) {
+    for (int i = 0; i < n; ++i) zp[i] = z[i];
+    for (int i = 0; i < m; ++i) zp[n + i] = EL(U, (k - 1) * m + i);
+    for (int i = 0; i < n; ++i) z[i] = EL(X, k * n + i);
+    pn_defect<M>(P, k, zp, z, x0, e);
+    for (int i = 0; i < ne; ++i) pn_upd_max(mx, fabs(e[i]));
+  }
+  out[b] = mx;
+}
+#endif
+
+}  // namespace to

@@ -614,4 +614,40 @@ __device__ __forceinline__ void state_diff(const double* x, const double* x0, do
   }
 }
 
+// xo (n) = x (+) dx (ne): the inverse of state_diff (state_diff(x (+) dx, x) = dx with the Cayley map) — the retraction the
+// projected-Newton polish (k_pn.h) moves states along.  Attitude: q (x) [1, phi] / sqrt(1 + |phi|^2) keeps |q|; three-parameter
+// attitudes compose through their unnormalised quaternion and map back (MRP p = v / (|q| + w), RodriguesParam g = v / w).
+template <class M>
+__device__ __forceinline__ void state_add(const double* x, const double* dx, double* xo) {
+  if constexpr (!M::lie) {
+#pragma unroll
+    for (int i = 0; i < M::n; ++i) xo[i] = x[i] + dx[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xo[i] = x[i] + dx[i];
+    constexpr int o = (M::att == ATT_QUAT) ? 7 : 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xo[o + i] = x[o + i] + dx[6 + i];
+    double w, a, b, c;
+    if constexpr (M::att == ATT_QUAT) { w = x[3]; a = x[4]; b = x[5]; c = x[6]; }
+    else if constexpr (M::att == ATT_MRP) { w = 1.0 - (x[3] * x[3] + x[4] * x[4] + x[5] * x[5]); a = 2.0 * x[3]; b = 2.0 * x[4]; c = 2.0 * x[5]; }
+    else { w = 1.0; a = x[3]; b = x[4]; c = x[5]; }
+    const double f1 = dx[3], f2 = dx[4], f3 = dx[5];
+    const double r0 = w - a * f1 - b * f2 - c * f3;
+    const double r1 = a + w * f1 + b * f3 - c * f2;
+    const double r2 = b + w * f2 + c * f1 - a * f3;
+    const double r3 = c + w * f3 + a * f2 - b * f1;
+    if constexpr (M::att == ATT_QUAT) {
+      const double s = 1.0 / sqrt(1.0 + (f1 * f1 + f2 * f2 + f3 * f3));
+      xo[3] = r0 * s; xo[4] = r1 * s; xo[5] = r2 * s; xo[6] = r3 * s;
+    } else if constexpr (M::att == ATT_MRP) {
+      const double s = 1.0 / (sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + r0);
+      xo[3] = r1 * s; xo[4] = r2 * s; xo[5] = r3 * s;
+    } else {
+      const double s = 1.0 / r0;
+      xo[3] = r1 * s; xo[4] = r2 * s; xo[5] = r3 * s;
+    }
+  }
+}
+
 }  // namespace to

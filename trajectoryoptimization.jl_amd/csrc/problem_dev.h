@@ -27,7 +27,9 @@ struct DevCon {
 // Read-only descriptor tables are addressed through the CONSTANT address space: with a wave-uniform address the
 // compiler then emits scalar loads (s_load, scalar cache) instead of per-lane vector loads that would sit on the
 // critical path of every knot (they may otherwise alias the kernels' double stores).
+#ifndef TO_CONST_AS  // (the host build of the projected-Newton kernel — tests/host_shim — defines it empty)
 #define TO_CONST_AS __attribute__((address_space(4)))
+#endif
 typedef const to_cost_desc TO_CONST_AS CostC;
 typedef const DevCon TO_CONST_AS ConC;
 typedef const double TO_CONST_AS DoubleC;

@@ -13,7 +13,9 @@
 #include <dlfcn.h>
 
 #include <mutex>
+#include <thread>
 
+#include "desc_lower.h"
 #include "handle.h"
 #include "k_generic.h"
 
@@ -30,6 +32,7 @@ namespace {
 
 #define CHECK_H(h) do { if (!(h)) return fail(TO_ERR_NULL, "null handle"); } while (0)
 #define CHECK_P(p) do { if (!(p)) return fail(TO_ERR_NULL, "null pointer"); } while (0)
+#define CHECK_IDLE(h) do { if ((h)->inflight) return fail(TO_ERR_ARGUMENT, "an asynchronous solve is in flight on this handle (call to_solve_wait first)"); } while (0)
 
 // launch table, one entry per model key; filled once by the ops_*.hip translation units
 ModelOps g_ops[N_MODEL_KEYS];
@@ -42,176 +45,9 @@ const ModelOps* model_ops(int key) {
     fill_ops_quad_forward2_a(g_ops); fill_ops_quad_forward2_b(g_ops); fill_ops_quad_forward2_c(g_ops);
     fill_ops_quadatt_misc(g_ops); fill_ops_quadmrp_expand(g_ops); fill_ops_quadrp_expand(g_ops);
     fill_ops_quadmrp_forward(g_ops); fill_ops_quadrp_forward(g_ops);
-    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops); fill_ops_small_scan(g_ops);
+    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops); fill_ops_small_scan(g_ops); fill_ops_pn(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
-}
-
-void default_opts(to_solver_opts* o) {
-  std::memset(o, 0, sizeof(*o));
-  o->cost_tolerance = 1e-4; o->gradient_tolerance = 10.0; o->iterations = 300; o->dJ_counter_limit = 10;
-  o->iterations_linesearch = 20; o->line_search_lower_bound = 1e-8; o->line_search_upper_bound = 10.0;
-  o->line_search_decrease_factor = 0.5; o->bp_reg_initial = 0.0; o->bp_reg_increase_factor = 1.6;
-  o->bp_reg_min = 1e-8; o->bp_reg_max = 1e8; o->bp_reg_fp = 10.0; o->max_cost_value = 1e8;
-  o->max_state_value = 1e8; o->max_control_value = 1e8; o->constraint_tolerance = 1e-6;
-  o->cost_tolerance_intermediate = 1e-4; o->penalty_initial = 1.0; o->penalty_scaling = 10.0;
-  o->penalty_max = 1e8; o->dual_max = 1e8; o->iterations_outer = 30; o->cost_dt_scaling = 0;
-  o->iterations_total = 1000;
-}
-
-// Nonsense options used to give silent non-termination-style behaviour (every trajectory runs to MAX_ITERATIONS).
-int validate_opts(const to_solver_opts& o) {
-  auto bad = [](const char* what) { return fail(TO_ERR_ARGUMENT, std::string("solver option out of range: ") + what); };
-  if (!(o.cost_tolerance >= 0) || !(o.cost_tolerance_intermediate >= 0) || !(o.gradient_tolerance >= 0) || !(o.constraint_tolerance >= 0))
-    return bad("tolerances must be >= 0");
-  if (o.iterations < 0 || o.iterations_outer < 0 || o.iterations_total < 0 || o.dJ_counter_limit < 0) return bad("iteration counts must be >= 0");
-  if (o.iterations_linesearch < 1 || o.iterations_linesearch > 64) return bad("iterations_linesearch must be in 1..64");
-  if (!(o.line_search_decrease_factor > 0.0 && o.line_search_decrease_factor < 1.0)) return bad("line_search_decrease_factor must be in (0,1)");
-  if (!(o.line_search_lower_bound >= 0.0) || !(o.line_search_upper_bound > o.line_search_lower_bound)) return bad("line-search bounds must satisfy 0 <= lower < upper");
-  if (!(o.bp_reg_increase_factor > 1.0)) return bad("bp_reg_increase_factor must be > 1");
-  if (!(o.bp_reg_initial >= 0.0) || !(o.bp_reg_min >= 0.0) || !(o.bp_reg_max > o.bp_reg_min) || !(o.bp_reg_fp >= 0.0)) return bad("regularisation bounds");
-  if (!(o.penalty_initial > 0.0) || !(o.penalty_scaling >= 1.0) || !(o.penalty_max >= o.penalty_initial) || !(o.dual_max > 0.0)) return bad("penalty parameters");
-  if (!(o.max_cost_value > 0.0) || !(o.max_state_value > 0.0) || !(o.max_control_value > 0.0)) return bad("max_*_value must be > 0");
-  if (o.cost_dt_scaling != 0 && o.cost_dt_scaling != 1) return bad("cost_dt_scaling must be 0 or 1");
-  if (o.al_full_newton != 0 && o.al_full_newton != 1) return bad("al_full_newton must be 0 or 1");
-  return TO_OK;
-}
-
-int model_dims(int id, const double* params, int* n, int* m, int* ne, int* key) {
-  switch (id) {
-    case TO_MODEL_DOUBLE_INTEGRATOR: {
-      const int D = (int)params[1];
-      if (D < 1 || D > 3) return -1;
-      *n = 2 * D; *m = D; *ne = 2 * D; *key = D - 1; return 0;
-    }
-    case TO_MODEL_CARTPOLE: *n = 4; *m = 1; *ne = 4; *key = 3; return 0;
-    case TO_MODEL_QUADROTOR: {  // params[10]: attitude representation of the state (to_rotation)
-      const int rot = (int)params[10];
-      if (rot == TO_ROT_QUATERNION) { *n = 13; *m = 4; *ne = 12; *key = 4; return 0; }
-      if (rot == TO_ROT_MRP || rot == TO_ROT_RODRIGUES) { *n = 12; *m = 4; *ne = 12; *key = rot == TO_ROT_MRP ? 5 : 6; return 0; }
-      return -1;
-    }
-    case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; *key = 7; return 0;
-  }
-  return -1;
-}
-
-}  // namespace
-
-namespace {
-
-int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon* out) {
-  const int nz = n + m;
-  DevCon ci;
-  std::memset(&ci, 0, sizeof(ci));
-  ci.d = d;
-  if (d.k_first < 1 || d.k_last > N || d.k_first > d.k_last)
-    return fail(TO_ERR_ASSERTION, "Invalid inds, inds[end] must be less than number of knotpoints");  // src/constraint_list.jl:112
-  if (d.n_inds < 0 || d.n_inds > TO_MAX_CON_INDS || d.n_params < 0 || d.n_params > TO_MAX_CON_PARAMS)
-    return fail(TO_ERR_ARGUMENT, "constraint inds/params count out of range");
-  auto dimerr = [&](const char* what) {
-    return fail(TO_ERR_DIMENSION_MISMATCH, std::string("New constraint not consistent with n=") + std::to_string(n) +
-                                               " and m=" + std::to_string(m) + ": " + what);  // src/constraint_list.jl:109
-  };
-  // index lists address [x;u] positions one-to-one: a duplicate would make the reported Jacobian (last duplicate wins)
-  // disagree with the one the solver accumulates
-  for (int i = 0; i < d.n_inds; ++i)
-    for (int j = i + 1; j < d.n_inds; ++j)
-      if (d.inds[i] == d.inds[j]) return fail(TO_ERR_ARGUMENT, "constraint indices must be distinct");
-  int p = 0;
-  switch (d.kind) {
-    case TO_CON_GOAL:
-      if (d.sense != TO_CONE_ZERO) return fail(TO_ERR_ARGUMENT, "GoalConstraint sense must be Equality");
-      if (d.n_params != d.n_inds) return dimerr("GoalConstraint length(xf) != length(inds)");
-      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return dimerr("GoalConstraint index outside the state");
-      ci.width = n; p = d.n_inds; ci.selector = 1;
-      for (int r = 0; r < p && r < TO_MAX_P; ++r) { ci.sidx[r] = d.inds[r] - 1; ci.ssgn[r] = 1.0; ci.soff[r] = d.params[r]; }
-      break;
-    case TO_CON_BOUND: {
-      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "BoundConstraint sense must be Inequality");
-      if (d.n_params != 2 * nz) return dimerr("BoundConstraint needs z_max and z_min of length n+m");
-      for (int i = 0; i < nz; ++i)
-        if (!(d.params[i] >= d.params[nz + i])) return fail(TO_ERR_ARGUMENT, "Upper bounds must be greater than or equal to lower bounds");  // src/constraints.jl:712
-      ci.width = nz; ci.selector = 1;
-      for (int j = 0; j < nz; ++j) if (std::isfinite(d.params[j])) { if (p < TO_MAX_P) { ci.sidx[p] = j; ci.ssgn[p] = 1.0; ci.soff[p] = d.params[j]; } ++p; }
-      for (int j = 0; j < nz; ++j) if (std::isfinite(d.params[nz + j])) { if (p < TO_MAX_P) { ci.sidx[p] = j; ci.ssgn[p] = -1.0; ci.soff[p] = d.params[nz + j]; } ++p; }
-      break;
-    }
-    case TO_CON_NORM:
-      if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "NormConstraint needs one parameter (val)");
-      if (!(d.params[0] >= 0)) return fail(TO_ERR_ASSERTION, "Value must be greater than or equal to zero");  // src/constraints.jl:453
-      if (d.sense != TO_CONE_ZERO && d.sense != TO_CONE_NEGATIVE_ORTHANT && d.sense != TO_CONE_SECOND_ORDER)
-        return fail(TO_ERR_ARGUMENT, "NormConstraint sense must be Equality, Inequality or SecondOrderCone");
-      if (d.n_inds < 1 || d.n_inds > nz) return dimerr("NormConstraint needs 1..n+m indices");
-      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > nz) return dimerr("NormConstraint index outside [x;u]");
-      ci.width = nz;
-      if (d.sense == TO_CONE_SECOND_ORDER) {
-        p = d.n_inds + 1; ci.selector = 1;
-        for (int r = 0; r < d.n_inds; ++r) { ci.sidx[r] = d.inds[r] - 1; ci.ssgn[r] = 1.0; ci.soff[r] = 0.0; }
-        ci.sidx[d.n_inds] = -1; ci.ssgn[d.n_inds] = 0.0; ci.soff[d.n_inds] = d.params[0];
-      } else p = 1;
-      break;
-    case TO_CON_CIRCLE:
-      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "CircleConstraint sense must be Inequality");
-      if (d.n_inds != 2 || d.n_params % 3 != 0 || d.n_params == 0) return fail(TO_ERR_ASSERTION, "Lengths of xc, yc, and radius must be equal.");
-      for (int i = 0; i < 2; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return dimerr("CircleConstraint index outside the state");
-      ci.width = n; p = d.n_params / 3;
-      break;
-    case TO_CON_SPHERE:
-      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "SphereConstraint sense must be Inequality");
-      if (d.n_inds != 3 || d.n_params % 4 != 0 || d.n_params == 0) return fail(TO_ERR_ASSERTION, "Lengths of xc, yc, zc, and radius must be equal.");
-      for (int i = 0; i < 3; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return dimerr("SphereConstraint index outside the state");
-      ci.width = n; p = d.n_params / 4;
-      break;
-    case TO_CON_LINEAR:
-      if (d.sense != TO_CONE_ZERO && d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "LinearConstraint sense must be Equality or Inequality");
-      if (d.n_inds < 1 || d.n_inds > nz || d.n_params == 0 || d.n_params % (d.n_inds + 1) != 0) return fail(TO_ERR_ASSERTION, "size(A,1) == length(b)");
-      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > nz) return dimerr("LinearConstraint index outside [x;u]");
-      ci.width = nz; p = d.n_params / (d.n_inds + 1);
-      break;
-    case TO_CON_COLLISION:
-      if (d.sense != TO_CONE_NEGATIVE_ORTHANT) return fail(TO_ERR_ARGUMENT, "CollisionConstraint sense must be Inequality");
-      if (d.n_inds < 2 || d.n_inds % 2 != 0) return fail(TO_ERR_ASSERTION, "Position dimensions must be of equal length"); /* src/constraints.jl:349 */
-      if (d.n_inds > n) return dimerr("CollisionConstraint has more position indices than states");
-      if (d.n_params != 1) return fail(TO_ERR_ARGUMENT, "CollisionConstraint needs one parameter (radius)");
-      for (int i = 0; i < d.n_inds; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "CollisionConstraint index outside state");
-      ci.width = n; p = 1; break;
-    case TO_CON_QUATVEC:
-      if (d.sense != TO_CONE_ZERO) return fail(TO_ERR_ARGUMENT, "QuatVecEq sense must be Equality");
-      if (d.n_inds != 4 || d.n_params != 4) return fail(TO_ERR_ARGUMENT, "QuatVecEq needs 4 quaternion indices and a 4-vector qf");
-      for (int i = 0; i < 4; ++i) if (d.inds[i] < 1 || d.inds[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "QuatVecEq index outside state");
-      ci.width = n; p = 3; break;
-    default: return fail(TO_ERR_UNSUPPORTED, "unknown constraint kind");
-  }
-  if (p < 1 || p > TO_MAX_P) return fail(TO_ERR_UNSUPPORTED, "constraint output dimension outside 1..TO_MAX_P");
-  if (ci.selector && (d.kind == TO_CON_GOAL || (d.kind == TO_CON_NORM && d.sense == TO_CONE_SECOND_ORDER))) {
-    // fast layouts: rows map to a state prefix z[r] or to the control block z[n+r] with sign +1 (see problem_dev.h)
-    const int D = d.n_inds;
-    bool prefix = D <= n, ctrl = D <= m;
-    for (int r = 0; r < D; ++r) { prefix = prefix && d.inds[r] == r + 1; ctrl = ctrl && d.inds[r] == n + r + 1; }
-    ci.fast = prefix ? 1 : ctrl ? 2 : 0;
-  }
-  if (d.p != 0 && d.p != p) return fail(TO_ERR_DIMENSION_MISMATCH, "constraint output dimension does not match its descriptor");
-  ci.p = p; ci.k1 = d.k_first - 1; ci.k2 = d.k_last - 1;
-  *out = ci;
-  return TO_OK;
-}
-
-// rot: attitude representation of the model's state (to_rotation), -1 for vector-space models
-int validate_cost(int n, int rot, const to_cost_desc& c) {
-  if (c.kind != TO_COST_DIAGONAL && c.kind != TO_COST_QUADRATIC && c.kind != TO_COST_DIAGONAL_QUAT && c.kind != TO_COST_ERROR_QUADRATIC)
-    return fail(TO_ERR_UNSUPPORTED, "unknown cost kind");
-  if (c.kind == TO_COST_ERROR_QUADRATIC) {  // needs the rigid-body state layout [r; attitude; v; w]
-    if (rot < 0) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic needs a rigid-body model");
-    if ((int)c.w != rot || c.w != (double)rot) return fail(TO_ERR_ARGUMENT, "ErrorQuadratic: w must name the model's attitude representation (to_rotation)");
-    if (rot == TO_ROT_QUATERNION)
-      for (int i = 0; i < 4; ++i) if (c.q_ind[i] != 4 + i) return fail(TO_ERR_UNSUPPORTED, "ErrorQuadratic: q_ind must be 4:7");
-  }
-  if (c.kind == TO_COST_DIAGONAL_QUAT) {
-    if (rot > TO_ROT_QUATERNION) return fail(TO_ERR_ARGUMENT, "DiagonalQuatCost needs a state that carries a unit quaternion");
-    for (int i = 0; i < 4; ++i) if (c.q_ind[i] < 1 || c.q_ind[i] > n) return fail(TO_ERR_DIMENSION_MISMATCH, "quat_ind outside the state");
-  }
-  return TO_OK;
 }
 
 template <class T>
@@ -371,6 +207,44 @@ int launch_forward(to_handle* h, bool accept = true, bool two_wave = false) {
 int launch_outer(to_handle* h) { return h->ops->outer(h); }
 int launch_violation(to_handle* h, double* out) { return h->ops->violation(h, out); }
 
+// stats of the last solve; with_defect: c_max also counts the dynamics / initial-condition defects (a polished trajectory is
+// not an exact rollout)
+int fill_stats(to_handle* h, to_solve_stats* st, bool with_defect) {
+  KArgs& a = h->a;
+  const DevProblem& P = a.P;
+  const int B = P.B;
+  std::vector<int32_t> its(B);
+  TRY(download_int(h, its.data(), a.iterations));
+  int64_t tot = 0;
+  for (int b = 0; b < B; ++b) tot += its[b];
+  if (st->iterations) std::memcpy(st->iterations, its.data(), sizeof(int32_t) * B);
+  TRY(download_int(h, st->iterations_outer, a.outer));
+  TRY(download_int(h, st->status, a.status));
+  TRY(download_int(h, st->iterations_pn, a.it_pn));
+  if (st->cost) { TRY(launch_cost(h, 0, h->d_tmp, nullptr)); TRY(download_scalar(h, st->cost, h->d_tmp)); }
+  TRY(download_scalar(h, st->dJ, a.dJ));
+  TRY(download_scalar(h, st->gradient, a.grad));
+  if (st->c_max) {
+    if (P.n_cons > 0) { TRY(launch_violation(h, h->d_tmp)); TRY(download_scalar(h, st->c_max, h->d_tmp)); }
+    else std::memset(st->c_max, 0, sizeof(double) * B);
+    if (with_defect) {
+      std::vector<double> df(B);
+      TRY(h->ops->defect(h, h->d_tmp));
+      TRY(download_scalar(h, df.data(), h->d_tmp));
+      for (int b = 0; b < B; ++b) if (df[b] > st->c_max[b] || df[b] != df[b]) st->c_max[b] = df[b];
+    }
+  }
+  if (st->penalty_max) {
+    hipLaunchKernelGGL(k_penalty_max, grid_b(h), dim3(BLOCK), 0, h->stream, a, h->d_tmp);
+    HIPCHECK(hipGetLastError());
+    TRY(download_scalar(h, st->penalty_max, h->d_tmp));
+  }
+  st->total_iterations = tot;
+  st->batch_steps = h->last_steps;
+  st->solve_ms = h->last_ms;
+  return TO_OK;
+}
+
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   const int rc = solve_impl(h, st, al_mode);
@@ -379,6 +253,67 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   h->a.CW = h->cw_base; h->a.TW = h->tw_base;
   return rc;
 }
+// Altro solve!(::ProjectedNewtonSolver) on the trajectories of `list` (k_pn.h); device time is added to h->last_ms
+int pn_run(to_handle* h, const std::vector<int>& list) {
+  if (list.empty()) return TO_OK;
+  if (!h->ops->pn) return fail(TO_ERR_UNSUPPORTED, "projected Newton not compiled for this model");
+  hipEvent_t e0 = h->sev[0], e1 = h->sev[1];
+  HIPCHECK(hipEventRecord(e0, h->stream));
+  TRY(h->ops->pn(h, list.data(), (int)list.size()));
+  HIPCHECK(hipEventRecord(e1, h->stream));
+  HIPCHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+  h->last_ms += ms;
+  if (h->profile) { h->prof_ms[3] += ms; h->prof_launches[3] += 1; }  // slot 3: the polish (all its launches of one solve)
+  return TO_OK;
+}
+int ensure_solve_events(to_handle* h) {
+  if (!h->sev[0]) {
+    HIPCHECK(hipEventCreate(&h->sev[0]));
+    HIPCHECK(hipEventCreate(&h->sev[1]));
+    HIPCHECK(hipEventCreateWithFlags(&h->sev[2], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&h->sev[3], hipEventDisableTiming));
+  }
+  return TO_OK;
+}
+int pn_solve(to_handle* h, to_solve_stats* st) {
+  TRY(use_device(h));
+  TRY(ensure_solve_events(h));
+  KArgs& a = h->a;
+  const int Bp = a.P.Bp, B = a.P.B;
+  HIPCHECK(hipMemsetAsync(a.iterations, 0, sizeof(int) * Bp, h->stream));
+  HIPCHECK(hipMemsetAsync(a.outer, 0, sizeof(int) * Bp, h->stream));
+  HIPCHECK(hipMemsetAsync(a.it_pn, 0, sizeof(int) * Bp, h->stream));
+  std::vector<int> list(B);
+  for (int b = 0; b < B; ++b) list[b] = b;
+  h->last_steps = 0; h->last_ms = 0.0;
+  TRY(pn_run(h, list));
+  if (st) TRY(fill_stats(h, st, true));
+  return TO_OK;
+}
+// Altro solve!(::ALTROSolver): AL stage down to projected_newton_tolerance, polish of what it left SOLVE_SUCCEEDED above
+// constraint_tolerance
+int altro_solve(to_handle* h, to_solve_stats* st) {
+  const to_solver_opts user = h->a.P.opts;
+  const bool pn = user.projected_newton && h->a.P.n_cons > 0;
+  if (!pn) return solve(h, st, 1);
+  h->a.P.opts.constraint_tolerance = user.projected_newton_tolerance;
+  const int rc = solve(h, nullptr, 1);
+  h->a.P.opts = user;
+  if (rc != TO_OK) return rc;
+  const int B = h->a.P.B;
+  std::vector<int32_t> status(B);
+  std::vector<double> cmax(B);
+  TRY(download_int(h, status.data(), h->a.status));
+  TRY(download_scalar(h, cmax.data(), h->a.cmax));
+  std::vector<int> list;
+  for (int b = 0; b < B; ++b) if (status[b] == TO_SOLVE_SUCCEEDED && cmax[b] > user.constraint_tolerance) list.push_back(b);
+  TRY(pn_run(h, list));
+  if (st) TRY(fill_stats(h, st, true));
+  return TO_OK;
+}
+
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   TRY(use_device(h));
   KArgs& a = h->a;
@@ -397,14 +332,10 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
     h->counter_len = max_steps;
   }
   HIPCHECK(hipMemsetAsync(a.counter, 0, sizeof(int) * max_steps, h->stream));
-  if (!h->sev[0]) {
-    HIPCHECK(hipEventCreate(&h->sev[0]));
-    HIPCHECK(hipEventCreate(&h->sev[1]));
-    HIPCHECK(hipEventCreateWithFlags(&h->sev[2], hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&h->sev[3], hipEventDisableTiming));
-  }
+  TRY(ensure_solve_events(h));
   const hipEvent_t e0 = h->sev[0], e1 = h->sev[1];
   HIPCHECK(hipEventRecord(e0, h->stream));
+  HIPCHECK(hipMemsetAsync(a.it_pn, 0, sizeof(int) * P.Bp, h->stream));
   hipLaunchKernelGGL(k_solve_init, grid_b(h), dim3(BLOCK), 0, h->stream, a, al_mode);
   HIPCHECK(hipGetLastError());
   TRY(launch_rollout(h));
@@ -493,31 +424,8 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
         h->prof_launches[s] += 1;
       }
   }
-  if (st) {
-    const int B = P.B;
-    std::vector<int32_t> its(B);
-    TRY(download_int(h, its.data(), a.iterations));
-    int64_t tot = 0;
-    for (int b = 0; b < B; ++b) tot += its[b];
-    if (st->iterations) std::memcpy(st->iterations, its.data(), sizeof(int32_t) * B);
-    TRY(download_int(h, st->iterations_outer, a.outer));
-    TRY(download_int(h, st->status, a.status));
-    if (st->cost) { TRY(launch_cost(h, 0, h->d_tmp, nullptr)); TRY(download_scalar(h, st->cost, h->d_tmp)); }
-    TRY(download_scalar(h, st->dJ, a.dJ));
-    TRY(download_scalar(h, st->gradient, a.grad));
-    if (st->c_max) {
-      if (P.n_cons > 0) { TRY(launch_violation(h, h->d_tmp)); TRY(download_scalar(h, st->c_max, h->d_tmp)); }
-      else std::memset(st->c_max, 0, sizeof(double) * B);
-    }
-    if (st->penalty_max) {
-      hipLaunchKernelGGL(k_penalty_max, grid_b(h), dim3(BLOCK), 0, h->stream, a, h->d_tmp);
-      HIPCHECK(hipGetLastError());
-      TRY(download_scalar(h, st->penalty_max, h->d_tmp));
-    }
-    st->total_iterations = tot;
-    st->batch_steps = steps;
-    st->solve_ms = ms;
-  }
+  h->last_steps = steps; h->last_ms = ms;
+  if (st) TRY(fill_stats(h, st, false));
   return TO_OK;
 }
 
@@ -798,6 +706,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &a.J, Bp)); TRYB(dev_alloc(h, &a.dJ, Bp)); TRYB(dev_alloc(h, &a.grad, Bp));
   TRYB(dev_alloc(h, &a.rho, Bp)); TRYB(dev_alloc(h, &a.drho, Bp)); TRYB(dev_alloc(h, &a.dV, 2 * Bp));
   TRYB(dev_alloc(h, &a.cmax, Bp)); TRYB(dev_alloc(h, &a.Jout, Bp));
+  TRYB(dev_alloc(h, &a.it_pn, Bp)); TRYB(dev_alloc(h, &a.pn_cmax, Bp));
   TRYB(dev_alloc(h, &a.status, Bp)); TRYB(dev_alloc(h, &a.iterations, Bp)); TRYB(dev_alloc(h, &a.it_inner, Bp));
   TRYB(dev_alloc(h, &a.outer, Bp)); TRYB(dev_alloc(h, &a.dJzero, Bp)); TRYB(dev_alloc(h, &a.ls_index, Bp));
   TRYB(dev_alloc(h, &a.active, Bp)); TRYB(dev_alloc(h, &a.budget, Bp)); TRYB(dev_alloc(h, &a.bpfail, Bp));
@@ -827,11 +736,16 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
 
 int to_destroy(to_handle* h) {
   if (!h) return TO_OK;
+  if (h->inflight) { h->worker.join(); h->inflight = false; }
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   for (void* p : h->allocs) hipFree(p);
   if (h->stage) hipFree(h->stage);
+  if (h->pn_ws) hipFree(h->pn_ws);
+  if (h->pn_pak) hipFree(h->pn_pak);
+  if (h->pn_koff) hipFree(h->pn_koff);
+  if (h->pn_list) hipFree(h->pn_list);
   if (h->counter_host) hipHostFree(h->counter_host);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   for (hipEvent_t e : h->sev) if (e) hipEventDestroy(e);
@@ -1013,8 +927,41 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
-int to_ilqr_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 0); }
-int to_al_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); return solve(h, st, 1); }
+int to_ilqr_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); CHECK_IDLE(h); return solve(h, st, 0); }
+int to_al_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); CHECK_IDLE(h); return solve(h, st, 1); }
+int to_pn_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); CHECK_IDLE(h); return pn_solve(h, st); }
+int to_altro_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); CHECK_IDLE(h); return altro_solve(h, st); }
+// Asynchronous solves: the solve loop — enqueue chunks of batch steps, read the activity counters back — runs on
+// a worker thread owned by the handle; the handle's stream carries the kernels as before.  Two handles (two streams) solved this
+// way overlap on the device: the drained tail of one batch leaves most of the chip to the other.
+static int solve_async(to_handle* h, to_solve_stats* st, int kind) {
+  CHECK_H(h);
+  if (h->inflight) return fail(TO_ERR_ARGUMENT, "a solve is already in flight on this handle (call to_solve_wait first)");
+  h->inflight = true;
+  h->async_rc = TO_OK;
+  h->worker = std::thread([h, st, kind] {
+    h->async_rc = kind == 0 ? solve(h, st, 0) : kind == 1 ? solve(h, st, 1) : altro_solve(h, st);
+    h->async_err = g_err;
+  });
+  return TO_OK;
+}
+int to_ilqr_solve_async(to_handle* h, to_solve_stats* st) { return solve_async(h, st, 0); }
+int to_al_solve_async(to_handle* h, to_solve_stats* st) { return solve_async(h, st, 1); }
+int to_altro_solve_async(to_handle* h, to_solve_stats* st) { return solve_async(h, st, 2); }
+int to_solve_wait(to_handle* h) {
+  CHECK_H(h);
+  if (!h->inflight) return TO_OK;
+  h->worker.join();
+  h->inflight = false;
+  if (h->async_rc != TO_OK) g_err = h->async_err;
+  return h->async_rc;
+}
+int to_dynamics_defect(to_handle* h, double* defect) {
+  CHECK_H(h); CHECK_P(defect);
+  TRY(use_device(h));
+  TRY(h->ops->defect(h, h->d_tmp));
+  return download_scalar(h, defect, h->d_tmp);
+}
 
 // expansion blocks -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0+r][col0+c], rows / columns counted
 // in error-state directions followed by control directions (whichever layout the backward pass uses)
