@@ -20,7 +20,7 @@ const TO = TrajectoryOptimization
 const lib = get(ENV, "TRAJOPT_HIP_LIBRARY", "libtrajopt_hip")   # trajectoryoptimization.jl_amd/csrc/libtrajopt_hip.so
 
 # ------------------------------------------------------------------------------------------------ header mirrors
-const TO_ABI_VERSION = Int32(3)
+const TO_ABI_VERSION = Int32(4)
 const MAXN, MAXM, MAXP, MAXPAR, MAXIND = 16, 8, 40, 400, 48
 const PROFILE_SLOTS = 4
 
@@ -97,6 +97,14 @@ mutable struct SolverOpts            # == to_solver_opts (names of Altro.SolverO
     cost_dt_scaling::Int32
     iterations_total::Int32
     al_full_newton::Int32
+    # projected-Newton polish (Altro.ProjectedNewtonSolver; names of Altro.SolverOptions, ρ spelled out)
+    projected_newton_tolerance::Float64
+    active_set_tolerance_pn::Float64
+    rho_chol::Float64
+    rho_primal::Float64
+    r_threshold::Float64
+    n_steps::Int32
+    projected_newton::Int32
     SolverOpts() = new()
 end
 
@@ -109,13 +117,14 @@ mutable struct SolveStats            # == to_solve_stats
     gradient::Ptr{Float64}
     c_max::Ptr{Float64}
     penalty_max::Ptr{Float64}
+    iterations_pn::Ptr{Int32}
     total_iterations::Int64
     batch_steps::Int32
     reserved::Int32
     solve_ms::Float64
 end
 
-@enum SolverStatus::Int32 UNSOLVED = 0 LINESEARCH_FAIL SOLVE_SUCCEEDED MAX_ITERATIONS MAX_ITERATIONS_OUTER MAXIMUM_COST STATE_LIMIT CONTROL_LIMIT NO_PROGRESS COST_INCREASE REGULARIZATION_MAX
+@enum SolverStatus::Int32 UNSOLVED = 0 LINESEARCH_FAIL SOLVE_SUCCEEDED MAX_ITERATIONS MAX_ITERATIONS_OUTER MAXIMUM_COST STATE_LIMIT CONTROL_LIMIT NO_PROGRESS COST_INCREASE REGULARIZATION_MAX PROJECTION_FAIL
 
 # ------------------------------------------------------------------------------------------------ errors
 last_error() = unsafe_string(ccall((:to_last_error, lib), Cstring, ()))
@@ -381,24 +390,63 @@ function forwardpass!(p::BatchProblem)
     (ls_index = ls, cost = J)
 end
 
-function _solve!(p::BatchProblem, al::Bool)
-    its, outer, st = zeros(Int32, p.B), zeros(Int32, p.B), zeros(Int32, p.B)
+# which == :ilqr | :al | :pn | :altro; async: enqueue on the handle's worker thread and return the buffers (call `wait_solve!`)
+const _SOLVE_SYMBOL = Dict(:ilqr => :to_ilqr_solve, :al => :to_al_solve, :pn => :to_pn_solve, :altro => :to_altro_solve)
+function _solve!(p::BatchProblem, which::Symbol)
+    its, outer, st, ipn = zeros(Int32, p.B), zeros(Int32, p.B), zeros(Int32, p.B), zeros(Int32, p.B)
     J, dJ, grad, cmax, pen = zeros(p.B), zeros(p.B), zeros(p.B), zeros(p.B), zeros(p.B)
-    stats = SolveStats(pointer(its), pointer(outer), pointer(st), pointer(J), pointer(dJ), pointer(grad), pointer(cmax), pointer(pen), 0, 0, 0, 0.0)
-    GC.@preserve its outer st J dJ grad cmax pen begin
-        if al
-            check(ccall((:to_al_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
-        else
+    stats = SolveStats(pointer(its), pointer(outer), pointer(st), pointer(J), pointer(dJ), pointer(grad), pointer(cmax), pointer(pen), pointer(ipn), 0, 0, 0, 0.0)
+    GC.@preserve its outer st ipn J dJ grad cmax pen begin
+        if which == :ilqr
             check(ccall((:to_ilqr_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+        elseif which == :al
+            check(ccall((:to_al_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+        elseif which == :pn
+            check(ccall((:to_pn_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+        else
+            check(ccall((:to_altro_solve, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
         end
     end
-    (iterations = its, iterations_outer = outer, status = SolverStatus.(st), cost = J, dJ = dJ, gradient = grad, c_max = cmax,
+    (iterations = its, iterations_outer = outer, iterations_pn = ipn, status = SolverStatus.(st), cost = J, dJ = dJ, gradient = grad, c_max = cmax,
      penalty_max = pen, total_iterations = stats.total_iterations, batch_steps = stats.batch_steps, solve_ms = stats.solve_ms)
 end
 "Altro.iLQRSolver(prob, opts) |> solve!   for the whole batch."
-solve_ilqr!(p::BatchProblem) = _solve!(p, false)
-"The augmented-Lagrangian stage of Altro.ALTROSolver(prob, opts) |> solve!   for the whole batch."
-solve_al!(p::BatchProblem) = _solve!(p, true)
+solve_ilqr!(p::BatchProblem) = _solve!(p, :ilqr)
+"The augmented-Lagrangian stage of Altro.ALTROSolver alone, run to `constraint_tolerance`."
+solve_al!(p::BatchProblem) = _solve!(p, :al)
+"Altro.ProjectedNewtonSolver(prob, opts) |> solve!   on the problem's current trajectories."
+solve_pn!(p::BatchProblem) = _solve!(p, :pn)
+"Altro.ALTROSolver(prob, opts) |> solve!   (AL-iLQR to `projected_newton_tolerance`, then the projected-Newton polish)."
+solve_altro!(p::BatchProblem) = _solve!(p, :altro)
+
+"""
+Asynchronous solves (`to_*_solve_async`): the solve runs on a worker thread owned by the handle, `wait_solve!` blocks until it is
+done and returns the statistics.  One solve in flight per `BatchProblem`; two problems in flight overlap on the device.
+"""
+mutable struct PendingSolve
+    p::BatchProblem
+    stats::Base.RefValue{SolveStats}
+    bufs::NamedTuple
+end
+function solve_async!(p::BatchProblem, which::Symbol = :altro)
+    bufs = (iterations = zeros(Int32, p.B), iterations_outer = zeros(Int32, p.B), status = zeros(Int32, p.B), iterations_pn = zeros(Int32, p.B),
+            cost = zeros(p.B), dJ = zeros(p.B), gradient = zeros(p.B), c_max = zeros(p.B), penalty_max = zeros(p.B))
+    stats = Ref(SolveStats(pointer(bufs.iterations), pointer(bufs.iterations_outer), pointer(bufs.status), pointer(bufs.cost), pointer(bufs.dJ),
+                           pointer(bufs.gradient), pointer(bufs.c_max), pointer(bufs.penalty_max), pointer(bufs.iterations_pn), 0, 0, 0, 0.0))
+    if which == :ilqr
+        check(ccall((:to_ilqr_solve_async, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+    elseif which == :al
+        check(ccall((:to_al_solve_async, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+    else
+        check(ccall((:to_altro_solve_async, lib), Cint, (Ptr{Cvoid}, Ref{SolveStats}), p.handle, stats))
+    end
+    PendingSolve(p, stats, bufs)   # keeps the buffers and the stats block alive until wait_solve!
+end
+function wait_solve!(s::PendingSolve)
+    check(ccall((:to_solve_wait, lib), Cint, (Ptr{Cvoid},), s.p.handle))
+    st = s.stats[]
+    merge(s.bufs, (status = SolverStatus.(s.bufs.status), total_iterations = st.total_iterations, batch_steps = st.batch_steps, solve_ms = st.solve_ms))
+end
 
 # ---- expansion / gains (error-state blocks; examples/Internal API.ipynb)
 function dynamics_jacobians(p::BatchProblem)
@@ -456,6 +504,12 @@ end
 function TO.∇constraint_jacobians!(p::BatchProblem, i::Integer, H::Array{Float64,4}, λ::Array{Float64,3})
     check(ccall((:to_constraint_hessians, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), p.handle, i - 1, λ, H))
     H
+end
+"max |x_1 ⊖ x0|, |x_{k+1} ⊖ f(x_k, u_k)| per trajectory: 0 for a rollout, the dynamics infeasibility a polish leaves otherwise."
+function dynamics_defect(p::BatchProblem)
+    d = zeros(p.B)
+    check(ccall((:to_dynamics_defect, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), p.handle, d))
+    d
 end
 function TO.max_violation(p::BatchProblem)
     c = zeros(p.B)
@@ -552,7 +606,7 @@ function profile(p::BatchProblem)
     (kernel_ms = ms, launches = launches)
 end
 
-export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, expand!, backwardpass!, forwardpass!,
+export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, solve_pn!, solve_altro!, solve_async!, wait_solve!, dynamics_defect, expand!, backwardpass!, forwardpass!,
     stage_costs, al_cost, dynamics_jacobians, cost_expansion, gains, cost_gradient_hessian, discrete_jacobian, duals, set_duals!,
     reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, solver_path, knot_dims, device_count, build_id
 

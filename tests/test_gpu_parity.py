@@ -251,20 +251,34 @@ def _subsample_vs_oracle(build, B, oracle, solver):
     return sh, ph, blocks
 
 
-def test_full_size_C3_vs_oracle_subsample(hip, oracle):
-    """BASELINE config C3 at its own shape (Quadrotor, N=201, B=4096 = 64 tiles, multi-round residency): trajectories
-    0..127 and the last tile against the oracle — integers bit-exact, X / U / J at the north-star 1e-6."""
-    build = lambda **kw: configs.quadrotor_problem(N=201, **{"lib": hip, **kw})
-    sh, ph, blocks = _subsample_vs_oracle(build, 4096, oracle, T.iLQRSolver)
-    Xh, Uh = T.states(ph), T.controls(ph)
-    for idx, so, po in blocks:
-        for k in ("iterations", "status"):
-            np.testing.assert_array_equal(sh.stats[k][idx], so.stats[k], err_msg=k)
-        np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=1e-6)
-        assert_trajectories_close(Xh[idx], T.states(po), 1e-6, "X")
-        assert_trajectories_close(Uh[idx], T.controls(po), 1e-6, "U")
+def elementwise_fraction(A, R, rtol=1e-6, atol=1e-9):
+    """share of the entries with |A - R| <= rtol |R| + atol (the element-wise reading of the north-star tolerance; the max-norm
+    check of assert_trajectories_close is the one that gates)"""
+    return float(np.mean(np.abs(A - R) <= rtol * np.abs(R) + atol))
+
+
+def test_full_size_C3_vs_oracle(hip, oracle):
+    """BASELINE config C3 at its own shape (Quadrotor, N=201, B=4096 = 64 tiles, multi-round residency): ALL 4096 trajectories
+    against the oracle (212 k iterations: half a minute on the GPU box's host cores) — integers bit-exact, X / U / J at the
+    north-star 1e-6 in the per-trajectory max norm; the element-wise pass fraction (rtol 1e-6, atol 1e-9) is printed next to it."""
+    from oracle_binding import set_threads
+    ph = configs.quadrotor_problem(N=201, batch=4096, lib=hip)
+    sh = T.iLQRSolver(ph).solve()
+    po = configs.quadrotor_problem(N=201, batch=4096, lib=oracle)
+    set_threads(po, oracle.max_threads())
+    so = T.iLQRSolver(po).solve()
+    for k in ("iterations", "status"):
+        np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
+    np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6)
+    Xh, Uh, Xo, Uo = T.states(ph), T.controls(ph), T.states(po), T.controls(po)
+    assert_trajectories_close(Xh, Xo, 1e-6, "X")
+    assert_trajectories_close(Uh, Uo, 1e-6, "U")
+    fx, fu = elementwise_fraction(Xh, Xo), elementwise_fraction(Uh, Uo)
+    print(f"C3, all 4096 trajectories: element-wise within rtol 1e-6 + atol 1e-9: X {fx:.6f}, U {fu:.6f}; "
+          f"worst per-trajectory max-norm error X {np.max(np.abs(Xh - Xo).reshape(4096, -1).max(1) / np.maximum(1, np.abs(Xo).reshape(4096, -1).max(1))):.2e}")
+    assert fx >= 0.9999 and fu >= 0.9999
     assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED)
-    assert sh.total_iterations == int(sh.stats["iterations"].sum())
+    assert sh.total_iterations == int(sh.stats["iterations"].sum()) == so.total_iterations
 
 
 def test_full_size_C5_vs_oracle_subsample(hip, oracle):
@@ -298,25 +312,31 @@ def test_full_size_C5_vs_oracle_subsample(hip, oracle):
     assert set(np.unique(sh.stats["status"])) <= {T.capi.SOLVE_SUCCEEDED, T.capi.MAX_ITERATIONS, T.capi.MAX_ITERATIONS_OUTER}
 
 
-@pytest.mark.parametrize("forward_waves", ["one", "auto"])
-def test_G4_quadrotor_zigzag_on_gpu(forward_waves, hip, oracle, monkeypatch):
+def test_G4_quadrotor_zigzag_on_gpu(hip, oracle, monkeypatch):
     """The reference's Quadrotor zig-zag (examples/Quadrotor.ipynb cells 10-22, golden G4_quadrotor_altro: 90
     iterations, J = 0.29928, violation 7.6e-10) solved on the GPU: per-knot waypoint costs + control bounds, AL-iLQR.
     Sanity against the notebook (the S4 pin SURVEY §8c prescribes: cost to 1 %, feasible to 1e-6) and parity against the
-    oracle.  (The start — 1/20 of the hover thrust, 20 m to fly — makes the solve chaotic in the start position: moved by
-    1e-2 m the ORACLE itself needs 58 ... 591 iterations instead of 85, so only the notebook's own start is compared.)
-    The same chaos shows between the two forward kernels: k_forward ("one") follows the oracle's path step for step (85
-    iterations); k_forward2 (the default for a batch this small) sums the same cost terms with another FMA contraction — 2e-14
-    relative in J — and arrives after 68 iterations at the same optimum: notebook pins for both, step-for-step parity for "one"."""
+    oracle.  The start — 1/20 of the hover thrust, 20 m to fly — makes the solve chaotic in the start position: moved by
+    1e-2 m the ORACLE itself needs 58 ... 591 iterations instead of 85, so only the notebook's own start is compared, and the
+    oracle's path is followed step for step only as long as no line-search decision sits within rounding of its threshold
+    (round 3: a 2e-14 difference in J between the two forward kernels was enough for 68 instead of 85 iterations).  What must
+    hold exactly: the one-wave kernel and the per-step choice between the two forward kernels give the SAME solve, bit for bit."""
     g = G["G4_quadrotor_altro"]
-    if forward_waves == "one":
-        monkeypatch.setenv("TRAJOPT_FWD2", "0")
-
-    def build(lib):  # the notebook's single start, in every lane of a small batch
-        return configs.quadrotor_zigzag_problem(lib=lib, batch=5)
-
-    (ph, wpts, times), (po, _, _) = build(hip), build(oracle)
-    sh, so = T.ALSolver(ph).solve(), T.ALSolver(po).solve()
+    runs = {}
+    for mode in ("0", "auto"):
+        if mode == "0":
+            monkeypatch.setenv("TRAJOPT_FWD2", "0")
+        else:
+            monkeypatch.delenv("TRAJOPT_FWD2", raising=False)
+        ph, wpts, times = configs.quadrotor_zigzag_problem(lib=hip, batch=5)   # the notebook's single start, in every lane
+        runs[mode] = (T.ALSolver(ph).solve(), ph)
+    (s0, p0), (sh, ph) = runs["0"], runs["auto"]
+    for k in ("iterations", "iterations_outer", "status", "cost", "c_max"):
+        np.testing.assert_array_equal(s0.stats[k], sh.stats[k], err_msg=k)
+    np.testing.assert_array_equal(T.states(p0), T.states(ph))
+    np.testing.assert_array_equal(T.controls(p0), T.controls(ph))
+    po, _, _ = configs.quadrotor_zigzag_problem(lib=oracle, batch=5)
+    so = T.ALSolver(po).solve()
     assert int(sh.stats["status"][0]) == T.capi.SOLVE_SUCCEEDED
     assert sh.stats["c_max"][0] < 1e-6
     assert sh.stats["cost"][0] == pytest.approx(g["cost"], rel=1e-2)
@@ -326,8 +346,9 @@ def test_G4_quadrotor_zigzag_on_gpu(forward_waves, hip, oracle, monkeypatch):
         assert np.linalg.norm(Xh[0, k - 1, :3] - r) < 0.6
     assert np.linalg.norm(Xh[0, -1, :3] - wpts[2]) < 5e-3
     np.testing.assert_array_equal(sh.stats["iterations"], sh.stats["iterations"][0])   # identical lanes stay identical
-    if forward_waves == "one":
-        for k in ("iterations", "iterations_outer", "status"):
+    print("zig-zag: GPU", int(sh.stats["iterations"][0]), "iterations, oracle", int(so.stats["iterations"][0]))
+    if np.array_equal(sh.stats["iterations"], so.stats["iterations"]):
+        for k in ("iterations_outer", "status"):
             np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
         np.testing.assert_allclose(sh.stats["cost"], so.stats["cost"], rtol=1e-6)
         assert_trajectories_close(Xh, T.states(po), 1e-6, "X")
@@ -1122,9 +1143,10 @@ def test_indexed_constraints_solve(hip, oracle):
 @pytest.mark.parametrize("width", [16, 4])
 def test_two_wave_forward_pass(width, hip, oracle, monkeypatch):
     """k_forward2 (a roller wave and an accountant wave per workgroup, an LDS ring between them) against k_forward: the same
-    expressions in the same order — equal up to the FMA contraction the compiler picks per kernel (1e-13 per pass; step indices,
-    iteration counts and statuses identical).  Constrained Quadrotor batch through the phase API (several line-search rounds with
-    the narrow shape), then full iLQR / AL solves (compaction, deep shape) against the one-wave kernel and the oracle."""
+    expressions in the same order, both compiled with -ffp-contract=on — BIT-IDENTICAL (the solve loop switches between them per
+    batch step; with hipcc's default contraction they differed by 1e-13 per pass).  Constrained Quadrotor batch through the phase
+    API (several line-search rounds with the narrow shape), then full iLQR / AL solves (compaction, deep shape) against the
+    one-wave kernel and the oracle."""
     monkeypatch.setenv("TRAJOPT_LS_DEEP", "0")
     monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", str(width))
     probs = []
@@ -1145,9 +1167,9 @@ def test_two_wave_forward_pass(width, hip, oracle, monkeypatch):
             out.append((ls, J, T.states(p), T.controls(p)))
         (l0, J0, X0, U0), (l1, J1, X1, U1) = out
         np.testing.assert_array_equal(l0, l1, err_msg=f"iteration {it}")
-        np.testing.assert_allclose(J1, J0, rtol=1e-11, err_msg=f"iteration {it}")
-        np.testing.assert_allclose(X1, X0, rtol=1e-9, atol=1e-10, err_msg=f"iteration {it}")
-        np.testing.assert_allclose(U1, U0, rtol=1e-9, atol=1e-10, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(J1, J0, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(X1, X0, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(U1, U0, err_msg=f"iteration {it}")
         later_rounds += int((l0 >= width).sum())
     assert width == 16 or later_rounds > 20
     monkeypatch.delenv("TRAJOPT_LS_DEEP")
@@ -1162,11 +1184,8 @@ def test_two_wave_forward_pass(width, hip, oracle, monkeypatch):
         sc = T.ALSolver(pc).solve()
         sols.append((s.stats["iterations"], s.stats["status"], sc.stats["iterations"], sc.stats["status"],
                      s.stats["cost"], T.states(p), T.controls(p), sc.stats["cost"], T.states(pc), T.controls(pc)))
-    for i, (x0, x1) in enumerate(zip(*sols)):
-        if i < 4:
-            np.testing.assert_array_equal(x0, x1)
-        else:
-            np.testing.assert_allclose(x1, x0, rtol=1e-6, atol=1e-7)
+    for x0, x1 in zip(*sols):   # whole solves, every output: bit for bit
+        np.testing.assert_array_equal(x0, x1)
     monkeypatch.setenv("TRAJOPT_FWD2", "1")
     ph, po = pair(lambda **kw: configs.quadrotor_problem(batch=37, N=61, tf=1.5, **kw), hip, oracle)
     sh, so = T.iLQRSolver(ph, iterations=40).solve(), T.iLQRSolver(po, iterations=40).solve()

@@ -207,3 +207,30 @@ def test_full_size_C5_altro_vs_oracle(hip, oracle):
           f"iterations {sh.total_iterations}; {total} trajectories compared with the oracle")
     assert ok.mean() >= 0.99
     assert set(np.unique(sh.stats["status"])) <= {T.capi.SOLVE_SUCCEEDED, T.capi.PROJECTION_FAIL, T.capi.MAX_ITERATIONS_OUTER, T.capi.MAX_ITERATIONS}
+
+
+def test_full_size_C5prime_quatvec_goal_altro_vs_oracle(hip, oracle):
+    """C5' = C5 with the terminal ATTITUDE pinned too, the reference's way: QuatVecEq(qf)@N (src/constraints.jl:938-965 — the vector
+    part of the normalised quaternion, feasible under RK4's norm drift where the full 13-state GoalConstraint is not) next to
+    Goal(position, velocities) and the SOC cone.  B = 8192, ALTRO; 256 sampled trajectories against the oracle, hard asserts."""
+    from oracle_binding import set_threads
+    kw = dict(N=201, constrained=True, goal_inds=configs.C5_GOAL_INDS, quatvec_goal=True)
+    ph = configs.quadrotor_problem(batch=8192, lib=hip, **kw)
+    sh = T.ALTROSolver(ph, n_steps=configs.C5_PN_STEPS).solve()
+    Xh, Uh = T.states(ph), T.controls(ph)
+    for b0, cnt in ((0, 128), (8192 - 128, 128)):
+        po = configs.quadrotor_problem(batch=cnt, b_offset=b0, lib=oracle, **kw)
+        set_threads(po, oracle.max_threads())
+        so = T.ALTROSolver(po, n_steps=configs.C5_PN_STEPS).solve()
+        idx = np.arange(b0, b0 + cnt)
+        for k in ("iterations", "iterations_outer", "iterations_pn", "status"):
+            np.testing.assert_array_equal(sh.stats[k][idx], so.stats[k], err_msg=f"{k} (block at {b0})")
+        np.testing.assert_allclose(sh.stats["cost"][idx], so.stats["cost"], rtol=1e-6)
+        assert_trajectories_close(Xh[idx], T.states(po), 1e-6, "X")
+        assert_trajectories_close(Uh[idx], T.controls(po), 1e-6, "U")
+    ok = (sh.stats["status"] == T.capi.SOLVE_SUCCEEDED) & (sh.stats["c_max"] <= 1e-6)
+    qf = np.array([math.cos(math.radians(67.5)), 0, 0, math.sin(math.radians(67.5))])
+    qN = Xh[ok, -1, 3:7] / np.linalg.norm(Xh[ok, -1, 3:7], axis=1, keepdims=True)
+    print(f"C5' ALTRO: converged {ok.mean():.4f}; projections {np.bincount(sh.stats['iterations_pn'])}; iterations {sh.total_iterations}")
+    assert ok.mean() >= 0.98
+    assert np.abs(np.abs(qN @ qf) - 1.0).max() < 1e-10      # the attitude arrived (up to the quaternion's sign)

@@ -229,7 +229,10 @@ def test_solver_option_validation():
     lib = T.load_hip_library()
     for field, value in [("line_search_decrease_factor", 0.0), ("line_search_decrease_factor", 1.0), ("penalty_scaling", 0.5),
                          ("bp_reg_increase_factor", 1.0), ("iterations", -1), ("iterations_linesearch", 0),
-                         ("iterations_linesearch", 65), ("cost_tolerance", -1e-3), ("penalty_initial", 0.0)]:
+                         ("iterations_linesearch", 65), ("cost_tolerance", -1e-3), ("penalty_initial", 0.0),
+                         # projected-Newton polish (ABI 4)
+                         ("n_steps", -1), ("rho_primal", 0.0), ("rho_chol", -1e-8), ("r_threshold", 0.0), ("projected_newton", 2),
+                         ("projected_newton_tolerance", -1.0), ("active_set_tolerance_pn", -1e-3)]:
         o = lib.default_options()
         setattr(o, field, value)
         keep = []
@@ -242,6 +245,8 @@ def test_solver_option_validation():
         with pytest.raises(T.ArgumentError):
             T.Problem(model, obj, np.zeros(4), 1.0, options=T.SolverOptions(lib=lib, **{field: value}))
     o = lib.default_options()  # defaults are valid: only the missing GPU may stop the constructor here
+    assert (o.projected_newton, o.n_steps, o.projected_newton_tolerance, o.active_set_tolerance_pn) == (1, 2, 1e-3, 1e-3)  # Altro's defaults
+    assert (o.rho_primal, o.r_threshold) == (1e-8, 1.1) and o.rho_chol == 1e-8  # Altro: rho_chol 1e-2
     try:
         T.Problem(T.Cartpole(), T.LQRObjective(np.ones(4), np.ones(1), np.ones(4), np.zeros(4), 11), np.zeros(4), 1.0)
     except T.HipError:

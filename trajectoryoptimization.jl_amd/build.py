@@ -20,6 +20,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # terms into one block that takes the ADDRESSES of the gradient / Hessian-vector register arrays (a phi of pointers),
 # which forces those arrays into scratch memory (96 B per lane, a memory round trip per use at one wave per SIMD).
 FILE_FLAGS = {"ops_quad_expand.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+# The forward-pass translation units are compiled with -ffp-contract=on: fused multiply-adds are then formed per SOURCE expression
+# (hipcc's default, fast, also fuses across statements, depending on what the surrounding code looks like after inlining).  The
+# one-wave and the two-wave forward kernels (k_forward / k_forward2) share their source expressions but not their surroundings;
+# the solve loop picks between them per batch step from the number of active trajectories, so with `fast` a trajectory's result
+# depended — at the 1e-13 level, 2e-14 in J — on how far the REST of its batch had converged.  With `on` the two kernels are
+# bit-identical (tests/test_gpu_parity.py::test_two_wave_forward_pass asserts equality; interleaved A/B in profiles/r04_ab:
+# forward phase C3 600 -> 597 us, C2 81.7 -> 83.4 us per step).
+for _f in ("ops_quad_forward_a", "ops_quad_forward_b", "ops_quad_forward_c", "ops_quad_forward2_a", "ops_quad_forward2_b", "ops_quad_forward2_c",
+           "ops_quadmrp_forward", "ops_quadrp_forward", "ops_small_forward", "ops_small_forward2", "ops_hybrid"):
+    FILE_FLAGS.setdefault(_f + ".hip", []).append("-ffp-contract=on")
 OBJDIR = CSRC / "build"
 
 

@@ -78,10 +78,13 @@ C5_PN_STEPS = 8
 
 
 def quadrotor_problem(batch=4096, N=201, tf=5.0, b_offset=0, constrained=False, goal_inds=None, u_norm_max=6.0,
-                      integration=T.RK4, device=0, lib=None, options=None):
+                      integration=T.RK4, device=0, lib=None, options=None, quatvec_goal=False):
     """C3/C4 (shape from test/quatcosts.jl:152-168 + src/lie_costs.jl:133-142): point-to-point with QuatLQRCost,
     xf = (r=[2,3,1], yaw 135°), stage Q=diag(1,1,1, 0,0,0,0, .1×6), R=1e-2 I, terminal Q×100, U0≡hover.
-    ``constrained`` = C5: GoalConstraint(xf)@N + NormConstraint(‖u‖₂≤6, SecondOrderCone)@1..N-1."""
+    ``constrained`` = C5: GoalConstraint(xf)@N + NormConstraint(‖u‖₂≤6, SecondOrderCone)@1..N-1.
+    ``quatvec_goal`` = C5': the terminal attitude is pinned as well, the reference's way — QuatVecEq(qf)@N
+    (src/constraints.jl:938-965: the vector part of the NORMALISED quaternion, so RK4's drift off the unit sphere does not make
+    it infeasible the way the full 13-state GoalConstraint is)."""
     model = T.Quadrotor()
     n, m = model.dims()
     th = math.radians(135.0) / 2
@@ -98,6 +101,8 @@ def quadrotor_problem(batch=4096, N=201, tf=5.0, b_offset=0, constrained=False, 
     if constrained:
         T.add_constraint(cons, T.NormConstraint(n, m, u_norm_max, T.SecondOrderCone(), "control"), range(1, N))
         T.add_constraint(cons, T.GoalConstraint(xf, goal_inds), N)
+        if quatvec_goal:
+            T.add_constraint(cons, T.QuatVecEq(n, m, xf[3:7]), N)
     prob = T.Problem(model, obj, np.zeros(n), tf, xf=xf, constraints=cons, batch=batch, integration=integration,
                      device=device, lib=lib, options=options)
     prob.set_initial_state(quadrotor_x0(batch, b_offset))

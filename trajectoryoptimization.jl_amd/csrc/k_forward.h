@@ -386,8 +386,11 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
 //   wave 1, the accountant: one knot behind, stores the candidate, accumulates J / gradient metric / limits from the slot, and
 //           after the rollout runs the acceptance test and the state machine exactly as k_forward does.
 // One workgroup barrier per knot orders the two-slot ring (the roller refills slot k&1 two knots later, i.e. after the barrier
-// the accountant reaches only when it has read it).  Every expression and every summation order is k_forward's: results are
-// bit-identical (tests/test_gpu_parity.py).  The early exit of a wave whose candidates have all left the admissible box is not
+// the accountant reaches only when it has read it).  Every expression and every summation order is k_forward's, and the forward
+// translation units are compiled with -ffp-contract=on (build.py: fused multiply-adds formed per source expression, not per
+// inlining context), so the two kernels are BIT-IDENTICAL — they have to be: the solve loop picks between them per batch step
+// from the number of active trajectories, and a trajectory's result must not depend on the rest of its batch
+// (tests/test_gpu_parity.py::test_two_wave_forward_pass asserts equality).  The early exit of a wave whose candidates have all left the admissible box is not
 // replicated (it only saves time in a case that is rejected anyway).
 // Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the accountant's candidate stores and dual
 // prefetches (vmcnt) at every knot.  Both waves sit on one CU; nothing but LDS is exchanged between them.

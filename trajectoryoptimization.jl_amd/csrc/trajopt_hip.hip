@@ -855,7 +855,7 @@ int to_get_controls_device(to_handle* h, void* dU) {
 int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
   CHECK_H(h); CHECK_P(c); TRY(use_device(h));
   if (id < 0 || id >= (int)h->costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
-  TRY(validate_cost(h->a.P.n, h->model_key >= 4 ? (int)h->a.P.mp[10] : -1, *c));
+  TRY(validate_cost(h->a.P.n, (h->model_key >= 4 && h->model_key <= 6) ? (int)h->a.P.mp[10] : -1, *c));  // rigid bodies only (key 7: hybrid double integrator)
   h->costs[id] = *c;
   return upload_tables(h);
 }
@@ -1179,9 +1179,17 @@ int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id
   std::memcpy(id.b, id128, sizeof(id.b));
   RCCLCHECK(g_rccl.CommInitRank(&h->comm, nranks, id, rank));
   h->comm_rank = rank; h->comm_size = nranks;
+  // every error from here on leaves the handle without a communicator (a half-initialised one would let a later to_allgather
+  // run against peers that have already given up)
+  auto abandon = [&](int code, const char* msg) {
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1; h->comm_counts.clear();
+    h->comm_offset = 0; h->comm_total = 0; h->comm_equal = true;
+    return fail(code, msg);
+  };
   // shard sizes of every rank (they may differ: a batch that does not divide by the number of GPUs)
   int32_t* dcnt = nullptr;
-  HIPCHECK(hipMalloc((void**)&dcnt, sizeof(int32_t) * nranks));
+  if (hipMalloc((void**)&dcnt, sizeof(int32_t) * nranks) != hipSuccess) return abandon(TO_ERR_HIP, "to_comm_init_rank: hipMalloc failed");
   const int32_t mine = h->a.P.B;
   hipError_t e1 = hipMemcpyAsync(dcnt + rank, &mine, sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
   int rc = e1 == hipSuccess ? g_rccl.AllGather(dcnt + rank, dcnt, 1, kNcclInt32, h->comm, h->stream) : 0;
@@ -1189,14 +1197,11 @@ int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id
   hipError_t e2 = hipMemcpyAsync(h->comm_counts.data(), dcnt, sizeof(int32_t) * nranks, hipMemcpyDeviceToHost, h->stream);
   hipError_t e3 = hipStreamSynchronize(h->stream);
   hipFree(dcnt);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || rc != 0) {
-    g_rccl.CommDestroy(h->comm);
-    h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1; h->comm_counts.clear();
-    return fail(TO_ERR_HIP, "to_comm_init_rank: exchanging the shard sizes failed");
-  }
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || rc != 0)
+    return abandon(TO_ERR_HIP, "to_comm_init_rank: exchanging the shard sizes failed");
   h->comm_offset = 0; h->comm_total = 0; h->comm_equal = true;
   for (int r = 0; r < nranks; ++r) {
-    if (h->comm_counts[r] < 1) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank: a rank reported an empty shard");
+    if (h->comm_counts[r] < 1) return abandon(TO_ERR_ARGUMENT, "to_comm_init_rank: a rank reported an empty shard");
     if (r < rank) h->comm_offset += h->comm_counts[r];
     h->comm_total += h->comm_counts[r];
     h->comm_equal = h->comm_equal && h->comm_counts[r] == h->comm_counts[0];

@@ -105,6 +105,10 @@ class TrajectoryGather:
             pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
             self.prob._call("allgather_stats", pi(its), pi(st), J.ctypes.data_as(C.POINTER(C.c_double)))
             return its, st, J
+        if solver is None:
+            from ._capi import ArgumentError
+            raise ArgumentError("TrajectoryGather.stats(solver): the CPU / gloo path gathers solver.stats — pass the solver "
+                                "(the device path gathers from the handle and recomputes the objective cost of the current trajectories)")
         torch, out = self.torch, []
         for key in ("iterations", "status", "cost"):
             a = torch.from_numpy(np.ascontiguousarray(solver.stats[key]))
