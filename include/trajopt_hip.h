@@ -50,7 +50,8 @@ extern "C" {
  * ERROR_QUADRATIC error maps.  3: TO_MODEL_HYBRID_DOUBLE_INTEGRATOR and to_knot_dims (model vectors whose dimensions change
  * along the horizon), to_solver_path reports 8 values.  4: projected-Newton polish — to_solver_opts gained the Altro
  * ProjectedNewtonSolver options (appended), to_solve_stats gained iterations_pn, new status TO_PROJECTION_FAIL, new entry
- * points to_pn_solve, to_altro_solve, to_dynamics_defect and the asynchronous to_*_solve_async / to_solve_wait.  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
+ * points to_pn_solve, to_altro_solve, to_dynamics_defect and the asynchronous to_*_solve_async / to_solve_wait; TO_MODEL_VECTOR with
+ * to_problem_desc::step_models (general model vectors).  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version. */
 #define TO_ABI_VERSION 4
@@ -97,14 +98,35 @@ typedef enum {
   TO_MODEL_QUADROTOR = 2,         /* examples/Quadrotor.ipynb cells 4,8; params = mass, Jx,Jy,Jz, gx,gy,gz,
                                      motor_dist, kf, km, rotation (to_rotation, params[10]; 0 = the notebook's
                                      Quadrotor{QuatRotation}: n = 13)                                            */
-  TO_MODEL_HYBRID_DOUBLE_INTEGRATOR = 3 /* the model VECTOR of test/hybrid_dynamics_model.jl:14-52 (src/dynamics.jl:15-31): a 2-D double
+  TO_MODEL_HYBRID_DOUBLE_INTEGRATOR = 3, /* the model VECTOR of test/hybrid_dynamics_model.jl:14-52 (src/dynamics.jl:15-31): a 2-D double
                                      integrator (4, 2) for the first S = params[1] time steps, a jump map (4, 2) -> 2,
                                      x+ = [(x3 + x4)/2, (u1 + u2)/2], on step S + 1, then a 1-D double integrator (2, 1);
                                      params[0] = mass; needs 1 <= S <= N - 2.  Stored at the largest dimensions (n = 4, m = 2):
                                      states / controls of the narrower knots are zero-padded, costs and constraints of
                                      those knots are given at (4, 2) with nothing on the padding (a padded control needs a
                                      positive R entry: it then stays exactly 0).  to_knot_dims reports the live dimensions. */
+  TO_MODEL_VECTOR = 4              /* Problem(models::Vector{<:DiscreteDynamics}, ...) in general (src/problem.jl:36-73, src/dynamics.jl:15-31):
+                                     one model per time step, to_problem_desc::step_models[N-1], any mix of the small compiled-in models
+                                     and linear discrete maps whose dimensions chain (output dimension of step k = state dimension of
+                                     step k+1, checked like RD.dims).  Stored at (n, m) = (TO_VECTOR_N, TO_VECTOR_M) = (6, 3), narrower
+                                     knots zero-padded exactly as for the hybrid double integrator; model_params are unused. */
 } to_model_id;
+
+/* One time step of a model vector (TO_MODEL_VECTOR).  A continuous model is discretised with the problem's integrator; a linear
+ * map is a discrete map x+ = A x + B u from (n, m) to n_out states (the jump map of test/hybrid_dynamics_model.jl:31-33 is one). */
+#define TO_VECTOR_N 6
+#define TO_VECTOR_M 3
+typedef enum {
+  TO_STEP_DOUBLE_INTEGRATOR = 0, /* n = 2D, m = D, n_out = n; params[0] = mass */
+  TO_STEP_CARTPOLE = 1,          /* n = 4, m = 1, n_out = 4; params = mc, mp, l, g */
+  TO_STEP_LINEAR_MAP = 2         /* params = A (n_out x n, column-major), then B (n_out x m, column-major) */
+} to_step_kind;
+typedef struct {
+  int32_t kind;   /* to_step_kind */
+  int32_t n, m;   /* state / control dimension of this step (RD.dims) */
+  int32_t n_out;  /* output dimension: the state dimension of the next knot */
+  double params[60];
+} to_step_model;
 
 /* Attitude representation R of a RigidBody{R} state (examples/Quadrotor.ipynb cell 5: "typically one of QuatRotation{T},
  * MRP{T}, or RodriguesParam{T}"; src/lie_costs.jl:1-3).  QUATERNION: x = [r, q(w,x,y,z), v, w], n = 13.  MRP / RODRIGUES:
@@ -194,6 +216,7 @@ typedef struct {
                                 NULL = Objective(stage, terminal, N): costs[0] for k<N, costs[1] at k=N (src/objective.jl:74-77) */
   int32_t n_constraints;
   const to_constraint_desc* constraints; /* ConstraintList order (src/constraint_list.jl:103-134) */
+  const to_step_model* step_models;      /* TO_MODEL_VECTOR: [N-1] one model per time step; NULL otherwise */
 } to_problem_desc;
 
 /* ---- solver options (names follow Altro.jl SolverOptions; examples/Cartpole.ipynb cell 17) -- */

@@ -50,6 +50,14 @@ struct ConstraintDesc                # == to_constraint_desc
     params::NTuple{MAXPAR,Float64}
 end
 
+struct StepModel                     # == to_step_model (one time step of a model vector, TO_MODEL_VECTOR)
+    kind::Int32                      # 0 double integrator, 1 Cartpole, 2 linear map
+    n::Int32
+    m::Int32
+    n_out::Int32
+    params::NTuple{60,Float64}
+end
+
 struct ProblemDesc                   # == to_problem_desc
     abi_version::Int32
     model::Int32
@@ -67,6 +75,7 @@ struct ProblemDesc                   # == to_problem_desc
     cost_index::Ptr{Int32}
     n_constraints::Int32
     constraints::Ptr{ConstraintDesc}
+    step_models::Ptr{StepModel}          # TO_MODEL_VECTOR: one model per time step (N-1), C_NULL otherwise
 end
 
 mutable struct SolverOpts            # == to_solver_opts (names of Altro.SolverOptions)
@@ -241,7 +250,53 @@ modelid(::RobotZoo.DoubleIntegrator) = Int32(0)
 modelparams(c::RobotZoo.Cartpole) = pad([c.mc, c.mp, c.l, c.g], 16)
 modelparams(q::RobotZoo.Quadrotor{R}) where {R} = pad([q.mass, q.J[1, 1], q.J[2, 2], q.J[3, 3], q.gravity..., q.motor_dist, q.kf, q.km,
     rotationcode(R)], 16)   # params[10] = attitude representation of the state: Quadrotor{QuatRotation} n = 13, {MRP} / {RodriguesParam} n = 12
-modelparams(d::RobotZoo.DoubleIntegrator{N,M}) where {N,M} = pad([1.0, M], 16)
+modelparams(d::RobotZoo.DoubleIntegrator{N,M}) where {N,M} = pad([1.0, M], 16)   # RobotZoo's double integrator is ẍ = u: unit mass
+# a user-defined double integrator with a `mass` field, like the one examples/quickstart.jl:11-23 defines (n = 2D, m = D)
+struct MassDoubleIntegrator{D} <: RD.ContinuousDynamics
+    mass::Float64
+end
+RD.state_dim(::MassDoubleIntegrator{D}) where {D} = 2D
+RD.control_dim(::MassDoubleIntegrator{D}) where {D} = D
+RD.dynamics(model::MassDoubleIntegrator{D}, x, u) where {D} = [x[D+1:2D]; u ./ model.mass]
+modelid(::MassDoubleIntegrator) = Int32(0)
+modelparams(d::MassDoubleIntegrator{D}) where {D} = pad([d.mass, D], 16)
+
+# ---- model vectors (Problem(models::Vector{<:DiscreteDynamics}, ...), src/problem.jl:36-73, src/dynamics.jl:15-31): TO_MODEL_VECTOR
+"""
+    LinearMap(A, B)
+
+The discrete map x⁺ = A x + B u from (size(A,2), size(B,2)) to size(A,1) states: the kind of jump map that connects the phases
+of a model vector (test/hybrid_dynamics_model.jl:31-33 is one).
+"""
+struct LinearMap <: RD.DiscreteDynamics
+    A::Matrix{Float64}
+    B::Matrix{Float64}
+end
+RD.state_dim(f::LinearMap) = size(f.A, 2)
+RD.control_dim(f::LinearMap) = size(f.B, 2)
+RD.output_dim(f::LinearMap) = size(f.A, 1)
+RD.discrete_dynamics(f::LinearMap, x, u, t, dt) = f.A * x + f.B * u
+stepmodel(f::LinearMap) = StepModel(2, size(f.A, 2), size(f.B, 2), size(f.A, 1), pad([vec(f.A); vec(f.B)], 60))
+stepmodel(d::RD.DiscretizedDynamics) = stepmodel(continuous(d))
+stepmodel(c::RobotZoo.Cartpole) = StepModel(1, 4, 1, 4, pad([c.mc, c.mp, c.l, c.g], 60))
+stepmodel(d::RobotZoo.DoubleIntegrator{N,M}) where {N,M} = StepModel(0, 2M, M, 2M, pad([1.0], 60))
+stepmodel(d::MassDoubleIntegrator{D}) where {D} = StepModel(0, 2D, D, 2D, pad([d.mass], 60))
+const VECTOR_N, VECTOR_M = 6, 3   # TO_VECTOR_N, TO_VECTOR_M: the storage dimensions of a model vector
+"A knot's cost on the zero-padded (6, 3) vectors: nothing on padded states; a padded control gets R = 1, so it stays exactly 0."
+function padcost(d::CostDesc, m0::Integer)
+    R = collect(d.R)
+    if d.kind == 1   # QuadraticCost: R is m0 x m0 column-major -> VECTOR_M x VECTOR_M with ones on the padded diagonal
+        Rm = Matrix{Float64}(I, VECTOR_M, VECTOR_M); Rm[1:m0, 1:m0] = reshape(R[1:m0*m0], m0, m0)
+        Hm = zeros(VECTOR_M, VECTOR_N); n0 = count(!iszero, d.q) > 0 ? length(d.q) : VECTOR_N   # H (m0 x n0) is rebuilt by the caller for dense costs
+        return CostDesc(d.kind, d.terminal, d.Q, pad(vec(Rm), MAXM * MAXM), d.H, d.q, d.r, d.c, d.w, d.q_ref, d.q_ind)
+    end
+    for j in m0+1:VECTOR_M
+        R[j] = 1.0
+    end
+    CostDesc(d.kind, d.terminal, d.Q, Tuple(R), d.H, d.q, d.r, d.c, d.w, d.q_ref, d.q_ind)
+end
+"One model for every step?  (Problem(model, ...) builds N-1 copies of one model, src/problem.jl:115.)"
+uniform_models(models) = all(m -> typeof(m) == typeof(models[1]) && m == models[1], models)
 continuous(model::RD.DiscretizedDynamics) = model.continuous_dynamics
 integratorid(::RD.DiscretizedDynamics{<:Any,<:RD.RK4}) = Int32(0)
 integratorid(::RD.DiscretizedDynamics{<:Any,<:RD.RK3}) = Int32(1)
@@ -272,12 +327,29 @@ function BatchProblem(prob::TO.Problem, B::Integer; device::Integer = 0, opts::U
     cons = ConstraintDesc[condesc(con, inds) for (inds, con) in zip(prob.constraints)]   # Base.zip(::ConstraintList) = zip(inds, constraints), src/constraint_list.jl:147
     dts = Float64[prob.Z[k].dt for k in 1:N-1]
     model = prob.model[1]
-    desc = ProblemDesc(TO_ABI_VERSION, modelid(continuous(model)), integratorid(model), n, m, N, B,
-        modelparams(continuous(model)), TO.get_initial_time(prob), TO.get_final_time(prob),   # src/problem.jl:186-196 (Problem has no tf field)
-        pointer(dts), length(descs), pointer(descs), pointer(index),
-        length(cons), isempty(cons) ? Ptr{ConstraintDesc}(C_NULL) : pointer(cons))
+    steps = StepModel[]
+    if uniform_models(prob.model)
+        desc = ProblemDesc(TO_ABI_VERSION, modelid(continuous(model)), integratorid(model), n, m, N, B,
+            modelparams(continuous(model)), TO.get_initial_time(prob), TO.get_final_time(prob),   # src/problem.jl:186-196 (Problem has no tf field)
+            pointer(dts), length(descs), pointer(descs), pointer(index),
+            length(cons), isempty(cons) ? Ptr{ConstraintDesc}(C_NULL) : pointer(cons), Ptr{StepModel}(C_NULL))
+    else
+        # a model vector: one table entry per time step; the library stores the trajectory at (6, 3) with the narrower knots
+        # zero-padded, so the per-knot costs / constraints must be given at (6, 3) as well (pad them like the Python mirror's
+        # pad_cost / IndexedConstraint: nothing on padded states, R = 1 on padded controls)
+        steps = StepModel[stepmodel(f) for f in prob.model]
+        descs = CostDesc[padcost(costdesc(c), RD.control_dim(c)) for c in costs]
+        # constraints of the narrower knots: wrap them in TO.IndexedConstraint(VECTOR_N, VECTOR_M, con, 1:n0, 1:m0) before building
+        # the Problem (condesc lowers the wrapper by remapping the inner constraint's indices onto the padded [x; u])
+        first_discretized = findfirst(f -> f isa RD.DiscretizedDynamics, prob.model)
+        integ = first_discretized === nothing ? Int32(0) : integratorid(prob.model[first_discretized])
+        desc = ProblemDesc(TO_ABI_VERSION, Int32(4), integ, VECTOR_N, VECTOR_M, N, B,
+            pad(Float64[], 16), TO.get_initial_time(prob), TO.get_final_time(prob),
+            pointer(dts), length(descs), pointer(descs), pointer(index),
+            length(cons), isempty(cons) ? Ptr{ConstraintDesc}(C_NULL) : pointer(cons), pointer(steps))
+    end
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve descs index cons dts begin
+    GC.@preserve descs index cons dts steps begin
         if opts === nothing
             check(ccall((:to_create, lib), Cint, (Ref{ProblemDesc}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), desc, C_NULL, device, h))
         else
@@ -606,7 +678,7 @@ function profile(p::BatchProblem)
     (kernel_ms = ms, launches = launches)
 end
 
-export BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, solve_pn!, solve_altro!, solve_async!, wait_solve!, dynamics_defect, expand!, backwardpass!, forwardpass!,
+export LinearMap, MassDoubleIntegrator, BatchProblem, SolverOpts, solver_options, default_options, solve_ilqr!, solve_al!, solve_pn!, solve_altro!, solve_async!, wait_solve!, dynamics_defect, expand!, backwardpass!, forwardpass!,
     stage_costs, al_cost, dynamics_jacobians, cost_expansion, gains, cost_gradient_hessian, discrete_jacobian, duals, set_duals!,
     reset_duals!, dual_update!, comm_unique_id, comm_init_rank!, allgather!, allgather_stats, comm_shards, comm_destroy!, solver_path, knot_dims, device_count, build_id
 

@@ -31,6 +31,7 @@ struct Model {
   int id = 0;
   int n = 0, m = 0, ne = 0; /* ne = error-state dim (RD.errstate_dim): n, or 12 for the quadrotor */
   double p[16];
+  const to_step_model* steps = nullptr; /* TO_MODEL_VECTOR: one model per time step (the descriptor's table, owned by the Problem) */
   /* attitude representation of a rigid-body state (to_rotation; -1: vector-space model) */
   int rot() const { return id == TO_MODEL_QUADROTOR ? (int)p[10] : -1; }
   bool lie() const { return id == TO_MODEL_QUADROTOR; }
@@ -50,6 +51,7 @@ inline int model_dims(int id, const double* params, int* n, int* m, int* ne) {
       *n = rot == TO_ROT_QUATERNION ? 13 : 12; *m = 4; *ne = 12; return 0;
     }
     case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; return 0; /* stored at the largest (n, m) of its phases */
+    case TO_MODEL_VECTOR: *n = TO_VECTOR_N; *m = TO_VECTOR_M; *ne = TO_VECTOR_N; return 0; /* stored at (6, 3), narrower knots zero-padded */
   }
   return -1;
 }
@@ -443,11 +445,35 @@ inline Model hybrid_phase(const Model& M, int D) {
   std::memset(S.p, 0, sizeof(S.p)); S.p[0] = M.p[0]; S.p[1] = D;
   return S;
 }
-inline void knot_dims(const Model& M, int k, int* nx, int* nu) { /* knot k = 0 .. N-1; RD.dims(models): the terminal knot carries the last model's control dimension */
+/* the model of one step of a model vector (TO_MODEL_VECTOR) as a stand-alone Model */
+inline Model step_model(const to_step_model& s) {
+  Model S; std::memset(S.p, 0, sizeof(S.p));
+  S.n = s.n; S.m = s.m; S.ne = s.n;
+  if (s.kind == TO_STEP_CARTPOLE) { S.id = TO_MODEL_CARTPOLE; for (int i = 0; i < 4; ++i) S.p[i] = s.params[i]; }
+  else { S.id = TO_MODEL_DOUBLE_INTEGRATOR; S.p[0] = s.params[0]; S.p[1] = s.m; }
+  return S;
+}
+inline void knot_dims(const Model& M, int k, int* nx, int* nu, int N = 0) { /* knot k = 0 .. N-1; RD.dims(models): the terminal knot carries the last model's control dimension */
   *nx = M.n; *nu = M.m;
+  if (M.id == TO_MODEL_VECTOR) {
+    if (k < N - 1) { *nx = M.steps[k].n; *nu = M.steps[k].m; } else { *nx = M.steps[N - 2].n_out; *nu = M.steps[N - 2].m; }
+  }
   if (M.id == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { const int S = (int)M.p[1]; *nx = k <= S ? 4 : 2; *nu = k <= S ? 2 : 1; }
 }
 inline void knot_step(const Model& M, int integrator, int k, const double* x, const double* u, double h, double* xn) {
+  if (M.id == TO_MODEL_VECTOR) { /* per-step model on the live prefix of the padded vectors; the padding of the result is zero */
+    const to_step_model& s = M.steps[k];
+    for (int i = 0; i < M.n; ++i) xn[i] = 0.0;
+    if (s.kind == TO_STEP_LINEAR_MAP) {
+      for (int i = 0; i < s.n_out; ++i) {
+        double v = 0.0;
+        for (int j = 0; j < s.n; ++j) v += s.params[i + s.n_out * j] * x[j];
+        for (int j = 0; j < s.m; ++j) v += s.params[s.n_out * s.n + i + s.n_out * j] * u[j];
+        xn[i] = v;
+      }
+    } else discrete_dynamics(step_model(s), integrator, x, u, h, xn);
+    return;
+  }
   if (M.id != TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { discrete_dynamics(M, integrator, x, u, h, xn); return; }
   const int S = (int)M.p[1];
   if (k < S) { discrete_dynamics(hybrid_phase(M, 2), integrator, x, u, h, xn); return; }
@@ -456,6 +482,22 @@ inline void knot_step(const Model& M, int integrator, int k, const double* x, co
   discrete_dynamics(hybrid_phase(M, 1), integrator, x, u, h, xn); /* reads x[0..1], u[0]; writes xn[0..1] */
 }
 inline void knot_step_jacobian(const Model& M, int integrator, int k, const double* x, const double* u, double h, double* A, double* Bm) {
+  if (M.id == TO_MODEL_VECTOR) { /* Jacobian of the live block, embedded in the padded (n x n), (n x m) */
+    const to_step_model& s = M.steps[k];
+    const int n = M.n, m = M.m;
+    std::memset(A, 0, sizeof(double) * n * n); std::memset(Bm, 0, sizeof(double) * n * m);
+    if (s.kind == TO_STEP_LINEAR_MAP) {
+      for (int i = 0; i < s.n_out; ++i) {
+        for (int j = 0; j < s.n; ++j) A[i * n + j] = s.params[i + s.n_out * j];
+        for (int j = 0; j < s.m; ++j) Bm[i * m + j] = s.params[s.n_out * s.n + i + s.n_out * j];
+      }
+    } else {
+      double a[MAXN * MAXN], b[MAXN * MAXM];
+      discrete_jacobian(step_model(s), integrator, x, u, h, a, b);
+      for (int i = 0; i < s.n; ++i) { for (int j = 0; j < s.n; ++j) A[i * n + j] = a[i * s.n + j]; for (int j = 0; j < s.m; ++j) Bm[i * m + j] = b[i * s.m + j]; }
+    }
+    return;
+  }
   if (M.id != TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { discrete_jacobian(M, integrator, x, u, h, A, Bm); return; }
   const int S = (int)M.p[1];
   if (k < S) { discrete_jacobian(hybrid_phase(M, 2), integrator, x, u, h, A, Bm); return; }

@@ -51,6 +51,7 @@ struct ConInfo {
 
 struct Problem {
   Model M;
+  std::vector<to_step_model> steps;  /* TO_MODEL_VECTOR */
   int integrator = TO_RK4;
   int n = 0, m = 0, ne = 0, N = 0, B = 0;
   std::vector<double> dt;
@@ -218,6 +219,18 @@ int build_problem(const to_problem_desc* desc, const to_solver_opts* opts, Probl
     const double S = desc->model_params[1];
     if (!(S >= 1.0) || !(S <= (double)(desc->N - 2)) || S != std::floor(S))
       return fail(TO_ERR_ARGUMENT, "hybrid double integrator: params[1] (time steps of the first model) must be an integer in 1 .. N-2");
+  }
+  if (desc->model == TO_MODEL_VECTOR) { /* RD.dims(models), src/dynamics.jl:15-31 */
+    if (!desc->step_models) return fail(TO_ERR_NULL, "TO_MODEL_VECTOR needs step_models[N-1]");
+    P->steps.assign(desc->step_models, desc->step_models + desc->N - 1);
+    for (int k = 0; k < desc->N - 1; ++k) {
+      const to_step_model& s = P->steps[k];
+      if (s.n < 1 || s.n > TO_VECTOR_N || s.m < 1 || s.m > TO_VECTOR_M || s.n_out < 1 || s.n_out > TO_VECTOR_N) return fail(TO_ERR_UNSUPPORTED, "model vector: step dimensions outside (6, 3)");
+      if (s.kind == TO_STEP_DOUBLE_INTEGRATOR) { if (s.n != 2 * s.m || s.n_out != s.n) return fail(TO_ERR_DIMENSION_MISMATCH, "double integrator step: n = 2D, m = D, n_out = n"); if (!(s.params[0] > 0.0)) return fail(TO_ERR_ARGUMENT, "double integrator step: mass must be positive"); }
+      else if (s.kind == TO_STEP_CARTPOLE) { if (s.n != 4 || s.m != 1 || s.n_out != 4) return fail(TO_ERR_DIMENSION_MISMATCH, "Cartpole step: (n, m, n_out) = (4, 1, 4)"); }
+      else if (s.kind != TO_STEP_LINEAR_MAP) return fail(TO_ERR_UNSUPPORTED, "unknown step model kind");
+      if (k + 1 < desc->N - 1 && P->steps[k + 1].n != s.n_out) return fail(TO_ERR_DIMENSION_MISMATCH, "Model mismatch at time step " + std::to_string(k + 1));
+    }
   }
   P->M.id = desc->model; P->M.n = n; P->M.m = m; P->M.ne = ne;
   std::memcpy(P->M.p, desc->model_params, sizeof(P->M.p));
@@ -931,6 +944,7 @@ int oracle_create(const to_problem_desc* desc, const to_solver_opts* opts, int /
   oracle_handle* h = new oracle_handle();
   int r = build_problem(desc, opts, &h->P);
   if (r) { delete h; return r; }
+  h->P.M.steps = h->P.steps.empty() ? nullptr : h->P.steps.data();  /* built in place: the table lives as long as the handle */
   h->T.resize(h->P.B);
   for (auto& t : h->T) alloc_traj(h->P, t);
   h->threads = 1;
@@ -1146,7 +1160,7 @@ int oracle_discrete_jacobian(oracle_handle* h, double* F) {
 
 int oracle_knot_dims(const oracle_handle* h, int32_t* nx, int32_t* nu) {
   CHECK_H(h);
-  for (int k = 0; k < h->P.N; ++k) { int a, b; knot_dims(h->P.M, k, &a, &b); nx[k] = a; nu[k] = b; }
+  for (int k = 0; k < h->P.N; ++k) { int a, b; knot_dims(h->P.M, k, &a, &b, h->P.N); nx[k] = a; nu[k] = b; }
   return TO_OK;
 }
 int oracle_constraint_info(const oracle_handle* h, int32_t id, int32_t* p, int32_t* width, int32_t* nk, int32_t* sense) {

@@ -63,6 +63,14 @@ extern "C" int pn_host_solve(const to_problem_desc* desc, const to_solver_opts* 
   std::memset(&P, 0, sizeof(P));
   P.n = n; P.m = m; P.ne = ne; P.N = N; P.B = B; P.Bp = Bp; P.integrator = desc->integrator;
   std::memcpy(P.mp, desc->model_params, sizeof(P.mp));
+  std::vector<double> step_table;
+  if (desc->model == TO_MODEL_VECTOR) {
+    int r = lower_step_models(desc->step_models, N, &step_table);
+    if (r) return r;
+    const unsigned long long bits = (unsigned long long)reinterpret_cast<uintptr_t>(step_table.data());
+    std::memset(P.mp, 0, sizeof(P.mp));
+    std::memcpy(&P.mp[0], &bits, sizeof(bits));
+  }
   if (opts) { int r = validate_opts(*opts); if (r) return r; P.opts = *opts; } else default_opts(&P.opts);
   std::vector<double> dt(N - 1);
   for (int k = 0; k < N - 1; ++k) dt[k] = desc->dt ? desc->dt[k] : (desc->tf - desc->t0) / (N - 1);
@@ -102,6 +110,7 @@ extern "C" int pn_host_solve(const to_problem_desc* desc, const to_solver_opts* 
     case 5: rc = run<QuadrotorAttModel<ATT_MRP>>(P, a, cons); break;
     case 6: rc = run<QuadrotorAttModel<ATT_RP>>(P, a, cons); break;
     case 7: rc = run<HybridDoubleIntegratorModel>(P, a, cons); break;
+    case 8: rc = run<ModelVectorModel>(P, a, cons); break;
   }
   if (rc) return rc;
   for (int b = 0; b < B; ++b) {

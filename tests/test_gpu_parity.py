@@ -1215,6 +1215,47 @@ def test_two_wave_forward_pass_small_models(two, hip, oracle, monkeypatch):
     assert_solve_parity(sh, so, ph, po)
 
 
+@pytest.mark.parametrize("mix", ["linear", "cartpole"])
+def test_general_model_vector_on_gpu(mix, hip, oracle):
+    """Problem(models::Vector, ...) in general (TO_MODEL_VECTOR; src/dynamics.jl:15-31): double integrators of three sizes, Cartpoles
+    and linear jump maps chained, through the per-step table on the device.  Every phase against the oracle (whose solve is pinned
+    against a Riccati recursion at the true per-knot dimensions in tests/test_model_vector.py), then iLQR, AL and ALTRO solves."""
+    from test_model_vector import build, cartpole_mix, linear_mix
+    models = linear_mix() if mix == "linear" else cartpole_mix()
+    (ph, _, _), (po, _, _) = build(models, hip, batch=70), build(models, oracle, batch=70)
+    assert ph.knot_dims() == po.knot_dims() == (ph.nx, ph.nu)
+    rng = np.random.default_rng(4)
+    U = np.zeros((70, ph.N - 1, ph.m))
+    for k, mk in enumerate(ph.nu[:-1]):
+        U[:, k, :mk] = rng.uniform(-1, 1, (70, mk))
+    for p in (ph, po):
+        T.initial_controls(p, U); T.rollout(p)
+    np.testing.assert_allclose(T.states(ph), T.states(po), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(T.cost(ph), T.cost(po), rtol=1e-12)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    (Ah, Bh), (Ao, Bo) = I.dynamics_jacobians(ph), I.dynamics_jacobians(po)
+    np.testing.assert_allclose(Ah, Ao, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(Bh, Bo, rtol=1e-10, atol=1e-12)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-7, atol=1e-9)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    X = T.states(ph)
+    for k in range(ph.N):
+        np.testing.assert_array_equal(X[:, k, ph.nx[k]:], 0.0)      # the padding stays exactly zero
+    (pc, _, _), (oc, _, _) = build(models, hip, batch=37, constrained=True), build(models, oracle, batch=37, constrained=True)
+    assert_solve_parity(T.ALSolver(pc).solve(), T.ALSolver(oc).solve(), pc, oc)
+    (pc, _, _), (oc, _, _) = build(models, hip, batch=37, constrained=True), build(models, oracle, batch=37, constrained=True)
+    sh, so = T.ALTROSolver(pc).solve(), T.ALTROSolver(oc).solve()
+    for k in ("iterations", "iterations_outer", "iterations_pn", "status"):
+        np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
+    assert_trajectories_close(T.states(pc), T.states(oc), 1e-6, "X")
+    assert_trajectories_close(T.controls(pc), T.controls(oc), 1e-6, "U")
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED) and sh.stats["c_max"].max() <= 1e-6
+
+
 @pytest.mark.parametrize("path", ["default", "lane", "split"])
 def test_hybrid_model_vector_on_gpu(path, hip, oracle, monkeypatch):
     """SURVEY §8(f)4, test/hybrid_dynamics_model.jl: the model vector 2-D double integrator x 5 -> jump map -> 1-D double

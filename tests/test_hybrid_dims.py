@@ -8,7 +8,8 @@ num_constraints, Problem's constraint / objective / initial-state checks — and
 is the per-step view of the compiled-in TO_MODEL_HYBRID_DOUBLE_INTEGRATOR (states / controls zero-padded at (4, 2), per-knot
 costs / constraints lowered by pad_cost / IndexedConstraint).  The oracle's solve is pinned here against an independent numpy
 Riccati recursion written at the TRUE per-knot dimensions (no padding anywhere); the GPU against the oracle in test_gpu_parity.py.
-A model vector that passes all checks but belongs to no compiled-in hybrid model ends in UnsupportedError, not silently."""
+Any other mix of the compiled-in step models runs through the general table (TO_MODEL_VECTOR, tests/test_model_vector.py); a
+vector with a step the library cannot evaluate (a bare DiscreteMap) ends in UnsupportedError, not silently."""
 import numpy as np
 import pytest
 
@@ -111,8 +112,9 @@ def test_problem_validation_over_a_model_vector(oracle):
     obj = T.Objective(costs)
     assert obj.knot_dims() == (nx, nu)
     x0, tf = np.zeros(4), 2.0
-    # every check passes; this vector's jump map belongs to no compiled-in hybrid model, and the error says so
-    with pytest.raises(T.UnsupportedError, match="hybrid model vector validated"):
+    # every check passes; this vector's jump map is a bare DiscreteMap (bookkeeping only: neither a compiled-in hybrid model's nor a
+    # LinearMap the general model-vector table can hold), and the error says so
+    with pytest.raises(T.UnsupportedError, match="model vector step of type DiscreteMap"):
         T.Problem(models, obj, x0, tf, lib=oracle)
     cons = T.ConstraintList(models)
     T.add_constraint(cons, T.BoundConstraint(4, 2, u_max=4, u_min=-4), range(1, 6))

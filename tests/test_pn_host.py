@@ -63,7 +63,14 @@ def _quickstart(oracle, batch):
     return p
 
 
+def _vector_mix(o):
+    from test_model_vector import build, cartpole_mix
+    return build(cartpole_mix(), o, batch=2, constrained=True)[0]
+
+
 CASES = {
+    # the general model vector (TO_MODEL_VECTOR): every step through the per-step table, double and dual-number paths
+    "model_vector_cartpole_mix": (_vector_mix, 5e-4),
     "cartpole_bounds_goal": (lambda o: configs.cartpole_problem(batch=3, N=41, tf=2.0, constrained=True, u_bnd=10.0, lib=o), 1e-3),
     "quickstart_circle_soc_bound_goal": (lambda o: _quickstart(o, 2), 1e-3),
     "quadrotor_goal_soc": (lambda o: configs.quadrotor_problem(batch=3, N=61, tf=3.0, constrained=True, goal_inds=configs.C5_GOAL_INDS, lib=o), 0.0),

@@ -26,7 +26,9 @@ TO_ERR_HIP, TO_ERR_UNSUPPORTED, TO_ERR_NULL, TO_ERR_CONE = -4, -5, -6, -7
 (UNSOLVED, LINESEARCH_FAIL, SOLVE_SUCCEEDED, MAX_ITERATIONS, MAX_ITERATIONS_OUTER, MAXIMUM_COST,
  STATE_LIMIT, CONTROL_LIMIT, NO_PROGRESS, COST_INCREASE, REGULARIZATION_MAX, PROJECTION_FAIL) = range(12)
 
-MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_HYBRID_DOUBLE_INTEGRATOR = 0, 1, 2, 3
+MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_HYBRID_DOUBLE_INTEGRATOR, MODEL_VECTOR = 0, 1, 2, 3, 4
+STEP_DOUBLE_INTEGRATOR, STEP_CARTPOLE, STEP_LINEAR_MAP = 0, 1, 2
+TO_VECTOR_N, TO_VECTOR_M = 6, 3
 RK4, RK3, EULER = 0, 1, 2
 COST_DIAGONAL, COST_QUADRATIC, COST_DIAGONAL_QUAT, COST_ERROR_QUADRATIC = 0, 1, 2, 3
 CONE_ZERO, CONE_NEGATIVE_ORTHANT, CONE_SECOND_ORDER, CONE_POSITIVE_ORTHANT, CONE_IDENTITY = range(5)
@@ -88,6 +90,10 @@ class ConstraintDesc(C.Structure):
     ]
 
 
+class StepModel(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("n_out", C.c_int32), ("params", C.c_double * 60)]
+
+
 class ProblemDesc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("model", C.c_int32), ("integrator", C.c_int32),
@@ -96,6 +102,7 @@ class ProblemDesc(C.Structure):
         ("dt", C.POINTER(C.c_double)),
         ("n_costs", C.c_int32), ("costs", C.POINTER(CostDesc)), ("cost_index", C.POINTER(C.c_int32)),
         ("n_constraints", C.c_int32), ("constraints", C.POINTER(ConstraintDesc)),
+        ("step_models", C.POINTER(StepModel)),
     ]
 
 

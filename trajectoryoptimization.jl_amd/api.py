@@ -33,7 +33,7 @@ from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, 
                     SolverOpts, SolveStats, UnsupportedError)
 
 __all__ = [
-    "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "HybridDoubleIntegrator", "pad_cost", "dims", "RK4", "RK3", "Euler",
+    "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "LinearMap", "ModelVector", "HybridDoubleIntegrator", "pad_cost", "dims", "RK4", "RK3", "Euler",
     "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
     "Equality", "ZeroCone", "Inequality", "NegativeOrthant", "SecondOrderCone", "PositiveOrthant", "IdentityCone",
@@ -107,6 +107,52 @@ class DiscreteMap(_Model):
 
     def params(self):
         return [float(self.n), float(self.m), float(self._ny)]
+
+
+class LinearMap(DiscreteMap):
+    """The discrete map x⁺ = A x + B u from (n, m) to ``output_dim = size(A, 1)`` states: the kind of jump map that connects the
+    phases of a model vector (test/hybrid_dynamics_model.jl:31-33 is one).  A step of ``TO_MODEL_VECTOR``."""
+
+    def __init__(self, A, B):
+        A, B = np.atleast_2d(np.asarray(A, dtype=np.float64)), np.atleast_2d(np.asarray(B, dtype=np.float64))
+        if A.shape[0] != B.shape[0]:
+            raise DimensionMismatch("LinearMap: A and B need the same number of rows")
+        super().__init__(A.shape[1], B.shape[1], A.shape[0])
+        self.A, self.B = A, B
+
+    def params(self):
+        return list(self.A.flatten(order="F")) + list(self.B.flatten(order="F"))
+
+
+class ModelVector(_Model):
+    """``Problem(models::Vector{<:DiscreteDynamics}, ...)`` in general (src/problem.jl:36-73, src/dynamics.jl:15-31; TO_MODEL_VECTOR):
+    one model per time step — DoubleIntegrator (D = 1, 2, 3), Cartpole, LinearMap — whose dimensions chain.  The library stores
+    the trajectory at (6, 3) with the narrower knots zero-padded; ``Problem`` lowers costs and constraints onto the padding
+    exactly as for ``HybridDoubleIntegrator``."""
+    model_id = capi.MODEL_VECTOR
+    n, m = capi.TO_VECTOR_N, capi.TO_VECTOR_M
+
+    def __init__(self, models):
+        self.steps = list(models)
+        for mod in self.steps:
+            if not isinstance(mod, (DoubleIntegrator, Cartpole, LinearMap)):
+                raise UnsupportedError(f"model vector step of type {type(mod).__name__}: the compiled-in step models are DoubleIntegrator, "
+                                       "Cartpole and LinearMap")
+            if mod.n > self.n or mod.m > self.m or getattr(mod, "output_dim", mod.n) > self.n:
+                raise UnsupportedError("model vector: step dimensions outside (6, 3)")
+
+    def params(self):
+        return []
+
+    def _step_descs(self):
+        arr = (capi.StepModel * len(self.steps))()
+        for d, mod in zip(arr, self.steps):
+            d.kind = (capi.STEP_LINEAR_MAP if isinstance(mod, LinearMap) else capi.STEP_CARTPOLE if isinstance(mod, Cartpole)
+                      else capi.STEP_DOUBLE_INTEGRATOR)
+            d.n, d.m, d.n_out = mod.n, mod.m, getattr(mod, "output_dim", mod.n)
+            p = mod.params() if not isinstance(mod, DoubleIntegrator) else [mod.mass]
+            d.params[: len(p)] = p
+        return arr
 
 
 def dims(models):
@@ -1034,10 +1080,8 @@ class Problem:
         if not all(_same_model(mod, models[0]) for mod in models) or isinstance(models[0], DiscreteMap):
             # every check of the reference's constructor has passed.  The library integrates ONE compiled-in model over the whole
             # horizon; a model vector runs when it is the per-step view of a compiled-in HYBRID model (models.h, model_step)
-            model = HybridDoubleIntegrator.match(models)
-            if model is None:
-                raise UnsupportedError(f"hybrid model vector validated (nx = {nx}, nu = {nu}), but libtrajopt_hip has no compiled-in "
-                                       "hybrid model with these per-step models (HybridDoubleIntegrator.models(N) is one)")
+            # (the general per-step table, TO_MODEL_VECTOR, otherwise)
+            model = HybridDoubleIntegrator.match(models) or ModelVector(models)
             self.hybrid = True
             n, m = model.dims()
             # costs and constraints of the narrower knots onto the zero-padded storage vectors
@@ -1058,6 +1102,8 @@ class Problem:
         n, m = model.dims()
         self.n, self.m, self.N, self.B = n, m, len(obj), int(batch)
         self.t0, self.tf = float(t0), float(tf)
+        if self.hybrid and xf is not None and np.asarray(xf).size == nx[-1] and nx[-1] < n:
+            xf = np.r_[np.asarray(xf, dtype=np.float64).ravel(), np.zeros(n - nx[-1])]   # the reference's xf has length nx[end] (src/problem.jl:47)
         self.xf = np.full(n, np.nan) if xf is None else _vec(xf, n, "xf")
         self.integration = integration
         self._dt = None if dt is None else np.ascontiguousarray(_vec(dt, self.N - 1, "dt"))
@@ -1078,6 +1124,8 @@ class Problem:
         d.n_costs, d.costs, d.cost_index = len(uniq), self._costs, self._cost_index
         d.n_constraints = len(cons_lowered)
         d.constraints = self._cons
+        self._steps = model._step_descs() if isinstance(model, ModelVector) else None
+        d.step_models = self._steps
         self._desc = d
         self._h = C.c_void_p()
         opts = options._o if isinstance(options, SolverOptions) else options

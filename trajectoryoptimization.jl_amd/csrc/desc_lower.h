@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "models.h"
 #include "problem_dev.h"
@@ -64,8 +65,46 @@ inline int model_dims(int id, const double* params, int* n, int* m, int* ne, int
       return -1;
     }
     case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; *key = 7; return 0;
+    case TO_MODEL_VECTOR: *n = TO_VECTOR_N; *m = TO_VECTOR_M; *ne = TO_VECTOR_N; *key = 8; return 0;
   }
   return -1;
+}
+
+// Model vector (TO_MODEL_VECTOR): every check RD.dims(models) makes (src/dynamics.jl:15-31), and the per-step table the kernels
+// read (models.h ModelVectorModel: 64 doubles per step).
+inline int lower_step_models(const to_step_model* sm, int N, std::vector<double>* table) {
+  if (!sm) return fail(TO_ERR_NULL, "TO_MODEL_VECTOR needs step_models[N-1]");
+  table->assign((size_t)64 * (N - 1), 0.0);
+  for (int k = 0; k < N - 1; ++k) {
+    const to_step_model& s = sm[k];
+    double* r = table->data() + (size_t)64 * k;
+    if (s.n < 1 || s.n > TO_VECTOR_N || s.m < 1 || s.m > TO_VECTOR_M || s.n_out < 1 || s.n_out > TO_VECTOR_N)
+      return fail(TO_ERR_UNSUPPORTED, "model vector: step dimensions outside (6, 3)");
+    switch (s.kind) {
+      case TO_STEP_DOUBLE_INTEGRATOR:
+        if (s.n != 2 * s.m || s.n_out != s.n) return fail(TO_ERR_DIMENSION_MISMATCH, "double integrator step: n = 2D, m = D, n_out = n");
+        if (!(s.params[0] > 0.0)) return fail(TO_ERR_ARGUMENT, "double integrator step: mass must be positive");
+        r[4] = s.params[0]; r[5] = s.m;
+        break;
+      case TO_STEP_CARTPOLE:
+        if (s.n != 4 || s.m != 1 || s.n_out != 4) return fail(TO_ERR_DIMENSION_MISMATCH, "Cartpole step: (n, m, n_out) = (4, 1, 4)");
+        for (int i = 0; i < 4; ++i) r[4 + i] = s.params[i];
+        break;
+      case TO_STEP_LINEAR_MAP:
+        for (int i = 0; i < s.n_out; ++i) {
+          for (int j = 0; j < s.n; ++j) r[8 + 6 * i + j] = s.params[i + s.n_out * j];
+          for (int j = 0; j < s.m; ++j) r[44 + 3 * i + j] = s.params[s.n_out * s.n + i + s.n_out * j];
+        }
+        break;
+      default: return fail(TO_ERR_UNSUPPORTED, "unknown step model kind");
+    }
+    r[0] = s.kind; r[1] = s.n; r[2] = s.m; r[3] = s.n_out;
+    if (k + 1 < N - 1 && sm[k + 1].n != s.n_out)  // RD.dims: "Model mismatch at time step k"
+      return fail(TO_ERR_DIMENSION_MISMATCH, "Model mismatch at time step " + std::to_string(k + 1) + ". Model " + std::to_string(k + 1) +
+                                                 " has an output dimension of " + std::to_string(s.n_out) + " but model " + std::to_string(k + 2) +
+                                                 " has a state dimension of " + std::to_string(sm[k + 1].n) + ".");
+  }
+  return TO_OK;
 }
 
 inline int validate_constraint(int n, int m, int N, const to_constraint_desc& d, DevCon* out) {

@@ -40,6 +40,7 @@ struct to_handle_s {
   std::vector<to::DevCon> cons;
   std::vector<double> dt;
   std::vector<int> cost_index;
+  std::vector<double> step_table;  // TO_MODEL_VECTOR: host copy of the per-step model table (models.h ModelVectorModel)
   std::vector<void*> allocs;
   double* stage = nullptr;  // device staging buffer in host layout
   size_t stage_bytes = 0;
@@ -128,8 +129,8 @@ struct ModelOps {
 };
 
 // each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole,
-// 4 Quadrotor, 5 Quadrotor{MRP}, 6 Quadrotor{RodriguesParam}, 7 hybrid double integrator)
-constexpr int N_MODEL_KEYS = 8;
+// 4 Quadrotor, 5 Quadrotor{MRP}, 6 Quadrotor{RodriguesParam}, 7 hybrid double integrator, 8 general model vector)
+constexpr int N_MODEL_KEYS = 9;
 void fill_ops_small(ModelOps* table);
 void fill_ops_small_forward(ModelOps* table);
 void fill_ops_quad_misc(ModelOps* table);
@@ -150,6 +151,7 @@ void fill_ops_hybrid(ModelOps* table);
 void fill_ops_small_forward2(ModelOps* table);
 void fill_ops_small_scan(ModelOps* table);
 void fill_ops_pn(ModelOps* table);
+void fill_ops_vector(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

@@ -495,6 +495,66 @@ struct HybridDoubleIntegratorModel {
   }
 };
 
+// Problem(models::Vector{<:DiscreteDynamics}, ...) in general (src/problem.jl:36-73, src/dynamics.jl:15-31; TO_MODEL_VECTOR): one
+// model per time step out of a per-step TABLE in device memory — any mix of double integrators (D = 1, 2, 3), Cartpoles and
+// linear discrete maps x+ = A x + B u whose dimensions chain.  Stored at (6, 3) with the narrower knots zero-padded, like the
+// hybrid double integrator above.  One record of 64 doubles per step: [0] kind (0 double integrator, 1 Cartpole, 2 linear map),
+// [1] n, [2] m, [3] n_out, [4..] the sub-model's parameters as that model reads them ([4] mass, [5] D / [4..7] mc, mp, l, g),
+// [8..44) A row-major 6 x 6, [44..62) B row-major 6 x 3 (zero-padded).  P[0] carries the table's ADDRESS (bit pattern: the
+// kernels move model parameters around as doubles, never compute with them).  Branch-free like the hybrid model: every kind is
+// evaluated, the record's kind selects (the lanes of the knot-parallel kernels sit on different steps).
+struct ModelVectorModel {
+  static constexpr int n = 6, m = 3, ne = 6;
+  static constexpr bool lie = false;
+  static constexpr int att = ATT_NONE;
+  static constexpr bool hybrid = true;
+  static constexpr bool pin_rk4 = true;
+  static constexpr int expand_knots = 1;
+  static constexpr bool accept_write_through = true;
+  static constexpr bool lds_gains = false;
+  static constexpr int ls_first_round = 4;
+  static constexpr bool mfma_backward = false, coop_backward = true;
+  static constexpr bool lane_backward = false;
+  static constexpr int REC = 64;
+  __host__ __device__ static const double* table(const double* P) {
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &P[0], sizeof(bits));
+    return reinterpret_cast<const double*>(bits);
+  }
+  template <class T>
+  __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) { DoubleIntegratorModel<3>::f(P, x, u, xd); }  // (unused: step dispatches)
+  template <class T, int FIXED>
+  __device__ __forceinline__ static void step(const double* P, int integrator_rt, int k, const T* x, const T* u, double h, T* xn) {
+    const double* rec = table(P) + (size_t)REC * k;
+    const int kind = (int)rec[0], D = (int)rec[1] / 2;
+    T y1[2], y2[4], y3[6], yc[4], yl[6];
+    rk_step<DoubleIntegratorModel<1>, T, FIXED>(rec + 4, integrator_rt, x, u, h, y1);
+    rk_step<DoubleIntegratorModel<2>, T, FIXED>(rec + 4, integrator_rt, x, u, h, y2);
+    rk_step<DoubleIntegratorModel<3>, T, FIXED>(rec + 4, integrator_rt, x, u, h, y3);
+    rk_step<CartpoleModel, T, FIXED>(rec + 4, integrator_rt, x, u, h, yc);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      T s(0.0);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) s = s + rec[8 + 6 * i + j] * x[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s = s + rec[44 + 3 * i + j] * u[j];
+      yl[i] = s;
+    }
+    const T zero(0.0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const T di = select_t(D == 1, i < 2 ? y1[i < 2 ? i : 0] : zero, select_t(D == 2, i < 4 ? y2[i < 4 ? i : 0] : zero, y3[i]));
+      xn[i] = select_t(kind == 2, yl[i], select_t(kind == 1, i < 4 ? yc[i < 4 ? i : 0] : zero, di));
+    }
+  }
+  __host__ __device__ static void knot_dims(const double* P, int N, int k, int* nx, int* nu) {  // knot k = 0 .. N-1 (host: table = host copy)
+    const double* tab = table(P);
+    if (k < N - 1) { *nx = (int)tab[(size_t)REC * k + 1]; *nu = (int)tab[(size_t)REC * k + 2]; }
+    else { *nx = (int)tab[(size_t)REC * (N - 2) + 3]; *nu = (int)tab[(size_t)REC * (N - 2) + 2]; }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Error-state maps.  Identity for vector-space models.
 // ------------------------------------------------------------------------------------------------

@@ -92,5 +92,6 @@ void fill_ops_pn(ModelOps* t) {
   fill_one<QuadrotorAttModel<ATT_MRP>>(t[5]);
   fill_one<QuadrotorAttModel<ATT_RP>>(t[6]);
   fill_one<HybridDoubleIntegratorModel>(t[7]);
+  fill_one<ModelVectorModel>(t[8]);
 }
 }  // namespace to

@@ -45,7 +45,7 @@ const ModelOps* model_ops(int key) {
     fill_ops_quad_forward2_a(g_ops); fill_ops_quad_forward2_b(g_ops); fill_ops_quad_forward2_c(g_ops);
     fill_ops_quadatt_misc(g_ops); fill_ops_quadmrp_expand(g_ops); fill_ops_quadrp_expand(g_ops);
     fill_ops_quadmrp_forward(g_ops); fill_ops_quadrp_forward(g_ops);
-    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops); fill_ops_small_scan(g_ops); fill_ops_pn(g_ops);
+    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops); fill_ops_small_scan(g_ops); fill_ops_pn(g_ops); fill_ops_vector(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
 }
@@ -526,6 +526,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     if (!(S >= 1.0) || !(S <= (double)(N - 2)) || S != std::floor(S))
       return fail(TO_ERR_ARGUMENT, "hybrid double integrator: params[1] (time steps of the first model) must be an integer in 1 .. N-2");
   }
+  std::vector<double> step_table;  // TO_MODEL_VECTOR: the per-step model table (models.h ModelVectorModel), validated like RD.dims(models)
+  if (desc->model == TO_MODEL_VECTOR) TRY(lower_step_models(desc->step_models, N, &step_table));
   std::vector<int> cost_index(N);
   if (desc->cost_index) {
     for (int k = 0; k < N; ++k) {
@@ -560,7 +562,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->ops = model_ops(key);
   if (!h->ops || !h->ops->rollout || !h->ops->expand || !h->ops->backward) { delete h; return fail(TO_ERR_UNSUPPORTED, "model kernels not linked"); }
   h->costs.assign(desc->costs, desc->costs + desc->n_costs);
-  h->cons = cons; h->dt = dt; h->cost_index = cost_index;
+  h->cons = cons; h->dt = dt; h->cost_index = cost_index; h->step_table = step_table;
   auto bail = [&](int rc) { std::string e = g_err; to_destroy(h); g_err = e; return rc; };
 #define TRYB(expr) do { int r_ = (expr); if (r_ != TO_OK) return bail(r_); } while (0)
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(TO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); } while (0)
@@ -580,6 +582,14 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   TRYB(dev_alloc(h, &h->d_cost_index, (size_t)N));
   HIPB(hipMemcpyAsync(h->d_dt, dt.data(), sizeof(double) * (N - 1), hipMemcpyHostToDevice, h->stream));
   HIPB(hipMemcpyAsync(h->d_cost_index, cost_index.data(), sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+  if (!h->step_table.empty()) {  // model vector: the table's device address travels in model_params[0] (bit pattern; models.h)
+    double* d_tab = nullptr;
+    TRYB(dev_alloc(h, &d_tab, h->step_table.size()));
+    HIPB(hipMemcpyAsync(d_tab, h->step_table.data(), sizeof(double) * h->step_table.size(), hipMemcpyHostToDevice, h->stream));
+    const unsigned long long bits = (unsigned long long)reinterpret_cast<uintptr_t>(d_tab);
+    std::memset(P.mp, 0, sizeof(P.mp));
+    std::memcpy(&P.mp[0], &bits, sizeof(bits));
+  }
   TRYB(upload_tables(h));
   P.dt = (DoubleC*)h->d_dt; P.cost_index = (IntC*)h->d_cost_index; P.costs = (CostC*)h->d_costs; P.cons = (ConC*)h->d_cons;
   // Line-search candidates evaluated concurrently per trajectory, CW (a power of two): a forward wave holds CW
@@ -781,6 +791,12 @@ int to_knot_dims(const to_handle* h, int32_t* nx, int32_t* nu) {
   for (int k = 0; k < P.N; ++k) {
     int a = P.n, b = P.m;
     if (h->model_key == 7) HybridDoubleIntegratorModel::knot_dims(P.mp, P.N, k, &a, &b);
+    if (h->model_key == 8) {  // the host copy of the table (P.mp[0] holds the DEVICE address)
+      const unsigned long long bits = (unsigned long long)reinterpret_cast<uintptr_t>(h->step_table.data());
+      double hp[1];
+      std::memcpy(&hp[0], &bits, sizeof(bits));
+      ModelVectorModel::knot_dims(hp, P.N, k, &a, &b);
+    }
     nx[k] = a; nu[k] = b;
   }
   return TO_OK;
