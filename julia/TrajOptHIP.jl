@@ -285,11 +285,7 @@ const VECTOR_N, VECTOR_M = 6, 3   # TO_VECTOR_N, TO_VECTOR_M: the storage dimens
 "A knot's cost on the zero-padded (6, 3) vectors: nothing on padded states; a padded control gets R = 1, so it stays exactly 0."
 function padcost(d::CostDesc, m0::Integer)
     R = collect(d.R)
-    if d.kind == 1   # QuadraticCost: R is m0 x m0 column-major -> VECTOR_M x VECTOR_M with ones on the padded diagonal
-        Rm = Matrix{Float64}(I, VECTOR_M, VECTOR_M); Rm[1:m0, 1:m0] = reshape(R[1:m0*m0], m0, m0)
-        Hm = zeros(VECTOR_M, VECTOR_N); n0 = count(!iszero, d.q) > 0 ? length(d.q) : VECTOR_N   # H (m0 x n0) is rebuilt by the caller for dense costs
-        return CostDesc(d.kind, d.terminal, d.Q, pad(vec(Rm), MAXM * MAXM), d.H, d.q, d.r, d.c, d.w, d.q_ref, d.q_ind)
-    end
+    d.kind == 1 && error("model vector: give a dense QuadraticCost at the padded dimensions (6, 3) yourself (Q, R, H are stored column-major at their own size)")
     for j in m0+1:VECTOR_M
         R[j] = 1.0
     end

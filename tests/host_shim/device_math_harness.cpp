@@ -24,6 +24,11 @@ void run(const char* name, const double* P) {
       printf("%s x", name); for (int i = 0; i < n; ++i) printf(" %.17g", x[i]);
       printf("\n%s u", name); for (int i = 0; i < m; ++i) printf(" %.17g", u[i]);
       printf("\n%s f", name); for (int i = 0; i < n; ++i) printf(" %.17g", xd[i]);
+      for (int integ = 0; integ < 3; ++integ) {  // one discrete step per integrator (RK4, RK3, Euler), h = 0.05
+        double xs[n];
+        rk_step<M, double>(P, integ, x, u, 0.05, xs);
+        printf("\n%s step%d", name, integ); for (int i = 0; i < n; ++i) printf(" %.17g", xs[i]);
+      }
       printf("\n");
     }
     for (int integ = 0; integ < 3; ++integ) {

@@ -25,7 +25,7 @@ def harness(tmp_path_factory):
     vals, summary = {}, {}
     for line in out.splitlines():
         tok = line.split()
-        if tok[1] in ("x", "u", "f"):
+        if tok[1] in ("x", "u", "f", "step0", "step1", "step2"):
             vals.setdefault(tok[0], {})[tok[1]] = np.array([float(t) for t in tok[2:]])
         else:
             summary[tok[0]] = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok), 2)}
@@ -47,6 +47,12 @@ def test_device_dynamics_match_the_oracle(name, harness, oracle):
     oracle.call("dynamics", model.model_id, params, pd(x), pd(u), pd(xd))
     # the device code multiplies by reciprocals and merges a few products where the oracle divides: a few ulp
     np.testing.assert_allclose(vals[name]["f"], xd, rtol=1e-13, atol=1e-13)
+    # one discrete step with every integrator (the Cartpole's later RK stages take sin / cos by angle addition from stage 1's:
+    # models.h trig_stage) against the oracle's step, which evaluates sin / cos of every stage point directly
+    for integ in (0, 1, 2):
+        xn = np.zeros(model.n)
+        oracle.call("discrete_dynamics", model.model_id, params, integ, pd(x), pd(u), 0.05, pd(xn))
+        np.testing.assert_allclose(vals[name][f"step{integ}"], xn, rtol=2e-15, atol=2e-16)
 
 
 @pytest.mark.parametrize("name", list(MODELS))

@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace to {
 
 // 1/x to ~1 ulp: hardware reciprocal estimate + two Newton steps (5 VALU ops instead of the ~27 of an IEEE
@@ -97,6 +99,41 @@ __device__ __forceinline__ void sincos_t(Dual x, Dual* s, Dual* c) {
   *s = Dual(sv, cv * x.d);
   *c = Dual(cv, -sv * x.d);
 }
+// sin and cos of a SMALL angle, |r| <= π/4: the polynomial kernels of sincos_fast without its range reduction and quadrant
+// select (12 FMAs instead of ~45 instructions).  Used by the RK stages of the models that declare `trig_index`: stages 2-4 evaluate
+// the dynamics at θ + δ with δ = O(h θ̇), and sin / cos of θ + δ follow from stage 1's by the angle-addition formulas.
+__device__ __forceinline__ void sincos_small(double r, double* s, double* c) {
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  *s = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  *c = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+constexpr double TRIG_SMALL_MAX = 0.75;  // beyond: the full evaluation (per lane: a lane's result never depends on its neighbours)
+__device__ __forceinline__ bool any_lane(bool p) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __ballot(p) != 0;
+#else
+  return p;
+#endif
+}
+__device__ __forceinline__ double value_of(double x) { return x; }
+__device__ __forceinline__ double value_of(Dual x) { return x.v; }
+__device__ __forceinline__ void sincos_small_t(double x, double* s, double* c) { sincos_small(x, s, c); }
+__device__ __forceinline__ void sincos_small_t(Dual x, Dual* s, Dual* c) {
+  double sv, cv;
+  sincos_small(x.v, &sv, &cv);
+  *s = Dual(sv, cv * x.d);
+  *c = Dual(cv, -sv * x.d);
+}
 // max(0, x): derivative is the indicator x > 0 (the rotor-force clamp of the Quadrotor)
 __device__ __forceinline__ double relu_t(double x) { return fmax(0.0, x); }
 // (component-wise selects: a select between two Dual objects was lowered through scratch memory in the larger kernels)
@@ -144,6 +181,13 @@ template <int K> __device__ __forceinline__ void sincos_t(MDual<K> x, MDual<K>* 
   s->v = sv; c->v = cv;
   TO_MD_LOOP { s->d[i_] = cv * x.d[i_]; c->d[i_] = -sv * x.d[i_]; }
 }
+template <int K> __device__ __forceinline__ double value_of(MDual<K> x) { return x.v; }
+template <int K> __device__ __forceinline__ void sincos_small_t(MDual<K> x, MDual<K>* s, MDual<K>* c) {
+  double sv, cv;
+  sincos_small(x.v, &sv, &cv);
+  s->v = sv; c->v = cv;
+  TO_MD_LOOP { s->d[i_] = cv * x.d[i_]; c->d[i_] = -sv * x.d[i_]; }
+}
 template <int K> __device__ __forceinline__ MDual<K> relu_t(MDual<K> x) {
   const bool on = x.v > 0.0;
   MDual<K> r; r.v = on ? x.v : 0.0;
@@ -151,6 +195,16 @@ template <int K> __device__ __forceinline__ MDual<K> relu_t(MDual<K> x) {
   return r;
 }
 #undef TO_MD_LOOP
+
+// component-wise select (a select between two dual-number objects went through scratch memory in the larger kernels)
+__device__ __forceinline__ double select_t(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ Dual select_t(bool c, Dual a, Dual b) { return Dual(c ? a.v : b.v, c ? a.d : b.d); }
+template <int K> __device__ __forceinline__ MDual<K> select_t(bool c, MDual<K> a, MDual<K> b) {
+  MDual<K> r; r.v = c ? a.v : b.v;
+#pragma unroll
+  for (int i = 0; i < K; ++i) r.d[i] = c ? a.d[i] : b.d[i];
+  return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Models.  P = model_params of the descriptor (wave-uniform, lives in SGPRs).
@@ -195,12 +249,18 @@ struct CartpoleModel {  // docs/src/model.md:34-50
                                                        // within the first 4 in 99.9 % of the iterations (tools/ls_hist.py); more only adds candidate traffic
   static constexpr bool mfma_backward = true, coop_backward = true;  // MFMA and cooperative backward passes stay built for A/B runs (TRAJOPT_BACKWARD)
   static constexpr bool lane_backward = true;  // default: one lane per trajectory
+  static constexpr int trig_index = 1;  // the state entry whose sine / cosine the dynamics need (rk_step carries them from stage to stage)
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
-    const double mc = P[0], mp = P[1], l = P[2], g = P[3];
-    T qd1 = x[2], qd2 = x[3];
     T s, c;
     sincos_t(x[1], &s, &c);
+    f_sc(P, x, u, s, c, xd);
+  }
+  // the dynamics with sin(x[1]), cos(x[1]) given
+  template <class T>
+  __device__ __forceinline__ static void f_sc(const double* P, const T* x, const T* u, T s, T c, T* xd) {
+    const double mc = P[0], mp = P[1], l = P[2], g = P[3];
+    T qd1 = x[2], qd2 = x[3];
     const double h11 = mc + mp, h22 = mp * l * l;
     T h12 = (mp * l) * c;
     T c12 = -((mp * qd2) * l) * s;
@@ -388,9 +448,65 @@ enum { INTEG_RK4 = 0, INTEG_RK3 = 1, INTEG_EULER = 2 };
 
 // FIXED >= 0 pins the scheme at compile time: with a runtime switch the compiler merges the three schemes into one loop
 // full of selects (the Cartpole rollout loop was 857 instructions per knot, 300 of them FP64).
+template <class M, class = void>
+struct has_trig : std::false_type {};
+template <class M>
+struct has_trig<M, decltype((void)M::trig_index)> : std::true_type {};
+
+// One stage evaluation at xt = x + (increment with xt[trig_index] - x[trig_index] = delta) for a model whose dynamics need sin / cos
+// of ONE state entry: sin(θ + δ) = s1 cos δ + c1 sin δ, cos(θ + δ) = c1 cos δ - s1 sin δ with the small-angle kernels — three
+// Cody-Waite reductions and quadrant selects per RK4 step saved (the Cartpole roller's knot: 358 -> ~285 instructions).  A lane
+// whose |δ| exceeds TRIG_SMALL_MAX takes the full evaluation of xt (computed for the whole wave only when some lane needs it,
+// selected per lane).
+template <class M, class T>
+__device__ __forceinline__ void trig_stage(const double* P, const T* xt, const T* u, T s1, T c1, T delta, T* k) {
+  T sd, cd;
+  sincos_small_t(delta, &sd, &cd);
+  T s = s1 * cd + c1 * sd, c = c1 * cd - s1 * sd;
+  const bool big = !(fabs(value_of(delta)) <= TRIG_SMALL_MAX);
+  if (any_lane(big)) {
+    T sf, cf;
+    sincos_t(xt[M::trig_index], &sf, &cf);
+    s = select_t(big, sf, s); c = select_t(big, cf, c);
+  }
+  M::f_sc(P, xt, u, s, c, k);
+}
+
 template <class M, class T, int FIXED = -1>
 __device__ __forceinline__ void rk_step(const double* P, int integrator_rt, const T* x, const T* u, double h, T* xn) {
   const int integrator = FIXED >= 0 ? FIXED : integrator_rt;
+  if constexpr (has_trig<M>::value) {  // same scheme, same operation order; only sin / cos of the later stages come by angle addition
+    if (integrator != INTEG_EULER) {
+      constexpr int n = M::n, ti = M::trig_index;
+      T k[n], acc[n], xt[n], s1, c1;
+      sincos_t(x[ti], &s1, &c1);
+      M::f_sc(P, x, u, s1, c1, k);
+#pragma unroll
+      for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = k[i]; xt[i] = x[i] + k[i] * 0.5; }
+      if (integrator == INTEG_RK3) {
+        T k1[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) k1[i] = k[i];
+        trig_stage<M, T>(P, xt, u, s1, c1, k1[ti] * 0.5, k);
+#pragma unroll
+        for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + 4.0 * k[i]; xt[i] = x[i] - k1[i] + 2.0 * k[i]; }
+        trig_stage<M, T>(P, xt, u, s1, c1, 2.0 * k[ti] - k1[ti], k);
+#pragma unroll
+        for (int i = 0; i < n; ++i) { k[i] = k[i] * h; xn[i] = x[i] + (acc[i] + k[i]) * (1.0 / 6.0); }
+        return;
+      }
+      trig_stage<M, T>(P, xt, u, s1, c1, k[ti] * 0.5, k);
+#pragma unroll
+      for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + 2.0 * k[i]; xt[i] = x[i] + k[i] * 0.5; }
+      trig_stage<M, T>(P, xt, u, s1, c1, k[ti] * 0.5, k);
+#pragma unroll
+      for (int i = 0; i < n; ++i) { k[i] = k[i] * h; acc[i] = acc[i] + 2.0 * k[i]; xt[i] = x[i] + k[i]; }
+      trig_stage<M, T>(P, xt, u, s1, c1, k[ti], k);
+#pragma unroll
+      for (int i = 0; i < n; ++i) { k[i] = k[i] * h; xn[i] = x[i] + (acc[i] + k[i]) * (1.0 / 6.0); }
+      return;
+    }
+  }
   // Stage slopes are folded into a running sum as they are produced (same left-to-right order as
   // x + (k1 + 2k2 + 2k3 + k4)/6), so only {x, xt, k, acc} are live instead of {x, xt, k1..k4}: for the Quadrotor in
   // dual numbers that is the difference between fitting the register file and spilling.
@@ -446,15 +562,6 @@ __device__ __forceinline__ void model_step(const double* P, int integrator_rt, i
   else rk_step<M, T, FIXED>(P, integrator_rt, x, u, h, xn);
 }
 
-// component-wise select (a select between two dual-number objects went through scratch memory in the larger kernels)
-__device__ __forceinline__ double select_t(bool c, double a, double b) { return c ? a : b; }
-__device__ __forceinline__ Dual select_t(bool c, Dual a, Dual b) { return Dual(c ? a.v : b.v, c ? a.d : b.d); }
-template <int K> __device__ __forceinline__ MDual<K> select_t(bool c, MDual<K> a, MDual<K> b) {
-  MDual<K> r; r.v = c ? a.v : b.v;
-#pragma unroll
-  for (int i = 0; i < K; ++i) r.d[i] = c ? a.d[i] : b.d[i];
-  return r;
-}
 
 // The model vector of test/hybrid_dynamics_model.jl:14-52: a 2-D double integrator (4, 2) for the first S = P[1] time steps, a
 // jump map (4, 2) -> 2, x+ = [(x3 + x4)/2, (u1 + u2)/2] (test :31-33; a discrete map here), then a 1-D double integrator (2, 1).
