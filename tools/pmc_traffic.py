@@ -49,6 +49,9 @@ def main(out, build_id, paths):
         if "SQ_INSTS_VALU_FMA_F64_per_launch" in e:  # wave-level FP64 instructions -> flops (64 lanes, FMA = 2)
             e["fp64_flops_per_launch"] = 64.0 * (2.0 * e["SQ_INSTS_VALU_FMA_F64_per_launch"] + e.get("SQ_INSTS_VALU_ADD_F64_per_launch", 0.0)
                                                  + e.get("SQ_INSTS_VALU_MUL_F64_per_launch", 0.0) + e.get("SQ_INSTS_VALU_TRANS_F64_per_launch", 0.0))
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch" in e:  # MOPS counts matrix-core operations in units of 512 flops
+            e["mfma_f64_flops_per_launch"] = 512.0 * e["SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch"]
+            e["fp64_flops_per_launch_incl_mfma"] = e.get("fp64_flops_per_launch", 0.0) + e["mfma_f64_flops_per_launch"]
         res[k] = e
     res["__meta__"] = {"build_id": build_id}
     with open(out, "w") as f:

@@ -54,6 +54,7 @@ struct PnArgs {
 #ifdef TO_PN_HOST
 #define PN_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define PN_SYNC() do { } while (0)
+#define PN_SYNC_LDS() do { } while (0)
 #define PN_FN inline
 #define PN_HD inline
 #else
@@ -65,6 +66,8 @@ struct PnArgs {
   for (int i##_b = 0, i##_n = (n); i##_b < i##_n; i##_b += 64)                   \
     for (int i = (i##_b + lane < i##_n ? i##_b + lane : i##_n - 1), i##_1 = 1; i##_1; i##_1 = 0)
 #define PN_SYNC() __syncthreads()   // the workgroup IS the wave: LDS and workspace writes of a phase become visible to the next
+// ... where the next phase only needs the LDS writes (the horizon sweeps: their workspace stores are read again after the sweep)
+#define PN_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PN_FN __device__ inline
 #define PN_HD __host__ __device__ inline
 #endif
@@ -72,12 +75,16 @@ struct PnArgs {
 PN_FN void pn_upd_max(double& m, double v) { if (v > m || v != v) m = v; }  // NaN sticks (v > NaN is false)
 PN_FN int pn_popc(unsigned long long m) { int c = 0; while (m) { m &= m - 1; ++c; } return c; }
 
+// header of a trajectory's workspace
+enum { PN_H_STATE = 0, PN_H_STEPS = 1, PN_H_VIOL = 2, PN_H_FAILED = 3, PN_HEADER = 8 };
+enum { PN_FRESH = 0, PN_ACTIVE = 1, PN_DONE = 2 };
+
 // vectors of a knot record: d (rhs on the active set), dn (candidate's), dl (multiplier step), r (residual), t (scratch)
 enum { PN_VD = 0, PN_VDN = 1, PN_VDL = 2, PN_VR = 3, PN_VT = 4, PN_NVEC = 5 };
 
 template <class M>
 struct PnRec {
-  double *Z, *Zb, *dZ, *W, *F, *C, *vec, *Ld, *Lo, *loc;
+  double *Z, *Zb, *dZ, *W, *F, *C, *vec, *Mi, *Nf, *Pb, *loc;
   unsigned long long* mask;
   int nbm;  // ne + pak[k]: stride of the record's vectors
   PN_FN double* v(int which) const { return vec + which * nbm; }
@@ -87,7 +94,7 @@ template <class M>
 PN_HD long long pn_rec_size(int pa, int pa_prev, bool first) {
   constexpr int ne = M::ne, nc = M::ne + M::m, nz = M::n + M::m;
   const int nb = ne + pa, nbp = first ? 0 : ne + pa_prev;
-  return 2 * nz + 2 * nc + ne * nc + (long long)pa * nc + PN_NVEC * nb + (long long)nb * nb + (long long)ne * nbp + 4;
+  return 2 * nz + 2 * nc + ne * nc + (long long)pa * nc + PN_NVEC * nb + (long long)nb * nb + (long long)nb * nbp + (long long)nbp * ne + 4;
 }
 template <class M>
 PN_FN PnRec<M> pn_rec(const PnArgs& q, double* w, int k) {
@@ -96,28 +103,28 @@ PN_FN PnRec<M> pn_rec(const PnArgs& q, double* w, int k) {
   PnRec<M> r;
   double* p = w + q.koff[k];
   r.Z = p; p += nz; r.Zb = p; p += nz; r.dZ = p; p += nc; r.W = p; p += nc; r.F = p; p += ne * nc; r.C = p; p += pa * nc;
-  r.vec = p; p += PN_NVEC * nb; r.Ld = p; p += nb * nb; r.Lo = p; p += ne * nbp;
+  r.vec = p; p += PN_NVEC * nb; r.Mi = p; p += nb * nb; r.Nf = p; p += nb * nbp; r.Pb = p; p += nbp * ne;
   r.mask = reinterpret_cast<unsigned long long*>(p); r.loc = p + 1;
   r.nbm = nb;
   return r;
 }
 
-// LDS of one wave (doubles): two diagonal blocks, the coupling block, the knot's Jacobian rows and metric, two vectors, a
+// LDS of one wave (doubles): three diagonal blocks (inverse factors of the previous and the current knot, work), the coupling block, the knot's Jacobian rows and metric, two vectors, a
 // 64-entry reduction buffer
 struct PnLds {
-  double *LA, *LB, *Lo, *F, *Ca, *Cb, *Wa, *Wb, *va, *vb, *red;
+  double *LA, *LB, *LW, *Lo, *F, *Ca, *Cb, *Wa, *Wb, *va, *vb, *red;
   int NB;
 };
 template <class M>
 PN_HD long long pn_lds_doubles(int NB) {
   constexpr int ne = M::ne, nc = M::ne + M::m;
-  return 2LL * NB * NB + (long long)ne * NB + ne * nc + 2LL * (NB - ne) * nc + 2 * nc + 2 * NB + 64;
+  return 3LL * NB * NB + (long long)ne * NB + ne * nc + 2LL * (NB - ne) * nc + 2 * nc + 2 * NB + 64;
 }
 template <class M>
 PN_FN PnLds pn_lds(double* p, int NB) {
   constexpr int ne = M::ne, nc = M::ne + M::m;
   PnLds l; l.NB = NB;
-  l.LA = p; p += NB * NB; l.LB = p; p += NB * NB; l.Lo = p; p += ne * NB; l.F = p; p += ne * nc;
+  l.LA = p; p += NB * NB; l.LB = p; p += NB * NB; l.LW = p; p += NB * NB; l.Lo = p; p += ne * NB; l.F = p; p += ne * nc;
   l.Ca = p; p += (NB - ne) * nc; l.Cb = p; p += (NB - ne) * nc; l.Wa = p; p += nc; l.Wb = p; p += nc;
   l.va = p; p += NB; l.vb = p; p += NB; l.red = p;
   return l;
@@ -255,36 +262,35 @@ PN_FN double pn_eval(const PnArgs& q, double* w, const PnLds& L, const double* x
   return pn_reduce_max<M>(q, w, L PN_LANE_ARG);
 }
 
-// inverse metric of knot k: 1 / (max(diag of the error-state OBJECTIVE Hessian, 0) + rho_primal)
+// inverse metric of knot k, entry j of nc: 1 / (max(diag of the error-state OBJECTIVE Hessian, 0) + rho_primal)
 template <class M>
-PN_FN void pn_metric(const DevProblem& P, int k, const double* z, bool terminal, double* W) {
+PN_FN double pn_metric_dir(const DevProblem& P, int k, const double* z, bool terminal, int j) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m;
   CostC& C = P.costs[P.cost_index[k]];
   const double sc = (P.opts.cost_dt_scaling && !terminal) ? P.dt[k] : 1.0;
   double v[nz], g[nz], y[nz];
-  for (int j = 0; j < ne; ++j) {
-    errstate_col<M>(z, j, v);
-    for (int i = n; i < nz; ++i) v[i] = 0.0;
-    cost_grad_hvp<n, m, true>(C, z, z + n, terminal, v, g, y);
-    double dj = 0.0;
-    for (int i = 0; i < n; ++i) dj += v[i] * y[i];
-    if constexpr (M::att == ATT_QUAT) {  // second-order term of the attitude map: -I3 (q' dJ/dq)
-      if (j >= 3 && j < 6) { double b1 = 0.0; for (int i = 0; i < 4; ++i) b1 += z[3 + i] * g[3 + i]; dj -= b1; }
-    } else if constexpr (M::att == ATT_MRP || M::att == ATT_RP) {
-      if (j >= 3 && j < 6) { double H2[9]; att_differential2<M::att>(z + 3, g + 3, H2); dj += H2[4 * (j - 3)]; }
-    }
-    W[j] = 1.0 / (fmax(dj * sc, 0.0) + P.opts.rho_primal);
+  errstate_col<M>(z, j < ne ? j : 0, v);
+  for (int i = 0; i < n; ++i) v[i] = (j < ne) ? v[i] : 0.0;
+  for (int i = n; i < nz; ++i) v[i] = (i == n + j - ne) ? 1.0 : 0.0;
+  cost_grad_hvp<n, m, true>(C, z, z + n, terminal, v, g, y);
+  double dj = 0.0;
+  for (int i = 0; i < nz; ++i) dj += v[i] * y[i];
+  if constexpr (M::att == ATT_QUAT) {  // second-order term of the attitude map: -I3 (q' dJ/dq)
+    double b1 = 0.0;
+    for (int i = 0; i < 4; ++i) b1 += z[3 + i] * g[3 + i];
+    dj -= (j >= 3 && j < 6) ? b1 : 0.0;
+  } else if constexpr (M::att == ATT_MRP || M::att == ATT_RP) {
+    double H2[9];
+    att_differential2<M::att>(z + 3, g + 3, H2);
+    const int jj = (j >= 3 && j < 6) ? j - 3 : 0;
+    dj += (j >= 3 && j < 6) ? H2[4 * jj] : 0.0;
   }
-  for (int j = 0; j < m; ++j) {
-    for (int i = 0; i < nz; ++i) v[i] = (i == n + j) ? 1.0 : 0.0;
-    cost_grad_hvp<n, m, true>(C, z, z + n, terminal, v, g, y);
-    W[ne + j] = terminal ? 0.0 : 1.0 / (fmax(y[n + j] * sc, 0.0) + P.opts.rho_primal);
-  }
+  return (terminal && j >= ne) ? 0.0 : 1.0 / (fmax(dj * sc, 0.0) + P.opts.rho_primal);
 }
 
 // Linearisation, item by item (one lane per item).  k_pn_lin_col, items [0, (N-1) nc): column j of the error-state Jacobian [A B]
 // of step k by a dual number through the RK stages (ForwardDiff-equivalent, like k_expand), stored in the record of the knot the
-// defect arrives at.  k_pn_lin_knot, items [0, N): metric and active constraint rows of a knot.
+// defect arrives at.  k_pn_lin_knot, one wave per knot: metric (lane = entry) and active constraint rows of the knot.
 template <class M>
 PN_FN void pn_lin_column(const PnArgs& q, double* w, int it) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
@@ -304,13 +310,13 @@ PN_FN void pn_lin_column(const PnArgs& q, double* w, int it) {
   errstate_invmul<M>(Rn.Z, y, col);
   for (int i = 0; i < ne; ++i) Rn.F[i * nc + j] = col[i];
 }
+// active constraint rows of knot k in error-state coordinates
 template <class M>
-PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
+PN_FN void pn_lin_rows(const PnArgs& q, double* w, int k) {
   constexpr int nc = M::ne + M::m;
   const DevProblem& P = q.a.P;
   const PnRec<M> R = pn_rec<M>(q, w, k);
   const bool terminal = (k == P.N - 1);
-  pn_metric<M>(P, k, R.Z, terminal, R.W);
   const unsigned long long mask = *R.mask;
   int na = 0;
   pn_for_candidates<M, true>(P, k, R.Z, [&](int qi, double, const double* gz, bool) {
@@ -319,13 +325,28 @@ PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
     ++na;
   });
 }
+#ifdef TO_PN_HOST
+template <class M>
+PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
+  constexpr int nc = M::ne + M::m;
+  const PnRec<M> R = pn_rec<M>(q, w, k);
+  for (int j = 0; j < nc; ++j) R.W[j] = pn_metric_dir<M>(q.a.P, k, R.Z, k == q.a.P.N - 1, j);
+  pn_lin_rows<M>(q, w, k);
+}
+#endif
 
-// block-tridiagonal Cholesky factor of S + rho I, S = D W D', into the records (Ld, Lo).  false: a pivot was not positive.
+// Block-tridiagonal Cholesky factor of S + rho I, S = D W D': L_k,k-1 = S_k,k-1 L_k-1^-T, L_k = chol(S_kk + rho I - L_k,k-1 L_k,k-1').
+// What the records keep is what the SOLVES need — they run several times per factorisation and walk the horizon knot after
+// knot, so a knot must cost them one phase, not one per column: the INVERSE of every diagonal factor block,
+//   Mi_k = L_k^-1,   Nf_k = Mi_k[:, 0:ne] L_k,k-1   (forward: y_k = Mi_k b_k - Nf_k y_k-1),
+//   Pb_k = Mi_k-1' L_k,k-1'                          (backward: x_k-1 = Mi_k-1' y_k-1 - Pb_k x_k[0:ne]).
+// (Triangular blocks of 13...21 rows with condition numbers around 1e3: the explicit inverse costs ~1e-13 against substitution,
+// far inside what reg_solve's refinement corrects.)  false: a pivot was not positive.
 template <class M>
 PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_LANE_PARAM) {
   constexpr int ne = M::ne, nc = M::ne + M::m;
   const int N = q.a.P.N, NB = L.NB;
-  double *Lc = L.LA, *Lp = L.LB, *Cc = L.Ca, *Cp = L.Cb, *Wc = L.Wa, *Wp = L.Wb;
+  double *Mc = L.LA, *Mp = L.LB, *Lc = L.LW, *Cc = L.Ca, *Cp = L.Cb, *Wc = L.Wa, *Wp = L.Wb;
   int nbp = 0;
   for (int k = 0; k < N; ++k) {
     const PnRec<M> R = pn_rec<M>(q, w, k);
@@ -347,28 +368,33 @@ PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_L
         Lc[i * NB + j] = v + (i == j ? rho : 0.0);
       }
     }
-    if (k > 0) {
+    if (k > 0) {  // S_k,k-1 (its ne defect rows) into R.Nf's place-holder in LDS: Mc is free until the inverse is formed
       PN_FOR(e, ne * nbp) {
         const int i = e / nbp, j = e % nbp;
         double v = 0.0;
         if (j < ne) v = sgp * L.F[i * nc + j] * Wp[j];
         else for (int c = 0; c < nc; ++c) v += L.F[i * nc + c] * Wp[c] * Cp[(j - ne) * nc + c];
-        L.Lo[i * NB + j] = v;
+        Mc[i * NB + j] = v;
       }
     }
     PN_SYNC();
     if (k > 0) {
-      PN_FOR(i, ne) {  // L_k,k-1 = S_k,k-1 L_k-1^-T, one row per lane
-        for (int j = 0; j < nbp; ++j) {
-          double v = L.Lo[i * NB + j];
-          for (int t = 0; t < j; ++t) v -= L.Lo[i * NB + t] * Lp[j * NB + t];
-          L.Lo[i * NB + j] = v / Lp[j * NB + j];
-        }
+      PN_FOR(e, ne * nbp) {  // L_k,k-1 = S_k,k-1 Mi_k-1'  (Mi lower triangular: column j of Mi' is row j of Mi, entries t <= j)
+        const int i = e / nbp, j = e % nbp;
+        double v = 0.0;
+        for (int t = 0; t <= j; ++t) v += Mc[i * NB + t] * Mp[j * NB + t];
+        L.Lo[i * NB + j] = v;
       }
       PN_SYNC();
       PN_FOR(e, ne * ne) {
         const int i = e / ne, j = e % ne;
         if (j <= i) { double v = 0.0; for (int t = 0; t < nbp; ++t) v += L.Lo[i * NB + t] * L.Lo[j * NB + t]; Lc[i * NB + j] -= v; }
+      }
+      PN_FOR(e, nbp * ne) {  // Pb_k = Mi_k-1' L_k,k-1'  (nbp x ne)
+        const int j = e / ne, i = e % ne;
+        double v = 0.0;
+        for (int t = j; t < nbp; ++t) v += Mp[t * NB + j] * L.Lo[i * NB + t];
+        R.Pb[e] = v;
       }
       PN_SYNC();
     }
@@ -385,66 +411,69 @@ PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_L
       }
       PN_SYNC();
     }
-    PN_FOR(e, nb * nb) { const int i = e / nb, j = e % nb; R.Ld[e] = (j <= i) ? Lc[i * NB + j] : 0.0; }
-    if (k > 0) PN_FOR(e, ne * nbp) R.Lo[e] = L.Lo[(e / nbp) * NB + e % nbp];
+    PN_FOR(j, nb) {  // Mi_k = L_k^-1, one column per lane (forward substitution on e_j)
+      for (int i = 0; i < nb; ++i) {
+        double v = (i == j) ? 1.0 : 0.0;
+        for (int t = j; t < i; ++t) v -= Lc[i * NB + t] * Mc[t * NB + j];
+        Mc[i * NB + j] = (i < j) ? 0.0 : v / Lc[i * NB + i];
+      }
+    }
+    PN_SYNC();
+    PN_FOR(e, nb * nb) R.Mi[e] = Mc[(e / nb) * NB + e % nb];
+    if (k > 0) PN_FOR(e, nb * nbp) {  // Nf_k = Mi_k[:, 0:ne] L_k,k-1
+      const int i = e / nbp, j = e % nbp;
+      double v = 0.0;
+      for (int t = 0; t < ne && t <= i; ++t) v += Mc[i * NB + t] * L.Lo[t * NB + j];
+      R.Nf[e] = v;
+    }
     PN_SYNC();
     double* t;
-    t = Lc; Lc = Lp; Lp = t; t = Cc; Cc = Cp; Cp = t; t = Wc; Wc = Wp; Wp = t;
+    t = Mc; Mc = Mp; Mp = t; t = Cc; Cc = Cp; Cp = t; t = Wc; Wc = Wp; Wp = t;
     nbp = nb;
   }
   return true;
 }
 
-// (L L') x = b in place on vector `which` of the records
+// (L L') x = b in place on vector `which` of the records: one phase per knot and direction (see pn_factor); inside a sweep only the
+// LDS traffic is ordered (the stores to the workspace vector are read again by the NEXT sweep, behind a full barrier).
 template <class M>
 PN_FN void pn_chol_solve(const PnArgs& q, double* w, const PnLds& L, int which PN_LANE_PARAM) {
   constexpr int ne = M::ne;
-  const int N = q.a.P.N, NB = L.NB;
-  double *yc = L.va, *yp = L.vb, *Lc = L.LA;
+  const int N = q.a.P.N;
+  double *yc = L.va, *yp = L.vb;
   int nbp = 0;
-  for (int k = 0; k < N; ++k) {  // forward: L y = b
+  for (int k = 0; k < N; ++k) {  // forward: y_k = Mi_k b_k - Nf_k y_k-1
     const PnRec<M> R = pn_rec<M>(q, w, k);
     const int nb = ne + pn_popc(*R.mask);
     double* v = R.v(which);
-    PN_FOR(e, nb * nb) Lc[(e / nb) * NB + e % nb] = R.Ld[e];
-    if (k > 0) PN_FOR(e, ne * nbp) L.Lo[(e / nbp) * NB + e % nbp] = R.Lo[e];
-    PN_FOR(i, nb) yc[i] = v[i];
-    PN_SYNC();
-    if (k > 0) {
-      PN_FOR(i, ne) { double s = 0.0; for (int t = 0; t < nbp; ++t) s += L.Lo[i * NB + t] * yp[t]; yc[i] -= s; }
-      PN_SYNC();
+    PN_FOR(i, nb) {
+      double s = 0.0;
+      for (int t = 0; t <= i; ++t) s += R.Mi[i * nb + t] * v[t];
+      if (k > 0) for (int t = 0; t < nbp; ++t) s -= R.Nf[i * nbp + t] * yp[t];
+      yc[i] = s;
     }
-    for (int j = 0; j < nb; ++j) {
-      const double yj = yc[j] / Lc[j * NB + j];
-      PN_FOR(i, nb - j) { if (i == 0) yc[j] = yj; else yc[j + i] -= Lc[(j + i) * NB + j] * yj; }
-      PN_SYNC();
-    }
+    PN_SYNC();   // (the rows above read v of the whole knot before any lane overwrites its entry)
     PN_FOR(i, nb) v[i] = yc[i];
-    PN_SYNC();
     double* t = yc; yc = yp; yp = t;
     nbp = nb;
   }
-  for (int k = N - 1; k >= 0; --k) {  // backward: L' x = y
+  PN_SYNC();
+  for (int k = N - 1; k >= 0; --k) {  // backward: x_k = Mi_k' y_k - Pb_k+1 x_k+1[0:ne]
     const PnRec<M> R = pn_rec<M>(q, w, k);
     const int nb = ne + pn_popc(*R.mask);
     double* v = R.v(which);
-    PN_FOR(e, nb * nb) Lc[(e / nb) * NB + e % nb] = R.Ld[e];
-    if (k < N - 1) { const PnRec<M> Rn = pn_rec<M>(q, w, k + 1); PN_FOR(e, ne * nb) L.Lo[(e / nb) * NB + e % nb] = Rn.Lo[e]; }
-    PN_FOR(i, nb) yc[i] = v[i];
+    const double* Pb = (k < N - 1) ? pn_rec<M>(q, w, k + 1).Pb : R.Pb;
+    PN_FOR(i, nb) {
+      double s = 0.0;
+      for (int t = i; t < nb; ++t) s += R.Mi[t * nb + i] * v[t];
+      if (k < N - 1) for (int t = 0; t < ne; ++t) s -= Pb[i * ne + t] * yp[t];
+      yc[i] = s;
+    }
     PN_SYNC();
-    if (k < N - 1) {
-      PN_FOR(j, nb) { double s = 0.0; for (int i = 0; i < ne; ++i) s += L.Lo[i * NB + j] * yp[i]; yc[j] -= s; }
-      PN_SYNC();
-    }
-    for (int j = nb - 1; j >= 0; --j) {
-      const double xj = yc[j] / Lc[j * NB + j];
-      PN_FOR(i, j + 1) { if (i == j) yc[j] = xj; else yc[i] -= Lc[j * NB + i] * xj; }
-      PN_SYNC();
-    }
     PN_FOR(i, nb) v[i] = yc[i];
-    PN_SYNC();
     double* t = yc; yc = yp; yp = t;
   }
+  PN_SYNC();
 }
 
 // dZ = -W D' lambda (lambda = vector `which`)
@@ -524,10 +553,6 @@ PN_FN void pn_reg_solve(const PnArgs& q, double* w, const PnLds& L PN_LANE_PARAM
     PN_SYNC();
   }
 }
-
-// header of a trajectory's workspace
-enum { PN_H_STATE = 0, PN_H_STEPS = 1, PN_H_VIOL = 2, PN_H_FAILED = 3, PN_HEADER = 8 };
-enum { PN_FRESH = 0, PN_ACTIVE = 1, PN_DONE = 2 };
 
 // Round `round` of the polish of trajectory b, first part: (round 0: fetch the trajectory;) fresh active set and its violation; if
 // that is within constraint_tolerance, the budget of n_steps + 1 linearisations is spent (Altro projection_solve!: while count
@@ -664,11 +689,19 @@ __global__ void __launch_bounds__(64) k_pn_lin_col(PnArgs q) {
   if (w[PN_H_STATE] != (double)PN_ACTIVE) return;
   pn_lin_column<M>(q, w, min((int)(blockIdx.y * 64 + threadIdx.x), (q.a.P.N - 1) * nc - 1));
 }
+// one WAVE per knot (grid.y = N): the knot's cost and constraint descriptors are wave-uniform then — scalar loads, uniform
+// branches (with a lane per knot the dense-cost branches of lanes on differently-costed knots diverged around the register-hungry
+// ErrorQuadratic duals, exactly where hipcc's spill placement is unsafe: DESIGN.md §6).  Lane j < nc owns metric entry j; the
+// active rows are built by every lane alike (same values to the same addresses).
 template <class M>
 __global__ void __launch_bounds__(64) k_pn_lin_knot(PnArgs q) {
+  constexpr int nc = M::ne + M::m;
   double* w = q.ws + (size_t)blockIdx.x * (size_t)q.koff[q.a.P.N];
   if (w[PN_H_STATE] != (double)PN_ACTIVE) return;
-  pn_lin_knot<M>(q, w, min((int)(blockIdx.y * 64 + threadIdx.x), q.a.P.N - 1));
+  const int k = blockIdx.y, j = min((int)threadIdx.x, nc - 1);
+  const PnRec<M> R = pn_rec<M>(q, w, k);
+  R.W[j] = pn_metric_dir<M>(q.a.P, k, R.Z, k == q.a.P.N - 1, j);
+  pn_lin_rows<M>(q, w, k);
 }
 
 // max |x_1 (-) x0|, |f(x_k, u_k) (-) x_{k+1}| of the nominal trajectory (to_dynamics_defect): one lane per trajectory

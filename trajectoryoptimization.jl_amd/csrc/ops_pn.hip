@@ -57,7 +57,7 @@ int op_pn(to_handle* h, const int* list, int count) {
   q.it_pn = h->a.it_pn; q.cmax_out = h->a.pn_cmax;
   const size_t lds = sizeof(double) * (size_t)pn_lds_doubles<M>(nbmax);
   constexpr int nc = M::ne + M::m;
-  const int col_blocks = ((N - 1) * nc + 63) / 64, knot_blocks = (N + 63) / 64;
+  const int col_blocks = ((N - 1) * nc + 63) / 64, knot_blocks = N;
   for (int base = 0; base < count; base += chunk) {
     q.base = base;
     const int cnt = std::min(chunk, count - base);
