@@ -2,8 +2,8 @@
 # A/B: default build (-ffp-contract=fast, hipcc's default) vs -ffp-contract=on: bit-identity of the two forward kernels, bench lines
 mkdir -p gpurun_out/ab_contract
 L=trajectoryoptimization.jl_amd/csrc
-python tools/scratch/fwd2_bitwise.py > gpurun_out/ab_contract/bitwise_default.txt 2>&1
-TRAJOPT_HIP_LIBRARY=$PWD/$L/libtrajopt_hip_contract_on.so python tools/scratch/fwd2_bitwise.py > gpurun_out/ab_contract/bitwise_on.txt 2>&1
+python tools/ab/fwd2_bitwise.py > gpurun_out/ab_contract/bitwise_default.txt 2>&1
+TRAJOPT_HIP_LIBRARY=$PWD/$L/libtrajopt_hip_contract_on.so python tools/ab/fwd2_bitwise.py > gpurun_out/ab_contract/bitwise_on.txt 2>&1
 for rep in 1 2; do
 for lib in libtrajopt_hip libtrajopt_hip_contract_on; do
   for w in cartpole quadrotor quadrotor_al; do
