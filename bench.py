@@ -107,11 +107,36 @@ def kernel_split_bytes(n, m, ne, N, duals):
     return {"expand": xu + ab + 8 * duals, "backward": ab + kd, "forward": kd + xu + 8 * duals}
 
 
+def physical_cores():
+    """(physical cores, logical CPUs) this process may run on: distinct (package, core) pairs of /proc/cpuinfo among the CPUs of
+    the affinity mask."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    cores, cpu, phys = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                cpu, phys = int(val), None
+            elif key == "physical id":
+                phys = val
+            elif key == "core id" and cpu in allowed:
+                cores.add((phys, val))
+    except OSError:
+        pass
+    return (len(cores) or len(allowed)), len(allowed)
+
+
+HOST_CORES = physical_cores()
+
+
 def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
-    """Oracle (port) on the host cores, bounded sample of the same workload."""
+    """Oracle (port) on the host cores, bounded sample of the same workload.  One OpenMP thread per PHYSICAL core, pinned
+    (OMP_PLACES=cores, OMP_PROC_BIND=close: set in main() before the OpenMP runtime starts)."""
     from oracle_binding import load_oracle_native, set_threads
     o, flags = load_oracle_native()
-    threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
+    phys, logical = HOST_CORES   # taken at start-up: OMP_PROC_BIND binds the main thread later, which shrinks its own affinity mask
+    threads = max(1, min(o.max_threads(), phys))
     sample = min(batch, 1024 if name == "cartpole" else 256 if name == "quadrotor" else 128)
     Solver = lambda pr: make_solver(T, configs, name, pr)
     prob = build_problem(T, configs, name, sample, 0, 0, o)
@@ -138,6 +163,8 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     single = {"value": s1.total_iterations / d1, "cores": 1,
               "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms (best of 5 after a warm call)"}
     return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "build": flags, "single_thread": single,
+            "physical_cores": phys, "logical_cpus": logical, "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core",
+            "parallel_speedup_over_one_thread": (solver.total_iterations / dt) / single["value"],
             "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve after a warm call, "
                       f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
 
@@ -212,6 +239,33 @@ def roofline_block(configs, name, batch, dims, iters, value_per_gpu, kms, kln, b
             "whole_iteration": {"algorithmic_bytes_per_unit": bytes_it,
                                 "achieved": bytes_it * value_per_gpu / 1e9,
                                 "frac": bytes_it * value_per_gpu / 1e9 / HBM_PEAK_GBS}}
+
+
+def overlap_run(T, configs, lib, name, batch, parts, device):
+    """The same batch as `parts` contiguous sub-batches, each on its own handle (= its own stream and worker thread), all solves in
+    flight at once.  A solve is batch-synchronous and its batch drains unevenly (C3: 141 batch steps for a mean of 52 iterations);
+    the drained tail of one sub-batch leaves most of the chip to the others.  Results are those of the single handle (a
+    trajectory's result does not depend on its batch).  Reported next to the headline, never as the headline."""
+    sizes = [batch // parts + (1 if i < batch % parts else 0) for i in range(parts)]
+    offs = [sum(sizes[:i]) for i in range(parts)]
+    probs = [build_problem(T, configs, name, sz, off, device, lib) for sz, off in zip(sizes, offs)]
+    solvers = [make_solver(T, configs, name, p) for p in probs]
+    u0 = initial_controls_value(T, probs[0], name)
+    best = None
+    for rep in range(3):
+        for p in probs:
+            T.initial_controls(p, u0)
+        t0 = time.perf_counter()
+        for s in solvers:
+            s.solve_async()
+        for s in solvers:
+            s.wait()
+        dt = time.perf_counter() - t0
+        its = sum(int(s.total_iterations) for s in solvers)
+        if best is None or dt < best[0]:
+            best = (dt, its)
+    return {"handles": parts, "sub_batches": sizes, "value": best[1] / best[0], "unit": "trajectory-iterations/s", "ms": 1e3 * best[0],
+            "trajectory_iterations": best[1], "note": "best of 3; sub-batches solved concurrently through to_*_solve_async on separate streams"}
 
 
 def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True):
@@ -307,6 +361,9 @@ def main():
                     help="skip the batch sweep (2x ... 64x the probe batch) that locates the throughput plateau")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate hipEvent-profiled pass (no roofline object)")
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="also solve the workload as this many sub-batches on as many handles / streams in flight at once (to_*_solve_async): "
+                         "what overlapping the drained tails recovers; reported separately under \"overlap\", never the headline")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: everything native code prints while we run (RCCL's version banner
@@ -315,6 +372,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("OMP_PLACES", "cores")       # the cpu_baseline leg: pinned threads (read when the OpenMP runtime starts)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
     import torch
     import trajopt_amd as T
     from trajectoryoptimization_jl_amd import configs
@@ -376,6 +435,8 @@ def main():
                         break
                 best = max((r for r in sweep if "value" in r), key=lambda r: r["value"])
                 out["throughput_sweep"] = {"points": sweep, "plateau": {k: best[k] for k in ("batch", "value", "whole_iteration_frac")}}
+        if args.overlap > 1:
+            out["overlap"] = overlap_run(T, configs, lib, name, batch, args.overlap, local_rank)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(T, configs, name, batch)

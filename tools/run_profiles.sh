@@ -21,5 +21,5 @@ cp $(find "$out/kt" -name '*kernel_stats.csv' | head -1) "$out/kernel_stats.csv"
 # the plain bench line quotes the traffic just measured: bench.py reads profiles/*_<workload>_b<batch>_hbm_traffic_pmc.json and
 # only accepts a file stamped with the build id of the library it loaded (PROFILE_COPY = that file name, e.g. r03_cartpole_b1024)
 if [ -n "${PROFILE_COPY:-}" ]; then cp "$out/hbm_traffic_pmc.json" "profiles/${PROFILE_COPY}_hbm_traffic_pmc.json"; fi
-python bench.py "$@" --no-extra --no-probe-sweep --throughput-probe 0 > "$out/bench.json" 2> "$out/bench.log"
+python bench.py "$@" --no-extra --no-probe-sweep --throughput-probe 0 ${FINAL_FLAGS:-} > "$out/bench.json" 2> "$out/bench.log"
 tail -c 600 "$out/bench.json"
