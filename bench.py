@@ -130,6 +130,22 @@ def physical_cores():
 HOST_CORES = physical_cores()
 
 
+def cgroup_cpu_quota():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown: a box can
+    SHOW 128 cores and grant a dozen — which caps what any number of OpenMP threads delivers."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     """Oracle (port) on the host cores, bounded sample of the same workload.  One OpenMP thread per PHYSICAL core, pinned
     (OMP_PLACES=cores, OMP_PROC_BIND=close: set in main() before the OpenMP runtime starts)."""
@@ -163,7 +179,7 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     single = {"value": s1.total_iterations / d1, "cores": 1,
               "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms (best of 5 after a warm call)"}
     return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "build": flags, "single_thread": single,
-            "physical_cores": phys, "logical_cpus": logical, "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core",
+            "physical_cores": phys, "logical_cpus": logical, "cgroup_cpu_quota_cores": cgroup_cpu_quota(), "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core",
             "parallel_speedup_over_one_thread": (solver.total_iterations / dt) / single["value"],
             "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve after a warm call, "
                       f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
@@ -462,6 +478,15 @@ def main():
             except Exception as e:
                 extra[key] = {"error": repr(e)}
         out["extra_workloads"] = extra
+    # Launched by torch.distributed.run (the N > 1 case): BASELINE config C4 alongside the headline — the Quadrotor point-to-point
+    # workload sharded 4096 trajectories per GPU (with 8 ranks: exactly C4's 32 768), same weak-scaling protocol, same RCCL gathers.
+    if dist is not None and name == "cartpole" and not args.batch and not args.no_extra:
+        r4, p4, _ = run_workload(T, configs, lib, "quadrotor", WORKLOADS["quadrotor"]["batch"], 2, 1, rank, local_rank, world, dist, torch,
+                                 profile=False)
+        del p4
+        if rank == 0:
+            r4["config"]["workload"] = "C4: " + r4["config"]["workload"] + f" x {world} ranks = {world * WORKLOADS['quadrotor']['batch']} trajectories, RCCL all-gather per solve"
+            out.setdefault("extra_workloads", {})["C4"] = r4
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
