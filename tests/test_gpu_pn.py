@@ -234,3 +234,24 @@ def test_full_size_C5prime_quatvec_goal_altro_vs_oracle(hip, oracle):
     print(f"C5' ALTRO: converged {ok.mean():.4f}; projections {np.bincount(sh.stats['iterations_pn'])}; iterations {sh.total_iterations}")
     assert ok.mean() >= 0.98
     assert np.abs(np.abs(qN @ qf) - 1.0).max() < 1e-10      # the attitude arrived (up to the quaternion's sign)
+
+
+def test_pn_without_constraints_and_minimal_horizon(hip, oracle):
+    """no constraint list: the active set is the initial condition + the dynamics defects; a rollout is left untouched; N = 3"""
+    for N, tf in ((31, 1.5), (3, 0.1)):
+        ph, po = configs.cartpole_problem(batch=70, N=N, tf=tf, lib=hip), configs.cartpole_problem(batch=70, N=N, tf=tf, lib=oracle)
+        T.rollout(ph); T.rollout(po)
+        X0 = T.states(po).copy()
+        s = T.ProjectedNewtonSolver(ph).solve()
+        assert np.all(s.stats["iterations_pn"] == 0) and np.all(s.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+        np.testing.assert_allclose(T.states(ph), X0, rtol=0, atol=1e-13)
+        rng = np.random.default_rng(N)
+        Xp = X0 + 1e-3 * rng.normal(size=X0.shape)
+        for p in (ph, po):
+            T.initial_states(p, Xp)
+        sh, so = T.ProjectedNewtonSolver(ph).solve(), T.ProjectedNewtonSolver(po).solve()
+        for k in ("iterations_pn", "status"):
+            np.testing.assert_array_equal(sh.stats[k], so.stats[k])
+        np.testing.assert_allclose(T.states(ph), T.states(po), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(T.controls(ph), T.controls(po), rtol=0, atol=1e-9)
+        assert sh.stats["c_max"].max() <= 1e-6 and T.dynamics_defect(ph).max() <= 1e-6

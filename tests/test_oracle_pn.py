@@ -344,3 +344,22 @@ def test_altro_small_quadrotor_batch_converges(oracle):
     sa = T.ALSolver(build()).solve()   # the AL stage alone: 30 outer iterations on half of them, twice the iLQR iterations
     assert np.sum(sa.stats["status"] == T.capi.SOLVE_SUCCEEDED) < 8
     assert s.stats["iterations"].sum() < sa.stats["iterations"].sum()
+
+
+def test_polish_of_an_unconstrained_problem_and_of_a_minimal_horizon(oracle):
+    """Without a constraint list the active set is the initial condition and the dynamics defects alone: a rollout is left untouched
+    (0 projections), a perturbed trajectory is projected back onto the dynamics.  N = 3: the smallest horizon with an interior knot."""
+    for N, tf in ((31, 1.5), (3, 0.1)):
+        prob = configs.cartpole_problem(batch=2, N=N, tf=tf, lib=oracle)
+        T.rollout(prob)
+        X0 = T.states(prob).copy()
+        s = T.ProjectedNewtonSolver(prob).solve()
+        assert np.all(s.stats["iterations_pn"] == 0) and np.all(s.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+        np.testing.assert_array_equal(T.states(prob), X0)
+        rng = np.random.default_rng(N)
+        T.initial_states(prob, X0 + 1e-3 * rng.normal(size=X0.shape))
+        assert T.dynamics_defect(prob).min() > 1e-5
+        s = T.ProjectedNewtonSolver(prob).solve()
+        assert np.all(s.stats["iterations_pn"] >= 1) and np.all(s.stats["status"] == T.capi.SOLVE_SUCCEEDED)
+        assert T.dynamics_defect(prob).max() <= 1e-6 and s.stats["c_max"].max() <= 1e-6
+        np.testing.assert_allclose(T.states(prob)[:, 0], prob.x0 if hasattr(prob, "x0") else X0[:, 0], atol=1e-6)

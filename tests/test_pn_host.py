@@ -91,3 +91,18 @@ def test_kernel_source_on_host_matches_oracle(name, pn_host, oracle):
     np.testing.assert_allclose(Uh, Uo, rtol=0, atol=1e-9)
     np.testing.assert_allclose(cmh, s.stats["c_max"], rtol=0, atol=1e-9)
     assert cmh.max() <= 1e-6
+
+
+def test_kernel_on_host_unconstrained_and_minimal_horizon(pn_host, oracle):
+    """no constraint list (defects only) and N = 3: the kernel source against the oracle"""
+    for N, tf in ((31, 1.5), (3, 0.1)):
+        prob = configs.cartpole_problem(batch=2, N=N, tf=tf, lib=oracle)
+        T.rollout(prob)
+        X0 = T.states(prob).copy()
+        rng = np.random.default_rng(N)
+        T.initial_states(prob, X0 + 1e-3 * rng.normal(size=X0.shape))
+        Xh, Uh, sth, iph, cmh = host_polish(pn_host, prob)
+        s = T.ProjectedNewtonSolver(prob).solve()
+        assert np.array_equal(sth, s.stats["status"]) and np.array_equal(iph, s.stats["iterations_pn"]) and np.all(iph >= 1)
+        np.testing.assert_allclose(Xh, T.states(prob), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(Uh, T.controls(prob), rtol=0, atol=1e-10)
