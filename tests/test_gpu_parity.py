@@ -1193,6 +1193,104 @@ def test_two_wave_forward_pass(width, hip, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("two", ["0", "1"])
+@pytest.mark.parametrize("width", [4, 8])
+def test_line_search_repack(width, two, hip, monkeypatch):
+    """The repacked last round of the line search (k_forward.h LsRound: the trajectories of a wave that are still searching after
+    the rounds of the static map share all 64 lanes for the remaining step sizes) against rounds of the static map only
+    (TRAJOPT_LS_REPACK=0): BIT-IDENTICAL accepted steps, costs and trajectories — through the phase API on a constrained
+    Quadrotor batch with dual updates (deep searches, failed searches), one-wave and two-wave kernels, then whole AL solves."""
+    monkeypatch.setenv("TRAJOPT_LS_DEEP", "0")
+    monkeypatch.setenv("TRAJOPT_LS_CANDIDATES", str(width))
+    monkeypatch.setenv("TRAJOPT_FWD2", two)
+    probs = []
+    for rp in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_LS_REPACK", rp)
+        o = T.SolverOptions(lib=hip, constraint_tolerance=1e-4)
+        p = configs.quadrotor_problem(batch=44, N=101, tf=5.0, constrained=True, lib=hip, options=o)
+        T.rollout(p)
+        probs.append(p)
+    deep = 0
+    for it in range(40):
+        out = []
+        for p in probs:
+            if it % 12 == 11:
+                I.dual_update(p)
+            I.expand(p); I.backwardpass(p)
+            ls, J = I.forwardpass(p)
+            out.append((ls, J, T.states(p), T.controls(p)))
+        (l0, J0, X0, U0), (l1, J1, X1, U1) = out
+        np.testing.assert_array_equal(l0, l1, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(J1, J0, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(X1, X0, err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(U1, U0, err_msg=f"iteration {it}")
+        deep += int((l0 >= width).sum()) + int((l0 < 0).sum())
+    assert deep > 20, "the searches never went past the first round"
+    sols = []
+    for rp in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_LS_REPACK", rp)
+        o = T.SolverOptions(lib=hip, constraint_tolerance=1e-4)
+        pc = configs.quadrotor_problem(batch=40, N=101, tf=5.0, constrained=True, lib=hip, options=o)
+        sc = T.ALSolver(pc).solve()
+        sols.append((sc.stats, T.states(pc), T.controls(pc)))
+    for k in ("iterations", "status", "cost"):
+        np.testing.assert_array_equal(sols[0][0][k], sols[1][0][k], err_msg=k)
+    np.testing.assert_array_equal(sols[0][1], sols[1][1])
+    np.testing.assert_array_equal(sols[0][2], sols[1][2])
+
+
+def _mrp_quadrotor(lib, constrained, batch, N=41, tf=2.0):
+    model = T.Quadrotor(rotation="mrp")
+    n, m = model.dims()
+    th = math.radians(70.0) / 2
+    xf = model.build_state([1.0, 1.5, 0.5], [math.cos(th), 0.0, 0.0, math.sin(th)])
+    Qe = np.r_[np.ones(3), 0.5 * np.ones(3), 0.1 * np.ones(6)]
+    stage = T.ErrorQuadratic(model, Qe, np.full(m, 1e-2), xf, model.hover_control())
+    term = T.ErrorQuadratic(model, 100 * Qe, np.full(m, 1e-2), xf, model.hover_control(), terminal=True)
+    cons = T.ConstraintList(n, m, N)
+    if constrained:
+        T.add_constraint(cons, T.BoundConstraint(n, m, u_min=0.0, u_max=2.2), range(1, N))
+        T.add_constraint(cons, T.GoalConstraint(xf, [1, 2, 3, 7, 8, 9, 10, 11, 12]), N)
+    prob = T.Problem(model, T.Objective(stage, term, N), np.zeros(n), tf, xf=xf, constraints=cons, batch=batch, lib=lib)
+    rng = np.random.default_rng(11)
+    x0 = np.zeros((batch, n)); x0[:, :3] = rng.uniform(-0.5, 0.5, (batch, 3)); x0[:, 3:6] = 0.1 * rng.standard_normal((batch, 3))
+    prob.set_initial_state(x0)
+    T.initial_controls(prob, model.hover_control())
+    return prob
+
+
+@pytest.mark.parametrize("att", ["quat", "mrp"])
+def test_accept_by_rollout(att, hip, oracle, monkeypatch):
+    """Batch steps whose forward pass fills the chip store only the candidates' controls and re-roll the accepted ones
+    (k_accept_roll, TRAJOPT_ACCEPT_ROLL_MIN): the nominal states must be BIT-IDENTICAL to the stored-candidate path (same step
+    function, -ffp-contract=on) — iLQR and AL solves, states, controls, costs and iteration counts compared for equality; then
+    against the oracle."""
+    sols = []
+    for waves in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_ACCEPT_ROLL_MIN", waves)
+        if att == "quat":
+            p = configs.quadrotor_problem(batch=200, N=61, tf=1.5, lib=hip)
+            o = T.SolverOptions(lib=hip, constraint_tolerance=1e-4)
+            pc = configs.quadrotor_problem(batch=72, N=101, tf=5.0, constrained=True, lib=hip, options=o)
+        else:
+            p, pc = _mrp_quadrotor(hip, False, 100), _mrp_quadrotor(hip, True, 40)
+        s = T.iLQRSolver(p, iterations=60).solve()
+        sc = T.ALSolver(pc).solve()
+        sols.append((s.stats, T.states(p), T.controls(p), sc.stats, T.states(pc), T.controls(pc)))
+    a, b = sols
+    for k in ("iterations", "status", "cost"):
+        np.testing.assert_array_equal(a[0][k], b[0][k], err_msg=k)
+        np.testing.assert_array_equal(a[3][k], b[3][k], err_msg="AL " + k)
+    for i in (1, 2, 4, 5):
+        np.testing.assert_array_equal(a[i], b[i])
+    assert a[0]["iterations"].max() > 3 and (a[3]["iterations"] > 10).any()
+    if att == "quat":
+        po = configs.quadrotor_problem(batch=200, N=61, tf=1.5, lib=oracle)
+        so = T.iLQRSolver(po, iterations=60).solve()
+        np.testing.assert_array_equal(b[0]["iterations"], so.stats["iterations"])
+        np.testing.assert_allclose(b[1], T.states(po), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("two", ["0", "1"])
 def test_two_wave_forward_pass_small_models(two, hip, oracle, monkeypatch):
     """The small models' forward pass (gains row in registers, accepted steps written through by the next expansion) with one
     wave per candidate group (TRAJOPT_FWD2=0) and as roller + accountant workgroups (=1; the default picks per batch step):

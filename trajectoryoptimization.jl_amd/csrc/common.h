@@ -23,6 +23,8 @@ struct KArgs {
                     // every candidate store of a wave is one 512-byte row of one stream (slot-major candidates made each
                     // store touch CW streams 85 MB apart: 4x slower forward pass, TLB- and partial-line-bound)
   int dump_wave;  // index of the spare block behind the last wave's in Xc / Uc: where lanes without a candidate store
+  int repack_block0;  // first of the second set of candidate blocks (wave w: repack_block0 + w), used by a repacked last line-search
+                      // round (k_forward.h LsRound); 0: no repacking
   int CW, TW;     // a forward wave holds CW line-search candidates x TW trajectories, CW*TW <= 64 (hardware lane q*TW + t); candidate
                   // "slot" q+1 of trajectory b lives in the block of wave b / TW (below).  Two shapes are in use: the base one (CW a
                   // power of two, TW = 64/CW) and, once the active trajectories fit the chip that way, CW = the whole search depth
@@ -64,6 +66,8 @@ struct KArgs {
   int al_mode;    // 0: iLQR, 1: AL-iLQR
   int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
   int step;
+  int store_x;    // 1: the forward pass stores every candidate's states (k_accept copies the accepted ones); 0: only their controls —
+                  // k_accept_roll (k_forward.h) then re-rolls the accepted candidates.  Set per batch step by the solve loop.
 };
 
 // gains row of one knot of one trajectory: m rows of (ne gains + 1 feed-forward) doubles

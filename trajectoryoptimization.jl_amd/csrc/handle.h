@@ -56,6 +56,8 @@ struct to_handle_s {
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
   int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
   int expand_lane = 1;    // lane layout: expansion by k_expand_lane (one lane per (trajectory, knot)); 0 = column-per-lane kernel (A/B knob TRAJOPT_EXPAND_LANE)
+  int roll_min_active = -1;  // solve loop: batch steps with at least this many active trajectories store candidate controls only and accept
+                             // by k_accept_roll (-1: the measured default per solver, 0: never; TRAJOPT_ACCEPT_ROLL_MIN)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   // device copies of the descriptor tables
   to_cost_desc* d_costs = nullptr;
@@ -124,6 +126,7 @@ struct ModelOps {
   int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
   int (*pn)(to_handle*, const int* list, int count) = nullptr;  // projected-Newton polish of the listed trajectories (k_pn.h)
   int (*defect)(to_handle*, double* out) = nullptr;             // max dynamics / initial-condition defect of the nominal trajectory
+  int (*accept_roll)(to_handle*) = nullptr;  // accept by re-rolling the stored controls (k_forward.h; models without write-through)
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
   int (*forward2[32])(to_handle*) = {};  // the same variants as two-wave workgroups (k_forward2; models with LDS-staged gains)
 };

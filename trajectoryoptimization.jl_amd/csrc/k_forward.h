@@ -64,15 +64,15 @@ __host__ __device__ inline int gains_lds_doubles(int TW) {  // per buffer, whole
   return ((TW * PCS + 63) / 64) * 64 * 2;
 }
 
-// One line-search candidate per lane: closed-loop rollout of trajectory (tile, lane) with step size alpha into slot cs,
-// its (AL) cost J, gradient metric gsum/(N-1) and admissibility ok.  Lanes with live == false roll out as well (a
+// One line-search candidate per lane: closed-loop rollout of trajectory (tile, lane) with step size alpha, stored in lane hw of
+// candidate block wblock; its (AL) cost J, gradient metric gsum/(N-1) and admissibility ok.  Lanes with live == false roll out as well (a
 // partially masked wave issues FP64 ~1.3x slower on gfx950) but store nothing.
 // MODE bit0: simple_stage (stage cost preloaded into registers, uniform dt); bit1: constraints present (AL terms);
 // bit2: RK4 fixed at compile time; bit3: dense costs / non-selector constraints possible (else compiled out);
 // bit4: the register-cached control constraints are unit SOCs (problem_dev.h unit_soc_desc).
 // kbuf: the wave's two LDS buffers for DMA-staged gains (M::lds_gains); krow: this lane's row offset in a buffer.
 template <class M, int MODE>
-__device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int lane, int b, bool live, double alpha, int cs, double* kbuf,
+__device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int lane, int b, bool live, double alpha, int wblock, double* kbuf,
                                                   int kbuf_len, int krow, int b0, int TW, int hw, double& J_out, double& g_out, bool& ok_out) {
   constexpr int n = M::n, m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
   constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0;
@@ -82,10 +82,10 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const int N = P.N;
   const double* Xc = TILE_PTR(a.Xs, N * n);  // the nominal (slot 0)
   const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
-  // candidates: forward-wave-major (common.h), slot cs = q + 1; a wave's candidate stores are whole 512-byte rows.  Lanes
+  // candidates: forward-wave-major (common.h); a wave's candidate stores are whole 512-byte rows.  Lanes
   // without a candidate store as well — into the dump block behind the last wave's, never read — so that the rollout loop
   // runs with EXEC full throughout (no lane-divergent region: see StageCostLds::load for what one cost here)
-  const size_t cblock = live ? (size_t)blockIdx.x : (size_t)a.dump_wave;
+  const size_t cblock = live ? (size_t)wblock : (size_t)a.dump_wave;
   double* Xn = a.Xc + (cblock * (size_t)(N * n)) * 64 + hw;
   double* Un = a.Uc + (cblock * (size_t)((N - 1) * m)) * 64 + hw;
   const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
@@ -149,9 +149,13 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
       if (ncs > 1) cs1.prefetch(k + 1);
     }
     pXn += n * 64; pUn += m * 64; pKn += RSK;
+    // candidate states are 3/4 of what this kernel moves, and with the chip full its duration follows the bytes it stores (C5: 560 /
+    // 950 / 1800 us per launch at 4 / 8 / 16 candidates per trajectory): the solve loop then has only the controls stored
+    if (a.store_x) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
-    pXo += n * 64;
+      for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];
+      pXo += n * 64;
+    }
     double dx[ne], ub[m], xn[n];
     state_diff<M>(xb, cur.x, dx);
     double gk = 0.0;
@@ -194,7 +198,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     if (!(mx <= max_x) || !(mu_ <= max_u)) ok = false;
     if (__ballot(live && ok) == 0) break;
   }
-  if (__ballot(live && ok) != 0) {  // wave-uniform: the loop ran to its end, pXo has walked to the terminal knot
+  if (a.store_x && __ballot(live && ok) != 0) {  // wave-uniform: the loop ran to its end, pXo has walked to the terminal knot
 #pragma unroll
     for (int i = 0; i < n; ++i) EL(pXo, i) = xb[i];  // x̄_N (a rejected candidate's is never read)
   }
@@ -206,6 +210,73 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   }
   if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be in flight when the next pass refills the buffers
   J_out = J; g_out = gsum / (N - 1); ok_out = ok;
+}
+
+// Accepting a step whose candidate states were not stored (KArgs::store_x == 0): one lane per trajectory copies the accepted
+// candidate's controls onto slot 0 and rolls them out again from x0.  Same step function, same operands and — this translation unit
+// is compiled with -ffp-contract=on — the same fused operations as in forward_candidate: the states are bit-identical to the ones
+// the line search evaluated (tests/test_gpu_parity.py::test_accept_by_rollout compares whole solves for equality).  Lanes that
+// accepted nothing roll out their nominal alongside (EXEC stays full) and store nothing.
+template <class M, int FIXED_INTEG>
+__global__ void __launch_bounds__(64) k_accept_roll(KArgs a) {
+  constexpr int n = M::n, m = M::m;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const int s = b < P.B ? a.acc[b] : 0;
+  if (__ballot(s != 0) == 0) return;
+  const int N = P.N;
+  const int bb = b < P.B ? b : 0;
+  const double* su = U_SLOT_PTR(a, bb, s);  // a gather: every lane reads its own accepted slot
+  double* dX = TILE_PTR(a.Xs, N * n);
+  double* dU = TILE_PTR(a.Us, (N - 1) * m);
+  const double* px0 = TILE_PTR(a.x0, n);
+  double mp[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mp[i] = in_vgpr(P.mp[i]);
+  const int integrator = P.integrator;
+  const bool st = s != 0;
+  double x[n], xn[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = EL(px0, i);
+  // a gathered load is a full trip to memory, several rollout steps long: the controls are fetched D knots at a time, the next
+  // group while the current one is stepped through (k_rollout's coalesced loads of one knot each: 222 us; this kernel with two
+  // knots in flight: 322 us)
+  constexpr int D = 4;
+  double ua[D][m], ub[D][m];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int j = 0; j < m; ++j) ua[d][j] = EL(su, (d < N - 1 ? d : N - 2) * m + j);
+  for (int k0 = 0; k0 < N - 1; k0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int kk = k0 + D + d < N - 1 ? k0 + D + d : N - 2;  // past the horizon: re-read the last knot (never used)
+#pragma unroll
+      for (int j = 0; j < m; ++j) ub[d][j] = EL(su, kk * m + j);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int k = k0 + d;
+      if (k >= N - 1) break;  // wave-uniform
+      if (st) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) EL(dX, k * n + i) = x[i];
+#pragma unroll
+        for (int j = 0; j < m; ++j) EL(dU, k * m + j) = ua[d][j];
+      }
+      model_step<M, double, FIXED_INTEG>(mp, integrator, k, x, ua[d], P.dt[k], xn);
+#pragma unroll
+      for (int i = 0; i < n; ++i) x[i] = xn[i];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int j = 0; j < m; ++j) ua[d][j] = ub[d][j];
+  }
+  if (st) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) EL(dX, (N - 1) * n + i) = x[i];
+  }
 }
 
 // gradient metric of the UNCHANGED nominal controls (zero step / failed line search): mean_k max_j |d_kj| / (|u_kj| + 1)
@@ -225,11 +296,55 @@ __device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int
   return gs / (N - 1);
 }
 
+// Lane map of one line-search round.  Round 0 — and every round of a kernel without repacking — uses the static map of the wave
+// shape: hardware lane q*TW + t evaluates step size c0 + q of the wave's trajectory t.  After it, most of a wave's trajectories have
+// accepted a step and the few that have not would drag the wave — and, through the slowest wave, the whole launch — through one
+// round of CW step sizes after the other (C5, CW = 8: half of the launches took three rollouts, 2.1 ms instead of 1.45).  When the
+// remaining depth fits that way, the LAST round is repacked: the u trajectories still searching share all 64 lanes, tw = pow2(u)
+// rows x (total - c0) step sizes, and the search ends with it.  Which lane evaluates a candidate does not change its value, and
+// the first accepted step size is taken as before: results are bit-identical (tests/test_gpu_parity.py::test_line_search_repack).
+// Repacked candidates go to a second block per wave (KArgs::repack_block0): the lanes of a trajectory that accepted earlier keep
+// its candidate in the first.
+struct LsRound {
+  int tw, cw;  // rows (trajectories) x step sizes of this round
+  int qc, tr;  // this lane evaluates step size c0 + qc of row tr ...
+  int ts;      // ... the trajectory held by the wave's lane ts (< TW)
+  int j;       // row of this lane's OWN trajectory (meaningful while it is still searching)
+  bool has;    // row tr holds a searching trajectory
+  bool repacked;
+};
+__device__ __forceinline__ LsRound ls_round(unsigned long long nm, int c0, int total, int CW, int TW, int q, int t, int hw, bool repack) {
+  LsRound R;
+  R.tw = TW; R.cw = CW; R.qc = q; R.tr = t; R.ts = t; R.j = t; R.has = ((nm >> t) & 1ull) != 0; R.repacked = false;
+  if (repack && c0 > 0) {
+    const int u = __popcll(nm);
+    int tw2 = 1;
+    while (tw2 < u) tw2 <<= 1;
+    if (tw2 < TW && 64 / tw2 >= total - c0) {  // wave-uniform
+      R.tw = tw2; R.cw = total - c0; R.repacked = true;
+      R.qc = hw / tw2; R.tr = hw - R.qc * tw2;
+      int cnt = 0, ts = -1, last = 0;
+      for (int i = 0; i < TW; ++i)
+        if ((nm >> i) & 1ull) { ts = (cnt == R.tr) ? i : ts; last = i; ++cnt; }
+      R.has = ts >= 0;
+      R.ts = ts >= 0 ? ts : last;  // rows past the last searching trajectory ride along on it
+      R.j = __popcll(nm & ((1ull << t) - 1ull));
+    }
+  }
+  return R;
+}
+// step size number i of the backtracking search: the products the sequential search forms
+__device__ __forceinline__ double ls_alpha(double f, int i, int total) {
+  double al = 1.0;
+  for (int k = 0; k < total; ++k) al = (k < i) ? al * f : al;
+  return al;
+}
+
 // End of a forward pass, one lane per trajectory (q == 0): failed-search regularisation, the solver state machine (rows S3, S4)
 // and — with active-list compaction — the settling of accepted steps of trajectories that leave the plain iteration path.
 template <class M>
 __device__ __forceinline__ void forward_finish(const KArgs& a, int tile, int lane, int b, int hw, int q, int t, int TW, bool act, bool bpfail,
-                                               bool zero_step, int accepted, int acc, double Jprev, double Jnew, double grad) {
+                                               bool zero_step, int accepted, int acc, int accpos, double Jprev, double Jnew, double grad) {
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
   // one lane per trajectory finishes the iteration; `settle`: the trajectory leaves the plain next-iteration path (it is done, or
@@ -247,7 +362,7 @@ __device__ __forceinline__ void forward_finish(const KArgs& a, int tile, int lan
     }
     a.ls_index[b] = accepted;
     a.acc[b] = acc;
-    if (acc) a.accp[b] = blockIdx.x * 64 + (acc - 1) * TW + t;  // wave and hardware lane that hold the accepted candidate (slot_ptr)
+    if (acc) a.accp[b] = accpos;  // candidate block and hardware lane that hold the accepted candidate (slot_ptr)
     if (!a.control) {  // phase API: report and leave the state machine alone
       a.Jout[b] = Jnew;
       a.rho[b] = rho; a.drho[b] = drho;
@@ -296,10 +411,9 @@ __device__ __forceinline__ void forward_finish(const KArgs& a, int tile, int lan
     while (todo) {
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      const int bs = __shfl(b, src), sl = __shfl(acc, src);
-      const int hl = (sl - 1) * TW + (src - (src / TW) * TW);  // hardware lane of the accepted candidate: q*TW + t with t = src % TW (src has q = 0)
-      const double* cx = a.Xc + ((size_t)blockIdx.x * (size_t)Lx) * 64 + hl;
-      const double* cu = a.Uc + ((size_t)blockIdx.x * (size_t)Lu) * 64 + hl;
+      const int bs = __shfl(b, src), pos = __shfl(accpos, src);  // where the accepted candidate sits: block * 64 + hardware lane
+      const double* cx = a.Xc + ((size_t)(pos >> 6) * (size_t)Lx) * 64 + (pos & 63);
+      const double* cu = a.Uc + ((size_t)(pos >> 6) * (size_t)Lu) * 64 + (pos & 63);
       double* nx = a.Xs + ((size_t)(bs >> 6) * (size_t)Lx) * 64 + (bs & 63);
       double* nu = a.Us + ((size_t)(bs >> 6) * (size_t)Lu) * 64 + (bs & 63);
       for (int e = hw; e < Lx; e += 64) EL(nx, e) = EL(cx, e);
@@ -346,34 +460,39 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   // stationary point (predicted improvement ~ rounding noise): take the zero step, dJ = 0 => converged
   const bool zero_step = act && !bpfail && (-(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev)));
   bool need = act && !bpfail && !zero_step;
-  int accepted = zero_step ? 0 : -1, acc = 0;
+  int accepted = zero_step ? 0 : -1, acc = 0, accpos = 0;
   double Jnew = Jprev, grad = 0.0;
   const double f = o.line_search_decrease_factor;
-  double alpha = 1.0, fCW = 1.0;
-  for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }  // same products the sequential search forms
   const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
-  const int krow = t * Gains<M>::RSK;
-  for (int c0 = 0; c0 < total; c0 += CW) {
-    if (__ballot(need) == 0) break;
-    const bool cand = need && q < CW && (c0 + q) < total;
+  const unsigned long long tmask = TW >= 64 ? ~0ull : (1ull << TW) - 1ull;  // lanes 0 .. TW-1 (q = 0): one per trajectory of the wave
+  for (int c0 = 0; c0 < total;) {
+    const unsigned long long nm = __ballot(need) & tmask;
+    if (nm == 0) break;
+    const LsRound R = ls_round(nm, c0, total, CW, TW, q, t, hw, a.repack_block0 != 0);
+    // the trajectory this lane works for in this round (its own one under the static map)
+    const int bR = __shfl(b, R.ts);
+    const double JprevR = __shfl(Jprev, R.ts), dV0R = __shfl(dV0, R.ts), dV1R = __shfl(dV1, R.ts);
+    const double alpha = ls_alpha(f, c0 + R.qc, total);
+    const bool cand = R.has && R.qc < R.cw && (c0 + R.qc) < total;
+    const int wblock = R.repacked ? a.repack_block0 + (int)blockIdx.x : (int)blockIdx.x;
     double J, gm;
     bool ok;
-    forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, q + 1, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
+    forward_candidate<M, MODE>(a, bR >> 6, bR & 63, bR, cand, alpha, wblock, kbuf, kbuf_len, R.tr * Gains<M>::RSK, b0, R.tw, hw, J, gm, ok);
     bool accept = false;
     if (cand && ok) {
-      const double expected = -alpha * (dV0 + alpha * dV1);
-      const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+      const double expected = -alpha * (dV0R + alpha * dV1R);
+      const double z = (expected > 0.0) ? (JprevR - J) / expected : -1.0;
       accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
     }
     const unsigned long long am = __ballot(accept);
-    int qs = -1;  // first accepted candidate of this lane's trajectory (bits qq*TW + t)
-    for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
-    const int src = (qs >= 0 ? qs : 0) * TW + t;
+    int qs = -1;  // first accepted candidate of this lane's own trajectory (bits qq*tw + j)
+    for (int qq = R.cw - 1; qq >= 0; --qq) qs = ((am >> ((qq * R.tw + R.j) & 63)) & 1ull) ? qq : qs;
+    const int src = ((qs >= 0 ? qs : 0) * R.tw + R.j) & 63;
     const double Js = __shfl(J, src), gs = __shfl(gm, src);
-    if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
-    alpha *= fCW;
+    if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; accpos = wblock * 64 + src; need = false; }
+    c0 += R.cw;
   }
-  forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, Jprev, Jnew, grad);
+  forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, accpos, Jprev, Jnew, grad);
 }
 
 // ------------------------------------------------------------------------------------------------ two-wave forward pass
@@ -490,7 +609,7 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
 }
 
 template <class M, int MODE>
-__device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane, int b, bool live, double* ctab, int hw, const double* ring,
+__device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane, int b, bool live, int wblock, double* ctab, int hw, const double* ring,
                                              double& J_out, double& g_out, bool& ok_out) {
   constexpr int n = M::n, m = M::m;
   constexpr bool SIMPLE = (MODE & 1) != 0, CONS = (MODE & 2) != 0, GEN = (MODE & 8) != 0;
@@ -498,7 +617,7 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
   const DevProblem& P = a.P;
   const to_solver_opts& o = P.opts;
   const int N = P.N;
-  const size_t cblock = live ? (size_t)blockIdx.x : (size_t)a.dump_wave;
+  const size_t cblock = live ? (size_t)wblock : (size_t)a.dump_wave;
   double* pXo = a.Xc + (cblock * (size_t)(N * n)) * 64 + hw;
   double* pUo = a.Uc + (cblock * (size_t)((N - 1) * m)) * 64 + hw;
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
@@ -633,39 +752,42 @@ __global__ void __launch_bounds__(128, TO_FWD2_WAVES) k_forward2(KArgs a) {
   const double dV0 = a.dV[b], dV1 = a.dV[(size_t)P.Bp + b];
   const bool zero_step = act && !bpfail && (-(dV0 + dV1) <= 1e-12 * (1.0 + fabs(Jprev)));
   bool need = act && !bpfail && !zero_step;
-  int accepted = zero_step ? 0 : -1, acc = 0;
+  int accepted = zero_step ? 0 : -1, acc = 0, accpos = 0;
   double Jnew = Jprev, grad = 0.0;
   const double f = o.line_search_decrease_factor;
-  double alpha = 1.0, fCW = 1.0;
-  for (int i = 0; i < CW; ++i) { alpha = (i < q) ? alpha * f : alpha; fCW *= f; }
   const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
-  const int krow = t * Gains<M>::RSK;
+  const unsigned long long tmask = TW >= 64 ? ~0ull : (1ull << TW) - 1ull;
   double* ctab = kbuf + 2 * (size_t)kbuf_len;
   double* ring = ctab + (M::lds_gains ? StageCostLds<M::n, M::m>::size : 0);
   unsigned long long* needmask = (unsigned long long*)(ring + 2 * (size_t)Fwd2Ring<M>::SLOT);
-  unsigned long long nm = __ballot(need);  // identical in both waves here; afterwards the accountant's word
-  for (int c0 = 0; c0 < total; c0 += CW) {
+  unsigned long long nm = __ballot(need) & tmask;  // identical in both waves here; afterwards the accountant's word
+  for (int c0 = 0; c0 < total;) {
     if (nm == 0) break;
+    const LsRound R = ls_round(nm, c0, total, CW, TW, q, t, hw, a.repack_block0 != 0);  // both waves: the same map (k_forward)
+    const int bR = __shfl(b, R.ts);
+    const double alpha = ls_alpha(f, c0 + R.qc, total);
     if (role == 0) {
-      fwd2_roll<M, MODE>(a, tile, lane, b, alpha, kbuf, kbuf_len, krow, TW, hw, ring);
+      fwd2_roll<M, MODE>(a, bR >> 6, bR & 63, bR, alpha, kbuf, kbuf_len, R.tr * Gains<M>::RSK, R.tw, hw, ring);
     } else {
-      const bool cand = need && q < CW && (c0 + q) < total;
+      const double JprevR = __shfl(Jprev, R.ts), dV0R = __shfl(dV0, R.ts), dV1R = __shfl(dV1, R.ts);
+      const bool cand = R.has && R.qc < R.cw && (c0 + R.qc) < total;
+      const int wblock = R.repacked ? a.repack_block0 + (int)blockIdx.x : (int)blockIdx.x;
       double J, gm;
       bool ok;
-      fwd2_account<M, MODE>(a, tile, lane, b, cand, ctab, hw, ring, J, gm, ok);
+      fwd2_account<M, MODE>(a, bR >> 6, bR & 63, bR, cand, wblock, ctab, hw, ring, J, gm, ok);
       bool accept = false;
       if (cand && ok) {
-        const double expected = -alpha * (dV0 + alpha * dV1);
-        const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+        const double expected = -alpha * (dV0R + alpha * dV1R);
+        const double z = (expected > 0.0) ? (JprevR - J) / expected : -1.0;
         accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
       }
       const unsigned long long am = __ballot(accept);
       int qs = -1;
-      for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
-      const int src = (qs >= 0 ? qs : 0) * TW + t;
+      for (int qq = R.cw - 1; qq >= 0; --qq) qs = ((am >> ((qq * R.tw + R.j) & 63)) & 1ull) ? qq : qs;
+      const int src = ((qs >= 0 ? qs : 0) * R.tw + R.j) & 63;
       const double Js = __shfl(J, src), gs = __shfl(gm, src);
-      if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; need = false; }
-      const unsigned long long left = __ballot(need);
+      if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; accpos = wblock * 64 + src; need = false; }
+      const unsigned long long left = __ballot(need) & tmask;
       if (hw == 0) *needmask = left;
     }
     FWD2_BARRIER();
@@ -673,10 +795,10 @@ __global__ void __launch_bounds__(128, TO_FWD2_WAVES) k_forward2(KArgs a) {
       const unsigned long long w = *needmask;
       nm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
     }
-    alpha *= fCW;
+    c0 += R.cw;
   }
   if (role == 0) return;
-  forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, Jprev, Jnew, grad);
+  forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, accpos, Jprev, Jnew, grad);
 }
 
 }  // namespace to

@@ -235,6 +235,18 @@ int op_forward(to_handle* h) {
   return TO_OK;
 }
 
+// accepted steps re-rolled from their stored controls (k_accept_roll; models without write-through)
+template <class M>
+int op_accept_roll(to_handle* h) {
+  bool done = false;
+  if constexpr (M::pin_rk4) {
+    if (h->a.P.integrator == INTEG_RK4) { hipLaunchKernelGGL((k_accept_roll<M, INTEG_RK4>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a); done = true; }
+  }
+  if (!done) hipLaunchKernelGGL((k_accept_roll<M, -1>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
+}
+
 template <class M, int MODE>
 int op_forward2(to_handle* h) {
   const KArgs& a = h->a;

@@ -4,6 +4,7 @@
 
 namespace to {
 void fill_ops_quadmrp_forward(ModelOps* t) {
+  t[5].accept_roll = op_accept_roll<QuadrotorAttModel<ATT_MRP>>;
   fill_forward<QuadrotorAttModel<ATT_MRP>, 8, 9>(t[5]);
   fill_forward<QuadrotorAttModel<ATT_MRP>, 10, 11>(t[5]);
   fill_forward2<QuadrotorAttModel<ATT_MRP>, 8, 9>(t[5]);

@@ -184,7 +184,8 @@ int launch_cost(to_handle* h, int with_al, double* out, double* Jk) { return h->
 int launch_expand(to_handle* h) { return h->ops->expand(h); }
 int launch_backward(to_handle* h) { return h->ops->backward(h); }
 int launch_accept(to_handle* h) {  // materialise accepted candidate slots on slot 0, then forget them
-  hipLaunchKernelGGL(k_accept, grid_b(h, 1, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
+  if (!h->a.store_x) TRY(h->ops->accept_roll(h));  // their states were not stored: rolled out again from the stored controls
+  else hipLaunchKernelGGL(k_accept, grid_b(h, 1, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
   hipLaunchKernelGGL(k_clear_acc, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
   HIPCHECK(hipGetLastError());
   return TO_OK;
@@ -251,6 +252,7 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
   h->a.compact = 0;  // ... nor take its trajectories from a solve's active list
   h->a.CW = h->cw_base; h->a.TW = h->tw_base;
+  h->a.store_x = 1;      // ... and stores whole candidates
   return rc;
 }
 // Altro solve!(::ProjectedNewtonSolver) on the trajectories of `list` (k_pn.h); device time is added to h->last_ms
@@ -374,7 +376,16 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       // chain by a third, but need twice the wave slots — taken once both waves of every workgroup get a SIMD of their own
       // (C3: 610 vs 812 us per step with the chip full, 480 vs 320 us once the batch has drained)
       const bool two = h->fwd2 == 2 && (long long)2 * ((last_active + a.TW - 1) / a.TW) <= (long long)h->simds;
+      // ... and what it stores per candidate: with the chip full the pass is bound by its stores, 3/4 of them candidate states
+      // that are read once (the accepted one) or never — from roll_min active trajectories on only the controls go out and the accepted
+      // candidates are rolled out again (k_accept_roll: bit-identical states, one more latency chain of N-1 steps)
+      // (measured, always vs never, whole solve: C5 +0.9 / +4.6 / +7.7 / +7.3 % at B = 2048 / 4096 / 8192 / 16384, C3 -3 / -1 / +1.9 / +4.4 %:
+      // the copy by k_accept grows with the accepted trajectories — 93 us at 4096, 227 us at 8192 — the second rollout does not,
+      // and an AL line search goes through more rounds, each of which stores its candidates, than an unconstrained one)
+      const int roll_min = h->roll_min_active >= 0 ? h->roll_min_active : (al_mode ? 2048 : 8192);
+      a.store_x = (roll_min > 0 && h->ops->accept_roll && !two && last_active >= roll_min) ? 0 : 1;
       TRY(launch_forward(h, !h->ops->write_through, two));
+      a.store_x = 1;
       if (al_mode) TRY(launch_outer(h));
       if (a.compact) {  // the list of the trajectories that go on, for the next step's kernels
         if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
@@ -655,6 +666,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_EXPAND_LANE")) h->expand_lane = std::atoi(env) != 0;
   h->fused_coop = (!a.bwd_lane && !a.bwd_mfma && h->ops->expand_backward_coop) ? 1 : 0;  // used while the cost blocks are diagonal (KArgs::h_diag)
   if (const char* env = std::getenv("TRAJOPT_FUSED_COOP")) if (!std::atoi(env)) h->fused_coop = 0;
+  h->roll_min_active = -1;
+  if (const char* env = std::getenv("TRAJOPT_ACCEPT_ROLL_MIN")) h->roll_min_active = std::atoi(env);
   h->fwd2 = 2;  // 0: one-wave forward pass only; 1: two-wave always (phase API included); 2: per batch step, by the active count
   if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env);
   if (h->fwd2 < 0 || h->fwd2 > 2) h->fwd2 = 2;
@@ -675,9 +688,19 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   {  // candidates, forward-wave-major (common.h): 64 lanes per wave in either shape
     size_t waves = (Bp + h->tw_base - 1) / h->tw_base;
     if (h->cw_deep) waves = std::max(waves, (Bp + h->tw_deep - 1) / h->tw_deep);
+    a.store_x = 1;
     a.dump_wave = (int)waves;  // one spare block: the store target of lanes that hold no candidate (k_forward.h)
-    TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * (waves + 1) * 64));
-    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * (waves + 1) * 64));
+    // ... and, for the models whose search goes through several rounds of the base shape, a second block per base-shape wave for
+    // the repacked last round (k_forward.h LsRound; TRAJOPT_LS_REPACK=0 switches it off)
+    size_t extra = 0;
+    const char* rp_env = std::getenv("TRAJOPT_LS_REPACK");
+    a.repack_block0 = 0;
+    if (!h->ops->write_through && !(rp_env && std::atoi(rp_env) == 0)) {
+      extra = (Bp + h->tw_base - 1) / h->tw_base;
+      a.repack_block0 = (int)waves + 1;
+    }
+    TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * (waves + 1 + extra) * 64));
+    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * (waves + 1 + extra) * 64));
   }
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
