@@ -175,6 +175,26 @@ def test_async_solves_match_sync_and_overlap(hip):
         np.testing.assert_array_equal(T.controls(p), T.controls(q))
 
 
+def test_early_polish_matches_polish_after_the_al_stage(hip, monkeypatch):
+    """ALTRO solves hand the trajectories whose AL stage has ended to the polish on a second stream while the rest of the batch
+    still iterates (trajopt_hip.hip, early polish).  The polish of a trajectory depends on nothing but its own (X, U), so every
+    output must EQUAL the one-polish-at-the-end path (TRAJOPT_PN_EARLY=0): trajectories, status, projection counts, violation."""
+    out = []
+    for early, at in (("0", "4"), ("1", "4"), ("4", "2"), ("8", "1")):  # hand-overs allowed, first one when B / at are left
+        monkeypatch.setenv("TRAJOPT_PN_EARLY", early)
+        monkeypatch.setenv("TRAJOPT_PN_EARLY_AT", at)
+        p = configs.quadrotor_problem(batch=600, N=101, tf=5.0, constrained=True, goal_inds=configs.C5_GOAL_INDS, lib=hip)
+        s = T.ALTROSolver(p, n_steps=configs.C5_PN_STEPS).solve()
+        out.append((s.stats, T.states(p), T.controls(p)))
+    ref = out[0]
+    assert (ref[0]["iterations_pn"] > 0).mean() > 0.5 and len(np.unique(ref[0]["iterations"])) > 20
+    for st, X, U in out[1:]:
+        for k in ("iterations", "iterations_outer", "iterations_pn", "status", "cost", "c_max"):
+            np.testing.assert_array_equal(st[k], ref[0][k], err_msg=k)
+        np.testing.assert_array_equal(X, ref[1])
+        np.testing.assert_array_equal(U, ref[2])
+
+
 def test_full_size_C5_altro_vs_oracle(hip, oracle):
     """BASELINE config C5 at its own shape (Quadrotor + GoalConstraint + SOC cone, N=201, B=8192) solved as the reference's stack
     solves constrained problems — ALTRO: AL-iLQR to 1e-3, projected-Newton polish to 1e-6 — against the oracle on 512 sampled

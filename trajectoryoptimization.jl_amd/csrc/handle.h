@@ -78,8 +78,20 @@ struct to_handle_s {
   size_t pn_ws_bytes = 0;
   int* pn_pak = nullptr;
   long long* pn_koff = nullptr;
-  int* pn_list = nullptr;
-  int pn_tab_len = 0, pn_list_len = 0;
+  int* pn_list = nullptr;        // [Bp] device: the trajectory polished in workspace slot i
+  int* pn_list_host = nullptr;   // [Bp] pinned: where the lists are assembled
+  int pn_tab_len = 0;
+  int pn_cap = 0, pn_nbmax = 0;  // workspace slots; max_k (ne + candidate rows of knot k)
+  long long pn_per = 0;          // doubles per slot
+  hipStream_t pn_stream = nullptr;  // low-priority stream of the early polish (altro_solve), created on first use
+  hipEvent_t pn_ev[3] = {nullptr, nullptr, nullptr};  // snapshot taken / early polish enqueued up to here / timing
+  int32_t *snap_status = nullptr, *snap_active = nullptr;  // pinned [Bp]: snapshots of the per-trajectory solver state
+  double* snap_cmax = nullptr;
+  int pn_early = 0;              // > 0 inside altro_solve: the AL loop hands finished trajectories to the polish up to this many times
+  std::vector<char> pn_done_early;  // [B] polished while the AL stage was still running
+  int pn_early_slots = 0;        // workspace slots handed out so far
+  to_solver_opts pn_opts;        // the options the polish runs with (the AL stage runs with a looser constraint_tolerance)
+  double pn_early_ms = 0.0;
   // asynchronous solves (to_*_solve_async / to_solve_wait)
   std::thread worker;
   bool inflight = false;
@@ -124,7 +136,8 @@ struct ModelOps {
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)
   int (*expand_backward_scan)(to_handle*) = nullptr;  // fused expansion + scan Riccati, one wave per trajectory (k_scan.h)
   int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
-  int (*pn)(to_handle*, const int* list, int count) = nullptr;  // projected-Newton polish of the listed trajectories (k_pn.h)
+  int (*pn_prepare)(to_handle*, int want) = nullptr;  // projected-Newton polish (k_pn.h): tables + workspace slots ...
+  int (*pn_launch)(to_handle*, int slot0, int count, hipStream_t stream, const to_solver_opts* opts) = nullptr;  // ... and its launches
   int (*defect)(to_handle*, double* out) = nullptr;             // max dynamics / initial-condition defect of the nominal trajectory
   int (*accept_roll)(to_handle*) = nullptr;  // accept by re-rolling the stored controls (k_forward.h; models without write-through)
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null

@@ -255,13 +255,21 @@ int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   h->a.store_x = 1;      // ... and stores whole candidates
   return rc;
 }
-// Altro solve!(::ProjectedNewtonSolver) on the trajectories of `list` (k_pn.h); device time is added to h->last_ms
-int pn_run(to_handle* h, const std::vector<int>& list) {
+// Altro solve!(::ProjectedNewtonSolver) on the trajectories of `list` (k_pn.h), with the options `opts`, on the handle's stream;
+// device time is added to h->last_ms.  The list goes through the workspace in chunks of h->pn_cap trajectories.
+int pn_run(to_handle* h, const std::vector<int>& list, const to_solver_opts& opts) {
   if (list.empty()) return TO_OK;
-  if (!h->ops->pn) return fail(TO_ERR_UNSUPPORTED, "projected Newton not compiled for this model");
+  if (!h->ops->pn_launch) return fail(TO_ERR_UNSUPPORTED, "projected Newton not compiled for this model");
+  const int count = (int)list.size();
+  TRY(h->ops->pn_prepare(h, count));
   hipEvent_t e0 = h->sev[0], e1 = h->sev[1];
   HIPCHECK(hipEventRecord(e0, h->stream));
-  TRY(h->ops->pn(h, list.data(), (int)list.size()));
+  std::memcpy(h->pn_list_host, list.data(), sizeof(int) * count);
+  for (int base = 0; base < count; base += h->pn_cap) {
+    const int cnt = std::min(h->pn_cap, count - base);
+    HIPCHECK(hipMemcpyAsync(h->pn_list, h->pn_list_host + base, sizeof(int) * cnt, hipMemcpyHostToDevice, h->stream));
+    TRY(h->ops->pn_launch(h, 0, cnt, h->stream, &opts));
+  }
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -279,6 +287,66 @@ int ensure_solve_events(to_handle* h) {
   }
   return TO_OK;
 }
+
+// ---- early polish: inside an ALTRO solve, trajectories whose AL stage has ended are polished on a second stream while the
+// rest of the batch is still iterating.  The last third of an AL solve's batch steps works on a drained batch (C5: 85 of 275
+// steps hold under a quarter of the trajectories: latency-bound kernels on a mostly idle chip), and the polish of a trajectory
+// depends on nothing but its own (X, U): the same result, partly hidden behind that tail.  When the active count has fallen
+// to B / 4 the AL loop takes a snapshot of the per-trajectory state, the host lists the trajectories that are finished,
+// converged and above constraint_tolerance, and their polish goes to a low-priority stream, into workspace slots of its own; the
+// rest is polished after the AL stage.  Finished trajectories are never touched again by the AL kernels; the polish writes
+// (X, U), status and its own statistics of ITS trajectories only — results are equal to the one-polish path
+// (tests/test_gpu_pn.py::test_early_polish_matches_polish_after_the_al_stage).
+// Measured on C5 (B = 8192, 3 solves each, M trajectory-iterations/s): no hand-over 1.060; one at B/2 1.072, at B/4 1.088-1.094, at
+// B/8 1.078, at B/16 1.067, at B/32 1.074; two from B/8 1.043, three from B/2 1.032, five 0.976 — the polish waves live for
+// milliseconds and k_expand needs whole SIMDs (256 VGPR + AGPR), so a polish that starts while the AL stage still fills
+// the chip costs it more than it hides; restricting the polish stream to half or a quarter of the compute units
+// (hipExtStreamCreateWithCUMask) changed nothing (1.092-1.100).  TRAJOPT_PN_EARLY=0 switches the hand-over off, =n allows n of them
+// (halving the threshold each time), TRAJOPT_PN_EARLY_AT=d starts at B / d.
+int early_polish_setup(to_handle* h) {
+  if (!h->pn_stream) {
+    int lo = 0, hi = 0;
+    HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo: the numerically largest = lowest priority
+    HIPCHECK(hipStreamCreateWithPriority(&h->pn_stream, hipStreamNonBlocking, lo));
+    HIPCHECK(hipEventCreateWithFlags(&h->pn_ev[0], hipEventDisableTiming));
+    HIPCHECK(hipEventCreate(&h->pn_ev[1]));
+    HIPCHECK(hipEventCreate(&h->pn_ev[2]));
+    const size_t Bp = h->a.P.Bp;
+    HIPCHECK(hipHostMalloc((void**)&h->snap_status, sizeof(int32_t) * Bp));
+    HIPCHECK(hipHostMalloc((void**)&h->snap_active, sizeof(int32_t) * Bp));
+    HIPCHECK(hipHostMalloc((void**)&h->snap_cmax, sizeof(double) * Bp));
+  }
+  return TO_OK;
+}
+// AL loop: the state of every trajectory as of this point of the handle's stream -> pinned host arrays; pn_ev[0] marks it
+int early_polish_snapshot(to_handle* h) {
+  const KArgs& a = h->a;
+  const size_t B = a.P.B;
+  HIPCHECK(hipMemcpyAsync(h->snap_status, a.status, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->snap_active, a.active, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->snap_cmax, a.cmax, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipEventRecord(h->pn_ev[0], h->stream));
+  return TO_OK;
+}
+// ... and, once it has arrived, the polish of what it shows finished (enqueued on pn_stream behind the snapshot)
+int early_polish_launch(to_handle* h) {
+  HIPCHECK(hipEventSynchronize(h->pn_ev[0]));
+  const int B = h->a.P.B, s0 = h->pn_early_slots;
+  int cnt = 0;
+  for (int b = 0; b < B; ++b)
+    if (!h->pn_done_early[b] && h->snap_active[b] == 0 && h->snap_status[b] == TO_SOLVE_SUCCEEDED && h->snap_cmax[b] > h->pn_opts.constraint_tolerance) {
+      h->pn_list_host[s0 + cnt++] = b;
+      h->pn_done_early[b] = 1;
+    }
+  if (cnt == 0) return TO_OK;
+  HIPCHECK(hipStreamWaitEvent(h->pn_stream, h->pn_ev[0], 0));
+  if (s0 == 0) HIPCHECK(hipEventRecord(h->pn_ev[2], h->pn_stream));
+  HIPCHECK(hipMemcpyAsync(h->pn_list + s0, h->pn_list_host + s0, sizeof(int) * cnt, hipMemcpyHostToDevice, h->pn_stream));
+  TRY(h->ops->pn_launch(h, s0, cnt, h->pn_stream, &h->pn_opts));
+  HIPCHECK(hipEventRecord(h->pn_ev[1], h->pn_stream));
+  h->pn_early_slots += cnt;
+  return TO_OK;
+}
 int pn_solve(to_handle* h, to_solve_stats* st) {
   TRY(use_device(h));
   TRY(ensure_solve_events(h));
@@ -290,28 +358,55 @@ int pn_solve(to_handle* h, to_solve_stats* st) {
   std::vector<int> list(B);
   for (int b = 0; b < B; ++b) list[b] = b;
   h->last_steps = 0; h->last_ms = 0.0;
-  TRY(pn_run(h, list));
+  TRY(pn_run(h, list, a.P.opts));
   if (st) TRY(fill_stats(h, st, true));
   return TO_OK;
 }
 // Altro solve!(::ALTROSolver): AL stage down to projected_newton_tolerance, polish of what it left SOLVE_SUCCEEDED above
-// constraint_tolerance
+// constraint_tolerance — as the trajectories finish (early polish, above) and, for the rest, after the AL stage
 int altro_solve(to_handle* h, to_solve_stats* st) {
   const to_solver_opts user = h->a.P.opts;
   const bool pn = user.projected_newton && h->a.P.n_cons > 0;
   if (!pn) return solve(h, st, 1);
+  TRY(use_device(h));
+  const int B = h->a.P.B;
+  int early = 1;
+  if (const char* env = std::getenv("TRAJOPT_PN_EARLY")) early = std::max(0, std::min(8, std::atoi(env)));
+  h->pn_early = 0; h->pn_early_slots = 0;
+  if (early > 0 && h->ops->pn_launch && !h->ops->write_through) {  // (write-through models keep accepted steps in candidate slots until the solve ends)
+    TRY(h->ops->pn_prepare(h, B));
+    if (h->pn_cap >= B) {  // every trajectory has a workspace slot of its own
+      TRY(early_polish_setup(h));
+      h->pn_done_early.assign(B, 0);
+      h->pn_opts = user;
+      h->pn_early = early;
+    }
+  }
+  const bool had_early = h->pn_early > 0;
   h->a.P.opts.constraint_tolerance = user.projected_newton_tolerance;
   const int rc = solve(h, nullptr, 1);
   h->a.P.opts = user;
+  h->pn_early = 0;
+  if (had_early && h->pn_early_slots > 0) {  // on every path: nothing of this solve may still be running when it returns
+    const hipError_t e = hipEventSynchronize(h->pn_ev[1]);
+    if (rc == TO_OK) HIPCHECK(e);
+  }
   if (rc != TO_OK) return rc;
-  const int B = h->a.P.B;
+  if (had_early && h->pn_early_slots > 0) {
+    float ms = 0.f, tail = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, h->pn_ev[2], h->pn_ev[1]));  // first launch .. end of the last: the span on the second stream
+    if (h->profile) { h->prof_ms[3] += ms; h->prof_launches[3] += 1; }
+    HIPCHECK(hipEventElapsedTime(&tail, h->sev[1], h->pn_ev[1]));   // what of it outlasted the AL stage
+    if (tail > 0.f) h->last_ms += tail;
+  }
   std::vector<int32_t> status(B);
   std::vector<double> cmax(B);
   TRY(download_int(h, status.data(), h->a.status));
   TRY(download_scalar(h, cmax.data(), h->a.cmax));
   std::vector<int> list;
-  for (int b = 0; b < B; ++b) if (status[b] == TO_SOLVE_SUCCEEDED && cmax[b] > user.constraint_tolerance) list.push_back(b);
-  TRY(pn_run(h, list));
+  for (int b = 0; b < B; ++b)
+    if (status[b] == TO_SOLVE_SUCCEEDED && cmax[b] > user.constraint_tolerance && !(had_early && h->pn_done_early[b])) list.push_back(b);
+  TRY(pn_run(h, list, user));
   if (st) TRY(fill_stats(h, st, true));
   return TO_OK;
 }
@@ -408,9 +503,18 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
     return TO_OK;
   };
   int waited = 0;  // chunks whose counters have been inspected
+  // early polish (ALTRO solves): the next active count at which the finished trajectories are handed over
+  int early_div = 4;  // hand-over when a quarter of the batch is left (TRAJOPT_PN_EARLY_AT: the divisor)
+  if (const char* env = std::getenv("TRAJOPT_PN_EARLY_AT")) early_div = std::max(1, std::atoi(env));
+  int early_thr = (al_mode && h->pn_early > 0) ? P.B / early_div : -1, early_left = h->pn_early;
+  bool snapshot_pending = false;
   if (max_steps > 0) TRY(enqueue_chunk());
   while (!done && waited < nchunks) {
     if (launched < max_steps) TRY(enqueue_chunk());  // keep the queue one chunk ahead
+    if (snapshot_pending) {  // taken before that chunk: the device keeps working while the host lists and launches
+      TRY(early_polish_launch(h));
+      snapshot_pending = false;
+    }
     HIPCHECK(hipEventSynchronize(cev[waited & 1]));
     const int upto = std::min(launched, (waited + 1) * CHECK_EVERY);
     for (; checked < upto; ++checked) {
@@ -419,6 +523,12 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       if (h->counter_host[checked] == 0) { done = true; break; }
     }
     ++waited;
+    if (!done && early_left > 0 && last_active <= early_thr) {
+      TRY(early_polish_snapshot(h));
+      snapshot_pending = true;
+      --early_left;
+      while (early_thr > 0 && last_active <= early_thr) early_thr /= 2;
+    }
   }
   TRY(launch_accept(h));  // trajectories keep the slot of their last accepted step until here
   a.CW = h->cw_base; a.TW = h->tw_base;
@@ -779,6 +889,12 @@ int to_destroy(to_handle* h) {
   if (h->pn_pak) hipFree(h->pn_pak);
   if (h->pn_koff) hipFree(h->pn_koff);
   if (h->pn_list) hipFree(h->pn_list);
+  if (h->pn_list_host) hipHostFree(h->pn_list_host);
+  if (h->snap_status) hipHostFree(h->snap_status);
+  if (h->snap_active) hipHostFree(h->snap_active);
+  if (h->snap_cmax) hipHostFree(h->snap_cmax);
+  for (hipEvent_t e : h->pn_ev) if (e) hipEventDestroy(e);
+  if (h->pn_stream) hipStreamDestroy(h->pn_stream);
   if (h->counter_host) hipHostFree(h->counter_host);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   for (hipEvent_t e : h->sev) if (e) hipEventDestroy(e);
