@@ -295,7 +295,8 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     info = (C.c_int32 * 8)()
     prob._call("solver_path", info)
     path = {"backward": ("coop", "mfma", "lane")[info[0]], "fused_expansion": bool(info[1]), "compaction": bool(info[2]),
-            "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4]), "scan_backward": bool(info[5])}
+            "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4]), "scan_backward": bool(info[5]),
+            "accept_by_rollout": bool(info[6]), "line_search_repack": bool(info[7])}
     gather = None
     if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
         from trajectoryoptimization_jl_amd.distributed import TrajectoryGather

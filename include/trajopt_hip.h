@@ -394,7 +394,7 @@ int to_discrete_jacobian(to_handle* h, double* F);
  * line-search round (default min(16, 1024 / tiles)); results do not depend on it. */
 /* Which kernels a solve on this handle runs.  Batch independence: a trajectory's result does not depend on the other trajectories
  * of its batch.  The choices made PER BATCH STEP from the number of active trajectories — line-search wave shape, one- or
- * two-wave forward kernel, active-list compaction — are between bit-identical kernels (tested).  The choices made ONCE at
+ * two-wave forward kernel, candidate states stored or re-rolled, active-list compaction — are between bit-identical kernels (tested).  The choices made ONCE at
  * to_create from the model, the cost / constraint kinds and the batch size B — backward-pass flavour, fused expansion, scan —
  * are between kernels that agree to rounding (gains to 2e-15), so two handles of very different B (1 000 vs
  * 100 000 trajectories) may differ in the last bits; shards of one batch have (near-)equal B and take the same kernels.
@@ -402,7 +402,9 @@ int to_discrete_jacobian(to_handle* h, double* F);
  * trajectory), 2 = lane (one lane per trajectory); info[1]: 1 = the expansion is fused into the backward-pass kernel (profile slot
  * 0 is then empty and slot 1 covers both); info[2]: 1 = active-list compaction; info[3]: step sizes tried concurrently in the
  * first line-search round; info[4]: waves per forward-pass workgroup (2: roller + accountant, k_forward2); info[5]: 1 = the backward pass runs as a scan over the
- * horizon (one wave per trajectory, k_scan.h); info[6..7]: 0. */
+ * horizon (one wave per trajectory, k_scan.h); info[6]: 1 = batch steps that fill the chip store only the controls of the line-search
+ * candidates and roll the accepted ones out again (bit-identical states; k_accept_roll); info[7]: 1 = the last line-search round
+ * is repacked (the trajectories of a wave that are still searching share all its lanes; bit-identical). */
 int to_solver_path(const to_handle* h, int32_t* info /* [8] */);
 /* Live state / control dimensions per knot, nx[N], nu[N] (RD.dims(models), src/dynamics.jl:15-31: the terminal knot carries the
  * last model's control dimension).  (n, m) on every knot unless the model is a hybrid model vector. */

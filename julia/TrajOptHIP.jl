@@ -642,12 +642,12 @@ function allgather_stats(p::BatchProblem)
 end
 comm_destroy!(p::BatchProblem) = check(ccall((:to_comm_destroy, lib), Cint, (Ptr{Cvoid},), p.handle))
 
-"(backward = :coop / :mfma / :lane, fused_expansion, compaction, first_round, forward_waves, scan_backward): the kernels a solve on this handle runs."
+"(backward = :coop / :mfma / :lane, fused_expansion, compaction, first_round, forward_waves, scan_backward, accept_by_rollout, line_search_repack): the kernels a solve on this handle runs."
 function solver_path(p::BatchProblem)
     info = zeros(Int32, 8)
     check(ccall((:to_solver_path, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), p.handle, info))
     (backward = (:coop, :mfma, :lane)[info[1] + 1], fused_expansion = info[2] != 0, compaction = info[3] != 0, first_round = Int(info[4]),
-     forward_waves = Int(info[5]), scan_backward = info[6] != 0)
+     forward_waves = Int(info[5]), scan_backward = info[6] != 0, accept_by_rollout = info[7] != 0, line_search_repack = info[8] != 0)
 end
 
 """

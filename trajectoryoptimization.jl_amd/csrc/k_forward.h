@@ -305,6 +305,7 @@ __device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int
 // the first accepted step size is taken as before: results are bit-identical (tests/test_gpu_parity.py::test_line_search_repack).
 // Repacked candidates go to a second block per wave (KArgs::repack_block0): the lanes of a trajectory that accepted earlier keep
 // its candidate in the first.
+template <class M> struct LsRepack { static constexpr bool value = !M::accept_write_through; };  // the models that repack (and have the second block)
 struct LsRound {
   int tw, cw;  // rows (trajectories) x step sizes of this round
   int qc, tr;  // this lane evaluates step size c0 + qc of row tr ...
@@ -464,6 +465,33 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   double Jnew = Jprev, grad = 0.0;
   const double f = o.line_search_decrease_factor;
   const int kbuf_len = M::lds_gains ? gains_lds_doubles<M>(TW) : 0;
+  if constexpr (!LsRepack<M>::value) {
+    // static lane map in every round (the models whose accepted steps are written through by the next expansion: their search
+    // rarely leaves the first round, and the general loop below cost the Cartpole kernel 2.3 us per launch)
+    const int krow = t * Gains<M>::RSK;
+    for (int c0 = 0; c0 < total; c0 += CW) {
+      if (__ballot(need) == 0) break;
+      const double alpha = ls_alpha(f, c0 + q, total);
+      const bool cand = need && q < CW && (c0 + q) < total;
+      double J, gm;
+      bool ok;
+      forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, (int)blockIdx.x, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
+      bool accept = false;
+      if (cand && ok) {
+        const double expected = -alpha * (dV0 + alpha * dV1);
+        const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+        accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
+      }
+      const unsigned long long am = __ballot(accept);
+      int qs = -1;  // first accepted candidate of this lane's trajectory (bits qq*TW + t)
+      for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
+      const int src = (qs >= 0 ? qs : 0) * TW + t;
+      const double Js = __shfl(J, src), gs = __shfl(gm, src);
+      if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; accpos = (int)blockIdx.x * 64 + src; need = false; }
+    }
+    forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, accpos, Jprev, Jnew, grad);
+    return;
+  }
   const unsigned long long tmask = TW >= 64 ? ~0ull : (1ull << TW) - 1ull;  // lanes 0 .. TW-1 (q = 0): one per trajectory of the wave
   for (int c0 = 0; c0 < total;) {
     const unsigned long long nm = __ballot(need) & tmask;
@@ -760,6 +788,44 @@ __global__ void __launch_bounds__(128, TO_FWD2_WAVES) k_forward2(KArgs a) {
   double* ctab = kbuf + 2 * (size_t)kbuf_len;
   double* ring = ctab + (M::lds_gains ? StageCostLds<M::n, M::m>::size : 0);
   unsigned long long* needmask = (unsigned long long*)(ring + 2 * (size_t)Fwd2Ring<M>::SLOT);
+  if constexpr (!LsRepack<M>::value) {  // static lane map in every round (k_forward)
+    const int krow = t * Gains<M>::RSK;
+    unsigned long long nm = __ballot(need);  // identical in both waves here; afterwards the accountant's word
+    for (int c0 = 0; c0 < total; c0 += CW) {
+      if (nm == 0) break;
+      const double alpha = ls_alpha(f, c0 + q, total);
+      if (role == 0) {
+        fwd2_roll<M, MODE>(a, tile, lane, b, alpha, kbuf, kbuf_len, krow, TW, hw, ring);
+      } else {
+        const bool cand = need && q < CW && (c0 + q) < total;
+        double J, gm;
+        bool ok;
+        fwd2_account<M, MODE>(a, tile, lane, b, cand, (int)blockIdx.x, ctab, hw, ring, J, gm, ok);
+        bool accept = false;
+        if (cand && ok) {
+          const double expected = -alpha * (dV0 + alpha * dV1);
+          const double z = (expected > 0.0) ? (Jprev - J) / expected : -1.0;
+          accept = z >= o.line_search_lower_bound && z <= o.line_search_upper_bound;
+        }
+        const unsigned long long am = __ballot(accept);
+        int qs = -1;
+        for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
+        const int src = (qs >= 0 ? qs : 0) * TW + t;
+        const double Js = __shfl(J, src), gs = __shfl(gm, src);
+        if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; accpos = (int)blockIdx.x * 64 + src; need = false; }
+        const unsigned long long left = __ballot(need);
+        if (hw == 0) *needmask = left;
+      }
+      FWD2_BARRIER();
+      {  // (the word is rewritten a whole rollout — N barriers — later)
+        const unsigned long long w = *needmask;
+        nm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+      }
+    }
+    if (role == 0) return;
+    forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, accpos, Jprev, Jnew, grad);
+    return;
+  }
   unsigned long long nm = __ballot(need) & tmask;  // identical in both waves here; afterwards the accountant's word
   for (int c0 = 0; c0 < total;) {
     if (nm == 0) break;

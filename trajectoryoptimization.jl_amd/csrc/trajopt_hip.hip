@@ -921,7 +921,8 @@ int to_solver_path(const to_handle* h, int32_t* info) {
   for (int i = 0; i < 32; ++i) has2 = has2 || h->ops->forward2[i] != nullptr;
   info[4] = (h->fwd2 && has2) ? 2 : 1;  // (two-wave workgroups are used while the active trajectories leave room for them)
   info[5] = (h->scan && fcoop && P.expand_variant == 0 && !a.bwd_mfma && !a.bwd_lane) ? 1 : 0;
-  info[6] = info[7] = 0;
+  info[6] = (h->ops->accept_roll && h->roll_min_active != 0) ? 1 : 0;  // full-chip batch steps store candidate controls only (k_accept_roll)
+  info[7] = a.repack_block0 != 0 ? 1 : 0;                               // repacked last line-search round
   return TO_OK;
 }
 int to_knot_dims(const to_handle* h, int32_t* nx, int32_t* nu) {
