@@ -195,6 +195,27 @@ def test_early_polish_matches_polish_after_the_al_stage(hip, monkeypatch):
         np.testing.assert_array_equal(U, ref[2])
 
 
+def test_polish_in_workspace_chunks(hip, monkeypatch):
+    """A workspace budget smaller than the batch (TRAJOPT_PN_WS_GB): the polish goes through the list in chunks that reuse the slots,
+    and ALTRO solves fall back to one polish after the AL stage.  Same results as with one slot per trajectory."""
+    out = []
+    for gb in (None, "0.02"):
+        if gb:
+            monkeypatch.setenv("TRAJOPT_PN_WS_GB", gb)
+        p = configs.quadrotor_problem(batch=150, N=61, tf=3.0, constrained=True, goal_inds=configs.C5_GOAL_INDS, lib=hip)
+        s = T.ALTROSolver(p, n_steps=configs.C5_PN_STEPS).solve()
+        q = configs.cartpole_problem(batch=90, N=41, tf=2.0, constrained=True, u_bnd=10.0, lib=hip)
+        sq = T.ALTROSolver(q).solve()
+        out.append((s.stats, T.states(p), T.controls(p), sq.stats, T.states(q), T.controls(q)))
+    a, b = out
+    assert (a[0]["iterations_pn"] > 0).sum() > 100 and (a[3]["iterations_pn"] > 0).sum() > 40   # more trajectories than 0.02 GB hold
+    for i in (0, 3):
+        for k in ("iterations", "iterations_pn", "status", "cost", "c_max"):
+            np.testing.assert_array_equal(a[i][k], b[i][k], err_msg=k)
+    for i in (1, 2, 4, 5):
+        np.testing.assert_array_equal(a[i], b[i])
+
+
 def test_full_size_C5_altro_vs_oracle(hip, oracle):
     """BASELINE config C5 at its own shape (Quadrotor + GoalConstraint + SOC cone, N=201, B=8192) solved as the reference's stack
     solves constrained problems — ALTRO: AL-iLQR to 1e-3, projected-Newton polish to 1e-6 — against the oracle on 512 sampled
