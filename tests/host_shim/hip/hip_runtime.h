@@ -19,3 +19,4 @@ using std::fmin;
 using std::rint;
 using std::sqrt;
 using std::log10;
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
