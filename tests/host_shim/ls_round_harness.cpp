@@ -38,13 +38,12 @@ int main() {
                 CHECK(R[hw].has == (((nm >> t) & 1) != 0), "static has");
               }
               // a repack was possible but not taken?  only when it is not allowed, not smaller, or does not finish the search
-              int tw2 = 1; while (tw2 < u) tw2 <<= 1;
-              if (rp && c0 > 0) CHECK(!(tw2 < TW && 64 / tw2 >= total - c0), "repack skipped although it fits");
+              if (rp && c0 > 0) CHECK(!(u < TW && 64 / u >= total - c0), "repack skipped although it fits");
               continue;
             }
             ++repacked;
             CHECK(rp && c0 > 0, "repacked without permission");
-            CHECK(R0.tw < TW && R0.tw >= u && R0.tw * R0.cw <= 64 && R0.cw == total - c0, "repacked shape tw %d cw %d u %d", R0.tw, R0.cw, u);
+            CHECK(R0.tw < TW && R0.tw == u && R0.tw * R0.cw <= 64 && R0.cw == total - c0, "repacked shape tw %d cw %d u %d", R0.tw, R0.cw, u);
             // every (searching trajectory, remaining step size) is evaluated by exactly one lane that has a candidate
             std::vector<int> seen(TW * 64, 0);
             for (int hw = 0; hw < 64; ++hw) {

@@ -8,7 +8,7 @@ namespace to {
 // shape: hardware lane q*TW + t evaluates step size c0 + q of the wave's trajectory t.  After it, most of a wave's trajectories have
 // accepted a step and the few that have not would drag the wave — and, through the slowest wave, the whole launch — through one
 // round of CW step sizes after the other (C5, CW = 8: half of the launches took three rollouts, 2.1 ms instead of 1.45).  When the
-// remaining depth fits that way, the LAST round is repacked: the u trajectories still searching share all 64 lanes, tw = pow2(u)
+// remaining depth fits that way, the LAST round is repacked: the u trajectories still searching share all 64 lanes, tw = u
 // rows x (total - c0) step sizes, and the search ends with it.  Which lane evaluates a candidate does not change its value, and
 // the first accepted step size is taken as before: results are bit-identical (tests/test_gpu_parity.py::test_line_search_repack).
 // Repacked candidates go to a second block per wave (KArgs::repack_block0): the lanes of a trajectory that accepted earlier keep
@@ -26,8 +26,7 @@ __device__ __forceinline__ LsRound ls_round(unsigned long long nm, int c0, int t
   R.tw = TW; R.cw = CW; R.qc = q; R.tr = t; R.ts = t; R.j = t; R.has = ((nm >> t) & 1ull) != 0; R.repacked = false;
   if (repack && c0 > 0) {
     const int u = __popcll(nm);
-    int tw2 = 1;
-    while (tw2 < u) tw2 <<= 1;
+    const int tw2 = u;  // one row per searching trajectory (any count: the gains staging and the lane split take arbitrary row counts)
     if (tw2 < TW && 64 / tw2 >= total - c0) {  // wave-uniform
       R.tw = tw2; R.cw = total - c0; R.repacked = true;
       R.qc = hw / tw2; R.tr = hw - R.qc * tw2;
