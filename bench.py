@@ -297,17 +297,33 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     path = {"backward": ("coop", "mfma", "lane")[info[0]], "fused_expansion": bool(info[1]), "compaction": bool(info[2]),
             "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4]), "scan_backward": bool(info[5]),
             "accept_by_rollout": bool(info[6]), "line_search_repack": bool(info[7])}
-    gather = None
+    gather, gather_note = None, None
     if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
         from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
-        gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
+        # The library's own communicator (to_comm_*).  Should it fail to come up on ANY rank (it has only ever run with one rank on
+        # the builder's boxes), every rank falls back to gathering through torch.distributed — the same RCCL, staged through host
+        # arrays — rather than losing the scaling run; the line says which path ran.
+        err = None
+        try:
+            if os.environ.get("TRAJOPT_BENCH_GATHER") == "torch":
+                raise RuntimeError("forced by TRAJOPT_BENCH_GATHER=torch")
+            gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
+        except Exception as e:  # noqa: BLE001 - any failure of the native communicator takes the fallback
+            err = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([0 if err else 1], device=torch.device("cuda", local_rank))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if gather is not None:
+                gather.close()
+            gather = TrajectoryGather(prob, dist, device=None)
+            gather_note = "torch.distributed all_gather of host-staged arrays (the library's RCCL communicator did not come up: %s)" % (err or "on another rank")
 
     def one_step():
         T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
         solver.solve()
         if gather is not None:
             gather()
-            gather.stats()
+            gather.stats(solver)
         return solver.total_iterations, solver.batch_steps
 
     def barrier():
@@ -359,7 +375,7 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
                           "ms_per_solve": (kms[3] / kln[3]) if (profile and kln[3] > 0) else None},
                       "collective": ("RCCL all_gather of converged (X,U) once per solve + stats gather (to_allgather / to_allgather_stats); "
                                      "ranks the RCCL communicator saw: %d, shards %s" % (len(gather.counts), gather.counts))
-                      if gather is not None else "none"},
+                      if gather is not None and gather_note is None else (gather_note or "none")},
            "roofline": roofline_block(configs, name, batch, dims, iters_prof, value / world, kms, kln, lib.build_id(), path) if profile else None}
     return res, prob, u0
 

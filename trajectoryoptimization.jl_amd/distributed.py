@@ -72,17 +72,20 @@ class TrajectoryGather:
     def _cpu_gather(self, out, mine):
         """torch.distributed gather of per-rank blocks of possibly different length (padded to the longest)."""
         torch = self.torch
-        if self.world == 1:
+        live = self.dist is not None and self.dist.is_initialized()
+        if not live:
             out.copy_(mine)
             return
+        # the collective needs device tensors under the nccl (= RCCL) backend, host tensors under gloo
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend() == "nccl" else torch.device("cpu")
         mx = max(self.counts)
-        pad = torch.zeros((mx,) + tuple(mine.shape[1:]), dtype=mine.dtype)
-        pad[: mine.shape[0]] = mine
+        pad = torch.zeros((mx,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=dev)
+        pad[: mine.shape[0]] = mine.to(dev)
         parts = [torch.empty_like(pad) for _ in range(self.world)]
         self.dist.all_gather(parts, pad)
         off = 0
         for r, c in enumerate(self.counts):
-            out[off:off + c] = parts[r][:c]
+            out[off:off + c] = parts[r][:c].to(out.device)
             off += c
 
     def __call__(self):
