@@ -1238,6 +1238,27 @@ def test_line_search_repack(width, two, hip, monkeypatch):
     np.testing.assert_array_equal(sols[0][2], sols[1][2])
 
 
+def test_line_search_deeper_than_the_deep_shape(hip, oracle, monkeypatch):
+    """The search depth raised AFTER the handle was created (the deep wave shape was sized for 20 step sizes; a solver object sets
+    40): the rounds beyond the deep shape's first one repack into the second set of candidate blocks, which must cover the deep
+    shape's wave count.  A strict acceptance window makes searches go that deep.  Equal with and without repacking; oracle parity."""
+    kw = dict(iterations_linesearch=40, line_search_lower_bound=0.35, line_search_upper_bound=1.5, iterations=25)
+    sols = []
+    for rp in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_LS_REPACK", rp)
+        p = configs.quadrotor_problem(batch=64, N=61, tf=1.5, lib=hip)
+        s = T.iLQRSolver(p, **kw).solve()
+        sols.append((s.stats, T.states(p), T.controls(p)))
+    for k in ("iterations", "status", "cost"):
+        np.testing.assert_array_equal(sols[0][0][k], sols[1][0][k], err_msg=k)
+    np.testing.assert_array_equal(sols[0][1], sols[1][1])
+    np.testing.assert_array_equal(sols[0][2], sols[1][2])
+    po = configs.quadrotor_problem(batch=64, N=61, tf=1.5, lib=oracle)
+    so = T.iLQRSolver(po, **kw).solve()
+    np.testing.assert_array_equal(sols[1][0]["iterations"], so.stats["iterations"])
+    np.testing.assert_allclose(sols[1][1], T.states(po), rtol=1e-6, atol=1e-8)
+
+
 def _mrp_quadrotor(lib, constrained, batch, N=41, tf=2.0):
     model = T.Quadrotor(rotation="mrp")
     n, m = model.dims()

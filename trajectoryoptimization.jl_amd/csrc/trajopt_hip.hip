@@ -800,13 +800,13 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     if (h->cw_deep) waves = std::max(waves, (Bp + h->tw_deep - 1) / h->tw_deep);
     a.store_x = 1;
     a.dump_wave = (int)waves;  // one spare block: the store target of lanes that hold no candidate (k_forward.h)
-    // ... and, for the models whose search goes through several rounds of the base shape, a second block per base-shape wave for
+    // ... and, for the models whose search goes through several rounds of the base shape, a second block per wave for
     // the repacked last round (k_forward.h LsRound; TRAJOPT_LS_REPACK=0 switches it off)
     size_t extra = 0;
     const char* rp_env = std::getenv("TRAJOPT_LS_REPACK");
     a.repack_block0 = 0;
     if (!h->ops->write_through && !(rp_env && std::atoi(rp_env) == 0)) {
-      extra = (Bp + h->tw_base - 1) / h->tw_base;
+      extra = waves;  // as many as either wave shape launches: a search deeper than the deep shape (options changed after creation) repacks there too
       a.repack_block0 = (int)waves + 1;
     }
     TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * (waves + 1 + extra) * 64));
