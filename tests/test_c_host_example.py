@@ -15,7 +15,6 @@ CSRC = ROOT / "trajectoryoptimization.jl_amd" / "csrc"
 
 
 def _build(tmp_path):
-    T.load_hip_library()   # builds the library if it is missing or stale
     exe = tmp_path / "cartpole_altro"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "examples" / "cartpole_altro.c"),
                     "-L", str(CSRC), "-ltrajopt_hip", "-lm", "-o", str(exe)], check=True)
@@ -24,8 +23,8 @@ def _build(tmp_path):
     return exe, env
 
 
-def test_c_host_compiles_links_and_refuses_without_a_device(tmp_path):
-    lib = T.load_hip_library()
+def test_c_host_compiles_links_and_refuses_without_a_device(tmp_path, hip):   # `hip`: the library, loaded in the order conftest.py prescribes
+    lib = hip
     try:
         ndev = lib.device_count()
     except T.HipError:
@@ -38,7 +37,7 @@ def test_c_host_compiles_links_and_refuses_without_a_device(tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_reproduces_the_notebook_result(tmp_path):
+def test_c_host_reproduces_the_notebook_result(tmp_path, hip):
     exe, env = _build(tmp_path)
     r = subprocess.run([str(exe), "16"], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
