@@ -20,3 +20,5 @@ using std::rint;
 using std::sqrt;
 using std::log10;
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+#include <cstring>
+inline long long __double_as_longlong(double x) { long long b; std::memcpy(&b, &x, sizeof(b)); return b; }

@@ -1,6 +1,7 @@
 """GPU parity: every phase of the hot path computed by libtrajopt_hip.so on the MI355X, through the C-ABI,
 against the CPU oracle on identical seeded inputs.  Tolerances: 1e-6 relative (north-star) for solves, much
 tighter for single phases; integer outputs (iterations, status, line-search index) bit-exact."""
+import ctypes
 import json
 import math
 from pathlib import Path
@@ -1309,6 +1310,45 @@ def test_accept_by_rollout(att, hip, oracle, monkeypatch):
         so = T.iLQRSolver(po, iterations=60).solve()
         np.testing.assert_array_equal(b[0]["iterations"], so.stats["iterations"])
         np.testing.assert_allclose(b[1], T.states(po), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("case", ["cartpole", "cartpole_lane", "cartpole_al", "quickstart", "hybrid", "vector"])
+def test_accept_by_rollout_small_models(case, hip, monkeypatch):
+    """The same for the small (write-through) models, whose large batches live on it by default (from 32 768 active trajectories on):
+    candidate controls only, k_accept_roll on this step's active list, the next expansion reads the nominal instead of gathering the
+    accepted candidate.  Whole solves must be BIT-IDENTICAL with the path forced on (every batch step) and off — on the scan /
+    cooperative path, on the fused lane path with compaction (ragged batch, part of it converged), AL solves, the hybrid model
+    vector and the general one."""
+    monkeypatch.setenv("TRAJOPT_FWD2", "0")   # (two-wave workgroups always store whole candidates)
+    if case == "cartpole_lane":
+        monkeypatch.setenv("TRAJOPT_BACKWARD", "lane")
+    sols = []
+    for roll in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_ACCEPT_ROLL_MIN", roll)
+        if case == "cartpole":
+            p = configs.cartpole_problem(batch=96, lib=hip); s = T.iLQRSolver(p).solve()
+        elif case == "cartpole_lane":
+            p = configs.cartpole_problem(batch=5000, N=41, tf=2.0, lib=hip); s = T.iLQRSolver(p, iterations=40).solve()
+        elif case == "cartpole_al":
+            p = configs.cartpole_problem(batch=70, constrained=True, lib=hip); s = T.ALSolver(p).solve()
+        elif case == "quickstart":
+            p = configs.quickstart_problem(batch=3, lib=hip); s = T.ALSolver(p).solve()
+        elif case == "hybrid":
+            from test_hybrid_dims import hybrid_problem
+            (p, _, _, _) = hybrid_problem(hip, batch=200); s = T.iLQRSolver(p).solve()
+        else:
+            from test_model_vector import build, cartpole_mix
+            (p, _, _) = build(cartpole_mix(), hip, batch=70); s = T.iLQRSolver(p).solve()
+        info = (ctypes.c_int32 * 8)()
+        p._call("solver_path", info)
+        assert info[6] == (1 if roll == "1" else 0)
+        sols.append(({k: np.array(v).copy() for k, v in s.stats.items()}, T.states(p), T.controls(p), s.batch_steps))
+    (s0, X0, U0, n0), (s1, X1, U1, n1) = sols
+    assert n0 == n1 and s0["iterations"].max() >= 2
+    for k in s0:
+        np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+    np.testing.assert_array_equal(X0, X1)
+    np.testing.assert_array_equal(U0, U1)
 
 
 @pytest.mark.parametrize("two", ["0", "1"])

@@ -167,6 +167,15 @@ def test_async_solves_match_sync_and_overlap(hip):
     ta.solve_async(); tb.solve_async()
     with pytest.raises(T.ArgumentError):
         ta.solve()                       # one solve in flight per handle
+    # ... and NO other call on it (the worker owns the handle's stream, staging buffer and argument block): getters, setters and the
+    # phase API all refuse until to_solve_wait; pure descriptor getters (to_dims) stay available
+    for call in (lambda: T.states(qb), lambda: T.controls(qb), lambda: T.cost(qb), lambda: T.rollout(qb), lambda: T.max_violation(qb),
+                 lambda: T.initial_controls(qb, np.zeros(qb.m)), lambda: qb._call("set_options", C.byref(qb.lib.default_options()))):
+        with pytest.raises(T.ArgumentError, match="in flight"):
+            call()
+    n_ = C.c_int32(0)
+    qb._call("dims", C.byref(n_), None, None, None, None)
+    assert n_.value == 13
     tb.wait(); ta.wait()
     for s, t, p, q in ((sa, ta, pa, qa), (sb, tb, pb, qb)):
         for k in ("iterations", "iterations_outer", "iterations_pn", "status"):

@@ -30,6 +30,12 @@ FILE_FLAGS = {"ops_quad_expand.hip": ["-mllvm", "-simplifycfg-sink-common=false"
 for _f in ("ops_quad_forward_a", "ops_quad_forward_b", "ops_quad_forward_c", "ops_quad_forward2_a", "ops_quad_forward2_b", "ops_quad_forward2_c",
            "ops_quadmrp_forward", "ops_quadrp_forward", "ops_small_forward", "ops_small_forward2", "ops_hybrid", "ops_vector"):
     FILE_FLAGS.setdefault(_f + ".hip", []).append("-ffp-contract=on")
+# The lane expansion kernels and the scan kernel differentiate the RK step with chunk-mode dual numbers whose seeds are unit vectors:
+# a third of their FP64 instructions were products with a literal 0.0, which IEEE semantics forbid folding (0 * NaN).  These three
+# flags allow exactly that folding (no reassociation, no reciprocal or contraction changes: finite results are bit-identical up to the
+# sign of a zero); the NaN-sensitive tests in those kernels work on bit patterns (common.h not_positive).
+for _f in ("ops_small_lane", "ops_small_scan"):
+    FILE_FLAGS.setdefault(_f + ".hip", []).extend(["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"])
 OBJDIR = CSRC / "build"
 
 

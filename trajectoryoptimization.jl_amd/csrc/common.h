@@ -234,6 +234,13 @@ struct Coop {
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ------------------------------------------------------------------------------------------------ regularisation
+// !(x > 0) on the bit pattern: true for zero, negatives and NaN.  The positive-definiteness tests of the backward passes use it so
+// that they keep their meaning in the translation units compiled with -fno-honor-nans (ops_lane.h), where the compiler may turn
+// !(x > 0) into x <= 0 and a NaN pivot would pass.
+__device__ __forceinline__ bool not_positive(double x) {
+  const long long b = __double_as_longlong(x);
+  return !(b > 0 && b <= 0x7ff0000000000000LL);
+}
 __device__ __forceinline__ void reg_increase(const to_solver_opts& o, double& rho, double& drho) {
   const double f = o.bp_reg_increase_factor;
   drho = fmax(drho * f, f);

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <thread>
@@ -58,6 +59,7 @@ struct to_handle_s {
   int expand_lane = 1;    // lane layout: expansion by k_expand_lane (one lane per (trajectory, knot)); 0 = column-per-lane kernel (A/B knob TRAJOPT_EXPAND_LANE)
   int roll_min_active = -1;  // solve loop: batch steps with at least this many active trajectories store candidate controls only and accept
                              // by k_accept_roll (-1: the measured default per solver, 0: never; TRAJOPT_ACCEPT_ROLL_MIN)
+  int roll_min_small = 32768;  // ... the default of the small (write-through) models
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   // device copies of the descriptor tables
   to_cost_desc* d_costs = nullptr;
@@ -94,7 +96,7 @@ struct to_handle_s {
   double pn_early_ms = 0.0;
   // asynchronous solves (to_*_solve_async / to_solve_wait)
   std::thread worker;
-  bool inflight = false;
+  std::atomic<bool> inflight{false};
   int async_rc = 0;
   std::string async_err;
   int last_steps = 0;     // batch steps and device time of the last solve (fill_stats)
@@ -133,6 +135,7 @@ struct ModelOps {
   int (*constraint_hessian)(to_handle*, int ci, const double* lambda, double* H) = nullptr;
   int (*expand)(to_handle*) = nullptr;
   int (*backward)(to_handle*) = nullptr;
+  int (*expand_lane_k)(to_handle*) = nullptr;    // lane-layout expansion, one lane per (trajectory, knot) (ops_lane.h; null: column-per-lane kernel)
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)
   int (*expand_backward_scan)(to_handle*) = nullptr;  // fused expansion + scan Riccati, one wave per trajectory (k_scan.h)
   int (*expand_backward_coop)(to_handle*) = nullptr;  // fused expansion + cooperative Riccati (small models with <= 8 directions)
@@ -149,6 +152,7 @@ struct ModelOps {
 constexpr int N_MODEL_KEYS = 9;
 void fill_ops_small(ModelOps* table);
 void fill_ops_small_forward(ModelOps* table);
+void fill_ops_small_lane(ModelOps* table);
 void fill_ops_quad_misc(ModelOps* table);
 void fill_ops_quad_expand(ModelOps* table);
 void fill_ops_quad_backward(ModelOps* table);

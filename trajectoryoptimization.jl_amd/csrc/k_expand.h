@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64, TO_FUSED_LANE_WAVES) k_expand_backward_lan
         double sj = Lc[q][q];
 #pragma unroll
         for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
-        if (!(sj > 0.0) && live) pd_ok = false;
+        if (not_positive(sj) && live) pd_ok = false;
         iL[q] = rsqrt_fast(sj);
         Lc[q][q] = sj * iL[q];
 #pragma unroll

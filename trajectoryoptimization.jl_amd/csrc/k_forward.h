@@ -221,9 +221,23 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
 template <class M, int FIXED_INTEG>
 __global__ void __launch_bounds__(64) k_accept_roll(KArgs a) {
   constexpr int n = M::n, m = M::m;
-  TILE_LANE();
   const DevProblem& P = a.P;
-  const int s = b < P.B ? a.acc[b] : 0;
+  // this lane's trajectory: lane of the tile, or — with active-list compaction — an entry of THIS step's list (every trajectory that
+  // accepted a step in this forward pass was on it; index order keeps the nominal stores of neighbouring lanes together)
+  int b;
+  bool inrange;
+  if (a.compact) {
+    const int cnt = a.acount[a.step & 1];
+    if ((int)blockIdx.x * 64 >= cnt) return;  // wave-uniform
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    inrange = li < cnt;
+    b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? li : cnt - 1)];
+  } else {
+    b = blockIdx.x * 64 + threadIdx.x;
+    inrange = b < P.B;
+  }
+  const int tile = b >> 6, lane = b & 63;
+  const int s = inrange ? a.acc[b] : 0;
   if (__ballot(s != 0) == 0) return;
   const int N = P.N;
   const int bb = b < P.B ? b : 0;
@@ -277,6 +291,7 @@ __global__ void __launch_bounds__(64) k_accept_roll(KArgs a) {
   if (st) {
 #pragma unroll
     for (int i = 0; i < n; ++i) EL(dX, (N - 1) * n + i) = x[i];
+    a.acc[b] = 0;  // settled: every later reader finds the step on the nominal
   }
 }
 
@@ -351,7 +366,8 @@ __device__ __forceinline__ void forward_finish(const KArgs& a, int tile, int lan
       if (!inner_done) {
         atomicAdd(&a.counter[a.step], 1);  // (with compaction k_compact rebuilds the list of active trajectories after this step)
       } else {
-        settle = a.compact && M::accept_write_through && acc != 0;  // (models without write-through run k_accept after every forward pass)
+        settle = a.compact && M::accept_write_through && acc != 0 && a.store_x;  // (models without write-through run k_accept after every forward pass;
+                                                                                // without stored states k_accept_roll follows this launch)
         if (!a.al_mode) { a.status[b] = st; a.active[b] = 0; }
         else {  // AL outer update: whole-trajectory passes, run knot-parallel by the k_outer_* kernels
           a.ost[b] = st; a.oflag[b] = 1;

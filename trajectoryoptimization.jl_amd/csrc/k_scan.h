@@ -178,7 +178,7 @@ __device__ __forceinline__ bool scan_element(const double* Mk, const double* Hd,
   bool ok = true;
   double iR[m];
 #pragma unroll
-  for (int c = 0; c < m; ++c) { if (!terminal && !(Hd[ne + c] > 0.0)) ok = false; iR[c] = rcp_fast(terminal ? 1.0 : Hd[ne + c]); }
+  for (int c = 0; c < m; ++c) { if (!terminal && not_positive(Hd[ne + c])) ok = false; iR[c] = rcp_fast(terminal ? 1.0 : Hd[ne + c]); }
 #pragma unroll
   for (int i = 0; i < ne; ++i) {
 #pragma unroll
@@ -269,7 +269,7 @@ __device__ __forceinline__ bool scan_riccati_step(const double* Me, const double
     double sj = Lc[q][q];
 #pragma unroll
     for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
-    if (!(sj > 0.0)) pd_ok = false;
+    if (not_positive(sj)) pd_ok = false;
     iL[q] = rsqrt_fast(sj);
     Lc[q][q] = sj * iL[q];
 #pragma unroll

@@ -102,16 +102,8 @@ int op_expand_fi(to_handle* h) {
   const int kc = var == 0 ? expand_kc<M, 0>() : expand_kc<M, 2>();
   const dim3 grid((P.B + h->G - 1) / h->G, (P.N + kc - 1) / kc);
   const int lay = h->a.bwd_lane ? 3 : !h->a.bwd_mfma ? 0 : (h->a.h_compact ? 2 : 1);
-  if constexpr (M::lane_backward && !M::lie) {  // one lane per (trajectory, knot), all columns at once (k_expand_lane)
-    if (lay == 3 && h->expand_lane) {
-      const dim3 lgrid(P.Bp / BLOCK, P.N);
-      if (var == 0) hipLaunchKernelGGL((k_expand_lane<M, FI, 0>), lgrid, dim3(BLOCK), 0, h->stream, h->a);
-      else if (var == 2) hipLaunchKernelGGL((k_expand_lane<M, FI, 2>), lgrid, dim3(BLOCK), 0, h->stream, h->a);
-      else hipLaunchKernelGGL((k_expand_lane<M, FI, 7>), lgrid, dim3(BLOCK), 0, h->stream, h->a);
-      HIPCHECK(hipGetLastError());
-      return TO_OK;
-    }
-  }
+  // lane layout: one lane per (trajectory, knot), all columns at once (k_expand_lane; instantiated in the lane translation units, ops_lane.h)
+  if (lay == 3 && h->expand_lane && h->ops->expand_lane_k) return h->ops->expand_lane_k(h);
 #define TO_EXPAND_CASE(V, LY) \
   if (var == V && lay == LY) { hipLaunchKernelGGL((k_expand<M, FI, V, LY>), grid, dim3(BLOCK), 0, h->stream, h->a); HIPCHECK(hipGetLastError()); return TO_OK; }
   if constexpr (M::mfma_backward) {
@@ -158,29 +150,6 @@ int op_backward(to_handle* h) {
     return TO_OK;
   }
   return fail(TO_ERR_UNSUPPORTED, "backward-pass variant not compiled for this model");
-}
-
-// large batches of the small models: expansion fused into the one-lane-per-trajectory backward pass (k_expand.h)
-template <class M, int FI>
-int op_expand_backward_fi(to_handle* h) {
-  if constexpr (M::lane_backward && !M::lie) {
-    const DevProblem& P = h->a.P;
-    const int var = P.expand_variant == 0 ? 0 : (P.expand_variant == 2 ? 2 : 7);
-    const dim3 grid(P.Bp / BLOCK);
-    if (var == 0) hipLaunchKernelGGL((k_expand_backward_lane<M, FI, 0>), grid, dim3(BLOCK), 0, h->stream, h->a);
-    else if (var == 2) hipLaunchKernelGGL((k_expand_backward_lane<M, FI, 2>), grid, dim3(BLOCK), 0, h->stream, h->a);
-    else hipLaunchKernelGGL((k_expand_backward_lane<M, FI, 7>), grid, dim3(BLOCK), 0, h->stream, h->a);
-    HIPCHECK(hipGetLastError());
-    return TO_OK;
-  }
-  return fail(TO_ERR_UNSUPPORTED, "fused lane expansion + backward pass not compiled for this model");
-}
-template <class M>
-int op_expand_backward(to_handle* h) {
-  if constexpr (M::pin_rk4) {
-    if (h->a.P.integrator == INTEG_RK4) return op_expand_backward_fi<M, INTEG_RK4>(h);
-  }
-  return op_expand_backward_fi<M, -1>(h);
 }
 
 // small batches of the small models with diagonal cost blocks: expansion fused into the cooperative backward pass (k_expand.h)

@@ -7,7 +7,6 @@ static void fill_one(ModelOps& o) {
   fill_misc<M>(o);
   o.expand = op_expand<M>;
   o.backward = op_backward<M>;
-  if constexpr (M::lane_backward && !M::lie) o.expand_backward = op_expand_backward<M>;
   if constexpr (!M::lie && Coop<M>::R <= 8) o.expand_backward_coop = op_expand_backward_coop<M>;
 }
 void fill_ops_small(ModelOps* t) {

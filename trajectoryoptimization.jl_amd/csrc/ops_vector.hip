@@ -10,6 +10,7 @@ void fill_ops_vector(ModelOps* t) {
   t[8].expand = op_expand<M>;
   t[8].backward = op_backward<M>;
   fill_forward<M, 0, 16>(t[8]);
+  t[8].accept_roll = op_accept_roll<M>;
   fill_forward2<M, 0, 16>(t[8]);
 }
 }  // namespace to

@@ -39,7 +39,7 @@ ModelOps g_ops[N_MODEL_KEYS];
 std::once_flag g_ops_once;
 const ModelOps* model_ops(int key) {
   std::call_once(g_ops_once, [] {
-    fill_ops_small(g_ops); fill_ops_small_forward(g_ops);
+    fill_ops_small(g_ops); fill_ops_small_forward(g_ops); fill_ops_small_lane(g_ops);
     fill_ops_quad_misc(g_ops); fill_ops_quad_expand(g_ops); fill_ops_quad_backward(g_ops);
     fill_ops_quad_forward_a(g_ops); fill_ops_quad_forward_b(g_ops); fill_ops_quad_forward_c(g_ops);
     fill_ops_quad_forward2_a(g_ops); fill_ops_quad_forward2_b(g_ops); fill_ops_quad_forward2_c(g_ops);
@@ -184,8 +184,8 @@ int launch_cost(to_handle* h, int with_al, double* out, double* Jk) { return h->
 int launch_expand(to_handle* h) { return h->ops->expand(h); }
 int launch_backward(to_handle* h) { return h->ops->backward(h); }
 int launch_accept(to_handle* h) {  // materialise accepted candidate slots on slot 0, then forget them
-  if (!h->a.store_x) TRY(h->ops->accept_roll(h));  // their states were not stored: rolled out again from the stored controls
-  else hipLaunchKernelGGL(k_accept, grid_b(h, 1, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
+  if (!h->a.store_x) return h->ops->accept_roll(h);  // their states were not stored: rolled out again from the stored controls (clears acc itself)
+  hipLaunchKernelGGL(k_accept, grid_b(h, 1, h->accept_chunks), dim3(BLOCK), 0, h->stream, h->a);
   hipLaunchKernelGGL(k_clear_acc, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
   HIPCHECK(hipGetLastError());
   return TO_OK;
@@ -374,8 +374,8 @@ int altro_solve(to_handle* h, to_solve_stats* st) {
   if (const char* env = std::getenv("TRAJOPT_PN_EARLY")) early = std::max(0, std::min(8, std::atoi(env)));
   h->pn_early = 0; h->pn_early_slots = 0;
   if (early > 0 && h->ops->pn_launch && !h->ops->write_through) {  // (write-through models keep accepted steps in candidate slots until the solve ends)
-    TRY(h->ops->pn_prepare(h, B));
-    if (h->pn_cap >= B) {  // every trajectory has a workspace slot of its own
+    // (a problem the polish cannot take — too many rows on a knot, no memory for the workspace — still gets its AL stage)
+    if (h->ops->pn_prepare(h, B) == TO_OK && h->pn_cap >= B) {  // every trajectory has a workspace slot of its own
       TRY(early_polish_setup(h));
       h->pn_done_early.assign(B, 0);
       h->pn_opts = user;
@@ -406,8 +406,11 @@ int altro_solve(to_handle* h, to_solve_stats* st) {
   std::vector<int> list;
   for (int b = 0; b < B; ++b)
     if (status[b] == TO_SOLVE_SUCCEEDED && cmax[b] > user.constraint_tolerance && !(had_early && h->pn_done_early[b])) list.push_back(b);
-  TRY(pn_run(h, list, user));
-  if (st) TRY(fill_stats(h, st, true));
+  // A problem outside the polish's limits (PN_NB_LIMIT rows on one knot) keeps the result of its AL stage: the call succeeds, the
+  // trajectories keep their AL status / violation and to_last_error() says why nothing was polished
+  const int prc = pn_run(h, list, user);
+  if (prc != TO_OK && prc != TO_ERR_UNSUPPORTED) return prc;
+  if (st) { const std::string note = prc == TO_OK ? std::string() : g_err; TRY(fill_stats(h, st, true)); if (!note.empty()) g_err = "polish skipped: " + note; }
   return TO_OK;
 }
 
@@ -477,9 +480,12 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       // (measured, always vs never, whole solve: C5 +0.9 / +4.6 / +7.7 / +7.3 % at B = 2048 / 4096 / 8192 / 16384, C3 -3 / -1 / +1.9 / +4.4 %:
       // the copy by k_accept grows with the accepted trajectories — 93 us at 4096, 227 us at 8192 — the second rollout does not,
       // and an AL line search goes through more rounds, each of which stores its candidates, than an unconstrained one)
-      const int roll_min = h->roll_min_active >= 0 ? h->roll_min_active : (al_mode ? 2048 : 8192);
+      // Small models (write-through; 4 step sizes x 16 trajectories per wave): at the large-batch plateau the forward pass wrote 19 KB per
+      // active trajectory for 4 KB of result and the next expansion gathered the accepted candidate through 4x-amplified sectors;
+      // with the controls only and the re-roll both kernels stream the nominal (TRAJOPT_ACCEPT_ROLL_MIN overrides every default)
+      const int roll_min = h->roll_min_active >= 0 ? h->roll_min_active : h->ops->write_through ? h->roll_min_small : (al_mode ? 2048 : 8192);
       a.store_x = (roll_min > 0 && h->ops->accept_roll && !two && last_active >= roll_min) ? 0 : 1;
-      TRY(launch_forward(h, !h->ops->write_through, two));
+      TRY(launch_forward(h, !h->ops->write_through || !a.store_x, two));
       a.store_x = 1;
       if (al_mode) TRY(launch_outer(h));
       if (a.compact) {  // the list of the trajectories that go on, for the next step's kernels
@@ -728,6 +734,11 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
     int lg = 0;
     while ((2 << lg) <= cw) ++lg;
     h->cw_base = 1 << lg; h->tw_base = 64 / h->cw_base;
+    // The small (write-through) models take any width: their lane map is the static one in every round (k_forward.h) and nothing in it
+    // needs a power of two — lanes CW*TW .. 63 ride along without a candidate.  THREE step sizes x 21 trajectories per wave: the C2-shaped
+    // Cartpole solves accept within the first three step sizes in 99.5 % of their line searches (alpha = 1 / 0.5 / 0.25: 18 / 40 / 42 %,
+    // measured on the oracle), so a wave serves 21 trajectories instead of 16 per pass for one extra pass in ~10 % of the waves.
+    if (h->ops->write_through && cw >= 1 && cw <= 16) { h->cw_base = cw; h->tw_base = 64 / cw; }
     a.CW = h->cw_base; a.TW = h->tw_base;
     // Deep shape: the WHOLE search depth in one round (20 step sizes x 3 trajectories per wave by default).  A trajectory
     // that rejects the first CW step sizes otherwise costs the batch a second full rollout pass (the Quadrotor solves do so
@@ -903,9 +914,9 @@ int to_destroy(to_handle* h) {
   return TO_OK;
 }
 
-int to_set_options(to_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_P(o); TRY(validate_opts(*o)); h->a.P.opts = *o; return TO_OK; }
+int to_set_options(to_handle* h, const to_solver_opts* o) { CHECK_H(h); CHECK_IDLE(h); CHECK_P(o); TRY(validate_opts(*o)); h->a.P.opts = *o; return TO_OK; }
 int to_get_options(const to_handle* h, to_solver_opts* o) { CHECK_H(h); CHECK_P(o); *o = h->a.P.opts; return TO_OK; }
-int to_sync(to_handle* h) { CHECK_H(h); TRY(use_device(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
+int to_sync(to_handle* h) { CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
 void* to_stream(to_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int to_solver_path(const to_handle* h, int32_t* info) {
@@ -941,9 +952,9 @@ int to_knot_dims(const to_handle* h, int32_t* nx, int32_t* nu) {
   }
   return TO_OK;
 }
-int to_set_profiling(to_handle* h, int enable) { CHECK_H(h); h->profile = enable != 0; return TO_OK; }
+int to_set_profiling(to_handle* h, int enable) { CHECK_H(h); CHECK_IDLE(h); h->profile = enable != 0; return TO_OK; }
 int to_reset_profile(to_handle* h) {
-  CHECK_H(h);
+  CHECK_H(h); CHECK_IDLE(h);
   for (int i = 0; i < TO_PROFILE_SLOTS; ++i) { h->prof_ms[i] = 0; h->prof_launches[i] = 0; }
   return TO_OK;
 }
@@ -967,23 +978,23 @@ int to_num_constraints(const to_handle* h, int32_t* p) {
 }
 
 int to_set_initial_state(to_handle* h, const double* x0) {
-  CHECK_H(h); CHECK_P(x0); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(x0); TRY(use_device(h));
   return upload_vec(h, x0, h->a.x0, h->a.P.n);
 }
 int to_get_initial_state(to_handle* h, double* x0) {
-  CHECK_H(h); CHECK_P(x0); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(x0); TRY(use_device(h));
   return download_vec(h, x0, h->a.x0, h->a.P.n);
 }
 int to_set_controls(to_handle* h, const double* U) {
-  CHECK_H(h); CHECK_P(U); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(U); TRY(use_device(h));
   return upload_vec(h, U, h->a.Us, h->a.P.m * (h->a.P.N - 1));
 }
 int to_set_states(to_handle* h, const double* X) {
-  CHECK_H(h); CHECK_P(X); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(X); TRY(use_device(h));
   return upload_vec(h, X, h->a.Xs, h->a.P.n * h->a.P.N);
 }
 int to_set_controls_uniform(to_handle* h, const double* u) {
-  CHECK_H(h); CHECK_P(u); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(u); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   TRY(ensure_stage(h, sizeof(double) * P.m));
   HIPCHECK(hipMemcpyAsync(h->stage, u, sizeof(double) * P.m, hipMemcpyHostToDevice, h->stream));
@@ -993,30 +1004,30 @@ int to_set_controls_uniform(to_handle* h, const double* u) {
   return TO_OK;
 }
 int to_get_states(to_handle* h, double* X) {
-  CHECK_H(h); CHECK_P(X); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(X); TRY(use_device(h));
   return download_nominal(h, X, h->a.Xs, h->a.P.n * h->a.P.N);
 }
 int to_get_controls(to_handle* h, double* U) {
-  CHECK_H(h); CHECK_P(U); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(U); TRY(use_device(h));
   return download_nominal(h, U, h->a.Us, h->a.P.m * (h->a.P.N - 1));
 }
 int to_get_states_device(to_handle* h, void* dX) {
-  CHECK_H(h); CHECK_P(dX); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(dX); TRY(use_device(h));
   return download_nominal(h, nullptr, h->a.Xs, h->a.P.n * h->a.P.N, dX);
 }
 int to_get_controls_device(to_handle* h, void* dU) {
-  CHECK_H(h); CHECK_P(dU); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(dU); TRY(use_device(h));
   return download_nominal(h, nullptr, h->a.Us, h->a.P.m * (h->a.P.N - 1), dU);
 }
 int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
-  CHECK_H(h); CHECK_P(c); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(c); TRY(use_device(h));
   if (id < 0 || id >= (int)h->costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
   TRY(validate_cost(h->a.P.n, (h->model_key >= 4 && h->model_key <= 6) ? (int)h->a.P.mp[10] : -1, *c));  // rigid bodies only (key 7: hybrid double integrator)
   h->costs[id] = *c;
   return upload_tables(h);
 }
 int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
-  CHECK_H(h); CHECK_P(c); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(c); TRY(use_device(h));
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   DevCon ci;
   TRY(validate_constraint(h->a.P.n, h->a.P.m, h->a.P.N, *c, &ci));
@@ -1027,19 +1038,19 @@ int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
   return upload_tables(h);
 }
 
-int to_rollout(to_handle* h) { CHECK_H(h); TRY(use_device(h)); TRY(launch_rollout(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
+int to_rollout(to_handle* h) { CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h)); TRY(launch_rollout(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
 int to_cost(to_handle* h, double* J) {
-  CHECK_H(h); CHECK_P(J); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(J); TRY(use_device(h));
   TRY(launch_cost(h, 0, h->d_tmp, nullptr));
   return download_scalar(h, J, h->d_tmp);
 }
 int to_al_cost(to_handle* h, double* J) {
-  CHECK_H(h); CHECK_P(J); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(J); TRY(use_device(h));
   TRY(launch_cost(h, 1, h->d_tmp, nullptr));
   return download_scalar(h, J, h->d_tmp);
 }
 int to_stage_costs(to_handle* h, double* Jk) {
-  CHECK_H(h); CHECK_P(Jk); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(Jk); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   // per-knot values land in a tiled array (L = N) in the upper half of the staging buffer, then transpose to host (N,B)
   const size_t cnt = (size_t)P.N * P.Bp;
@@ -1053,13 +1064,13 @@ int to_stage_costs(to_handle* h, double* Jk) {
   return TO_OK;
 }
 int to_expand(to_handle* h) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   TRY(launch_set_active(h, 1)); TRY(launch_expand(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
 int to_backward(to_handle* h) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   TRY(launch_set_active(h, 1));
   const DevProblem& P = h->a.P;
   if (h->scan == 2 && h->a.h_diag && P.expand_variant == 0) {
@@ -1071,7 +1082,7 @@ int to_backward(to_handle* h) {
   return TO_OK;
 }
 int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   h->a.control = 0;
   // keep bpfail from a preceding to_backward: set active without clearing it
   TRY(launch_cost(h, 1, h->a.J, nullptr));
@@ -1095,10 +1106,15 @@ static int solve_async(to_handle* h, to_solve_stats* st, int kind) {
   if (h->inflight) return fail(TO_ERR_ARGUMENT, "a solve is already in flight on this handle (call to_solve_wait first)");
   h->inflight = true;
   h->async_rc = TO_OK;
-  h->worker = std::thread([h, st, kind] {
-    h->async_rc = kind == 0 ? solve(h, st, 0) : kind == 1 ? solve(h, st, 1) : altro_solve(h, st);
-    h->async_err = g_err;
-  });
+  try {  // no exception may cross the C ABI (std::system_error: out of threads)
+    h->worker = std::thread([h, st, kind] {
+      h->async_rc = kind == 0 ? solve(h, st, 0) : kind == 1 ? solve(h, st, 1) : altro_solve(h, st);
+      h->async_err = g_err;
+    });
+  } catch (const std::exception& e) {
+    h->inflight = false;
+    return fail(TO_ERR_HIP, std::string("could not start the solve thread: ") + e.what());
+  }
   return TO_OK;
 }
 int to_ilqr_solve_async(to_handle* h, to_solve_stats* st) { return solve_async(h, st, 0); }
@@ -1113,7 +1129,7 @@ int to_solve_wait(to_handle* h) {
   return h->async_rc;
 }
 int to_dynamics_defect(to_handle* h, double* defect) {
-  CHECK_H(h); CHECK_P(defect);
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(defect);
   TRY(use_device(h));
   TRY(h->ops->defect(h, h->d_tmp));
   return download_scalar(h, defect, h->d_tmp);
@@ -1172,14 +1188,14 @@ static int download_gradient(to_handle* h, double* host, int col0, int Cc) {
   return TO_OK;
 }
 int to_get_dynamics_jacobians(to_handle* h, double* A, double* Bm) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   TRY(download_block(h, A, BLK_M, 0, P.ne, 0, P.ne));
   TRY(download_block(h, Bm, BLK_M, 0, P.ne, P.ne, P.m));
   return TO_OK;
 }
 int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, double* qx, double* qu) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   TRY(download_block(h, Qxx, BLK_H, 0, P.ne, 0, P.ne));
   TRY(download_block(h, Quu, BLK_H, P.ne, P.m, P.ne, P.m));
@@ -1189,7 +1205,7 @@ int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, d
   return TO_OK;
 }
 int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   if (K || d) {
     const size_t nK = (size_t)P.m * P.ne * (P.N - 1) * P.B, nd = (size_t)P.m * (P.N - 1) * P.B;
@@ -1211,7 +1227,7 @@ int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
   return TO_OK;
 }
 int to_cost_expansion(to_handle* h, double* grad, double* hess) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   const size_t nz = P.n + P.m, ng = nz * P.N * P.B, nh = nz * nz * P.N * P.B;
   TRY(ensure_stage(h, (ng + nh) * sizeof(double)));
@@ -1223,7 +1239,7 @@ int to_cost_expansion(to_handle* h, double* grad, double* hess) {
   return TO_OK;
 }
 int to_discrete_jacobian(to_handle* h, double* F) {
-  CHECK_H(h); CHECK_P(F); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(F); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   const size_t cnt = (size_t)P.n * (P.n + P.m) * (P.N - 1) * P.B;
   TRY(ensure_stage(h, cnt * sizeof(double)));
@@ -1255,10 +1271,10 @@ static int constraint_eval(to_handle* h, int32_t id, double* vals, double* jac) 
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
-int to_evaluate_constraints(to_handle* h, int32_t id, double* vals) { CHECK_H(h); CHECK_P(vals); return constraint_eval(h, id, vals, nullptr); }
-int to_constraint_jacobians(to_handle* h, int32_t id, double* jac) { CHECK_H(h); CHECK_P(jac); return constraint_eval(h, id, nullptr, jac); }
+int to_evaluate_constraints(to_handle* h, int32_t id, double* vals) { CHECK_H(h); CHECK_IDLE(h); CHECK_P(vals); return constraint_eval(h, id, vals, nullptr); }
+int to_constraint_jacobians(to_handle* h, int32_t id, double* jac) { CHECK_H(h); CHECK_IDLE(h); CHECK_P(jac); return constraint_eval(h, id, nullptr, jac); }
 int to_constraint_hessians(to_handle* h, int32_t id, const double* lambda, double* H) {
-  CHECK_H(h); CHECK_P(lambda); CHECK_P(H); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(lambda); CHECK_P(H); TRY(use_device(h));
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   const DevCon& ci = h->cons[id];
   const DevProblem& P = h->a.P;
@@ -1274,13 +1290,13 @@ int to_constraint_hessians(to_handle* h, int32_t id, const double* lambda, doubl
   return TO_OK;
 }
 int to_max_violation(to_handle* h, double* c_max) {
-  CHECK_H(h); CHECK_P(c_max); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(c_max); TRY(use_device(h));
   if (h->a.P.n_cons == 0) { std::memset(c_max, 0, sizeof(double) * h->a.P.B); return TO_OK; }
   TRY(launch_violation(h, h->d_tmp));
   return download_scalar(h, c_max, h->d_tmp);
 }
 int to_get_duals(to_handle* h, int32_t id, double* lambda, double* mu) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   const DevCon& ci = h->cons[id];
   const DevProblem& P = h->a.P;
@@ -1289,7 +1305,7 @@ int to_get_duals(to_handle* h, int32_t id, double* lambda, double* mu) {
   return TO_OK;
 }
 int to_set_duals(to_handle* h, int32_t id, const double* lambda, const double* mu) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   const DevCon& ci = h->cons[id];
   const DevProblem& P = h->a.P;
@@ -1298,7 +1314,7 @@ int to_set_duals(to_handle* h, int32_t id, const double* lambda, const double* m
   return TO_OK;
 }
 int to_reset_duals(to_handle* h) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   const DevProblem& P = h->a.P;
   if (P.n_cons == 0) return TO_OK;
   HIPCHECK(hipMemsetAsync(h->a.lam, 0, sizeof(double) * (size_t)P.n_duals * P.Bp, h->stream));
@@ -1308,7 +1324,7 @@ int to_reset_duals(to_handle* h) {
   return TO_OK;
 }
 int to_dual_update(to_handle* h) {
-  CHECK_H(h); TRY(use_device(h));
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   if (h->a.P.n_cons == 0) return TO_OK;
   TRY(h->ops->dual_update(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1326,7 +1342,7 @@ int to_comm_unique_id(void* id128) {
   return TO_OK;
 }
 int to_comm_init_rank(to_handle* h, int32_t nranks, int32_t rank, const void* id128) {
-  CHECK_H(h); CHECK_P(id128);
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(id128);
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(TO_ERR_ARGUMENT, "rank outside 0..nranks-1");
   if (h->comm) return fail(TO_ERR_ARGUMENT, "communicator already initialised (to_comm_destroy first)");
   TRY(load_rccl());
@@ -1374,7 +1390,7 @@ int to_comm_shards(const to_handle* h, int32_t* nranks, int32_t* rank, int64_t* 
   return TO_OK;
 }
 int to_comm_destroy(to_handle* h) {
-  CHECK_H(h);
+  CHECK_H(h); CHECK_IDLE(h);
   if (!h->comm) return TO_OK;
   TRY(use_device(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1406,7 +1422,7 @@ static int gather_blocks(to_handle* h, void* all, size_t per, int dtype, size_t 
 // sizes, to_comm_shards); on return (the call synchronises the handle's stream) they hold every rank's trajectories in host
 // layout (n, N, B_total), rank-major = global trajectory order.  Shards may differ in size.
 int to_allgather(to_handle* h, void* dX_all, void* dU_all) {
-  CHECK_H(h);
+  CHECK_H(h); CHECK_IDLE(h);
   if (!dX_all && !dU_all) return fail(TO_ERR_NULL, "null pointer");
   if (!h->comm) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank first");
   TRY(use_device(h));
@@ -1431,7 +1447,7 @@ int to_allgather(to_handle* h, void* dX_all, void* dU_all) {
 // objective cost J[B_total] of every rank's CURRENT trajectories, rank-major, into caller-owned HOST arrays (any may be
 // NULL).  Staged through a device buffer of the library (a few bytes per trajectory), gathered over the same communicator.
 int to_allgather_stats(to_handle* h, int32_t* iterations_all, int32_t* status_all, double* J_all) {
-  CHECK_H(h);
+  CHECK_H(h); CHECK_IDLE(h);
   if (!h->comm) return fail(TO_ERR_ARGUMENT, "to_comm_init_rank first");
   if (!iterations_all && !status_all && !J_all) return fail(TO_ERR_NULL, "null pointer");
   TRY(use_device(h));
