@@ -60,6 +60,7 @@ struct to_handle_s {
   int roll_min_active = -1;  // solve loop: batch steps with at least this many active trajectories store candidate controls only and accept
                              // by k_accept_roll (-1: the measured default per solver, 0: never; TRAJOPT_ACCEPT_ROLL_MIN)
   int roll_min_small = 32768;  // ... the default of the small (write-through) models
+  double roll_min_frac = 0.25;  // ... which also need at least this fraction of the batch active (TRAJOPT_ACCEPT_ROLL_FRAC)
   int accept_chunks = 1;  // grid.z of k_accept (a chunk is >= 32 elements of [X; U]: the copy is latency-bound per wave)
   // device copies of the descriptor tables
   to_cost_desc* d_costs = nullptr;

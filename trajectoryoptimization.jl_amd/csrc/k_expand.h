@@ -509,7 +509,13 @@ __global__ void __launch_bounds__(64, TO_FUSED_LANE_WAVES) k_expand_backward_lan
     for (int i = 0; i < n; ++i) xn_[i] = EL(X, (N - 2) * n + i);
 #pragma unroll
     for (int i = 0; i < m; ++i) un_[i] = EL(U, (N - 2) * m + i);
-    for (int k = N - 2; k >= 0; --k) {
+    for (int kv = N - 2; kv >= 0; --kv) {
+      // Lanes leave this loop one by one (a Cholesky failure breaks out for ITS lane), so the compiler treats the counter as lane-
+      // dependent and fetched everything indexed by it — P.dt[k], P.cost_index[k], the cost descriptor behind it — with VECTOR loads
+      // and a vmcnt(0) wait each: three dependent memory round trips per knot that also drained the prefetch of the next knot's
+      // nominal (r05 counters: 44 % of the wave cycles waiting at one wave per SIMD).  Every lane still in the loop holds the same
+      // value: read it from the first one, and the tables come through scalar loads again.
+      const int k = __builtin_amdgcn_readfirstlane(kv);
       double x[n], u[m];
 #pragma unroll
       for (int i = 0; i < n; ++i) x[i] = xn_[i];

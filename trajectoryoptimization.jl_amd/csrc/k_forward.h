@@ -213,86 +213,116 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   J_out = J; g_out = gsum / (N - 1); ok_out = ok;
 }
 
-// Accepting a step whose candidate states were not stored (KArgs::store_x == 0): one lane per trajectory copies the accepted
-// candidate's controls onto slot 0 and rolls them out again from x0.  Same step function, same operands and — this translation unit
-// is compiled with -ffp-contract=on — the same fused operations as in forward_candidate: the states are bit-identical to the ones
-// the line search evaluated (tests/test_gpu_parity.py::test_accept_by_rollout compares whole solves for equality).  Lanes that
-// accepted nothing roll out their nominal alongside (EXEC stays full) and store nothing.
-template <class M, int FIXED_INTEG>
-__global__ void __launch_bounds__(64) k_accept_roll(KArgs a) {
-  constexpr int n = M::n, m = M::m;
+// Accepting a step whose candidate states were not stored (KArgs::store_x == 0), in two launches over the trajectories of this step
+// (one lane per trajectory; with active-list compaction: the entries of this step's list, in index order):
+//   k_accept_gather_u  copies the accepted candidate's CONTROLS onto slot 0 — gathered loads (every lane reads its own accepted
+//                      slot), nothing depends on them inside the wave, so dozens are in flight per lane;
+//   k_accept_roll      rolls the nominal controls out again from x0 onto the nominal states.  Same step function, same operands and —
+//                      this translation unit is compiled with -ffp-contract=on — the same fused operations as in forward_candidate:
+//                      the states are bit-identical to the ones the line search evaluated (tests/test_gpu_parity.py::
+//                      test_accept_by_rollout* compare whole solves for equality).
+// One kernel did both at first (gathered control loads four knots ahead of the rollout): with the chip full of stores the gathered
+// loads took ~10 us to come back, the wave's counted vmcnt waits — one counter for loads and stores on gfx950 — turned that into a
+// stall per group of four knots, and the kernel ran at 5.4 us per knot where the same step takes 0.8 us in k_forward (r05 traces,
+// Cartpole at B = 1 048 576: 2.2 ms per launch against 1.05 ms in the first batch step, where every trajectory accepts the same
+// step size and the gather happens to be coalesced).
+template <class M>
+__device__ __forceinline__ bool accept_lane(const KArgs& a, int& b, int& s) {
   const DevProblem& P = a.P;
-  // this lane's trajectory: lane of the tile, or — with active-list compaction — an entry of THIS step's list (every trajectory that
-  // accepted a step in this forward pass was on it; index order keeps the nominal stores of neighbouring lanes together)
-  int b;
   bool inrange;
   if (a.compact) {
     const int cnt = a.acount[a.step & 1];
-    if ((int)blockIdx.x * 64 >= cnt) return;  // wave-uniform
+    if ((int)blockIdx.x * 64 >= cnt) return false;  // wave-uniform
     const int li = blockIdx.x * 64 + threadIdx.x;
     inrange = li < cnt;
     b = a.alist[(size_t)(a.step & 1) * P.Bp + (inrange ? li : cnt - 1)];
   } else {
     b = blockIdx.x * 64 + threadIdx.x;
     inrange = b < P.B;
+    if (!inrange) b = P.B - 1;
   }
+  s = inrange ? a.acc[b] : 0;
+  return __ballot(s != 0) != 0;
+}
+template <class M>
+__global__ void __launch_bounds__(64) k_accept_gather_u(KArgs a) {
+  constexpr int m = M::m;
+  int b, s;
+  if (!accept_lane<M>(a, b, s)) return;
+  const int Lu = (a.P.N - 1) * m;
+  const double* su = U_SLOT_PTR(a, b, s);
+  double* du = U_SLOT_PTR(a, b, 0);
+  if (s == 0) return;
+  int e = 0;
+  for (; e + 16 <= Lu; e += 16) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = EL(su, e + i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) EL(du, e + i) = v[i];
+  }
+  for (; e < Lu; ++e) EL(du, e) = EL(su, e);
+}
+template <class M, int FIXED_INTEG>
+__global__ void __launch_bounds__(64) k_accept_roll(KArgs a) {
+  constexpr int n = M::n, m = M::m;
+  const DevProblem& P = a.P;
+  int b, s;
+  if (!accept_lane<M>(a, b, s)) return;
   const int tile = b >> 6, lane = b & 63;
-  const int s = inrange ? a.acc[b] : 0;
-  if (__ballot(s != 0) == 0) return;
   const int N = P.N;
-  const int bb = b < P.B ? b : 0;
-  const double* su = U_SLOT_PTR(a, bb, s);  // a gather: every lane reads its own accepted slot
-  double* dX = TILE_PTR(a.Xs, N * n);
-  double* dU = TILE_PTR(a.Us, (N - 1) * m);
+  // Lanes that accepted nothing roll their own nominal alongside (EXEC stays full) and store into the spare tile behind the batch
+  // (Xs is allocated one tile longer): the stores sit in straight-line code, no per-lane branch around them
+  const bool st = s != 0;
+  const int dtile = st ? tile : P.Bp / 64;
+  double* dX = a.Xs + ((size_t)dtile * (size_t)(N * n)) * 64 + lane;
+  const double* pU = TILE_PTR(a.Us, (N - 1) * m);  // the accepted controls, already on the nominal (k_accept_gather_u): coalesced rows
   const double* px0 = TILE_PTR(a.x0, n);
   double mp[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) mp[i] = in_vgpr(P.mp[i]);
   const int integrator = P.integrator;
-  const bool st = s != 0;
   double x[n], xn[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = EL(px0, i);
-  // a gathered load is a full trip to memory, several rollout steps long: the controls are fetched D knots at a time, the next
-  // group while the current one is stepped through (k_rollout's coalesced loads of one knot each: 222 us; this kernel with two
-  // knots in flight: 322 us)
+  // controls and time steps are fetched D knots at a time, the next group while the current one is stepped through
   constexpr int D = 4;
-  double ua[D][m], ub[D][m];
+  double ua[D][m], ub[D][m], ha[D], hb[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d)
+  for (int d = 0; d < D; ++d) {
+    const int kk = d < N - 1 ? d : N - 2;
 #pragma unroll
-    for (int j = 0; j < m; ++j) ua[d][j] = EL(su, (d < N - 1 ? d : N - 2) * m + j);
+    for (int j = 0; j < m; ++j) ua[d][j] = EL(pU, kk * m + j);
+    ha[d] = P.dt[kk];
+  }
   for (int k0 = 0; k0 < N - 1; k0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int kk = k0 + D + d < N - 1 ? k0 + D + d : N - 2;  // past the horizon: re-read the last knot (never used)
 #pragma unroll
-      for (int j = 0; j < m; ++j) ub[d][j] = EL(su, kk * m + j);
+      for (int j = 0; j < m; ++j) ub[d][j] = EL(pU, kk * m + j);
+      hb[d] = P.dt[kk];
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int k = k0 + d;
       if (k >= N - 1) break;  // wave-uniform
-      if (st) {
 #pragma unroll
-        for (int i = 0; i < n; ++i) EL(dX, k * n + i) = x[i];
-#pragma unroll
-        for (int j = 0; j < m; ++j) EL(dU, k * m + j) = ua[d][j];
-      }
-      model_step<M, double, FIXED_INTEG>(mp, integrator, k, x, ua[d], P.dt[k], xn);
+      for (int i = 0; i < n; ++i) EL(dX, k * n + i) = x[i];
+      model_step<M, double, FIXED_INTEG>(mp, integrator, k, x, ua[d], ha[d], xn);
 #pragma unroll
       for (int i = 0; i < n; ++i) x[i] = xn[i];
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < D; ++d) {
 #pragma unroll
       for (int j = 0; j < m; ++j) ua[d][j] = ub[d][j];
+      ha[d] = hb[d];
+    }
   }
-  if (st) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) EL(dX, (N - 1) * n + i) = x[i];
-    a.acc[b] = 0;  // settled: every later reader finds the step on the nominal
-  }
+  for (int i = 0; i < n; ++i) EL(dX, (N - 1) * n + i) = x[i];
+  if (st) a.acc[b] = 0;  // settled: every later reader finds the step on the nominal
 }
 
 // gradient metric of the UNCHANGED nominal controls (zero step / failed line search): mean_k max_j |d_kj| / (|u_kj| + 1)

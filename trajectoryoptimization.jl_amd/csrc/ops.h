@@ -207,6 +207,7 @@ int op_forward(to_handle* h) {
 // accepted steps re-rolled from their stored controls (k_accept_roll; models without write-through)
 template <class M>
 int op_accept_roll(to_handle* h) {
+  hipLaunchKernelGGL(k_accept_gather_u<M>, grid_b(h), dim3(BLOCK), 0, h->stream, h->a);
   bool done = false;
   if constexpr (M::pin_rk4) {
     if (h->a.P.integrator == INTEG_RK4) { hipLaunchKernelGGL((k_accept_roll<M, INTEG_RK4>), grid_b(h), dim3(BLOCK), 0, h->stream, h->a); done = true; }

@@ -484,7 +484,12 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       // active trajectory for 4 KB of result and the next expansion gathered the accepted candidate through 4x-amplified sectors;
       // with the controls only and the re-roll both kernels stream the nominal (TRAJOPT_ACCEPT_ROLL_MIN overrides every default)
       const int roll_min = h->roll_min_active >= 0 ? h->roll_min_active : h->ops->write_through ? h->roll_min_small : (al_mode ? 2048 : 8192);
-      a.store_x = (roll_min > 0 && h->ops->accept_roll && !two && last_active >= roll_min) ? 0 : 1;
+      // ... and, for those models, only while the batch is still DENSE: the active list is in index order, so once half of the batch has
+      // converged a wave's 64 trajectories sit in several tiles and every store of the re-roll becomes scattered 8-byte writes (r05 trace,
+      // Cartpole at B = 1 048 576: the re-roll takes 0.9 ms with every trajectory active and 1.8 ms with a quarter of them); the
+      // write-through of the next expansion makes the same scattered stores, but behind 2 000 instructions per knot
+      const bool dense = !h->ops->write_through || (double)last_active >= h->roll_min_frac * (double)P.B;
+      a.store_x = (roll_min > 0 && h->ops->accept_roll && !two && last_active >= roll_min && dense) ? 0 : 1;
       TRY(launch_forward(h, !h->ops->write_through || !a.store_x, two));
       a.store_x = 1;
       if (al_mode) TRY(launch_outer(h));
@@ -789,6 +794,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_FUSED_COOP")) if (!std::atoi(env)) h->fused_coop = 0;
   h->roll_min_active = -1;
   if (const char* env = std::getenv("TRAJOPT_ACCEPT_ROLL_MIN")) h->roll_min_active = std::atoi(env);
+  if (const char* env = std::getenv("TRAJOPT_ACCEPT_ROLL_FRAC")) h->roll_min_frac = std::atof(env);
   h->fwd2 = 2;  // 0: one-wave forward pass only; 1: two-wave always (phase API included); 2: per batch step, by the active count
   if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env);
   if (h->fwd2 < 0 || h->fwd2 > 2) h->fwd2 = 2;
@@ -804,7 +810,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_FUSED_LANE")) if (!std::atoi(env)) h->fused_lane = 0;
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
   h->accept_chunks = std::max(1, std::min(128, (N * n + (N - 1) * P.m + 31) / 32));
-  TRYB(dev_alloc(h, &a.Xs, (size_t)N * n * Bp));
+  TRYB(dev_alloc(h, &a.Xs, (size_t)N * n * (Bp + 64)));  // (+ one spare tile: where k_accept_roll's lanes without an accepted step store)
   TRYB(dev_alloc(h, &a.Us, (size_t)(N - 1) * m * Bp));
   {  // candidates, forward-wave-major (common.h): 64 lanes per wave in either shape
     size_t waves = (Bp + h->tw_base - 1) / h->tw_base;
