@@ -54,7 +54,7 @@ extern "C" {
  * to_problem_desc::step_models (general model vectors).  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version. */
-#define TO_ABI_VERSION 4
+#define TO_ABI_VERSION 5
 
 #define TO_MAX_N 16       /* max state dimension            */
 #define TO_MAX_M 8        /* max control dimension          */
@@ -105,11 +105,20 @@ typedef enum {
                                      states / controls of the narrower knots are zero-padded, costs and constraints of
                                      those knots are given at (4, 2) with nothing on the padding (a padded control needs a
                                      positive R entry: it then stays exactly 0).  to_knot_dims reports the live dimensions. */
-  TO_MODEL_VECTOR = 4              /* Problem(models::Vector{<:DiscreteDynamics}, ...) in general (src/problem.jl:36-73, src/dynamics.jl:15-31):
+  TO_MODEL_VECTOR = 4,             /* Problem(models::Vector{<:DiscreteDynamics}, ...) in general (src/problem.jl:36-73, src/dynamics.jl:15-31):
                                      one model per time step, to_problem_desc::step_models[N-1], any mix of the small compiled-in models
                                      and linear discrete maps whose dimensions chain (output dimension of step k = state dimension of
                                      step k+1, checked like RD.dims).  Stored at (n, m) = (TO_VECTOR_N, TO_VECTOR_M) = (6, 3), narrower
                                      knots zero-padded exactly as for the hybrid double integrator; model_params are unused. */
+  TO_MODEL_INFEASIBLE = 5          /* Altro's InfeasibleModel — the state augmentation of ALTRO's infeasible start, what the reference's
+                                     change_dimension family exists for (src/constraints.jl:820-936, src/constraint_list.jl:208-217,
+                                     src/cost_functions.jl:391-401): x+ = f_d(x, u[1:m0]) + u[m0+1 : m0+n], one slack control per state on top
+                                     of a base model.  model_params[15] = to_model_id of the base (DOUBLE_INTEGRATOR with D = 1, 2 or
+                                     CARTPOLE), model_params[0..14] = the base model's parameters; n = n_base, m = m_base + n_base.  The
+                                     host composes the rest as Altro does (costs / constraints lifted with change_dimension, R_inf on the
+                                     slacks, the equality u[m0+1:] = 0 on every stage knot) and seeds the slacks from a state guess with
+                                     to_infeasible_controls.  A Quadrotor base (13, 17) exceeds TO_MAX_M and the 16 x 16 tile of its
+                                     backward pass: TO_ERR_UNSUPPORTED. */
 } to_model_id;
 
 /* One time step of a model vector (TO_MODEL_VECTOR).  A continuous model is discretised with the problem's integrator; a linear
@@ -320,6 +329,10 @@ int to_set_controls_uniform(to_handle* h, const double* u /* [m] */);  /* initia
 int to_get_states(to_handle* h, double* X);
 int to_get_controls(to_handle* h, double* U);
 int to_get_initial_state(to_handle* h, double* x0);
+/* TO_MODEL_INFEASIBLE only — Altro's infeasible_controls: from the CURRENT states X (an initial_states! guess, src/problem.jl:242-253,
+ * with x_1 = x0) and the base controls U[1:m0], set the slack controls w_k = x_{k+1} - f_d(x_k, u_k) so that a rollout reproduces X:
+ * the guess is then what the solve starts from (every solve begins with a rollout of the controls). */
+int to_infeasible_controls(to_handle* h);
 /* device-to-device copies into caller-provided DEVICE buffers (same (n,N,B) layout), for RCCL all-gather */
 int to_get_states_device(to_handle* h, void* dX);
 int to_get_controls_device(to_handle* h, void* dU);
@@ -379,6 +392,11 @@ int to_solve_wait(to_handle* h);
 int to_get_dynamics_jacobians(to_handle* h, double* A, double* Bm);
 int to_get_cost_expansion(to_handle* h, double* Qxx, double* Quu, double* Qux, double* qx, double* qu);
 int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho);
+/* Cost-to-go of the last backward pass's recursion, recomputed from the stored expansion and gains:
+ *   S[ne,ne,N,B]  s[ne,N,B]   S_N = Qxx_N, s_N = qx_N;  S_k = Qxx + K'Quu K + K'Qux + Qux'K,  s_k = qx + K'Quu d + K'qu + Qux'd
+ * with the Q-function blocks of knot k (to_get_cost_expansion holds l_xx etc.; Q = l + [A B]'S_{k+1}[A B]).  Needs to_expand + to_backward
+ * (phase API) on a handle whose backward pass keeps its expansion in memory (not inside a fused solve). */
+int to_get_cost_to_go(to_handle* h, double* S, double* s);
 
 /* raw (non error-state) per-knot cost derivatives of the objective at the current trajectory
  * (RD.gradient! / RD.hessian!): grad[(n+m),N,B], hess[(n+m),(n+m),N,B] */

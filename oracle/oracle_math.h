@@ -52,6 +52,12 @@ inline int model_dims(int id, const double* params, int* n, int* m, int* ne) {
     }
     case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; return 0; /* stored at the largest (n, m) of its phases */
     case TO_MODEL_VECTOR: *n = TO_VECTOR_N; *m = TO_VECTOR_M; *ne = TO_VECTOR_N; return 0; /* stored at (6, 3), narrower knots zero-padded */
+    case TO_MODEL_INFEASIBLE: { /* Altro's InfeasibleModel over a vector-space base (params[15] = its to_model_id): one slack control per state */
+      int base = (int)params[15], n0, m0, ne0;
+      if (base != TO_MODEL_DOUBLE_INTEGRATOR && base != TO_MODEL_CARTPOLE) return -1;
+      if (model_dims(base, params, &n0, &m0, &ne0) != 0 || m0 + n0 > TO_MAX_M) return -1;
+      *n = n0; *m = m0 + n0; *ne = ne0; return 0;
+    }
   }
   return -1;
 }
@@ -460,7 +466,21 @@ inline void knot_dims(const Model& M, int k, int* nx, int* nu, int N = 0) { /* k
   }
   if (M.id == TO_MODEL_HYBRID_DOUBLE_INTEGRATOR) { const int S = (int)M.p[1]; *nx = k <= S ? 4 : 2; *nu = k <= S ? 2 : 1; }
 }
+/* Altro's InfeasibleModel (the state augmentation of ALTRO's infeasible start; SURVEY §8(f)4 — what the reference's change_dimension
+ * family exists for, src/constraints.jl:820-936, src/constraint_list.jl:208-217, src/cost_functions.jl:391-401):
+ *   x+ = f_d(x, u[0 .. m0)) + u[m0 .. m0 + n)        Jacobian [A  B  I] */
+inline Model infeasible_base(const Model& M) {
+  Model S; S.id = (int)M.p[15]; std::memcpy(S.p, M.p, sizeof(S.p)); S.p[15] = 0.0;
+  S.n = M.n; S.m = M.m - M.n; S.ne = M.ne;
+  return S;
+}
 inline void knot_step(const Model& M, int integrator, int k, const double* x, const double* u, double h, double* xn) {
+  if (M.id == TO_MODEL_INFEASIBLE) {
+    const Model S = infeasible_base(M);
+    discrete_dynamics(S, integrator, x, u, h, xn);
+    for (int i = 0; i < M.n; ++i) xn[i] = xn[i] + u[S.m + i];
+    return;
+  }
   if (M.id == TO_MODEL_VECTOR) { /* per-step model on the live prefix of the padded vectors; the padding of the result is zero */
     const to_step_model& s = M.steps[k];
     for (int i = 0; i < M.n; ++i) xn[i] = 0.0;
@@ -482,6 +502,17 @@ inline void knot_step(const Model& M, int integrator, int k, const double* x, co
   discrete_dynamics(hybrid_phase(M, 1), integrator, x, u, h, xn); /* reads x[0..1], u[0]; writes xn[0..1] */
 }
 inline void knot_step_jacobian(const Model& M, int integrator, int k, const double* x, const double* u, double h, double* A, double* Bm) {
+  if (M.id == TO_MODEL_INFEASIBLE) {
+    const Model S = infeasible_base(M);
+    const int n = M.n, m = M.m, m0 = S.m;
+    double b0[MAXN * MAXM];
+    discrete_jacobian(S, integrator, x, u, h, A, b0);
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < m0; ++j) Bm[i * m + j] = b0[i * m0 + j];
+      for (int j = 0; j < n; ++j) Bm[i * m + m0 + j] = (i == j) ? 1.0 : 0.0;
+    }
+    return;
+  }
   if (M.id == TO_MODEL_VECTOR) { /* Jacobian of the live block, embedded in the padded (n x n), (n x m) */
     const to_step_model& s = M.steps[k];
     const int n = M.n, m = M.m;

@@ -67,6 +67,7 @@ struct Traj {
   std::vector<double> A, Bm;                 /* [(N-1)] ne*ne, ne*m row-major */
   std::vector<double> Qxx, Quu, Qux, qx, qu;  /* [N] */
   std::vector<double> K, d;                   /* [(N-1)] m*ne, m */
+  std::vector<double> Sall, sall;             /* [N] ne*ne, ne: cost-to-go of the last backward pass (oracle_get_cost_to_go) */
   std::vector<double> lambda, mu;             /* duals (n_duals), penalties (ncons) */
   double dV[2] = {0, 0};
   double rho = 0, drho = 0;
@@ -534,6 +535,9 @@ bool backward(const Problem& P, Traj& t) {
     t.dV[0] = t.dV[1] = 0.0;
     for (int i = 0; i < ne * ne; ++i) S[i] = t.Qxx[(size_t)(N - 1) * ne * ne + i];
     for (int i = 0; i < ne; ++i) s[i] = t.qx[(size_t)(N - 1) * ne + i];
+    t.Sall.resize((size_t)N * ne * ne); t.sall.resize((size_t)N * ne);
+    for (int i = 0; i < ne * ne; ++i) t.Sall[(size_t)(N - 1) * ne * ne + i] = S[i];
+    for (int i = 0; i < ne; ++i) t.sall[(size_t)(N - 1) * ne + i] = s[i];
     for (int k = N - 2; k >= 0; --k) {
       const double* A = &t.A[(size_t)k * ne * ne]; const double* Bm = &t.Bm[(size_t)k * ne * m];
       const double* cQxx = &t.Qxx[(size_t)k * ne * ne]; const double* cQuu = &t.Quu[(size_t)k * m * m];
@@ -580,6 +584,8 @@ bool backward(const Problem& P, Traj& t) {
       }
       for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) S[i * ne + j] = 0.5 * (Snew[i * ne + j] + Snew[j * ne + i]);
       for (int i = 0; i < ne; ++i) s[i] = snew[i];
+      for (int i = 0; i < ne * ne; ++i) t.Sall[(size_t)k * ne * ne + i] = S[i];
+      for (int i = 0; i < ne; ++i) t.sall[(size_t)k * ne + i] = s[i];
       double dv1 = 0.0, dv2 = 0.0;
       for (int i = 0; i < m; ++i) { dv1 += d[i] * Qu[i]; double v = 0.0; for (int j = 0; j < m; ++j) v += Quu[i * m + j] * d[j]; dv2 += d[i] * v; }
       t.dV[0] += dv1; t.dV[1] += 0.5 * dv2;
@@ -1127,6 +1133,37 @@ int oracle_get_gains(oracle_handle* h, double* K, double* d, double* dV, double*
     }
     if (dV) { dV[2 * b] = t.dV[0]; dV[2 * b + 1] = t.dV[1]; }
     if (rho) rho[b] = t.rho;
+  }
+  return TO_OK;
+}
+int oracle_get_cost_to_go(oracle_handle* h, double* S, double* s) {
+  CHECK_H(h);
+  const int ne = h->P.ne, N = h->P.N;
+  for (int b = 0; b < h->P.B; ++b) {
+    const Traj& t = h->T[b];
+    if (t.Sall.size() != (size_t)N * ne * ne) return fail(TO_ERR_ARGUMENT, "no backward pass has run on this handle");
+    for (int k = 0; k < N; ++k) {
+      size_t kb = k + (size_t)N * b;
+      if (S) for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) S[i + ne * (j + ne * kb)] = t.Sall[(size_t)k * ne * ne + i * ne + j];
+      if (s) for (int i = 0; i < ne; ++i) s[i + ne * kb] = t.sall[(size_t)k * ne + i];
+    }
+  }
+  return TO_OK;
+}
+/* Altro's infeasible_controls: slack controls w_k = x_{k+1} - f_d(x_k, u_k) of an InfeasibleModel from the current states */
+int oracle_infeasible_controls(oracle_handle* h) {
+  CHECK_H(h);
+  const Problem& P = h->P;
+  if (P.M.id != TO_MODEL_INFEASIBLE) return fail(TO_ERR_ARGUMENT, "to_infeasible_controls: the handle's model is not TO_MODEL_INFEASIBLE");
+  const int n = P.n, m = P.m, N = P.N, m0 = m - n;
+  for (int b = 0; b < P.B; ++b) {
+    Traj& t = h->T[b];
+    for (int k = 0; k < N - 1; ++k) {
+      double u[MAXM], xn[MAXN];
+      for (int j = 0; j < m; ++j) u[j] = j < m0 ? t.U[(size_t)k * m + j] : 0.0;
+      knot_step(P.M, P.integrator, k, &t.X[(size_t)k * n], u, P.dt[k], xn);
+      for (int i = 0; i < n; ++i) t.U[(size_t)k * m + m0 + i] = t.X[(size_t)(k + 1) * n + i] - xn[i];
+    }
   }
   return TO_OK;
 }

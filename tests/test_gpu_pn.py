@@ -170,7 +170,7 @@ def test_async_solves_match_sync_and_overlap(hip):
     # ... and NO other call on it (the worker owns the handle's stream, staging buffer and argument block): getters, setters and the
     # phase API all refuse until to_solve_wait; pure descriptor getters (to_dims) stay available
     for call in (lambda: T.states(qb), lambda: T.controls(qb), lambda: T.cost(qb), lambda: T.rollout(qb), lambda: T.max_violation(qb),
-                 lambda: T.initial_controls(qb, np.zeros(qb.m)), lambda: qb._call("set_options", C.byref(qb.lib.default_options()))):
+                 lambda: T.initial_controls(qb, np.zeros(qb.m)), lambda: qb._call("set_options", C.byref(qb._lib.default_options()))):
         with pytest.raises(T.ArgumentError, match="in flight"):
             call()
     n_ = C.c_int32(0)

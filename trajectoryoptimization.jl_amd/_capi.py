@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-TO_ABI_VERSION = 4
+TO_ABI_VERSION = 5
 TO_MAX_N, TO_MAX_M, TO_MAX_P = 16, 8, 40
 TO_MAX_CON_PARAMS, TO_MAX_CON_INDS = 400, 48
 
@@ -26,7 +26,7 @@ TO_ERR_HIP, TO_ERR_UNSUPPORTED, TO_ERR_NULL, TO_ERR_CONE = -4, -5, -6, -7
 (UNSOLVED, LINESEARCH_FAIL, SOLVE_SUCCEEDED, MAX_ITERATIONS, MAX_ITERATIONS_OUTER, MAXIMUM_COST,
  STATE_LIMIT, CONTROL_LIMIT, NO_PROGRESS, COST_INCREASE, REGULARIZATION_MAX, PROJECTION_FAIL) = range(12)
 
-MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_HYBRID_DOUBLE_INTEGRATOR, MODEL_VECTOR = 0, 1, 2, 3, 4
+MODEL_DOUBLE_INTEGRATOR, MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_HYBRID_DOUBLE_INTEGRATOR, MODEL_VECTOR, MODEL_INFEASIBLE = 0, 1, 2, 3, 4, 5
 STEP_DOUBLE_INTEGRATOR, STEP_CARTPOLE, STEP_LINEAR_MAP = 0, 1, 2
 TO_VECTOR_N, TO_VECTOR_M = 6, 3
 RK4, RK3, EULER = 0, 1, 2
@@ -179,6 +179,8 @@ SIGNATURES = {
     "get_dynamics_jacobians": [_H, _PD, _PD],
     "get_cost_expansion": [_H, _PD, _PD, _PD, _PD, _PD],
     "get_gains": [_H, _PD, _PD, _PD, _PD],
+    "get_cost_to_go": [_H, _PD, _PD],
+    "infeasible_controls": [_H],
     "cost_expansion": [_H, _PD, _PD],
     "discrete_jacobian": [_H, _PD],
     "evaluate_constraints": [_H, C.c_int32, _PD],

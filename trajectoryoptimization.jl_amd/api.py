@@ -33,6 +33,7 @@ from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, 
                     SolverOpts, SolveStats, UnsupportedError)
 
 __all__ = [
+    "InfeasibleModel", "InfeasibleConstraint", "InfeasibleProblem", "infeasible_controls",
     "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "LinearMap", "ModelVector", "HybridDoubleIntegrator", "pad_cost", "dims", "RK4", "RK3", "Euler",
     "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
@@ -252,6 +253,26 @@ class Cartpole(_Model):
 
     def params(self):
         return [self.mc, self.mp, self.l, self.g]
+
+
+class InfeasibleModel(_Model):
+    """Altro's ``InfeasibleModel`` — the state augmentation of ALTRO's infeasible start (TO_MODEL_INFEASIBLE): the base model plus
+    one slack control per state, x⁺ = f_d(x, u[1:m0]) + u[m0+1 : m0+n].  With the slacks of ``infeasible_controls`` ANY state guess
+    (``initial_states!``, src/problem.jl:242-253) is dynamically feasible.  The reference carries the ``change_dimension`` family for
+    exactly this (src/constraints.jl:820-936, src/constraint_list.jl:208-217, src/cost_functions.jl:391-401).  Bases: the 1-D / 2-D
+    double integrator and the Cartpole (a Quadrotor base, (13, 17), exceeds the library's control dimension)."""
+    model_id = capi.MODEL_INFEASIBLE
+
+    def __init__(self, model):
+        if not isinstance(model, (DoubleIntegrator, Cartpole)) or model.m + model.n > capi.TO_MAX_M:
+            raise UnsupportedError("InfeasibleModel: the base must be a 1-D / 2-D double integrator or a Cartpole")
+        self.model = model
+        self.n, self.m = model.n, model.m + model.n
+
+    def params(self):
+        p = list(self.model.params()) + [0.0] * 16
+        p[15] = float(self.model.model_id)
+        return p[:16]
 
 
 class Quadrotor(_Model):
@@ -911,7 +932,87 @@ def change_dimension(obj, n, m, ix=None, iu=None):
         for con, inds in zip(obj.constraints, obj.inds):
             add_constraint(new, change_dimension(con, n, m, ix, iu), inds)
         return new
+    if isinstance(obj, QuadraticCostFunction):
+        return _change_cost_dimension(obj, n, m, ix, iu)
+    if isinstance(obj, Objective):
+        lifted = {}
+        return Objective([lifted.setdefault(id(c), _change_cost_dimension(c, n, m, ix, iu)) for c in obj.cost])
     return IndexedConstraint(n, m, obj, ix, iu)
+
+
+def _change_cost_dimension(cost, n, m, ix=None, iu=None):
+    """change_dimension(cost::DiagonalCost, n, m, ix, iu) (src/cost_functions.jl:391-401): the cost of a problem of dimensions
+    (n, m) that acts on x[ix], u[iu] as ``cost`` does and ignores the rest (zero weights there).  Also for dense QuadraticCosts
+    (the blocks scattered the same way)."""
+    n0, m0 = cost.n, cost.m
+    ix = (1, n0) if ix is None else _knot_range(ix, n)
+    iu = (1, m0) if iu is None else _knot_range(iu, m)
+    if ix[1] - ix[0] + 1 != n0 or iu[1] - iu[0] + 1 != m0 or ix[1] > n or iu[1] > m or ix[0] < 1 or iu[0] < 1:
+        raise DimensionMismatch("change_dimension: length(ix), length(iu) must equal the cost's dimensions and lie inside (n, m)")
+    sx, su = slice(ix[0] - 1, ix[1]), slice(iu[0] - 1, iu[1])
+    q, r = np.zeros(n), np.zeros(m)
+    q[sx], r[su] = cost.q, cost.r
+    if type(cost) in (DiagonalCost,):
+        Q, R = np.zeros(n), np.zeros(m)
+        Q[sx], R[su] = cost.Q, cost.R
+        return DiagonalCost(Q, R, q, r, cost.c, terminal=cost.terminal)
+    if type(cost) is QuadraticCost:
+        Q, R, H = np.zeros((n, n)), np.zeros((m, m)), np.zeros((m, n))
+        Q[sx, sx], R[su, su], H[su, sx] = cost.Q, cost.R, cost.H
+        return QuadraticCost(Q, R, H, q, r, cost.c, terminal=cost.terminal)
+    raise UnsupportedError("change_dimension: DiagonalCost and QuadraticCost only (src/cost_functions.jl:391-401)")
+
+
+def InfeasibleConstraint(n, m):
+    """Altro's ``InfeasibleConstraint``: the slack controls of an ``InfeasibleModel`` of dimensions (n, m) — its last n controls —
+    are zero, an equality on every stage knot."""
+    m0 = m - n
+    return LinearConstraint(n, m, np.eye(n), np.zeros(n), Equality(), inds=list(range(n + m0 + 1, n + m + 1)))
+
+
+def infeasible_controls(prob):
+    """Altro's ``infeasible_controls``: from the problem's CURRENT states (an ``initial_states!`` guess) and base controls, the slack
+    controls that make the guess dynamically feasible (to_infeasible_controls)."""
+    prob._call("infeasible_controls")
+
+
+def InfeasibleProblem(prob, X0, R_inf=1.0, U0=None):
+    """Altro's ``InfeasibleProblem(prob, Z0, R_inf)`` — what ``ALTROSolver(prob, infeasible=true)`` solves: the model wrapped in an
+    ``InfeasibleModel``, costs and constraints lifted to (n, m + n) with ``change_dimension``, ½ R_inf |w|² on the slack controls,
+    ``InfeasibleConstraint`` (w = 0) on knots 1..N-1, and the slack controls seeded from the state guess ``X0`` ([N, n] or
+    [B, N, n]; ``U0`` = base controls, default the problem's current ones).  Altro passes ``opts.R_inf / dt``."""
+    if not isinstance(prob.model, (DoubleIntegrator, Cartpole)):
+        raise UnsupportedError("InfeasibleProblem: the base model must be a double integrator or a Cartpole")
+    model = InfeasibleModel(prob.model)
+    n, m0, N = prob.n, prob.m, prob.N
+    m = m0 + n
+    lifted = {}
+    costs = []
+    for c in prob.obj.cost:
+        if id(c) not in lifted:
+            cc = _change_cost_dimension(c, n, m)
+            if isinstance(cc, DiagonalCost):
+                cc.R[m0:] += R_inf
+            else:
+                cc.R[m0:, m0:] += R_inf * np.eye(n)
+            lifted[id(c)] = cc
+        costs.append(lifted[id(c)])
+    cons = change_dimension(prob.constraints, n, m, (1, n), (1, m0))
+    add_constraint(cons, InfeasibleConstraint(n, m), (1, N - 1))
+    opts = SolverOptions(lib=prob._lib)
+    prob._call("get_options", C.byref(opts._o))
+    x0 = np.empty((prob.B, n))
+    prob._call("get_initial_state", prob._pd(x0))
+    new = Problem(model, Objective(costs), x0[0], prob.tf, xf=prob.xf, constraints=cons, t0=prob.t0, dt=prob._dt,
+                  integration=prob.integration, batch=prob.B, options=opts, lib=prob._lib)
+    new.set_initial_state(x0)
+    Ub = controls(prob) if U0 is None else prob._batch(np.asarray(U0, dtype=np.float64), (m0, N - 1), "U0").reshape(prob.B, N - 1, m0)
+    U = np.zeros((prob.B, N - 1, m))
+    U[:, :, :m0] = Ub
+    initial_controls(new, U)
+    initial_states(new, X0)
+    infeasible_controls(new)
+    return new
 
 
 def _knot_range(inds, N):
@@ -1472,6 +1573,15 @@ class ALTROSolver(_Solver):
     ``projected_newton_tolerance``, then the projected-Newton polish down to ``constraint_tolerance``
     (``projected_newton=0``: the AL stage alone, like Altro's option of the same name)."""
     _entry = "altro_solve"
+
+    def __init__(self, prob, opts=None, infeasible=False, R_inf=1.0, **kw):
+        """``infeasible=True`` (Altro's keyword): the solver works on ``InfeasibleProblem(prob, states(prob), R_inf / dt)`` — the
+        problem's current states (``initial_states!``) are the start, made dynamically feasible by slack controls that the AL stage
+        and the polish drive to zero; ``solver.prob`` is that augmented problem (controls [u; w])."""
+        if infeasible:
+            dt = (prob.tf - prob.t0) / (prob.N - 1) if prob._dt is None else float(prob._dt[0])
+            prob = InfeasibleProblem(prob, states(prob), R_inf / dt)
+        super().__init__(prob, opts, **kw)
 
 
 def solve(solver):

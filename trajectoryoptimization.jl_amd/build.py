@@ -28,7 +28,8 @@ FILE_FLAGS = {"ops_quad_expand.hip": ["-mllvm", "-simplifycfg-sink-common=false"
 # bit-identical (tests/test_gpu_parity.py::test_two_wave_forward_pass asserts equality; interleaved A/B in profiles/r04_ab:
 # forward phase C3 600 -> 597 us, C2 81.7 -> 83.4 us per step).
 for _f in ("ops_quad_forward_a", "ops_quad_forward_b", "ops_quad_forward_c", "ops_quad_forward2_a", "ops_quad_forward2_b", "ops_quad_forward2_c",
-           "ops_quadmrp_forward", "ops_quadrp_forward", "ops_small_forward", "ops_small_forward2", "ops_hybrid", "ops_vector"):
+           "ops_quadmrp_forward", "ops_quadrp_forward", "ops_small_forward", "ops_small_forward2", "ops_hybrid", "ops_vector",
+           "ops_infeasible_a", "ops_infeasible_b"):
     FILE_FLAGS.setdefault(_f + ".hip", []).append("-ffp-contract=on")
 # The lane expansion kernels and the scan kernel differentiate the RK step with chunk-mode dual numbers whose seeds are unit vectors:
 # a third of their FP64 instructions were products with a literal 0.0, which IEEE semantics forbid folding (0 * NaN).  These three

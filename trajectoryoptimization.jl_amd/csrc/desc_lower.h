@@ -66,6 +66,16 @@ inline int model_dims(int id, const double* params, int* n, int* m, int* ne, int
     }
     case TO_MODEL_HYBRID_DOUBLE_INTEGRATOR: *n = 4; *m = 2; *ne = 4; *key = 7; return 0;
     case TO_MODEL_VECTOR: *n = TO_VECTOR_N; *m = TO_VECTOR_M; *ne = TO_VECTOR_N; *key = 8; return 0;
+    case TO_MODEL_INFEASIBLE: {  // Altro's InfeasibleModel over a small vector-space base (models.h InfeasibleModel): params[15] = base id
+      const int base = (int)params[15];
+      if (base == TO_MODEL_DOUBLE_INTEGRATOR) {
+        const int D = (int)params[1];
+        if (D < 1 || D > 2) return -1;  // (D = 3: m = 3 + 6 exceeds TO_MAX_M)
+        *n = 2 * D; *m = 3 * D; *ne = 2 * D; *key = 8 + D; return 0;
+      }
+      if (base == TO_MODEL_CARTPOLE) { *n = 4; *m = 5; *ne = 4; *key = 11; return 0; }
+      return -1;
+    }
   }
   return -1;
 }

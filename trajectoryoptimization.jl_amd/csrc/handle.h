@@ -143,6 +143,7 @@ struct ModelOps {
   int (*pn_prepare)(to_handle*, int want) = nullptr;  // projected-Newton polish (k_pn.h): tables + workspace slots ...
   int (*pn_launch)(to_handle*, int slot0, int count, hipStream_t stream, const to_solver_opts* opts) = nullptr;  // ... and its launches
   int (*defect)(to_handle*, double* out) = nullptr;             // max dynamics / initial-condition defect of the nominal trajectory
+  int (*infeasible_controls)(to_handle*) = nullptr;             // InfeasibleModel only: slack controls from the current states (k_misc.h)
   int (*accept_roll)(to_handle*) = nullptr;  // accept by re-rolling the stored controls (k_forward.h; models without write-through)
   int (*forward[32])(to_handle*) = {};  // by kernel variant (k_forward.h MODE bits); variants a model never uses stay null
   int (*forward2[32])(to_handle*) = {};  // the same variants as two-wave workgroups (k_forward2; models with LDS-staged gains)
@@ -150,7 +151,7 @@ struct ModelOps {
 
 // each ops_*.hip fills the entries it instantiates; table indexed by model key (0..2 double integrator D=1..3, 3 Cartpole,
 // 4 Quadrotor, 5 Quadrotor{MRP}, 6 Quadrotor{RodriguesParam}, 7 hybrid double integrator, 8 general model vector)
-constexpr int N_MODEL_KEYS = 9;
+constexpr int N_MODEL_KEYS = 12;  // ... 9, 10 InfeasibleModel over the 1-D / 2-D double integrator, 11 over the Cartpole
 void fill_ops_small(ModelOps* table);
 void fill_ops_small_forward(ModelOps* table);
 void fill_ops_small_lane(ModelOps* table);
@@ -173,6 +174,8 @@ void fill_ops_small_forward2(ModelOps* table);
 void fill_ops_small_scan(ModelOps* table);
 void fill_ops_pn(ModelOps* table);
 void fill_ops_vector(ModelOps* table);
+void fill_ops_infeasible_a(ModelOps* table);
+void fill_ops_infeasible_b(ModelOps* table);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

@@ -530,7 +530,8 @@ struct Tm {
   static constexpr int NEP = (ne + 3) / 4 * 4;  // tangent index of control 0
   static constexpr int RS = NEP / 4;            // registers that hold state rows
   static constexpr int NR = RS + 1;             // ... plus the control rows
-  static_assert(NEP + m <= 16 && m <= 4, "one 16x16 tile per knot");
+  static constexpr bool fits = NEP + m <= 16 && m <= 4;  // one 16 x 16 tile per knot (asserted where the layout is used: k_backward_mfma,
+                                                         // the tangent-matrix expansions; models with more controls never instantiate those)
 };
 
 // Compact cost block (KArgs::h_compact): when the Q-function cost block is block-diagonal — diagonal Qxx (plus the 3x3
@@ -557,6 +558,7 @@ struct MfmaLds {  // doubles; rows padded to 17 so that transposed reads spread 
 template <class M, bool HC>
 __global__ void __launch_bounds__(64, TO_BWD_WAVES) k_backward_mfma(KArgs a) {
   constexpr int m = M::m, ne = M::ne, NEP = Tm<M>::NEP, RS = Tm<M>::RS, NR = Tm<M>::NR, RSK = Gains<M>::RSK;
+  static_assert(Tm<M>::fits, "one 16x16 tile per knot");
   constexpr int HR = HC ? 1 : NR;  // rows of the cost block per knot
   using L = MfmaLds<M>;
   __shared__ double lds[L::size];

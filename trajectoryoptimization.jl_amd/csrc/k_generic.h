@@ -247,6 +247,55 @@ __global__ void k_tmvec_to_host(const double* __restrict__ gt, double* __restric
   h[(size_t)c + (size_t)Cc * (k + (size_t)K * b)] = gt[((size_t)b * K + k) * 16 + col0 + c];
 }
 
+// Cost-to-go of the backward pass (to_get_cost_to_go), recomputed from the expansion and the gains of the last backward pass: one
+// thread per trajectory walks S_N = lxx_N, s_N = lx_N;  Q = l + [A B]' S [A B];  S_k = Qxx + K'Quu K + K'Qux + Qux'K (symmetrised),
+// s_k = Qx + K'Quu d + K'Qu + Qux'd — the un-regularised update the solve's recursion makes.  All arrays in the host layouts of the
+// getters (column-major, trajectory slowest), in device memory.  An introspection getter, not a hot path: runtime dimensions, local
+// arrays in scratch.
+__global__ void k_cost_to_go(const double* __restrict__ A, const double* __restrict__ Bm, const double* __restrict__ lxx, const double* __restrict__ luu,
+                             const double* __restrict__ lux, const double* __restrict__ lx, const double* __restrict__ lu, const double* __restrict__ K,
+                             const double* __restrict__ d, double* __restrict__ Sout, double* __restrict__ sout, int ne, int m, int N, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  constexpr int NE = TO_MAX_N, MM = TO_MAX_M;
+  double S[NE * NE], s[NE], SA[NE * NE], SB[NE * MM], Qxx[NE * NE], Qux[MM * NE], Quu[MM * MM], Qx[NE], Qu[MM], KtQuu[NE * MM], Sn[NE * NE];
+  auto at = [&](const double* p, int R, int Cc, int Kn, int r, int c, int k) { return p[(size_t)r + (size_t)R * (c + (size_t)Cc * (k + (size_t)Kn * b))]; };
+  for (int i = 0; i < ne; ++i) { for (int j = 0; j < ne; ++j) S[i * ne + j] = at(lxx, ne, ne, N, i, j, N - 1); s[i] = at(lx, ne, 1, N, i, 0, N - 1); }
+  for (int i = 0; i < ne; ++i) { for (int j = 0; j < ne; ++j) Sout[(size_t)i + (size_t)ne * (j + (size_t)ne * ((N - 1) + (size_t)N * b))] = S[i * ne + j]; sout[(size_t)i + (size_t)ne * ((N - 1) + (size_t)N * b)] = s[i]; }
+  for (int k = N - 2; k >= 0; --k) {
+    for (int i = 0; i < ne; ++i) {
+      for (int j = 0; j < ne; ++j) { double v = 0.0; for (int r = 0; r < ne; ++r) v += S[i * ne + r] * at(A, ne, ne, N - 1, r, j, k); SA[i * ne + j] = v; }
+      for (int j = 0; j < m; ++j) { double v = 0.0; for (int r = 0; r < ne; ++r) v += S[i * ne + r] * at(Bm, ne, m, N - 1, r, j, k); SB[i * m + j] = v; }
+    }
+    for (int i = 0; i < ne; ++i) {
+      for (int j = 0; j < ne; ++j) { double v = at(lxx, ne, ne, N, i, j, k); for (int r = 0; r < ne; ++r) v += at(A, ne, ne, N - 1, r, i, k) * SA[r * ne + j]; Qxx[i * ne + j] = v; }
+      double v = at(lx, ne, 1, N, i, 0, k); for (int r = 0; r < ne; ++r) v += at(A, ne, ne, N - 1, r, i, k) * s[r]; Qx[i] = v;
+    }
+    for (int i = 0; i < m; ++i) {
+      for (int j = 0; j < ne; ++j) { double v = at(lux, m, ne, N, i, j, k); for (int r = 0; r < ne; ++r) v += at(Bm, ne, m, N - 1, r, i, k) * SA[r * ne + j]; Qux[i * ne + j] = v; }
+      for (int j = 0; j < m; ++j) { double v = at(luu, m, m, N, i, j, k); for (int r = 0; r < ne; ++r) v += at(Bm, ne, m, N - 1, r, i, k) * SB[r * m + j]; Quu[i * m + j] = v; }
+      double v = at(lu, m, 1, N, i, 0, k); for (int r = 0; r < ne; ++r) v += at(Bm, ne, m, N - 1, r, i, k) * s[r]; Qu[i] = v;
+    }
+    for (int i = 0; i < ne; ++i) for (int j = 0; j < m; ++j) { double v = 0.0; for (int r = 0; r < m; ++r) v += at(K, m, ne, N - 1, r, i, k) * Quu[r * m + j]; KtQuu[i * m + j] = v; }
+    for (int i = 0; i < ne; ++i) {
+      double v = Qx[i];
+      for (int j = 0; j < m; ++j) v += KtQuu[i * m + j] * at(d, m, 1, N - 1, j, 0, k);
+      for (int j = 0; j < m; ++j) v += at(K, m, ne, N - 1, j, i, k) * Qu[j];
+      for (int j = 0; j < m; ++j) v += Qux[j * ne + i] * at(d, m, 1, N - 1, j, 0, k);
+      s[i] = v;
+    }
+    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) {
+      double v = Qxx[i * ne + j];
+      for (int r = 0; r < m; ++r) v += KtQuu[i * m + r] * at(K, m, ne, N - 1, r, j, k);
+      for (int r = 0; r < m; ++r) v += at(K, m, ne, N - 1, r, i, k) * Qux[r * ne + j];
+      for (int r = 0; r < m; ++r) v += Qux[r * ne + i] * at(K, m, ne, N - 1, r, j, k);
+      Sn[i * ne + j] = v;
+    }
+    for (int i = 0; i < ne; ++i) for (int j = 0; j < ne; ++j) S[i * ne + j] = 0.5 * (Sn[i * ne + j] + Sn[j * ne + i]);
+    for (int i = 0; i < ne; ++i) { for (int j = 0; j < ne; ++j) Sout[(size_t)i + (size_t)ne * (j + (size_t)ne * (k + (size_t)N * b))] = S[i * ne + j]; sout[(size_t)i + (size_t)ne * (k + (size_t)N * b)] = s[i]; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ cones (src/cones.jl), stateless
 // x[dim,count] column-major; one thread per vector.
 __global__ void k_cone_projection(int cone, int dim, long long count, const double* x, double* px, int* status) {

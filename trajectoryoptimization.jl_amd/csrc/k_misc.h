@@ -336,4 +336,28 @@ __global__ void __launch_bounds__(64) k_constraint_hessian(KArgs a, int ci, cons
   }
 }
 
+// Altro's infeasible_controls for an InfeasibleModel (models.h): w_k = x_{k+1} - f_d(x_k, u_k[0 .. m0)) from the current nominal states,
+// one lane per (trajectory, knot), written into the slack entries of the nominal controls.  grid (tiles, N-1).
+template <class M>
+__global__ void __launch_bounds__(64) k_infeasible_controls(KArgs a) {
+  constexpr int n = M::n, m = M::m, m0 = M::m0;
+  TILE_LANE();
+  const DevProblem& P = a.P;
+  const int N = P.N, k = blockIdx.y;
+  if (b >= P.B) return;
+  const double* X = TILE_PTR(a.Xs, N * n);
+  double* U = TILE_PTR(a.Us, (N - 1) * m);
+  double x[n], u[m], xn[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
+#pragma unroll
+  for (int j = 0; j < m; ++j) u[j] = j < m0 ? EL(U, k * m + j) : 0.0;
+  double mp[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mp[i] = P.mp[i];
+  model_step<M, double, -1>(mp, P.integrator, k, x, u, P.dt[k], xn);
+#pragma unroll
+  for (int i = 0; i < n; ++i) EL(U, k * m + m0 + i) = EL(X, (k + 1) * n + i) - xn[i];
+}
+
 }  // namespace to

@@ -662,6 +662,40 @@ struct ModelVectorModel {
   }
 };
 
+// Altro's InfeasibleModel (the state augmentation behind ALTRO's infeasible start; SURVEY §8(f)4, the reason the reference carries
+// the change_dimension family: src/constraints.jl:820-936, src/constraint_list.jl:208-217, src/cost_functions.jl:391-401):
+//     x+ = f_d(x, u[0 .. m0)) + u[m0 .. m0 + n)
+// — the discretised base model plus one slack control per state, so that ANY state trajectory (initial_states!, src/problem.jl:242-253)
+// is dynamically feasible with the slacks w_k = X_{k+1} - f_d(X_k, U_k) (to_infeasible_controls).  The host mirrors compose the rest
+// exactly as Altro does: costs and constraints lifted with change_dimension, R_inf on the slacks, the equality w = 0 on every stage
+// knot.  A hybrid-style model (step hook): every kernel takes its time step through model_step; dual numbers flow through the sum, so
+// the expansions see [A  B  I].  Vector-space bases only.
+template <class Base>
+struct InfeasibleModel {
+  static_assert(!Base::lie, "infeasible start: vector-space base models only");
+  static constexpr int n = Base::n, m = Base::m + Base::n, ne = Base::ne, m0 = Base::m;
+  static constexpr bool lie = false;
+  static constexpr int att = ATT_NONE;
+  static constexpr bool hybrid = true;
+  static constexpr bool pin_rk4 = true;
+  static constexpr int expand_knots = 1;
+  static constexpr bool accept_write_through = true;
+  static constexpr bool lds_gains = false;
+  static constexpr int ls_first_round = 4;
+  static constexpr bool mfma_backward = false, coop_backward = true;
+  static constexpr bool lane_backward = false;
+  template <class T>
+  __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) { Base::f(P, x, u, xd); }  // (unused: step dispatches)
+  template <class T, int FIXED>
+  __device__ __forceinline__ static void step(const double* P, int integrator_rt, int k, const T* x, const T* u, double h, T* xn) {
+    T y[n];
+    rk_step<Base, T, FIXED>(P, integrator_rt, x, u, h, y);  // reads u[0 .. m0)
+#pragma unroll
+    for (int i = 0; i < n; ++i) xn[i] = y[i] + u[m0 + i];
+  }
+  __host__ __device__ static void knot_dims(const double*, int, int, int* nx, int* nu) { *nx = n; *nu = m; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Error-state maps.  Identity for vector-space models.
 // ------------------------------------------------------------------------------------------------

@@ -19,9 +19,11 @@ void fill_traits(ModelOps& o) {
   o.expand_knots = M::expand_knots;
   o.ls_first_round = M::ls_first_round;
   o.gains_lds_pieces = Gains<M>::RSK / 2;
-  o.nep = Tm<M>::NEP; o.rs = Tm<M>::RS;
-  for (int g = 0; g < 4; ++g)
-    for (int c = 0; c < 16; ++c) o.crow[g * 16 + c] = compact_row<M>(g, c);
+  if constexpr (M::mfma_backward) {  // tangent-matrix layout traits (one 16 x 16 tile per knot: models with m <= 4)
+    o.nep = Tm<M>::NEP; o.rs = Tm<M>::RS;
+    for (int g = 0; g < 4; ++g)
+      for (int c = 0; c < 16; ++c) o.crow[g * 16 + c] = compact_row<M>(g, c);
+  }
 }
 
 template <class M>

@@ -107,5 +107,8 @@ void fill_ops_pn(ModelOps* t) {
   fill_one<QuadrotorAttModel<ATT_RP>>(t[6]);
   fill_one<HybridDoubleIntegratorModel>(t[7]);
   fill_one<ModelVectorModel>(t[8]);
+  fill_one<InfeasibleModel<DoubleIntegratorModel<1>>>(t[9]);
+  fill_one<InfeasibleModel<DoubleIntegratorModel<2>>>(t[10]);
+  fill_one<InfeasibleModel<CartpoleModel>>(t[11]);
 }
 }  // namespace to

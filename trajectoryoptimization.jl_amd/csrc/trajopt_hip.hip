@@ -45,7 +45,7 @@ const ModelOps* model_ops(int key) {
     fill_ops_quad_forward2_a(g_ops); fill_ops_quad_forward2_b(g_ops); fill_ops_quad_forward2_c(g_ops);
     fill_ops_quadatt_misc(g_ops); fill_ops_quadmrp_expand(g_ops); fill_ops_quadrp_expand(g_ops);
     fill_ops_quadmrp_forward(g_ops); fill_ops_quadrp_forward(g_ops);
-    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops); fill_ops_small_scan(g_ops); fill_ops_pn(g_ops); fill_ops_vector(g_ops);
+    fill_ops_hybrid(g_ops); fill_ops_small_forward2(g_ops); fill_ops_small_scan(g_ops); fill_ops_pn(g_ops); fill_ops_vector(g_ops); fill_ops_infeasible_a(g_ops); fill_ops_infeasible_b(g_ops);
   });
   return (key >= 0 && key < N_MODEL_KEYS) ? &g_ops[key] : nullptr;
 }
@@ -999,6 +999,13 @@ int to_set_states(to_handle* h, const double* X) {
   CHECK_H(h); CHECK_IDLE(h); CHECK_P(X); TRY(use_device(h));
   return upload_vec(h, X, h->a.Xs, h->a.P.n * h->a.P.N);
 }
+int to_infeasible_controls(to_handle* h) {
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
+  if (!h->ops->infeasible_controls) return fail(TO_ERR_ARGUMENT, "to_infeasible_controls: the handle's model is not TO_MODEL_INFEASIBLE");
+  TRY(h->ops->infeasible_controls(h));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return TO_OK;
+}
 int to_set_controls_uniform(to_handle* h, const double* u) {
   CHECK_H(h); CHECK_IDLE(h); CHECK_P(u); TRY(use_device(h));
   const DevProblem& P = h->a.P;
@@ -1144,51 +1151,55 @@ int to_dynamics_defect(to_handle* h, double* defect) {
 // expansion blocks -> host column-major blocks: h[r + Rr*(c + Cc*(k + K*b))] = X_k[row0+r][col0+c], rows / columns counted
 // in error-state directions followed by control directions (whichever layout the backward pass uses)
 enum { BLK_M = 0, BLK_H = 1 };
-static int download_block(to_handle* h, double* host, int which, int row0, int Rr, int col0, int Cc) {
-  if (!host) return TO_OK;
+static int download_block(to_handle* h, double* host, int which, int row0, int Rr, int col0, int Cc, double* dev_out = nullptr) {
+  if (!host && !dev_out) return TO_OK;
   const DevProblem& P = h->a.P;
   const int K = which == BLK_M ? P.N - 1 : P.N;
   const size_t cnt = (size_t)Rr * Cc * K * P.B;
-  TRY(ensure_stage(h, cnt * sizeof(double)));
+  if (!dev_out) TRY(ensure_stage(h, cnt * sizeof(double)));
+  double* const out = dev_out ? dev_out : h->stage;  // (dev_out: a caller-owned device buffer, no host copy)
   if (h->a.bwd_lane) {
     const int nc = P.ne + P.m;
     if (which == BLK_M)
-      hipLaunchKernelGGL(k_lane_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, h->a.Mc, h->stage, P.ne * nc, 0, nc, row0, Rr, col0, Cc, K, P.B);
+      hipLaunchKernelGGL(k_lane_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, h->a.Mc, out, P.ne * nc, 0, nc, row0, Rr, col0, Cc, K, P.B);
     else
-      hipLaunchKernelGGL(k_lane_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, h->a.Hc, h->stage, nc * (nc + 1) / 2, 1, nc, row0, Rr, col0, Cc, K, P.B);
+      hipLaunchKernelGGL(k_lane_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, h->a.Hc, out, nc * (nc + 1) / 2, 1, nc, row0, Rr, col0, Cc, K, P.B);
   } else if (h->a.bwd_mfma) {
     const int nep = h->ops->nep, rs = h->ops->rs;
     auto tix = [&](int i) { return i < P.ne ? i : nep + (i - P.ne); };  // tangent index (control directions start at NEP)
     const bool compact = which == BLK_H && h->a.h_compact;
-    hipLaunchKernelGGL(k_tm_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mt : h->a.Ht, h->stage,
+    hipLaunchKernelGGL(k_tm_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mt : h->a.Ht, out,
                        which == BLK_M ? rs : rs + 1, tix(row0), Rr, tix(col0), Cc, K, P.B, compact ? h->d_crow : nullptr);
   } else {
     const int nc = P.ne + P.m;
     const int diag = (which == BLK_H && h->a.h_diag) ? 1 : 0;
-    hipLaunchKernelGGL(k_col_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mc : h->a.Hc, h->stage,
+    hipLaunchKernelGGL(k_col_to_host, grid_b(h, K * Rr * Cc), dim3(BLOCK), 0, h->stream, which == BLK_M ? h->a.Mc : h->a.Hc, out,
                        which == BLK_M ? (P.N - 1) * P.ne : (diag ? P.N : P.N * nc), which == BLK_M ? P.ne : nc, row0, Rr, col0, Cc, K, P.B,
                        h->R, h->G, diag);
   }
   HIPCHECK(hipGetLastError());
+  if (dev_out) return TO_OK;
   HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
-static int download_gradient(to_handle* h, double* host, int col0, int Cc) {
-  if (!host) return TO_OK;
+static int download_gradient(to_handle* h, double* host, int col0, int Cc, double* dev_out = nullptr) {
+  if (!host && !dev_out) return TO_OK;
   const DevProblem& P = h->a.P;
   const size_t cnt = (size_t)Cc * P.N * P.B;
-  TRY(ensure_stage(h, cnt * sizeof(double)));
+  if (!dev_out) TRY(ensure_stage(h, cnt * sizeof(double)));
+  double* const out = dev_out ? dev_out : h->stage;
   if (h->a.bwd_lane) {
     const int nc = P.ne + P.m;
-    hipLaunchKernelGGL(k_lane_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, h->stage, nc, 0, nc, 0, 1, col0, Cc, P.N, P.B);
+    hipLaunchKernelGGL(k_lane_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, out, nc, 0, nc, 0, 1, col0, Cc, P.N, P.B);
   } else if (h->a.bwd_mfma) {
     const int tcol = col0 < P.ne ? col0 : h->ops->nep + (col0 - P.ne);
-    hipLaunchKernelGGL(k_tmvec_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gt, h->stage, tcol, Cc, P.N, P.B);
+    hipLaunchKernelGGL(k_tmvec_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gt, out, tcol, Cc, P.N, P.B);
   } else {
-    hipLaunchKernelGGL(k_col_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, h->stage, P.N, 1, 0, 1, col0, Cc, P.N, P.B, h->R, h->G, 0);
+    hipLaunchKernelGGL(k_col_to_host, grid_b(h, P.N * Cc), dim3(BLOCK), 0, h->stream, h->a.gc, out, P.N, 1, 0, 1, col0, Cc, P.N, P.B, h->R, h->G, 0);
   }
   HIPCHECK(hipGetLastError());
+  if (dev_out) return TO_OK;
   HIPCHECK(hipMemcpyAsync(host, h->stage, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
@@ -1230,6 +1241,33 @@ int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
     for (int b = 0; b < P.B; ++b) { dV[2 * b] = tmp[b]; dV[2 * b + 1] = tmp[(size_t)P.Bp + b]; }
   }
   TRY(download_scalar(h, rho, h->a.rho));
+  return TO_OK;
+}
+int to_get_cost_to_go(to_handle* h, double* S, double* s) {
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
+  if (!S && !s) return fail(TO_ERR_NULL, "null pointer");
+  const DevProblem& P = h->a.P;
+  const size_t ne = P.ne, m = P.m, N = P.N, B = P.B;
+  // every block in its getter layout, side by side in one device buffer, then the recursion (k_generic.h k_cost_to_go)
+  const size_t nA = ne * ne * (N - 1) * B, nB = ne * m * (N - 1) * B, nxx = ne * ne * N * B, nuu = m * m * N * B, nux = m * ne * N * B,
+               nx = ne * N * B, nu = m * N * B, nK = m * ne * (N - 1) * B, nd = m * (N - 1) * B;
+  struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) hipFree(p); } } buf;
+  HIPCHECK(hipMalloc(&buf.p, (nA + nB + nxx + nuu + nux + nx + nu + nK + nd + nxx + nx) * sizeof(double)));
+  double* dA = (double*)buf.p; double* dB = dA + nA; double* dxx = dB + nB; double* duu = dxx + nxx; double* dux = duu + nuu;
+  double* dx = dux + nux; double* du = dx + nx; double* dK = du + nu; double* dd = dK + nK; double* dS = dd + nd; double* ds = dS + nxx;
+  TRY(download_block(h, nullptr, BLK_M, 0, P.ne, 0, P.ne, dA));
+  TRY(download_block(h, nullptr, BLK_M, 0, P.ne, P.ne, P.m, dB));
+  TRY(download_block(h, nullptr, BLK_H, 0, P.ne, 0, P.ne, dxx));
+  TRY(download_block(h, nullptr, BLK_H, P.ne, P.m, P.ne, P.m, duu));
+  TRY(download_block(h, nullptr, BLK_H, P.ne, P.m, 0, P.ne, dux));
+  TRY(download_gradient(h, nullptr, 0, P.ne, dx));
+  TRY(download_gradient(h, nullptr, P.ne, P.m, du));
+  hipLaunchKernelGGL(k_gains_to_host, grid_b(h, (P.N - 1) * P.m * (P.ne + 1)), dim3(BLOCK), 0, h->stream, h->a.Kt, dK, dd, P.m, P.ne, P.N - 1, P.B);
+  hipLaunchKernelGGL(k_cost_to_go, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, dA, dB, dxx, duu, dux, dx, du, dK, dd, dS, ds, P.ne, P.m, P.N, P.B);
+  HIPCHECK(hipGetLastError());
+  if (S) HIPCHECK(hipMemcpyAsync(S, dS, nxx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (s) HIPCHECK(hipMemcpyAsync(s, ds, nx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
   return TO_OK;
 }
 int to_cost_expansion(to_handle* h, double* grad, double* hess) {

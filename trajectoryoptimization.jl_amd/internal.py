@@ -70,6 +70,14 @@ def cost_gradient_hessian(prob):
     return g, H.transpose(0, 1, 3, 2)
 
 
+def cost_to_go(prob):
+    """Cost-to-go of the last backward pass (to_get_cost_to_go) -> S [B, N, ne, ne] (symmetric), s [B, N, ne]."""
+    ne, N, B = prob.errstate_dim, prob.N, prob.B
+    S, s = np.empty((B, N, ne, ne)), np.empty((B, N, ne))
+    prob._call("get_cost_to_go", _pd(S), _pd(s))
+    return S.transpose(0, 1, 3, 2), s
+
+
 def discrete_jacobian(prob):
     """RD.jacobian! of the discretised dynamics: F = [A B] -> [B, N-1, n, n+m]."""
     n, nz, N, B = prob.n, prob.n + prob.m, prob.N, prob.B
