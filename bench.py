@@ -40,13 +40,13 @@ WORKLOADS = {
                      desc="C2 Cartpole swing-up iLQR (n=4,m=1), N=101, batch=1024 per GPU"),
     "quadrotor": dict(batch=4096, N=201, solver="ilqr",
                       desc="C3 Quadrotor point-to-point iLQR (n=13,m=4,ne=12), N=201, batch=4096 per GPU"),
-    "quadrotor_al": dict(batch=8192, N=201, solver="altro", opts={"n_steps": "C5_PN_STEPS"},
+    "quadrotor_altro": dict(batch=8192, N=201, solver="altro", opts={"n_steps": "C5_PN_STEPS"},
                          desc="C5 Quadrotor + GoalConstraint(xf, inds=[1,2,3,8..13]: position + velocities) + NormConstraint(SOC, |u|<=6), "
                               "solved as the reference's stack solves constrained problems: ALTRO = AL-iLQR to 1e-3 + projected-Newton "
                               "polish to constraint_tolerance 1e-6 (n_steps = 8); N=201, batch=8192 per GPU; the metric counts the "
                               "inner iLQR iterations, the time includes the polish"),
-    "quadrotor_al_nopn": dict(batch=8192, N=201, solver="al",
-                              desc="C5 without the polish (AL-iLQR run to 1e-6 on its own; round-3 definition, kept for comparison)"),
+    "quadrotor_al": dict(batch=8192, N=201, solver="al",
+                         desc="C5 without the polish (AL-iLQR run to 1e-6 on its own: the definition of the rounds-1..3 records under this key)"),
 }
 
 
@@ -61,7 +61,7 @@ def build_problem(T, configs, name, batch, b_offset, device, lib):
         return configs.cartpole_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
     if name == "quadrotor":
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
-    if name in ("quadrotor_al", "quadrotor_al_nopn"):
+    if name in ("quadrotor_altro", "quadrotor_al"):
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib, constrained=True,
                                          goal_inds=configs.C5_GOAL_INDS)
     raise ValueError(name)
@@ -181,8 +181,10 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
     return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "build": flags, "single_thread": single,
             "physical_cores": phys, "logical_cpus": logical, "cgroup_cpu_quota_cores": cgroup_cpu_quota(), "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core",
             "parallel_speedup_over_one_thread": (solver.total_iterations / dt) / single["value"],
+            "effective_cores": (min(float(threads), cgroup_cpu_quota()) if cgroup_cpu_quota() else float(threads)),
             "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve after a warm call, "
-                      f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories)"}
+                      f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories; {threads} threads on {phys} physical cores, "
+                      f"cgroup CPU quota {cgroup_cpu_quota()} cores: the quota, not the thread count, is the denominator of this number)"}
 
 
 def c1_cpu_line(T, configs):
@@ -284,6 +286,35 @@ def overlap_run(T, configs, lib, name, batch, parts, device):
             "trajectory_iterations": best[1], "note": "best of 3; sub-batches solved concurrently through to_*_solve_async on separate streams"}
 
 
+class Watchdog:
+    """A collective that never returns (a peer that died inside ncclCommInitRank, a rank that took another branch) must end as a
+    LABELLED failure of this rank, not as the driver's wall-clock limit: `with Watchdog("what", seconds)` exits the process with code 3
+    and a rank-tagged line on stderr when the body is still running after `seconds` (TRAJOPT_BENCH_TIMEOUT overrides; 0 disables)."""
+
+    def __init__(self, what, seconds=300.0):
+        import threading
+        env = os.environ.get("TRAJOPT_BENCH_TIMEOUT")
+        self.seconds = float(env) if env else seconds
+        self.what, self._timer, self._threading = what, None, threading
+
+    def _fire(self):
+        sys.stderr.write("[bench.py rank %s] TIMEOUT after %.0f s in: %s — giving up (exit 3)\n" % (os.environ.get("RANK", "0"), self.seconds, self.what))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self._timer = self._threading.Timer(self.seconds, self._fire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
 def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True):
     """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings."""
     W = WORKLOADS[name]
@@ -304,14 +335,28 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
         # the builder's boxes), every rank falls back to gathering through torch.distributed — the same RCCL, staged through host
         # arrays — rather than losing the scaling run; the line says which path ran.
         err = None
+        dev = torch.device("cuda", local_rank)
+        # Step 1, symmetric by construction: can EVERY rank load RCCL through the library (dlopen + ncclGetUniqueId)?  A rank that
+        # cannot must not leave its peers waiting inside ncclCommInitRank, so the answer is reduced before anyone enters it.
         try:
             if os.environ.get("TRAJOPT_BENCH_GATHER") == "torch":
                 raise RuntimeError("forced by TRAJOPT_BENCH_GATHER=torch")
-            gather = TrajectoryGather(prob, dist, device=torch.device("cuda", local_rank))
-        except Exception as e:  # noqa: BLE001 - any failure of the native communicator takes the fallback
+            lib.call("comm_unique_id", (C.c_char * 128)())
+        except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        ok = torch.tensor([0 if err else 1], device=torch.device("cuda", local_rank))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ok = torch.tensor([0 if err else 1], device=dev)
+        with Watchdog("all_reduce of the RCCL availability flag (%s)" % name):
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:  # Step 2: the communicator itself (a failure here — e.g. a duplicate device — hits every rank alike)
+            try:
+                with Watchdog("to_comm_init_rank with %d ranks (%s)" % (world, name)):
+                    gather = TrajectoryGather(prob, dist, device=dev)
+            except Exception as e:  # noqa: BLE001 - any failure of the native communicator takes the fallback
+                err = f"{type(e).__name__}: {e}"
+                sys.stderr.write("[bench.py rank %d] library communicator failed: %s\n" % (rank, err))
+        ok = torch.tensor([0 if err else 1], device=dev)
+        with Watchdog("all_reduce of the communicator status (%s)" % name):
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             if gather is not None:
                 gather.close()
@@ -322,13 +367,15 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
         T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
         solver.solve()
         if gather is not None:
-            gather()
-            gather.stats(solver)
+            with Watchdog("all-gather of the converged trajectories and stats (%s)" % name):
+                gather()
+                gather.stats(solver)
         return solver.total_iterations, solver.batch_steps
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            with Watchdog("barrier (%s)" % name, 900.0):
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(warmup):
@@ -423,7 +470,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        with Watchdog("torch.distributed.init_process_group with %d ranks" % world):
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=900))
 
     lib = T.load_hip_library()
     if lib.device_count() < 1:
@@ -445,14 +495,18 @@ def main():
             n, m, N = prob.dims()
             bytes_it = configs.algorithmic_bytes_per_iteration(n, m, prob.errstate_dim, N, sum(prob.constraints.p))
 
-            def probe_once(pbatch):
+            def probe_once(pbatch, reps=3):
+                """One warm solve, then `reps` timed solves (each from the initial guess, reset on the device): the point is their mean."""
                 pb = build_problem(T, configs, name, pbatch, 0, local_rank, lib)
                 ps = make_solver(T, configs, name, pb)
                 ps.solve()
-                T.initial_controls(pb, u0)
-                t1 = time.perf_counter(); ps.solve(); d1 = time.perf_counter() - t1
+                ms = []
+                for _ in range(reps):
+                    T.initial_controls(pb, u0)
+                    t1 = time.perf_counter(); ps.solve(); ms.append(1e3 * (time.perf_counter() - t1))
+                d1 = 1e-3 * float(np.mean(ms))
                 r = {"batch": pbatch, "value": ps.total_iterations / d1, "unit": "trajectory-iterations/s", "ms": 1e3 * d1,
-                     "batch_steps": int(ps.batch_steps),
+                     "solves_averaged": reps, "ms_each": [round(x, 2) for x in ms], "batch_steps": int(ps.batch_steps),
                      "whole_iteration_frac": bytes_it * ps.total_iterations / d1 / 1e9 / HBM_PEAK_GBS}
                 del ps, pb
                 return r
@@ -484,7 +538,7 @@ def main():
     # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
     if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:
         extra = {}
-        for key, wname in (("C3", "quadrotor"), ("C5", "quadrotor_al")):
+        for key, wname in (("C3", "quadrotor"), ("C5", "quadrotor_altro")):
             try:
                 r, p2, _ = run_workload(T, configs, lib, wname, WORKLOADS[wname]["batch"], 2, 1, 0, local_rank, 1, None, torch,
                                         profile=not args.no_profile)

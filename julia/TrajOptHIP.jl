@@ -20,7 +20,7 @@ const TO = TrajectoryOptimization
 const lib = get(ENV, "TRAJOPT_HIP_LIBRARY", "libtrajopt_hip")   # trajectoryoptimization.jl_amd/csrc/libtrajopt_hip.so
 
 # ------------------------------------------------------------------------------------------------ header mirrors
-const TO_ABI_VERSION = Int32(4)
+const TO_ABI_VERSION = Int32(5)
 const MAXN, MAXM, MAXP, MAXPAR, MAXIND = 16, 8, 40, 400, 48
 const PROFILE_SLOTS = 4
 
@@ -260,6 +260,21 @@ RD.control_dim(::MassDoubleIntegrator{D}) where {D} = D
 RD.dynamics(model::MassDoubleIntegrator{D}, x, u) where {D} = [x[D+1:2D]; u ./ model.mass]
 modelid(::MassDoubleIntegrator) = Int32(0)
 modelparams(d::MassDoubleIntegrator{D}) where {D} = pad([d.mass, D], 16)
+# Altro's InfeasibleModel (the state augmentation of ALTRO's infeasible start, TO_MODEL_INFEASIBLE): x⁺ = f_d(x, u[1:m0]) + u[m0+1:end].
+# Altro builds it (and the lifted costs / constraints: TO.change_dimension, src/constraints.jl:820-936, src/constraint_list.jl:208-217,
+# src/cost_functions.jl:391-401, plus its InfeasibleConstraint) in ALTROSolver(prob; infeasible=true); here the wrapper only has to name
+# the base model.  `InfeasibleBase(model)` stands in for Altro.InfeasibleModel when Altro is not loaded.
+struct InfeasibleBase{M<:RD.ContinuousDynamics} <: RD.ContinuousDynamics
+    model::M
+end
+RD.state_dim(m::InfeasibleBase) = RD.state_dim(m.model)
+RD.control_dim(m::InfeasibleBase) = RD.control_dim(m.model) + RD.state_dim(m.model)
+modelid(::InfeasibleBase) = Int32(5)
+function modelparams(m::InfeasibleBase)
+    p = modelparams(m.model)
+    p[16] = Float64(modelid(m.model))      # model_params[15] (0-based): to_model_id of the base
+    p
+end
 
 # ---- model vectors (Problem(models::Vector{<:DiscreteDynamics}, ...), src/problem.jl:36-73, src/dynamics.jl:15-31): TO_MODEL_VECTOR
 """
@@ -534,6 +549,15 @@ function gains(p::BatchProblem)
     check(ccall((:to_get_gains, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), p.handle, K, d, dV, rho))
     (K = K, d = d, dV = dV, rho = rho)
 end
+"Cost-to-go of the last backward pass: S[ne,ne,N,B], s[ne,N,B] (S_N = Qxx_N; S_k = Qxx + K'Quu K + K'Qux + Qux'K)."
+function cost_to_go(p::BatchProblem)
+    S, s = zeros(p.ne, p.ne, p.N, p.B), zeros(p.ne, p.N, p.B)
+    check(ccall((:to_get_cost_to_go, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), p.handle, S, s))
+    (S = S, s = s)
+end
+"Altro's infeasible_controls for a handle whose model is an InfeasibleBase: slack controls w_k = x_{k+1} - f_d(x_k, u_k) from the current
+states (TO.initial_states!, src/problem.jl:242-253), so that the rollout every solve starts with reproduces the state guess."
+infeasible_controls!(p::BatchProblem) = check(ccall((:to_infeasible_controls, lib), Cint, (Ptr{Cvoid},), p.handle))
 "RD.gradient! / RD.hessian! of the objective on every knot (src/cost_functions.jl:137-233)."
 function cost_gradient_hessian(p::BatchProblem)
     nz = p.n + p.m

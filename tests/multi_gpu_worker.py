@@ -24,8 +24,10 @@ def main():
     id_file, out_file = Path(sys.argv[4]), Path(sys.argv[5])
     lib = T.load_hip_library()
     b0, cnt = shard_range(rank, world, total)
-    torch.cuda.set_device(rank)
-    prob = configs.cartpole_problem(batch=cnt, b_offset=b0, N=41, tf=2.0, device=rank, lib=lib)
+    # TRAJOPT_WORKER_SAME_DEVICE=1 (the "dry" communicator test of a 1-GPU box): every rank on device 0
+    dev = 0 if os.environ.get("TRAJOPT_WORKER_SAME_DEVICE") == "1" else rank
+    torch.cuda.set_device(dev)
+    prob = configs.cartpole_problem(batch=cnt, b_offset=b0, N=41, tf=2.0, device=dev, lib=lib)
     sv = T.iLQRSolver(prob, iterations=25).solve()
     if rank == 0:
         buf = (C.c_char * 128)()
@@ -38,13 +40,15 @@ def main():
             break
         time.sleep(0.1)
     uid = (C.c_char * 128).from_buffer_copy(id_file.read_bytes())
+    print(f"[rank {rank}] to_comm_init_rank(nranks={world}) on device {dev}", flush=True)
     prob._call("comm_init_rank", world, rank, uid)
+    print(f"[rank {rank}] communicator up", flush=True)
     nr, rk, tot = C.c_int32(0), C.c_int32(0), C.c_int64(0)
     counts = (C.c_int32 * world)()
     prob._call("comm_shards", C.byref(nr), C.byref(rk), C.byref(tot), counts)
     n, m, N = prob.dims()
-    xg = torch.zeros((total, N, n), dtype=torch.float64, device=f"cuda:{rank}")
-    ug = torch.zeros((total, N - 1, m), dtype=torch.float64, device=f"cuda:{rank}")
+    xg = torch.zeros((total, N, n), dtype=torch.float64, device=f"cuda:{dev}")
+    ug = torch.zeros((total, N - 1, m), dtype=torch.float64, device=f"cuda:{dev}")
     prob._call("allgather", C.c_void_p(xg.data_ptr()), C.c_void_p(ug.data_ptr()))
     its, st, J = np.zeros(total, np.int32), np.zeros(total, np.int32), np.zeros(total)
     pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))

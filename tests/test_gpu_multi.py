@@ -43,3 +43,37 @@ def test_two_rank_rccl_allgather(total, hip, tmp_path):
         np.testing.assert_array_equal(g["its"], sv.stats["iterations"])
         np.testing.assert_array_equal(g["st"], sv.stats["status"])
         np.testing.assert_allclose(g["J"], sv.stats["cost"], rtol=0, atol=0)
+
+
+def test_two_rank_bootstrap_on_one_gpu(hip, tmp_path):
+    """What a 1-GPU box CAN show of the N > 1 path: two processes, both on device 0, go through the whole hand-shake — rank 0 creates
+    the id (to_comm_unique_id), ships it through a file, both enter to_comm_init_rank(nranks = 2) and RCCL's bootstrap brings the two
+    ranks together.  RCCL 2.26 then refuses the communicator ("Duplicate GPU detected": one device cannot hold two ranks), and that
+    must surface on BOTH ranks as a clean TO_ERR_HIP carrying RCCL's message — no hang, no half-initialised handle.  Should a future
+    RCCL allow it, the workers finish and the gather is checked like the two-GPU test."""
+    import os
+    world, total = 2, 12
+    id_file, out = tmp_path / "nccl_id.bin", tmp_path / "gather"
+    env = dict(os.environ, TRAJOPT_WORKER_SAME_DEVICE="1", NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "multi_gpu_worker.py"), str(r), str(world), str(total),
+                               str(id_file), str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung in the communicator hand-shake")
+        logs.append((p.returncode, log.decode()))
+    if all(rc == 0 for rc, _ in logs):   # an RCCL that accepts two ranks on one device: the full check
+        ref = configs.cartpole_problem(batch=total, N=41, tf=2.0, lib=hip)
+        T.iLQRSolver(ref, iterations=25).solve()
+        for r in range(world):
+            np.testing.assert_array_equal(np.load(str(out) + f".rank{r}.npz")["X"], T.states(ref))
+        return
+    for r, (rc, log) in enumerate(logs):
+        assert rc != 0 and f"[rank {r}] to_comm_init_rank(nranks=2)" in log, log[-2000:]     # both reached the hand-shake ...
+        assert "to_comm_init_rank" in log and "HipError" in log, log[-2000:]                  # ... and failed through the C-ABI's error path
+        assert "Duplicate GPU detected" in log or "invalid usage" in log, log[-2000:]
+        assert "communicator up" not in log
