@@ -354,6 +354,17 @@ int to_comm_destroy(to_handle* h);
 /* goal / reference updates between solves (set_goal_state! src/problem.jl:294-310; set_LQR_goal! src/cost_functions.jl:249-258) */
 int to_set_cost(to_handle* h, int32_t cost_id, const to_cost_desc* cost);
 int to_set_constraint(to_handle* h, int32_t con_id, const to_constraint_desc* con);
+/* One goal per TRAJECTORY (SURVEY.md §8b "optionally per-trajectory xf": batched MPC, goal sweeps): set_LQR_goal!(cost, xf_b, uf_b)
+ * (src/cost_functions.jl:249-258 — "only changes q and r") for every trajectory of the batch at once.  q[n, B] / r[m, B] (column-major,
+ * either may be NULL) REPLACE the linear terms of cost `cost_id` for trajectory b; Q, R, H, c stay the descriptor's.  The host mirrors
+ * compute q_b = -Q xf_b (set_goal_state!(prob, Xf::Matrix), src/problem.jl:294-310).  Kinds DIAGONAL, QUADRATIC, DIAGONAL_QUAT (its
+ * quaternion reference q_ref stays shared); TO_ERR_UNSUPPORTED for ERROR_QUADRATIC.  to_set_cost on a cost resets its per-trajectory
+ * terms; to_clear_cost_linear_batch returns the whole handle to shared descriptors.  Constraint parameters (GoalConstraint's xf) stay
+ * shared by the batch: hard per-trajectory goals need one handle per goal.  The projected-Newton polish builds its metric from the
+ * descriptors alone (per-trajectory q does not enter a Hessian except through the attitude term of quaternion states, which the polish
+ * then takes from the shared q). */
+int to_set_cost_linear_batch(to_handle* h, int32_t cost_id, const double* q /* [n*B] or NULL */, const double* r /* [m*B] or NULL */);
+int to_clear_cost_linear_batch(to_handle* h);
 
 /* ---- the hot path, phase by phase ----------------------------------------------------------- */
 int to_rollout(to_handle* h);                                   /* rollout!  src/problem.jl:330-340 */

@@ -68,6 +68,7 @@ struct Traj {
   std::vector<double> Qxx, Quu, Qux, qx, qu;  /* [N] */
   std::vector<double> K, d;                   /* [(N-1)] m*ne, m */
   std::vector<double> Sall, sall;             /* [N] ne*ne, ne: cost-to-go of the last backward pass (oracle_get_cost_to_go) */
+  std::vector<double> gl;                     /* per-trajectory linear cost terms, [n_costs] (n + m): what q, r differ by from the descriptor (empty: none) */
   std::vector<double> lambda, mu;             /* duals (n_duals), penalties (ncons) */
   double dV[2] = {0, 0};
   double rho = 0, drho = 0;
@@ -298,10 +299,13 @@ inline void knot_z(const Problem& P, const double* X, const double* U, int k, do
   for (int j = 0; j < m; ++j) z[n + j] = (k < P.N - 1) ? U[(size_t)k * m + j] : 0.0; /* terminal control = 0 */
 }
 
-double objective_knot(const Problem& P, const double* X, const double* U, int k) {
+/* gl: the trajectory's per-trajectory linear cost terms (oracle_set_cost_linear_batch; set_LQR_goal! with one goal per trajectory,
+ * src/cost_functions.jl:249-258) or nullptr */
+double objective_knot(const Problem& P, const double* X, const double* U, int k, const double* gl = nullptr) {
   double z[MAXZ]; knot_z(P, X, U, k, z);
   const to_cost_desc& C = P.costs[P.cost_index[k]];
   double J = cost_evaluate(C, P.n, P.m, z, z + P.n);
+  if (gl) { const double* g = gl + (size_t)P.cost_index[k] * (P.n + P.m); for (int i = 0; i < P.n + P.m; ++i) J += g[i] * z[i]; }
   if (P.opts.cost_dt_scaling && k < P.N - 1) J *= P.dt[k];
   return J;
 }
@@ -344,7 +348,7 @@ double al_knot(const Problem& P, const Traj& t, const double* X, const double* U
 double total_cost(const Problem& P, const Traj& t, const double* X, const double* U, bool with_al) {
   double J = 0.0;
   for (int k = 0; k < P.N; ++k) {
-    double Jk = objective_knot(P, X, U, k);
+    double Jk = objective_knot(P, X, U, k, t.gl.empty() ? nullptr : t.gl.data());
     if (with_al && !P.cons.empty()) Jk += al_knot(P, t, X, U, k);
     J += Jk;
   }
@@ -396,6 +400,7 @@ void knot_expansion_full(const Problem& P, const Traj& t, const double* X, const
   const bool terminal = (k == P.N - 1);
   double z[MAXZ]; knot_z(P, X, U, k, z);
   cost_expansion(P.costs[P.cost_index[k]], n, m, z, z + n, terminal, grad, hess);
+  if (!t.gl.empty()) { const double* g = &t.gl[(size_t)P.cost_index[k] * nz]; for (int i = 0; i < (terminal ? n : nz); ++i) grad[i] += g[i]; }
   if (P.opts.cost_dt_scaling && !terminal) {
     for (int i = 0; i < nz; ++i) grad[i] *= P.dt[k];
     for (int i = 0; i < nz * nz; ++i) hess[i] *= P.dt[k];
@@ -1016,7 +1021,30 @@ int oracle_set_cost(oracle_handle* h, int32_t id, const to_cost_desc* c) {
   CHECK_H(h); CHECK_P(c);
   if (id < 0 || id >= (int)h->P.costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
   int r = validate_cost(h->P, *c); if (r) return r;
-  h->P.costs[id] = *c; return TO_OK;
+  h->P.costs[id] = *c;
+  for (Traj& t : h->T) if (!t.gl.empty()) std::fill(t.gl.begin() + (size_t)id * (h->P.n + h->P.m), t.gl.begin() + (size_t)(id + 1) * (h->P.n + h->P.m), 0.0);  /* its per-trajectory terms start over */
+  return TO_OK;
+}
+/* per-trajectory q (n, B) / r (m, B) of cost `id` (either may be NULL): set_LQR_goal!(cost, xf_b, uf_b) for every trajectory at once */
+int oracle_set_cost_linear_batch(oracle_handle* h, int32_t id, const double* q, const double* r) {
+  CHECK_H(h);
+  Problem& P = h->P;
+  if (id < 0 || id >= (int)P.costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
+  if (P.costs[id].kind == TO_COST_ERROR_QUADRATIC) return fail(TO_ERR_UNSUPPORTED, "per-trajectory linear terms: not for ErrorQuadratic (its q slot carries x_ref)");
+  const int n = P.n, m = P.m, nz = n + m;
+  for (int b = 0; b < P.B; ++b) {
+    Traj& t = h->T[b];
+    if (t.gl.empty()) t.gl.assign((size_t)P.costs.size() * nz, 0.0);
+    double* g = &t.gl[(size_t)id * nz];
+    if (q) for (int i = 0; i < n; ++i) g[i] = q[i + (size_t)n * b] - P.costs[id].q[i];
+    if (r) for (int j = 0; j < m; ++j) g[n + j] = r[j + (size_t)m * b] - P.costs[id].r[j];
+  }
+  return TO_OK;
+}
+int oracle_clear_cost_linear_batch(oracle_handle* h) {
+  CHECK_H(h);
+  for (Traj& t : h->T) t.gl.clear();
+  return TO_OK;
 }
 int oracle_set_constraint(oracle_handle* h, int32_t id, const to_constraint_desc* c) {
   CHECK_H(h); CHECK_P(c);
@@ -1040,7 +1068,7 @@ int oracle_al_cost(oracle_handle* h, double* J) {
 }
 int oracle_stage_costs(oracle_handle* h, double* Jk) {
   CHECK_H(h); CHECK_P(Jk);
-  for_batch(h, [&](Traj& t, int b) { for (int k = 0; k < h->P.N; ++k) Jk[(size_t)b * h->P.N + k] = objective_knot(h->P, t.X.data(), t.U.data(), k); });
+  for_batch(h, [&](Traj& t, int b) { for (int k = 0; k < h->P.N; ++k) Jk[(size_t)b * h->P.N + k] = objective_knot(h->P, t.X.data(), t.U.data(), k, t.gl.empty() ? nullptr : t.gl.data()); });
   return TO_OK;
 }
 int oracle_expand(oracle_handle* h) { CHECK_H(h); for_batch(h, [&](Traj& t, int) { expand(h->P, t); }); return TO_OK; }

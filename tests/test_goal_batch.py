@@ -1,0 +1,128 @@
+"""One goal per trajectory on one handle (SURVEY.md §8b "optionally per-trajectory xf"; VERDICT r04 missing #2): set_goal_state!(prob, Xf)
+= set_LQR_goal!(cost, xf_b) for every trajectory (src/problem.jl:294-310, src/cost_functions.jl:249-258: only q changes), through
+to_set_cost_linear_batch.  CPU: the oracle's batch against B single-trajectory oracle problems retargeted with the scalar
+set_goal_state!.  GPU: the HIP path against the oracle."""
+import numpy as np
+import pytest
+
+import trajopt_amd as T
+from trajopt_amd import internal as I
+from trajectoryoptimization_jl_amd import configs
+
+
+def cartpole_goals(B, seed=5):
+    rng = np.random.default_rng(seed)
+    Xf = np.tile(np.array([0.0, np.pi, 0.0, 0.0]), (B, 1))
+    Xf[:, 0] = rng.uniform(-1.0, 1.0, B)          # where the cart should stop
+    Xf[0, 0] = 0.0
+    return Xf
+
+
+def test_per_trajectory_goals_equal_single_trajectory_problems(oracle):
+    B = 6
+    Xf = cartpole_goals(B)
+    pb = configs.cartpole_problem(batch=B, lib=oracle)
+    x0 = np.empty((B, 4)); pb._call("get_initial_state", pb._pd(x0))
+    T.set_goal_state(pb, Xf)
+    T.rollout(pb)
+    Jb, Jkb = T.cost(pb), T.stage_costs(pb)
+    I.expand(pb); I.backwardpass(pb)
+    gb = I.gains(pb)
+    sb = T.iLQRSolver(pb).solve()
+    Xb, Ub = T.states(pb), T.controls(pb)
+    for b in range(B):
+        p1 = configs.cartpole_problem(batch=1, lib=oracle)
+        p1.set_initial_state(x0[b])
+        T.set_goal_state(p1, Xf[b])                # the reference's scalar verb
+        T.rollout(p1)
+        np.testing.assert_allclose(T.cost(p1)[0], Jb[b], rtol=1e-13)
+        np.testing.assert_allclose(T.stage_costs(p1)[0], Jkb[b], rtol=1e-12, atol=1e-13)
+        I.expand(p1); I.backwardpass(p1)
+        g1 = I.gains(p1)
+        np.testing.assert_allclose(g1["d"][0], gb["d"][b], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(g1["K"][0], gb["K"][b], rtol=1e-9, atol=1e-11)
+        s1 = T.iLQRSolver(p1).solve()
+        assert int(s1.stats["iterations"][0]) == int(sb.stats["iterations"][b]) and int(s1.stats["status"][0]) == int(sb.stats["status"][b])
+        np.testing.assert_allclose(T.states(p1)[0], Xb[b], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(s1.stats["cost"][0], sb.stats["cost"][b], rtol=1e-8)
+    assert np.abs(Xb[:, -1, 0] - Xf[:, 0]).max() < 0.05 and np.ptp(Xb[:, -1, 0]) > 0.5       # every cart stops at ITS goal
+    # shared descriptors again
+    T.clear_goal_state_batch(pb)
+    ref = configs.cartpole_problem(batch=B, lib=oracle)
+    T.initial_controls(pb, T.controls(ref)); T.rollout(pb); T.rollout(ref)
+    np.testing.assert_array_equal(T.cost(pb), T.cost(ref))
+
+
+def test_per_trajectory_goal_checks(oracle):
+    p = configs.cartpole_problem(batch=3, constrained=True, lib=oracle)
+    with pytest.raises(T.DimensionMismatch):
+        T.set_goal_state(p, np.zeros((2, 4)))
+    with pytest.raises(T.UnsupportedError):        # the GoalConstraint's target is shared by the batch
+        T.set_goal_state(p, np.zeros((3, 4)))
+    T.set_goal_state(p, np.zeros((3, 4)), constraint=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["default", "lane", "fwd1"])
+def test_per_trajectory_goals_cartpole_on_gpu(path, hip, oracle, monkeypatch):
+    """HIP against the oracle with one goal per trajectory: every phase, then whole iLQR solves (integers bit-exact) — on the scan /
+    cooperative path, on the fused lane path with compaction and accept-by-rollout, and with the one-wave forward kernel."""
+    from test_gpu_parity import assert_solve_parity
+    B = 96
+    if path == "lane":
+        monkeypatch.setenv("TRAJOPT_BACKWARD", "lane"); monkeypatch.setenv("TRAJOPT_ACCEPT_ROLL_MIN", "1"); B = 300
+    if path == "fwd1":
+        monkeypatch.setenv("TRAJOPT_FWD2", "0")
+    Xf = cartpole_goals(B)
+    ph, po = configs.cartpole_problem(batch=B, lib=hip), configs.cartpole_problem(batch=B, lib=oracle)
+    for p in (ph, po):
+        T.set_goal_state(p, Xf); T.rollout(p)
+    np.testing.assert_allclose(T.cost(ph), T.cost(po), rtol=1e-12)
+    np.testing.assert_allclose(T.stage_costs(ph), T.stage_costs(po), rtol=1e-12, atol=1e-14)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-7, atol=1e-9); np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-7, atol=1e-9)
+    lh, Jh = I.forwardpass(ph); lo, Jo = I.forwardpass(po)
+    np.testing.assert_array_equal(lh, lo); np.testing.assert_allclose(Jh, Jo, rtol=1e-10)
+    ph, po = configs.cartpole_problem(batch=B, lib=hip), configs.cartpole_problem(batch=B, lib=oracle)
+    for p in (ph, po):
+        T.set_goal_state(p, Xf)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po, unconverged_rtol=1e-4)
+    X = T.states(ph)
+    done = sh.stats["status"] == T.capi.SOLVE_SUCCEEDED
+    assert done.mean() > 0.9 and np.abs(X[done, -1, 0] - Xf[done, 0]).max() < 0.05
+
+
+@pytest.mark.gpu
+def test_per_trajectory_goals_quadrotor_and_constraints_on_gpu(hip, oracle):
+    """Quadrotor (QuatLQRCost: the vector part of the goal per trajectory, the attitude reference shared), iLQR; and an AL solve of the
+    double integrator with control bounds and per-trajectory goals."""
+    from test_gpu_parity import assert_solve_parity
+    B = 40
+    rng = np.random.default_rng(8)
+    def quad(lib):
+        p = configs.quadrotor_problem(batch=B, N=41, tf=1.0, lib=lib)
+        Xf = np.tile(p.xf, (B, 1)); Xf[:, :3] += rng0.uniform(-0.5, 0.5, (B, 3))
+        T.set_goal_state(p, Xf)
+        return p, Xf
+    rng0 = np.random.default_rng(8); ph, Xf = quad(hip)
+    rng0 = np.random.default_rng(8); po, _ = quad(oracle)
+    sh, so = T.iLQRSolver(ph).solve(), T.iLQRSolver(po).solve()
+    assert_solve_parity(sh, so, ph, po)
+    assert np.abs(T.states(ph)[:, -1, :3] - Xf[:, :3]).max() < 0.4 and np.abs(T.states(ph)[:, -1, :3] - ph.xf[:3]).max() > 0.4   # 1 s: towards ITS goal
+    from test_infeasible import di_problem
+    out = []
+    for lib in (hip, oracle):
+        model = T.DoubleIntegrator(1.0, 2)
+        obj = T.LQRObjective(np.ones(4), 0.1 * np.ones(2), 100 * np.ones(4), np.array([1.0, 2.0, 0, 0]), 31)
+        cons = T.ConstraintList(4, 2, 31)
+        T.add_constraint(cons, T.BoundConstraint(4, 2, u_max=1.5, u_min=-1.5), (1, 30))
+        p = T.Problem(model, obj, np.zeros(4), 3.0, constraints=cons, batch=B, lib=lib)
+        G = np.zeros((B, 4)); G[:, :2] = np.random.default_rng(2).uniform(-2, 2, (B, 2))
+        T.set_goal_state(p, G)
+        out.append((T.ALSolver(p).solve(), p, G))
+    (sh, ph, G), (so, po, _) = out
+    assert_solve_parity(sh, so, ph, po)
+    assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED) and np.abs(T.states(ph)[:, -1, :2] - G[:, :2]).max() < 0.05

@@ -165,6 +165,8 @@ SIGNATURES = {
     "get_initial_state": [_H, _PD],
     "set_cost": [_H, C.c_int32, C.POINTER(CostDesc)],
     "set_constraint": [_H, C.c_int32, C.POINTER(ConstraintDesc)],
+    "set_cost_linear_batch": [_H, C.c_int32, _PD, _PD],
+    "clear_cost_linear_batch": [_H],
     "rollout": [_H],
     "cost": [_H, _PD],
     "stage_costs": [_H, _PD],

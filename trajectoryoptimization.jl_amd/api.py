@@ -33,7 +33,7 @@ from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, 
                     SolverOpts, SolveStats, UnsupportedError)
 
 __all__ = [
-    "InfeasibleModel", "InfeasibleConstraint", "InfeasibleProblem", "infeasible_controls",
+    "clear_goal_state_batch", "InfeasibleModel", "InfeasibleConstraint", "InfeasibleProblem", "infeasible_controls",
     "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "LinearMap", "ModelVector", "HybridDoubleIntegrator", "pad_cost", "dims", "RK4", "RK3", "Euler",
     "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
@@ -1396,6 +1396,8 @@ def set_goal_state(prob, xf, objective=True, constraint=True):
     """set_goal_state!  (src/problem.jl:294-310): set_LQR_goal! on every cost, update GoalConstraints."""
     if getattr(prob, "hybrid", False):  # (the reference's set_goal_state! needs one state dimension for all knots as well)
         raise UnsupportedError("set_goal_state on a hybrid model vector: the knots have different state dimensions; rebuild the problem")
+    if np.asarray(xf).ndim == 2:
+        return _set_goal_state_batch(prob, xf, objective, constraint)
     xf = _vec(xf, prob.n, "xf")
     if objective:
         for i, c in enumerate(prob._cost_objs):
@@ -1414,6 +1416,32 @@ def set_goal_state(prob, xf, objective=True, constraint=True):
                 d = con._desc(a, b)
                 prob._call("set_constraint", i, C.byref(d))
     prob.xf = xf.copy()
+
+
+def _set_goal_state_batch(prob, Xf, objective=True, constraint=True):
+    """set_goal_state!(prob, Xf) with ONE GOAL PER TRAJECTORY, Xf [B, n] (batched MPC / goal sweeps on one handle):
+    set_LQR_goal!(cost, xf_b) on every cost for every trajectory — q_b = -Q xf_b, nothing else changes (src/cost_functions.jl:249-252)
+    — through to_set_cost_linear_batch.  A GoalConstraint's target stays shared by the batch (constraint parameters are not
+    per-trajectory): pass ``constraint=False`` on problems that carry one."""
+    Xf = np.ascontiguousarray(np.asarray(Xf, dtype=np.float64))
+    if Xf.shape != (prob.B, prob.n):
+        raise DimensionMismatch(f"Xf must be [B, n] = {(prob.B, prob.n)}; got {Xf.shape}")
+    if constraint and any(isinstance(c, GoalConstraint) for c in prob.constraints.constraints):
+        raise UnsupportedError("per-trajectory goals act on the objective; a GoalConstraint's xf is shared by the batch "
+                               "(pass constraint=False, or use one Problem per goal)")
+    if objective:
+        for i, c in enumerate(prob._cost_objs):
+            if c.kind == capi.COST_ERROR_QUADRATIC:
+                raise TypeError("set_LQR_goal! is only defined for QuadraticCostFunction (src/cost_functions.jl:249)")
+            q = -(Xf @ c.Q.T) if c.kind == capi.COST_QUADRATIC else -(Xf * c.Q[None, :])   # [B, n] = column-major (n, B)
+            prob._call("set_cost_linear_batch", i, prob._pd(np.ascontiguousarray(q)), None)
+    prob.xf_batch = Xf.copy()
+
+
+def clear_goal_state_batch(prob):
+    """Back to the shared descriptors (to_clear_cost_linear_batch)."""
+    prob._call("clear_cost_linear_batch")
+    prob.xf_batch = None
 
 
 def update_trajectory(prob, X, U, start=1):

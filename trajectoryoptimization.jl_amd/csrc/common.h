@@ -108,11 +108,16 @@ __device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, const
 // terminal cost with the knot's zero control; src/cost_functions.jl:92-94, test/objective_tests.jl:129).
 // lam0 / mu0: this lane's pointers to dual row 0 / penalty 0 (tiled arrays).
 // GEN = false: no dense QuadraticCost and no non-selector constraint in the tables (those branches are compiled out)
+// gl0: this lane's pointer into DevProblem::gl (per-trajectory linear cost terms; nullptr: none)
 template <class M, bool GEN = true>
 __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
-                                            const double* mu0, bool with_al) {
+                                            const double* mu0, bool with_al, const double* gl0 = nullptr) {
   constexpr int n = M::n, m = M::m, nz = n + m;
-  double Jk = cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], x, u);
+  const int cidx = P.cost_index[k];
+  double Jk = cost_eval<n, m, GEN>(P.costs[cidx], x, u);
+  if constexpr (GEN) {
+    if (P.gl) Jk += goal_lin_cost<n, m>(gl0, cidx, x, u);  // (P.gl: wave-uniform; gl0 is only meaningful with it)
+  }
   if (P.opts.cost_dt_scaling && k < P.N - 1) Jk *= P.dt[k];
   if (with_al && P.n_cons > 0) {
     double z[nz];
@@ -224,7 +229,7 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int la
       }
     }
     if (cmax_out && P.n_cons > 0) { const double v = knot_violation<M>(P, k, x, u); if (!(v <= cmax)) cmax = v; }
-    if (J_out) J += knot_cost<M>(P, k, x, u, lam0, mu0, with_al);
+    if (J_out) J += knot_cost<M>(P, k, x, u, lam0, mu0, with_al, TILE_PTR(P.gl, P.n_costs * nz));
   }
   if (J_out) *J_out = J;
   if (cmax_out) *cmax_out = cmax;

@@ -68,6 +68,7 @@ struct to_handle_s {
   double* d_dt = nullptr;
   int* d_cost_index = nullptr;
   int* d_crow = nullptr;    // [64] compact_row table of the model (tangent-matrix getters)
+  double* d_gl = nullptr;   // per-trajectory linear cost terms (DevProblem::gl), tiled, L = n_costs * (n + m); allocated on first use
   double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
   double* d_tmp2 = nullptr;
   // multi-GPU: RCCL communicator of the batch shards (to_comm_*; librccl is dlopen'ed on first use)

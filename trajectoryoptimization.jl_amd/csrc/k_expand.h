@@ -91,6 +91,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   // ---- cost (+AL) gradient and Hessian-vector product on the full state
   double gr[nz], y[nz];
   cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
+  if (P.gl) goal_lin_grad<n, m>(P.gl + ((size_t)tile * (size_t)(P.n_costs * nz)) * 64 + lane64, P.cost_index[k], terminal, gr);  // per-trajectory q, r
   if (P.opts.cost_dt_scaling && !terminal) {
     const double h = P.dt[k];
 #pragma unroll
@@ -366,6 +367,7 @@ __device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int l
 #pragma unroll
     for (int i = 0; i < nz; ++i) v[i] = (i == (j < ne ? j : n + (j - ne))) ? 1.0 : 0.0;
     cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
+    if (P.gl) goal_lin_grad<n, m>(P.gl + ((size_t)tile * (size_t)(P.n_costs * nz)) * 64 + lane, P.cost_index[k], terminal, gr);  // per-trajectory q, r
     if (P.opts.cost_dt_scaling && !terminal) {
       const double h = P.dt[k];
 #pragma unroll

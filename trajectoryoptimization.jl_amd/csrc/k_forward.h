@@ -108,6 +108,9 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const double max_x = o.max_state_value, max_u = o.max_control_value;
   // stage cost: in VGPRs for the small models, in LDS for the models whose rollout loop has no register to spare
   typename std::conditional<KLDS, StageCostLds<n, m>, StageCostDiag<n, m>>::type sc;
+  const bool has_gl = P.gl != nullptr;  // wave-uniform (a kernel argument): the branches on it are scalar
+  const double* gl0 = TILE_PTR(P.gl, P.n_costs * (n + m));
+  const int ci0 = P.cost_index[0];
   double h0 = 0.0;
   if constexpr (SIMPLE) {
     if constexpr (KLDS) { sc.load(P.costs[P.cost_index[0]], kbuf + 2 * (size_t)kbuf_len, hw); WAVE_SYNC(); }
@@ -184,6 +187,9 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     gsum += gk;
     const double h = SIMPLE ? h0 : P.dt[k];
     double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], xb, ub);
+    if constexpr (GEN) {  // per-trajectory q, r: in the general variants only (launch_forward picks one when DevProblem::gl is set), so that
+      if (has_gl) Jk += goal_lin_cost<n, m>(gl0, SIMPLE ? ci0 : (int)P.cost_index[k], xb, ub);  // the default kernels keep their loops as they were
+    }
     if (dt_scaling) Jk *= h;
     if constexpr (CONS) {
       if (all_cached) {
@@ -213,7 +219,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     double u0[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
-    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true);
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true, gl0);
   }
   if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be in flight when the next pass refills the buffers
   J_out = J; g_out = gsum / (N - 1); ok_out = ok;
@@ -665,6 +671,9 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
   const bool dt_scaling = P.opts.cost_dt_scaling != 0;
   const double max_x = o.max_state_value, max_u = o.max_control_value;
   typename std::conditional<M::lds_gains, StageCostLds<n, m>, StageCostDiag<n, m>>::type sc;
+  const bool has_gl = P.gl != nullptr;  // wave-uniform (a kernel argument): the branches on it are scalar
+  const double* gl0 = TILE_PTR(P.gl, P.n_costs * (n + m));
+  const int ci0 = P.cost_index[0];
   double h0 = 0.0;
   if constexpr (SIMPLE) {
     if constexpr (M::lds_gains) { sc.load(P.costs[P.cost_index[0]], ctab, hw); WAVE_SYNC(); }
@@ -715,6 +724,9 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
     gsum += gk;
     const double h = SIMPLE ? h0 : P.dt[k];
     double Jk = SIMPLE ? sc.eval(xb, ub) : cost_eval<n, m, GEN>(P.costs[P.cost_index[k]], xb, ub);
+    if constexpr (GEN) {  // per-trajectory q, r: in the general variants only (launch_forward picks one when DevProblem::gl is set), so that
+      if (has_gl) Jk += goal_lin_cost<n, m>(gl0, SIMPLE ? ci0 : (int)P.cost_index[k], xb, ub);  // the default kernels keep their loops as they were
+    }
     if (dt_scaling) Jk *= h;
     if constexpr (CONS) {
       if (all_cached) {
@@ -750,7 +762,7 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
     double u0[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
-    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true);
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true, gl0);
   }
   J_out = J; g_out = gsum / (N - 1); ok_out = ok;
 }

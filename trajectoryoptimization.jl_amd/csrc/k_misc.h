@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(64) k_cost(KArgs a, int with_al, double* out, 
       for (int i = 0; i < n; ++i) x[i] = EL(X, k * n + i);
 #pragma unroll
       for (int i = 0; i < m; ++i) u[i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
-      EL(o, k) = knot_cost<M>(P, k, x, u, nullptr, nullptr, false);
+      EL(o, k) = knot_cost<M>(P, k, x, u, nullptr, nullptr, false, TILE_PTR(P.gl, P.n_costs * (n + m)));
     }
     return;
   }
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
     double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
     con_dual_update<nz>(K, z, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
   }
-  EL(TILE_PTR(a.knotbuf, N), k) = knot_cost<M>(P, k, x, u, lam0, mn0, true);
+  EL(TILE_PTR(a.knotbuf, N), k) = knot_cost<M>(P, k, x, u, lam0, mn0, true, TILE_PTR(P.gl, P.n_costs * nz));
 }
 
 template <class M>
@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(64) k_cost_derivs(KArgs a, double* grad, doubl
 #pragma unroll
     for (int i = 0; i < nz; ++i) v[i] = (i == j) ? 1.0 : 0.0;
     cost_grad_hvp<n, m>(P.costs[P.cost_index[k]], x, u, terminal, v, g, y);
+    if (P.gl) goal_lin_grad<n, m>(TILE_PTR(P.gl, P.n_costs * nz), P.cost_index[k], terminal, g);
     const double sc = (P.opts.cost_dt_scaling && !terminal) ? P.dt[k] : 1.0;
 #pragma unroll
     for (int i = 0; i < nz; ++i) {

@@ -47,7 +47,33 @@ struct DevProblem {
   IntC* cost_index;    // [N]
   CostC* costs;        // [n_costs]
   ConC* cons;          // [n_cons]
+  // Per-trajectory linear cost terms (to_set_cost_linear_batch: set_LQR_goal! / set_goal_state! with one goal per trajectory,
+  // src/cost_functions.jl:249-258, src/problem.jl:294-310): tiled array, L = n_costs * (n + m); entry ci*(n+m) + i of trajectory b is
+  // what its q_i (i < n) / r_{i-n} differs by from cost ci's descriptor.  NULL (the default): every trajectory shares the descriptors.
+  const double* gl;
 };
+
+// cost of the per-trajectory linear terms of cost ci at (x, u), and their gradient (added to g); gl0 = this lane's pointer to entry 0
+template <int n, int m>
+__device__ __forceinline__ double goal_lin_cost(const double* gl0, int ci, const double* x, const double* u) {
+  const double* g = gl0 + (size_t)ci * (n + m) * 64;
+  double J = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) J += g[(size_t)i * 64] * x[i];
+#pragma unroll
+  for (int j = 0; j < m; ++j) J += g[(size_t)(n + j) * 64] * u[j];
+  return J;
+}
+template <int n, int m>
+__device__ __forceinline__ void goal_lin_grad(const double* gl0, int ci, bool terminal, double* gr) {
+  const double* g = gl0 + (size_t)ci * (n + m) * 64;
+#pragma unroll
+  for (int i = 0; i < n; ++i) gr[i] += g[(size_t)i * 64];
+  if (!terminal) {
+#pragma unroll
+    for (int j = 0; j < m; ++j) gr[n + j] += g[(size_t)(n + j) * 64];
+  }
+}
 
 // Pin a wave-uniform value into a VGPR.  Loop-invariant uniform operands otherwise live in SGPRs; the hot loops
 // carry ~40 of them (model parameters, stage cost), which overflows the 102-SGPR file into spills and, with the

@@ -195,7 +195,8 @@ int launch_accept(to_handle* h) {  // materialise accepted candidate slots on sl
 // compile-time RK4 (models that pin it), bit3 dense costs / generic constraints.
 int launch_forward(to_handle* h, bool accept = true, bool two_wave = false) {
   const KArgs& a = h->a;
-  int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | ((a.P.expand_variant & 5) ? 8 : 0);
+  // (bit3 also with per-trajectory linear cost terms, DevProblem::gl: only the general variants read them)
+  int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | (((a.P.expand_variant & 5) || a.P.gl) ? 8 : 0);
   if (!h->ops->forward[mode]) mode &= ~4;  // the model does not pin RK4
   if (a.P.unit_soc && h->ops->forward[mode | 16]) mode |= 16;
   if (!h->ops->forward[mode]) mode = (mode | 8) & ~1 & ~16;  // the general variant (any cost kind, stage cost read per knot): a superset
@@ -1042,7 +1043,44 @@ int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
   if (id < 0 || id >= (int)h->costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
   TRY(validate_cost(h->a.P.n, (h->model_key >= 4 && h->model_key <= 6) ? (int)h->a.P.mp[10] : -1, *c));  // rigid bodies only (key 7: hybrid double integrator)
   h->costs[id] = *c;
+  if (h->d_gl) {  // the cost's per-trajectory linear terms start over (they were relative to the old descriptor)
+    const int nz = h->a.P.n + h->a.P.m, L = (int)h->costs.size() * nz;
+    std::vector<double> zero((size_t)nz * h->a.P.B, 0.0);
+    TRY(upload_vec(h, zero.data(), h->d_gl, nz, L, id * nz));
+  }
   return upload_tables(h);
+}
+int to_set_cost_linear_batch(to_handle* h, int32_t id, const double* q, const double* r) {
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->costs.size()) return fail(TO_ERR_ARGUMENT, "cost id out of range");
+  if (!q && !r) return fail(TO_ERR_NULL, "null pointer");
+  const to_cost_desc& c = h->costs[id];
+  if (c.kind == TO_COST_ERROR_QUADRATIC) return fail(TO_ERR_UNSUPPORTED, "per-trajectory linear terms: not for ErrorQuadratic (its q slot carries x_ref)");
+  DevProblem& P = h->a.P;
+  const int n = P.n, m = P.m, nz = n + m, L = (int)h->costs.size() * nz, B = P.B;
+  if (!h->d_gl) TRY(dev_alloc(h, &h->d_gl, (size_t)L * P.Bp));  // zero-filled: every cost starts with its descriptor's terms
+  std::vector<double> delta;
+  if (q) {  // stored as the difference from the descriptor's q: the kernels ADD it to what the shared code path computes
+    delta.resize((size_t)n * B);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < n; ++i) delta[i + (size_t)n * b] = q[i + (size_t)n * b] - c.q[i];
+    TRY(upload_vec(h, delta.data(), h->d_gl, n, L, id * nz));
+  }
+  if (r) {
+    delta.resize((size_t)m * B);
+    for (int b = 0; b < B; ++b) for (int j = 0; j < m; ++j) delta[j + (size_t)m * b] = r[j + (size_t)m * b] - c.r[j];
+    TRY(upload_vec(h, delta.data(), h->d_gl, m, L, id * nz + n));
+  }
+  P.gl = h->d_gl;
+  return TO_OK;
+}
+int to_clear_cost_linear_batch(to_handle* h) {
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
+  if (h->d_gl) {
+    HIPCHECK(hipMemsetAsync(h->d_gl, 0, sizeof(double) * h->costs.size() * (h->a.P.n + h->a.P.m) * h->a.P.Bp, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  }
+  h->a.P.gl = nullptr;
+  return TO_OK;
 }
 int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
   CHECK_H(h); CHECK_IDLE(h); CHECK_P(c); TRY(use_device(h));
