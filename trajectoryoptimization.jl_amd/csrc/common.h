@@ -66,26 +66,12 @@ struct KArgs {
   int al_mode;    // 0: iLQR, 1: AL-iLQR
   int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
   int step;
-  int k_tiled;    // gains layout: 0 = trajectory-major rows (below); 1 = tiled like X / U (lane path: the lane-per-trajectory kernels write
-                  // and the forward pass reads whole 512-byte rows instead of 40-byte pieces 4 KB apart) — see gains_base
   int store_x;    // 1: the forward pass stores every candidate's states (k_accept copies the accepted ones); 0: only their controls —
                   // k_accept_roll (k_forward.h) then re-rolls the accepted candidates.  Set per batch step by the solve loop.
 };
 
 // gains row of one knot of one trajectory: m rows of (ne gains + 1 feed-forward) doubles
 template <class M> struct Gains { static constexpr int RSK = M::m * (M::ne + 1); };
-// Where the gains of trajectory b start, and the strides between the entries of a row (ks) and between knots (kk), in doubles.
-// Trajectory-major rows (k_tiled == 0): Kt[(b*(N-1) + k)*RSK + i] — what the cooperative / scan / MFMA passes write and the LDS-staged
-// forward pass DMA-copies.  Tiled (k_tiled == 1, the lane path of the small models): Kt[((b/64)*(N-1)*RSK + k*RSK + i)*64 + b%64]: a
-// lane-per-trajectory writer stores whole 512-byte rows, and the 16 (or 21) trajectories of a forward wave read one 128-byte line per entry.
-template <class M>
-__device__ __forceinline__ size_t gains_base(const KArgs& a, int b, int& ks, int& kk) {
-  constexpr int RSK = Gains<M>::RSK;
-  const int N = a.P.N;
-  if (a.k_tiled) { ks = 64; kk = RSK * 64; return ((size_t)(b >> 6) * (size_t)(N - 1) * RSK) * 64 + (b & 63); }
-  ks = 1; kk = RSK;
-  return ((size_t)b * (N - 1)) * RSK;
-}
 
 // per-lane pointer to element 0 of this lane's trajectory in a tiled array with L elements per trajectory;
 // element e is then p[e*64] (e wave-uniform -> scalar address arithmetic, immediate offsets for small constants)

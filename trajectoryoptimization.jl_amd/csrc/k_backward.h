@@ -298,8 +298,7 @@ __global__ void __launch_bounds__(64) k_backward_lane(KArgs a) {
   const double* Ml = a.Mc + ((size_t)tile * (size_t)(N - 1) * EM) * 64 + lane;
   const double* Hl = a.Hc + ((size_t)tile * (size_t)N * NS) * 64 + lane;
   const double* gl = a.gc + ((size_t)tile * (size_t)N * nc) * 64 + lane;
-  int ks, kk;
-  double* pK = a.Kt + gains_base<M>(a, b, ks, kk);
+  double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   double rho = a.rho[b], drho = a.drho[b];
   double dV0 = 0.0, dV1 = 0.0;
   bool failed = false, init = true, fresh = true;
@@ -318,7 +317,7 @@ __global__ void __launch_bounds__(64) k_backward_lane(KArgs a) {
       }
       dV0 = 0.0; dV1 = 0.0; k = N - 2; init = false; fresh = true;
       pMk = Ml + (size_t)(N - 2) * EM * 64; pHk = Hl + (size_t)(N - 2) * NS * 64; pgk = gl + (size_t)(N - 2) * nc * 64;
-      pKk = pK + (size_t)(N - 2) * kk;
+      pKk = pK + (size_t)(N - 2) * RSK;
     }
     if (k < 0) break;
     if (fresh) {
@@ -438,8 +437,8 @@ __global__ void __launch_bounds__(64) k_backward_lane(KArgs a) {
 #pragma unroll
       for (int r = 0; r < m; ++r) {
 #pragma unroll
-        for (int j = 0; j < ne; ++j) pKk[(size_t)(r * (ne + 1) + j) * ks] = Kg[r][j];
-        pKk[(size_t)(r * (ne + 1) + ne) * ks] = dk[r];
+        for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
+        pKk[r * (ne + 1) + ne] = dk[r];
       }
     }
     // cost-to-go with the un-regularised Quu:  S' = Qxx + K'(Quu K + Qux) + Qux'K,  s' = Qx + K'(Quu d + Qu) + Qux'd
@@ -495,7 +494,7 @@ __global__ void __launch_bounds__(64) k_backward_lane(KArgs a) {
       s[i] = sn[i];
     }
     --k;
-    pMk -= (size_t)EM * 64; pHk -= (size_t)NS * 64; pgk -= (size_t)nc * 64; pKk -= kk;
+    pMk -= (size_t)EM * 64; pHk -= (size_t)NS * 64; pgk -= (size_t)nc * 64; pKk -= RSK;
   }
   if (!failed) reg_decrease(P.opts, rho, drho);
   if (live) {

@@ -480,8 +480,7 @@ __global__ void __launch_bounds__(64, TO_FUSED_LANE_WAVES) k_expand_backward_lan
   double* X0 = X_SLOT_PTR(a, b, 0);
   double* U0 = U_SLOT_PTR(a, b, 0);
   const bool wt = M::accept_write_through && c != 0 && live;
-  int ks, kk;
-  double* pK = a.Kt + gains_base<M>(a, b, ks, kk);
+  double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   double rho = a.rho[b], drho = a.drho[b];
   double dV0 = 0.0, dV1 = 0.0;
   bool failed = false;
@@ -628,21 +627,12 @@ __global__ void __launch_bounds__(64, TO_FUSED_LANE_WAVES) k_expand_backward_lan
         for (int i = 0; i < m; ++i) { if (cc < ne) Kg[i][cc < ne ? cc : 0] = -col[i]; else dk[i] = -col[i]; }
       }
       if (live) {
-        double* pKk = pK + (size_t)k * kk;
-        if (ks == 1) {
+        double* pKk = pK + (size_t)k * RSK;
 #pragma unroll
-          for (int r = 0; r < m; ++r) {
+        for (int r = 0; r < m; ++r) {
 #pragma unroll
-            for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
-            pKk[r * (ne + 1) + ne] = dk[r];
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < m; ++r) {
-#pragma unroll
-            for (int j = 0; j < ne; ++j) EL(pKk, r * (ne + 1) + j) = Kg[r][j];
-            EL(pKk, r * (ne + 1) + ne) = dk[r];
-          }
+          for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
+          pKk[r * (ne + 1) + ne] = dk[r];
         }
       }
       double W[m][ne], qd[m];

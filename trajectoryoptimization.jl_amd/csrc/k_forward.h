@@ -25,19 +25,14 @@ struct FwdKnot {  // nominal state/control of one knot (+ its gains row for mode
   static constexpr int n = M::n, m = M::m, RSK = Gains<M>::RSK;
   double x[n], u[m], kd[WITHK ? RSK : 1];
   // pointers are already at this knot (the caller walks them): constant offsets, no address arithmetic per load
-  __device__ __forceinline__ void load(const double* pXk, const double* pUk, const double* pKk, int ks = 1) {
+  __device__ __forceinline__ void load(const double* pXk, const double* pUk, const double* pKk) {
 #pragma unroll
     for (int i = 0; i < n; ++i) x[i] = EL(pXk, i);
 #pragma unroll
     for (int j = 0; j < m; ++j) u[j] = EL(pUk, j);
     if constexpr (WITHK) {
-      if (ks == 1) {  // trajectory-major row; else the tiled layout (common.h gains_base): wave-uniform
 #pragma unroll
-        for (int i = 0; i < RSK; ++i) kd[i] = pKk[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < RSK; ++i) kd[i] = EL(pKk, i);
-      }
+      for (int i = 0; i < RSK; ++i) kd[i] = pKk[i];
     }
   }
 };
@@ -94,8 +89,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   const size_t cblock = live ? (size_t)wblock : (size_t)a.dump_wave;
   double* Xn = a.Xc + (cblock * (size_t)(N * n)) * 64 + hw;
   double* Un = a.Uc + (cblock * (size_t)((N - 1) * m)) * 64 + hw;
-  int ks = 1, kk = RSK;
-  const double* pK = a.Kt + (KLDS ? ((size_t)b * (N - 1)) * RSK : gains_base<M>(a, b, ks, kk));
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const double* px0 = TILE_PTR(a.x0, n);
   const double* lam0 = TILE_PTR(a.lam, P.n_duals);
   const double* mu0 = TILE_PTR(a.mu, P.n_cons);
@@ -136,8 +130,8 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
   if constexpr (KLDS) stage_gains<M>(a.Kt, b, TW, 0, N, kbuf, hw);
   FwdKnot<M, !KLDS> nxt;
-  nxt.load(Xc, Uc, pK, ks);
-  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + kk;  // knot k+1 of the nominal
+  nxt.load(Xc, Uc, pK);
+  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + RSK;  // knot k+1 of the nominal
   double *pXo = Xn, *pUo = Un;                                          // where knot k's candidate state / control go
   const bool all_cached = CONS && uncached == 0;  // wave-uniform: the loop then never touches the descriptor table
   if (ncs > 0) cs0.prefetch(0);
@@ -154,11 +148,11 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
     if (k + 1 < N - 1) {
       if constexpr (KLDS) stage_gains<M>(a.Kt, b, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
-      nxt.load(pXn, pUn, pKn, ks);
+      nxt.load(pXn, pUn, pKn);
       if (ncs > 0) cs0.prefetch(k + 1);
       if (ncs > 1) cs1.prefetch(k + 1);
     }
-    pXn += n * 64; pUn += m * 64; pKn += kk;
+    pXn += n * 64; pUn += m * 64; pKn += RSK;
     // candidate states are 3/4 of what this kernel moves, and with the chip full its duration follows the bytes it stores (C5: 560 /
     // 950 / 1800 us per launch at 4 / 8 / 16 candidates per trajectory): the solve loop then has only the controls stored
     if (a.store_x) {
@@ -343,13 +337,12 @@ __device__ __forceinline__ double nominal_gradient(const KArgs& a, int tile, int
   constexpr int m = M::m, ne = M::ne, RSK = Gains<M>::RSK;
   const int N = a.P.N;
   const double* Uc = U_SLOT_PTR(a, b, 0);
-  int ks = 1, kk = RSK;
-  const double* pK = a.Kt + (M::lds_gains ? ((size_t)b * (N - 1)) * RSK : gains_base<M>(a, b, ks, kk));
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   double gs = 0.0;
   for (int k = 0; k < N - 1; ++k) {
     double gk = 0.0;
 #pragma unroll
-    for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(pK[(size_t)k * kk + (size_t)(j * (ne + 1) + ne) * ks]) * rcp_fast(fabs(EL(Uc, k * m + j)) + 1.0));
+    for (int j = 0; j < m; ++j) gk = fmax(gk, fabs(pK[(size_t)k * RSK + j * (ne + 1) + ne]) * rcp_fast(fabs(EL(Uc, k * m + j)) + 1.0));
     gs += gk;
   }
   return gs / (N - 1);
@@ -576,8 +569,7 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
   const int N = P.N;
   const double* Xc = TILE_PTR(a.Xs, N * n);
   const double* Uc = TILE_PTR(a.Us, (N - 1) * m);
-  int ks = 1, kk = RSK;
-  const double* pK = a.Kt + (KLDS ? ((size_t)b * (N - 1)) * RSK : gains_base<M>(a, b, ks, kk));
+  const double* pK = a.Kt + ((size_t)b * (N - 1)) * RSK;
   const double* px0 = TILE_PTR(a.x0, n);
   double mp[16];
 #pragma unroll
@@ -589,15 +581,15 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
   for (int i = 0; i < n; ++i) xb[i] = EL(px0, i);
   if constexpr (KLDS) stage_gains<M>(a.Kt, b, TW, 0, N, kbuf, hw);
   FwdKnot<M, !KLDS> nxt;
-  nxt.load(Xc, Uc, pK, ks);
-  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + kk;
+  nxt.load(Xc, Uc, pK);
+  const double *pXn = Xc + n * 64, *pUn = Uc + m * 64, *pKn = pK + RSK;
   for (int k = 0; k < N - 1; ++k) {
     if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const FwdKnot<M, !KLDS> cur = nxt;
     const double* kcur = kbuf + (size_t)(k & 1) * kbuf_len + krow;
     if constexpr (!KLDS) {  // gains row in registers: plain loads, the compiler waits for exactly what it uses — issue them first
-      if (k + 1 < N - 1) nxt.load(pXn, pUn, pKn, ks);
-      pXn += n * 64; pUn += m * 64; pKn += kk;
+      if (k + 1 < N - 1) nxt.load(pXn, pUn, pKn);
+      pXn += n * 64; pUn += m * 64; pKn += RSK;
     }
     double vals[2 * R::PAIRS];  // [x_k | u_k | d_k | pad]
 #pragma unroll
@@ -635,9 +627,9 @@ __device__ __forceinline__ void fwd2_roll(const KArgs& a, int tile, int lane, in
     if constexpr (KLDS) {
       if (k + 1 < N - 1) {
         stage_gains<M>(a.Kt, b, TW, k + 1, N, kbuf + (size_t)((k + 1) & 1) * kbuf_len, hw);
-        nxt.load(pXn, pUn, pKn, ks);
+        nxt.load(pXn, pUn, pKn);
       }
-      pXn += n * 64; pUn += m * 64; pKn += kk;
+      pXn += n * 64; pUn += m * 64; pKn += RSK;
     }
     const double h = SIMPLE ? h0 : P.dt[k];
     model_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, k, xb, ub, h, xn);

@@ -182,14 +182,12 @@ __global__ void k_fill_uniform(double* d, const double* u, int dim, int L, int B
 }
 // gains: Kt rows (trajectory-major, [r][ne gains + 1 feed-forward]) -> host K[m,ne,N-1,B] / d[m,N-1,B] column-major.
 // grid (tiles, (N-1)*m*(ne+1)): e = (k*m + r)*(ne+1) + i
-// tiled: the lane path's layout (common.h gains_base)
-__global__ void k_gains_to_host(const double* __restrict__ Kt, double* __restrict__ hK, double* __restrict__ hd, int m, int ne, int K, int B, int tiled) {
+__global__ void k_gains_to_host(const double* __restrict__ Kt, double* __restrict__ hK, double* __restrict__ hd, int m, int ne, int K, int B) {
   TILE_LANE();
   const int e = blockIdx.y;
   if (b >= B) return;
   const int i = e % (ne + 1), r = (e / (ne + 1)) % m, k = e / ((ne + 1) * m);
-  const int RSK = m * (ne + 1);
-  const double v = tiled ? Kt[(((size_t)tile * K + k) * RSK + r * (ne + 1) + i) * 64 + lane] : Kt[((size_t)b * K + k) * RSK + r * (ne + 1) + i];
+  const double v = Kt[((size_t)b * K + k) * (m * (ne + 1)) + r * (ne + 1) + i];
   if (i < ne) { if (hK) hK[(size_t)r + (size_t)m * (i + (size_t)ne * (k + (size_t)K * b))] = v; }
   else if (hd) hd[(size_t)r + (size_t)m * (k + (size_t)K * b)] = v;
 }

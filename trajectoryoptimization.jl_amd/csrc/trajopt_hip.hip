@@ -807,11 +807,6 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_SCAN")) { if (!std::atoi(env)) h->scan = 0; else if (h->scan && std::atoi(env) == 2) h->scan = 2; }
   h->scan_max_active = 1 << 30;
   if (const char* env = std::getenv("TRAJOPT_SCAN_MAX")) h->scan_max_active = std::atoi(env);
-  // gains layout of the lane path: trajectory-major rows like everywhere else.  TRAJOPT_K_TILED=1 (A/B knob) stores them tiled like
-  // X / U (common.h gains_base) — measured SLOWER (r05, Cartpole: 64.5 vs 70.3 M it/s at B = 1 048 576, 59.0 vs 61.2 at 131 072): once the
-  // batch thins the tiled rows become scattered 8-byte writes, while a trajectory's row-major gains stay one contiguous 4 KB stream
-  a.k_tiled = 0;
-  if (const char* env = std::getenv("TRAJOPT_K_TILED")) if (std::atoi(env) && a.bwd_lane && !h->ops->lds_gains) a.k_tiled = 1;
   h->fused_lane = (a.bwd_lane && h->ops->expand_backward) ? 1 : 0;
   if (const char* env = std::getenv("TRAJOPT_FUSED_LANE")) if (!std::atoi(env)) h->fused_lane = 0;
   TRYB(upload_tables(h));  // again: h_compact depends on bwd_mfma
@@ -1271,7 +1266,7 @@ int to_get_gains(to_handle* h, double* K, double* d, double* dV, double* rho) {
     const size_t nK = (size_t)P.m * P.ne * (P.N - 1) * P.B, nd = (size_t)P.m * (P.N - 1) * P.B;
     TRY(ensure_stage(h, (nK + nd) * sizeof(double)));
     double *dK = h->stage, *dd = h->stage + nK;
-    hipLaunchKernelGGL(k_gains_to_host, grid_b(h, (P.N - 1) * P.m * (P.ne + 1)), dim3(BLOCK), 0, h->stream, h->a.Kt, dK, dd, P.m, P.ne, P.N - 1, P.B, h->a.k_tiled);
+    hipLaunchKernelGGL(k_gains_to_host, grid_b(h, (P.N - 1) * P.m * (P.ne + 1)), dim3(BLOCK), 0, h->stream, h->a.Kt, dK, dd, P.m, P.ne, P.N - 1, P.B);
     HIPCHECK(hipGetLastError());
     if (K) HIPCHECK(hipMemcpyAsync(K, dK, nK * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (d) HIPCHECK(hipMemcpyAsync(d, dd, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1305,7 +1300,7 @@ int to_get_cost_to_go(to_handle* h, double* S, double* s) {
   TRY(download_block(h, nullptr, BLK_H, P.ne, P.m, 0, P.ne, dux));
   TRY(download_gradient(h, nullptr, 0, P.ne, dx));
   TRY(download_gradient(h, nullptr, P.ne, P.m, du));
-  hipLaunchKernelGGL(k_gains_to_host, grid_b(h, (P.N - 1) * P.m * (P.ne + 1)), dim3(BLOCK), 0, h->stream, h->a.Kt, dK, dd, P.m, P.ne, P.N - 1, P.B, h->a.k_tiled);
+  hipLaunchKernelGGL(k_gains_to_host, grid_b(h, (P.N - 1) * P.m * (P.ne + 1)), dim3(BLOCK), 0, h->stream, h->a.Kt, dK, dd, P.m, P.ne, P.N - 1, P.B);
   hipLaunchKernelGGL(k_cost_to_go, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, dA, dB, dxx, duu, dux, dx, du, dK, dd, dS, ds, P.ne, P.m, P.N, P.B);
   HIPCHECK(hipGetLastError());
   if (S) HIPCHECK(hipMemcpyAsync(S, dS, nxx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
