@@ -1351,6 +1351,30 @@ def test_accept_by_rollout_small_models(case, hip, monkeypatch):
     np.testing.assert_array_equal(U0, U1)
 
 
+def test_two_launch_line_search(hip, monkeypatch):
+    """Large dense batches of the small models run the line search in two launches (common.h ls_phase): one round for every active
+    trajectory, a compaction of the trajectories that accepted nothing yet, the rest of the search for those only.  Same candidates,
+    same first accepted step size: whole solves must be BIT-IDENTICAL to the one-launch search, whatever the widths of the two launches —
+    33 000 Cartpole trajectories (ragged last tile), the re-roll path forced on for every batch step so that the two-launch search
+    serves the thinning batch as well, 40 iterations (part of the batch converged, searches of every depth)."""
+    monkeypatch.setenv("TRAJOPT_ACCEPT_ROLL_MIN", "1")
+    monkeypatch.setenv("TRAJOPT_ACCEPT_ROLL_FRAC", "0")
+    out = []
+    for two in ("0", "1,2", "2,2", "1,4", "3,1"):
+        monkeypatch.setenv("TRAJOPT_LS_TWO", two)
+        p = configs.cartpole_problem(batch=33000, N=41, tf=2.0, lib=hip)
+        s = T.iLQRSolver(p, iterations=40).solve()
+        out.append(({k: np.array(v).copy() for k, v in s.stats.items()}, T.states(p), T.controls(p), s.batch_steps))
+    ref = out[0]
+    assert len(set(ref[0]["iterations"])) > 5
+    for st, X, U, n in out[1:]:
+        assert n == ref[3]
+        for k in st:
+            np.testing.assert_array_equal(st[k], ref[0][k], err_msg=k)
+        np.testing.assert_array_equal(X, ref[1])
+        np.testing.assert_array_equal(U, ref[2])
+
+
 @pytest.mark.parametrize("two", ["0", "1"])
 def test_two_wave_forward_pass_small_models(two, hip, oracle, monkeypatch):
     """The small models' forward pass (gains row in registers, accepted steps written through by the next expansion) with one

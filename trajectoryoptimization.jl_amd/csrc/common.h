@@ -66,6 +66,16 @@ struct KArgs {
   int al_mode;    // 0: iLQR, 1: AL-iLQR
   int control;    // 1: run the solver state machine at the end of the forward pass; 0: phase API
   int step;
+  // Two-launch line search (large dense batches of the small models): the forward pass as launch A — ONE round of CW_A step sizes for
+  // every active trajectory; whoever accepted one (or has nothing to search) finishes there, the others are flagged — a compaction of
+  // the flags, and launch B over the flagged trajectories only, which continues at step size ls_c0 with rounds of its own width.  Which
+  // launch evaluates a candidate changes nothing in its value, and the first accepted step size is taken as before: bit-identical.
+  int ls_phase;   // 0: one launch, every round in-kernel; 1: launch A; 2: launch B
+  int ls_c0;      // launch B: index of its first step size (= CW of launch A)
+  int blk0;       // first candidate block of this launch (launch B's blocks sit behind launch A's)
+  int* pending;   // [Bp] launch A: this trajectory's search goes on in launch B
+  int* plist;     // [Bp] the flagged trajectories in index order ...
+  int* pcount;    // [1]  ... and their number (k_flags_count / k_flags_write)
   int store_x;    // 1: the forward pass stores every candidate's states (k_accept copies the accepted ones); 0: only their controls —
                   // k_accept_roll (k_forward.h) then re-rolls the accepted candidates.  Set per batch step by the solve loop.
 };

@@ -449,7 +449,12 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
   const int b0 = blockIdx.x * TW;
   // trajectory of this lane: position b0 + t of the batch, or — with active-list compaction — of this step's list
   int b, inrange;
-  if (a.compact) {
+  if (a.ls_phase == 2) {  // launch B of the two-launch line search (common.h): the trajectories launch A flagged, in index order
+    const int cnt = a.pcount[0];
+    if (b0 >= cnt) return;  // wave-uniform
+    inrange = (b0 + t) < cnt;
+    b = a.plist[inrange ? b0 + t : cnt - 1];
+  } else if (a.compact) {
     const int cnt = a.acount[a.step & 1];
     if (b0 >= cnt) return;  // wave-uniform
     inrange = (b0 + t) < cnt;
@@ -479,13 +484,14 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
     // static lane map in every round (the models whose accepted steps are written through by the next expansion: their search
     // rarely leaves the first round, and the general loop below cost the Cartpole kernel 2.3 us per launch)
     const int krow = t * Gains<M>::RSK;
-    for (int c0 = 0; c0 < total; c0 += CW) {
+    const int wblk = a.blk0 + (int)blockIdx.x;  // this wave's candidate block
+    for (int c0 = (a.ls_phase == 2 ? a.ls_c0 : 0); c0 < total; c0 += CW) {
       if (__ballot(need) == 0) break;
       const double alpha = ls_alpha(f, c0 + q, total);
       const bool cand = need && q < CW && (c0 + q) < total;
       double J, gm;
       bool ok;
-      forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, (int)blockIdx.x, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
+      forward_candidate<M, MODE>(a, tile, lane, b, cand, alpha, wblk, kbuf, kbuf_len, krow, b0, TW, hw, J, gm, ok);
       bool accept = false;
       if (cand && ok) {
         const double expected = -alpha * (dV0 + alpha * dV1);
@@ -497,9 +503,13 @@ __global__ void __launch_bounds__(64, TO_FWD_WAVES) k_forward(KArgs a) {
       for (int qq = CW - 1; qq >= 0; --qq) qs = ((am >> (qq * TW + t)) & 1ull) ? qq : qs;
       const int src = (qs >= 0 ? qs : 0) * TW + t;
       const double Js = __shfl(J, src), gs = __shfl(gm, src);
-      if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; accpos = (int)blockIdx.x * 64 + src; need = false; }
+      if (need && qs >= 0) { Jnew = Js; grad = gs; accepted = c0 + qs; acc = qs + 1; accpos = wblk * 64 + src; need = false; }
+      if (a.ls_phase == 1) break;  // launch A: one round
     }
-    forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act, bpfail, zero_step, accepted, acc, accpos, Jprev, Jnew, grad);
+    // launch A: a trajectory that has accepted nothing yet (and still has step sizes to try) goes on in launch B and is finished there
+    const bool later = a.ls_phase == 1 && need && CW < total;
+    if (later && q == 0) a.pending[b] = 1;
+    forward_finish<M>(a, tile, lane, b, hw, q, t, TW, act && !later, bpfail, zero_step, accepted, acc, accpos, Jprev, Jnew, grad);
     return;
   }
   const unsigned long long tmask = TW >= 64 ? ~0ull : (1ull << TW) - 1ull;  // lanes 0 .. TW-1 (q = 0): one per trajectory of the wave

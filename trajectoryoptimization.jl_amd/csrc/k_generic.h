@@ -142,6 +142,53 @@ __global__ void __launch_bounds__(1024) k_compact_write(KArgs a, int per) {
   }
 }
 
+// The two compaction launches for an arbitrary flag array: flags[0 .. n) -> out (ascending index), *outcount; the flags are cleared on the
+// way (each is read by exactly one thread of each launch).  Used by the two-launch line search (KArgs::pending -> plist, pcount).
+__global__ void __launch_bounds__(1024) k_flags_count(const int* __restrict__ flags, int n, int per, int* __restrict__ ccount) {
+  __shared__ int wcount[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = blockIdx.x * per;
+  int cnt = 0;
+  for (int i = lo + wave * 64; i < lo + per; i += 1024) {
+    const int b = i + lane;
+    cnt += __popcll(__ballot(b < n && flags[b] != 0));
+  }
+  if (lane == 0) wcount[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wcount[w];
+    ccount[blockIdx.x] = t;
+  }
+}
+__global__ void __launch_bounds__(1024) k_flags_write(int* __restrict__ flags, int n, int per, const int* __restrict__ ccount, int* __restrict__ out,
+                                                      int* __restrict__ outcount) {
+  __shared__ int scount[16 * 64];
+  __shared__ int base_s;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lo = blockIdx.x * per, nsl = per / 1024;
+  for (int i = 0; i < nsl; ++i) {
+    const int b = lo + i * 1024 + wave * 64 + lane;
+    const int c = __popcll(__ballot(b < n && flags[b] != 0));
+    if (lane == 0) scount[i * 16 + wave] = c;
+  }
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int g = 0; g < (int)blockIdx.x; ++g) t += ccount[g];
+    base_s = t;
+    if (blockIdx.x == gridDim.x - 1) outcount[0] = t + ccount[blockIdx.x];
+  }
+  __syncthreads();
+  for (int i = 0; i < nsl; ++i) {
+    int off = base_s;
+    for (int q = 0; q < i * 16 + wave; ++q) off += scount[q];
+    const int b = lo + i * 1024 + wave * 64 + lane;
+    const bool on = b < n && flags[b] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) { out[off + __popcll(m & ((1ull << lane) - 1ull))] = b; flags[b] = 0; }
+  }
+}
+
 __global__ void k_set_active(KArgs a, int value, int clear_bpfail) {
   TILE_LANE();
   if (b >= a.P.Bp) return;

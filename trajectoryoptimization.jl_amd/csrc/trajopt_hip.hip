@@ -491,6 +491,27 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       // write-through of the next expansion makes the same scattered stores, but behind 2 000 instructions per knot
       const bool dense = !h->ops->write_through || (double)last_active >= h->roll_min_frac * (double)P.B;
       a.store_x = (roll_min > 0 && h->ops->accept_roll && !two && last_active >= roll_min && dense) ? 0 : 1;
+      if (!a.store_x && h->ls2_cwa && a.compact && h->fwd2 != 1) {
+        // two-launch line search (common.h ls_phase): launch A — one round for everybody; flags -> list; launch B — the rest of the
+        // search for the flagged trajectories only; then the accept.  Same candidates, same first accepted step size: bit-identical.
+        const int cw0 = a.CW, tw0 = a.TW, dump0 = a.dump_wave;
+        a.dump_wave = h->ls2_dump;
+        a.CW = h->ls2_cwa; a.TW = 64 / h->ls2_cwa; a.ls_phase = 1; a.blk0 = 0;
+        TRY(launch_forward(h, false, false));
+        {
+          int per = ((P.Bp + 255) / 256 + 1023) / 1024 * 1024;
+          if (per > 65536) per = 65536;
+          const int nb = (P.Bp + per - 1) / per;
+          if (nb > 256) return fail(TO_ERR_UNSUPPORTED, "batch too large for the compaction kernels (16 777 216 trajectories)");
+          hipLaunchKernelGGL(k_flags_count, dim3(nb), dim3(1024), 0, h->stream, a.pending, P.Bp, per, a.ccount);
+          hipLaunchKernelGGL(k_flags_write, dim3(nb), dim3(1024), 0, h->stream, a.pending, P.Bp, per, a.ccount, a.plist, a.pcount);
+          HIPCHECK(hipGetLastError());
+        }
+        a.CW = h->ls2_cwb; a.TW = 64 / h->ls2_cwb; a.ls_phase = 2; a.ls_c0 = h->ls2_cwa; a.blk0 = h->ls2_blkA;
+        TRY(launch_forward(h, false, false));
+        a.ls_phase = 0; a.blk0 = 0; a.CW = cw0; a.TW = tw0; a.dump_wave = dump0;
+        TRY(launch_accept(h));
+      } else
       TRY(launch_forward(h, !h->ops->write_through || !a.store_x, two));
       a.store_x = 1;
       if (al_mode) TRY(launch_outer(h));
@@ -827,9 +848,24 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
       extra = waves;  // as many as either wave shape launches: a search deeper than the deep shape (options changed after creation) repacks there too
       a.repack_block0 = (int)waves + 1;
     }
+    // two-launch line search (small models, dense large batches: the steps that store candidate controls only): launch A's blocks,
+    // launch B's behind them, one dump block — control candidates only, so only Uc grows
+    size_t ublocks = waves + 1 + extra;
+    h->ls2_cwa = 0;
+    if (h->ops->write_through && h->ops->accept_roll && Bp >= 32768) {
+      int ca = 2, cb = 2;  // measured default (r05, Cartpole at B = 1 048 576: 74.1 M it/s with 2 + 2, 71.5 with 1 + 2, 70.9 with one launch; TRAJOPT_LS_TWO=a,b overrides, a = 0: off)
+      if (const char* env = std::getenv("TRAJOPT_LS_TWO")) { ca = std::atoi(env); const char* c2 = std::strchr(env, ','); cb = c2 ? std::atoi(c2 + 1) : 2; }
+      if (ca >= 1 && ca <= 16 && cb >= 1 && cb <= 16 && ca < P.opts.iterations_linesearch) {
+        h->ls2_cwa = ca; h->ls2_cwb = cb;
+        const size_t nA = (Bp + (64 / ca) - 1) / (64 / ca), nB = (Bp + (64 / cb) - 1) / (64 / cb);
+        h->ls2_blkA = (int)nA; h->ls2_dump = (int)(nA + nB);
+        ublocks = std::max(ublocks, nA + nB + 1);
+      }
+    }
     TRYB(dev_alloc(h, &a.Xc, (size_t)N * n * (waves + 1 + extra) * 64));
-    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * (waves + 1 + extra) * 64));
+    TRYB(dev_alloc(h, &a.Uc, (size_t)(N - 1) * m * ublocks * 64));
   }
+  if (h->ls2_cwa) { TRYB(dev_alloc(h, &a.pending, Bp)); TRYB(dev_alloc(h, &a.plist, Bp)); TRYB(dev_alloc(h, &a.pcount, 1)); }
   TRYB(dev_alloc(h, &a.x0, (size_t)n * Bp));
   TRYB(dev_alloc(h, &a.acc, Bp));
   TRYB(dev_alloc(h, &a.accp, Bp));
