@@ -1351,6 +1351,33 @@ def test_accept_by_rollout_small_models(case, hip, monkeypatch):
     np.testing.assert_array_equal(U0, U1)
 
 
+@pytest.mark.parametrize("goals,at", [(False, "0.7"), (True, "0.5"), (False, "0.3")])
+def test_repacked_working_set(goals, at, hip, monkeypatch):
+    """Once the active count of a large batch has halved, the solve loop moves the state of the trajectories still being solved into a
+    dense working set and goes on there (k_generic.h k_repack_*), again and again as the batch drains; finished trajectories go back
+    to their home position.  Which position holds a trajectory changes nothing in its arithmetic: every output must be BIT-IDENTICAL
+    to the solve that never moves anything (TRAJOPT_REPACK=0) — 70 000 Cartpole trajectories, moves allowed down to 2 048 (so that
+    several happen, across the change of compaction kernels at 16 384 and of the accept path at 32 768), with and without one goal per
+    trajectory (the per-trajectory cost terms travel with the state)."""
+    out = []
+    monkeypatch.setenv("TRAJOPT_REPACK_AT", at)     # the fraction of the working set that has to be left for a move
+    for rp in ("0", "2048"):
+        monkeypatch.setenv("TRAJOPT_REPACK", rp)
+        p = configs.cartpole_problem(batch=70000, N=41, tf=2.0, lib=hip)
+        if goals:
+            Xf = np.tile(p.xf, (p.B, 1)); Xf[:, 0] = np.random.default_rng(1).uniform(-1, 1, p.B)
+            T.set_goal_state(p, Xf)
+        s = T.iLQRSolver(p, iterations=80).solve()
+        out.append(({k: np.array(v).copy() for k, v in s.stats.items()}, T.states(p), T.controls(p), s.batch_steps, T.cost(p)))
+        s2 = T.iLQRSolver(p, iterations=80).solve()       # a second solve on the same handle starts from the home arrays again
+        assert s2.batch_steps >= 1
+    (s0, X0, U0, n0, J0), (s1, X1, U1, n1, J1) = out
+    assert n0 == n1 and 0.02 < np.mean(s0["status"] == T.capi.SOLVE_SUCCEEDED) and len(set(s0["iterations"])) > 10
+    for k in s0:
+        np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+    np.testing.assert_array_equal(X0, X1); np.testing.assert_array_equal(U0, U1); np.testing.assert_array_equal(J0, J1)
+
+
 def test_two_launch_line_search(hip, monkeypatch):
     """Large dense batches of the small models run the line search in two launches (common.h ls_phase): one round for every active
     trajectory, a compaction of the trajectories that accepted nothing yet, the rest of the search for those only.  Same candidates,

@@ -98,6 +98,17 @@ struct to_handle_s {
   int pn_early_slots = 0;        // workspace slots handed out so far
   to_solver_opts pn_opts;        // the options the polish runs with (the AL stage runs with a looser constraint_tolerance)
   double pn_early_ms = 0.0;
+  // repacked working set (k_generic.h k_repack_*): the per-trajectory arrays a solve carries from step to step, their home pointers,
+  // two working copies (B/2 and B/4 trajectories: ping-pong) and the working position -> home index maps
+  struct RpArr { size_t off; int kind; int L; };  // off: byte offset of the pointer field inside KArgs
+  std::vector<RpArr> rp_arr;
+  std::vector<void*> rp_home, rp_work[2];
+  int* rp_map[2] = {nullptr, nullptr};
+  int rp_cap[2] = {0, 0};
+  int rp_level = 0;      // 0: the kernels work on the home arrays; else on rp_work[(rp_level - 1) & 1]
+  int rp_B = 0, rp_Bp = 0;  // the batch of the handle while a solve works on a smaller set
+  double rp_at = 0.7;    // ... the fraction of the working set that has to be left for a move (TRAJOPT_REPACK_AT)
+  int rp_min = 16384;    // repack once the active count has halved, while the set holds at least this many (TRAJOPT_REPACK=0: never)
   // asynchronous solves (to_*_solve_async / to_solve_wait)
   std::thread worker;
   std::atomic<bool> inflight{false};

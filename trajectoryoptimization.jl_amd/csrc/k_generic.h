@@ -142,6 +142,60 @@ __global__ void __launch_bounds__(1024) k_compact_write(KArgs a, int per) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ repacking the working set
+// Large batches drain unevenly, and the active lists are in index order: once half of a batch has converged, a wave's 64 trajectories
+// sit in two or more tiles and every nominal load / store of every kernel touches that many 512-byte rows for 64 values (r05 trace,
+// Cartpole at B = 1 048 576: 95 M trajectory-iterations/s while all are active, 60 M over the rest of the solve).  When the active count
+// has halved, the solve loop therefore MOVES the per-trajectory state of the trajectories still being solved into a dense working set
+// (position j <- the j-th active trajectory, in index order) and goes on there with B = the number that is left; the converged ones stay
+// where they are (first move) or are written back to their home position (later moves, end of the solve).  Which position holds a
+// trajectory changes nothing in its arithmetic: bit-identical solves (tests/test_gpu_parity.py::test_repacked_working_set).
+constexpr int RP_MAX = 32;
+struct RpArgs {
+  int n;                // arrays
+  int kind[RP_MAX];     // 0: tiled doubles, L per trajectory; 1: plain double [B]; 2: plain int [B]
+  int L[RP_MAX];
+  const void* src[RP_MAX];
+  void* dst[RP_MAX];
+};
+// dst position j <- src position list[j], j < count; omap_new[j] = home index of that trajectory.  grid (ceil(count/64), n arrays)
+__global__ void __launch_bounds__(64) k_repack_move(RpArgs r, const int* __restrict__ list, int count, const int* __restrict__ omap_old,
+                                                    int* __restrict__ omap_new) {
+  const int j = blockIdx.x * 64 + threadIdx.x, ai = blockIdx.y;
+  if (j >= count) return;
+  const int p = list[j];
+  if (ai == 0) omap_new[j] = omap_old ? omap_old[p] : p;
+  if (r.kind[ai] == 0) {
+    const int L = r.L[ai];
+    const double* s = (const double*)r.src[ai] + ((size_t)(p >> 6) * (size_t)L) * 64 + (p & 63);
+    double* d = (double*)r.dst[ai] + ((size_t)(j >> 6) * (size_t)L) * 64 + (j & 63);
+#pragma unroll 8
+    for (int e = 0; e < L; ++e) d[(size_t)e * 64] = s[(size_t)e * 64];
+  } else if (r.kind[ai] == 1) ((double*)r.dst[ai])[j] = ((const double*)r.src[ai])[p];
+  else ((int*)r.dst[ai])[j] = ((const int*)r.src[ai])[p];
+}
+// working position j -> home position omap[j], for the trajectories that are finished (all != 0: every position).  src = working, dst = home
+__global__ void __launch_bounds__(64) k_repack_home(RpArgs r, const int* __restrict__ active, int count, const int* __restrict__ omap, int all) {
+  const int j = blockIdx.x * 64 + threadIdx.x, ai = blockIdx.y;
+  if (j >= count) return;
+  if (!all && active[j] != 0) return;
+  const int q = omap[j];
+  if (r.kind[ai] == 0) {
+    const int L = r.L[ai];
+    const double* s = (const double*)r.src[ai] + ((size_t)(j >> 6) * (size_t)L) * 64 + (j & 63);
+    double* d = (double*)r.dst[ai] + ((size_t)(q >> 6) * (size_t)L) * 64 + (q & 63);
+#pragma unroll 8
+    for (int e = 0; e < L; ++e) d[(size_t)e * 64] = s[(size_t)e * 64];
+  } else if (r.kind[ai] == 1) ((double*)r.dst[ai])[q] = ((const double*)r.src[ai])[j];
+  else ((int*)r.dst[ai])[q] = ((const int*)r.src[ai])[j];
+}
+// the active list of the step after a move: everybody, in place
+__global__ void k_repack_list(int* __restrict__ list, int* __restrict__ acount, int count) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) list[j] = j;
+  if (j == 0) acount[0] = count;
+}
+
 // The two compaction launches for an arbitrary flag array: flags[0 .. n) -> out (ascending index), *outcount; the flags are cleared on the
 // way (each is read by exactly one thread of each launch).  Used by the two-launch line search (KArgs::pending -> plist, pcount).
 __global__ void __launch_bounds__(1024) k_flags_count(const int* __restrict__ flags, int n, int per, int* __restrict__ ccount) {

@@ -247,9 +247,97 @@ int fill_stats(to_handle* h, to_solve_stats* st, bool with_defect) {
   return TO_OK;
 }
 
+// ---- repacked working set (k_generic.h k_repack_*) ------------------------------------------------------------------------
+void*& rp_field(to_handle* h, size_t off) { return *reinterpret_cast<void**>(reinterpret_cast<char*>(&h->a) + off); }
+int rp_setup(to_handle* h) {
+  if (!h->rp_arr.empty()) return TO_OK;
+  KArgs& a = h->a;
+  const DevProblem& P = a.P;
+  auto add = [&](void* field_addr, int kind, int L) {
+    h->rp_arr.push_back({(size_t)(reinterpret_cast<char*>(field_addr) - reinterpret_cast<char*>(&a)), kind, L});
+  };
+  add(&a.Xs, 0, P.N * P.n); add(&a.Us, 0, (P.N - 1) * P.m); add(&a.x0, 0, P.n);
+  if (a.P.gl) add(&a.P.gl, 0, P.n_costs * (P.n + P.m));
+  for (double** f : {&a.J, &a.dJ, &a.grad, &a.rho, &a.drho, &a.cmax}) add(f, 1, 1);
+  for (int** f : {&a.status, &a.iterations, &a.it_inner, &a.outer, &a.dJzero, &a.ls_index, &a.active, &a.budget, &a.bpfail, &a.acc, &a.accp}) add(f, 2, 1);
+  if ((int)h->rp_arr.size() > RP_MAX) return fail(TO_ERR_UNSUPPORTED, "repack table too long");
+  return TO_OK;
+}
+size_t rp_bytes(const to_handle::RpArr& r, int Bp) { return r.kind == 0 ? sizeof(double) * (size_t)r.L * Bp : (r.kind == 1 ? sizeof(double) : sizeof(int)) * (size_t)Bp; }
+// move the `count` active trajectories (list of the NEXT step, built by k_compact) into the other working set and go on there
+int rp_move(to_handle* h, int count) {
+  KArgs& a = h->a;
+  TRY(rp_setup(h));
+  const int lvl = h->rp_level, w = lvl & 1;          // target working set: 0, 1, 0, ...
+  const int Bp_new = (count + 63) / 64 * 64;
+  if (lvl == 0) {
+    h->rp_home.clear();
+    for (const auto& r : h->rp_arr) h->rp_home.push_back(rp_field(h, r.off));
+    h->rp_B = a.P.B; h->rp_Bp = a.P.Bp;
+  }
+  if (h->rp_cap[w] < Bp_new || h->rp_work[w].size() != h->rp_arr.size()) {  // (sized once per handle: the first move of a solve is the largest for this working set)
+    for (void* q : h->rp_work[w]) if (q) HIPCHECK(hipFree(q));
+    h->rp_work[w].assign(h->rp_arr.size(), nullptr);
+    if (h->rp_map[w]) HIPCHECK(hipFree(h->rp_map[w]));
+    // (+ one spare tile, like the home arrays: k_accept_roll's lanes without an accepted step store into the tile behind the batch)
+    for (size_t i = 0; i < h->rp_arr.size(); ++i) HIPCHECK(hipMalloc(&h->rp_work[w][i], rp_bytes(h->rp_arr[i], Bp_new + 64)));
+    HIPCHECK(hipMalloc((void**)&h->rp_map[w], sizeof(int) * Bp_new));
+    h->rp_cap[w] = Bp_new;
+  }
+  RpArgs mv, hm;
+  mv.n = hm.n = (int)h->rp_arr.size();
+  for (int i = 0; i < mv.n; ++i) {
+    mv.kind[i] = hm.kind[i] = h->rp_arr[i].kind; mv.L[i] = hm.L[i] = h->rp_arr[i].L;
+    mv.src[i] = rp_field(h, h->rp_arr[i].off); mv.dst[i] = h->rp_work[w][i];
+    hm.src[i] = rp_field(h, h->rp_arr[i].off); hm.dst[i] = h->rp_home[i];
+    HIPCHECK(hipMemsetAsync(h->rp_work[w][i], 0, rp_bytes(h->rp_arr[i], Bp_new), h->stream));  // the padding lanes hold valid (zero) data, active = 0
+  }
+  const int* omap_old = lvl == 0 ? nullptr : h->rp_map[(lvl - 1) & 1];
+  const int next = (a.step + 1) & 1;
+  const int* list = a.alist + (size_t)next * a.P.Bp;
+  const bool dbg = std::getenv("TRAJOPT_SYNC_DEBUG") != nullptr;
+  auto dbg_sync = [&](const char* what) {
+    if (!dbg) return;
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    std::fprintf(stderr, "[sync-debug] rp_move level %d -> %d count %d (B %d Bp %d, cap %d / %d) after %s: %s\n", lvl, lvl + 1, count, a.P.B, a.P.Bp, h->rp_cap[0], h->rp_cap[1], what, hipGetErrorString(e));
+  };
+  dbg_sync("memsets");
+  if (lvl > 0)  // what has finished in the set we leave goes home first (level 0 IS home)
+    hipLaunchKernelGGL(k_repack_home, dim3((a.P.B + 63) / 64, hm.n), dim3(64), 0, h->stream, hm, a.active, a.P.B, omap_old, 0);
+  dbg_sync("k_repack_home");
+  hipLaunchKernelGGL(k_repack_move, dim3((count + 63) / 64, mv.n), dim3(64), 0, h->stream, mv, list, count, omap_old, h->rp_map[w]);
+  HIPCHECK(hipGetLastError());
+  dbg_sync("k_repack_move");
+  for (int i = 0; i < mv.n; ++i) rp_field(h, h->rp_arr[i].off) = h->rp_work[w][i];
+  a.P.B = count; a.P.Bp = Bp_new;
+  hipLaunchKernelGGL(k_repack_list, dim3((count + 255) / 256), dim3(256), 0, h->stream, a.alist + (size_t)next * a.P.Bp, a.acount + next, count);
+  HIPCHECK(hipGetLastError());
+  h->rp_level = lvl + 1;
+  return TO_OK;
+}
+// end of a solve: everything in the working set goes home; the handle works on its home arrays again
+int rp_finish(to_handle* h, bool copy) {
+  if (h->rp_level == 0) return TO_OK;
+  KArgs& a = h->a;
+  const int w = (h->rp_level - 1) & 1;
+  int rc = TO_OK;
+  if (copy) {
+    RpArgs hm;
+    hm.n = (int)h->rp_arr.size();
+    for (int i = 0; i < hm.n; ++i) { hm.kind[i] = h->rp_arr[i].kind; hm.L[i] = h->rp_arr[i].L; hm.src[i] = rp_field(h, h->rp_arr[i].off); hm.dst[i] = h->rp_home[i]; }
+    hipLaunchKernelGGL(k_repack_home, dim3((a.P.B + 63) / 64, hm.n), dim3(64), 0, h->stream, hm, a.active, a.P.B, h->rp_map[w], 1);
+    if (hipGetLastError() != hipSuccess) rc = fail(TO_ERR_HIP, "k_repack_home launch failed");
+  }
+  for (size_t i = 0; i < h->rp_arr.size(); ++i) rp_field(h, h->rp_arr[i].off) = h->rp_home[i];
+  a.P.B = h->rp_B; a.P.Bp = h->rp_Bp;
+  h->rp_level = 0;
+  return rc;
+}
+
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   const int rc = solve_impl(h, st, al_mode);
+  rp_finish(h, false);   // (an error path may leave the handle on a working set: back to the home arrays, without the copy)
   h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
   h->a.compact = 0;  // ... nor take its trajectories from a solve's active list
   h->a.CW = h->cw_base; h->a.TW = h->tw_base;
@@ -421,6 +509,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   const DevProblem& P = a.P;
   a.al_mode = al_mode;
   a.control = 1;
+  h->rp_arr.clear();  // the table of carried arrays is rebuilt per solve (per-trajectory cost terms may have appeared)
   a.compact = h->compact;
   const int max_steps = (al_mode ? P.opts.iterations_total : P.opts.iterations) + 1;
   if (h->counter_len < max_steps) {
@@ -453,6 +542,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   const hipEvent_t cev[2] = {h->sev[2], h->sev[3]};
   int launched = 0, checked = 0, nchunks = 0, last_active = P.B;
   bool done = false;
+  const bool dbg_sync = std::getenv("TRAJOPT_SYNC_DEBUG") != nullptr;
   auto enqueue_chunk = [&]() -> int {
     const int chunk = std::min(CHECK_EVERY, max_steps - launched);
     for (int c = 0; c < chunk; ++c) {
@@ -528,6 +618,11 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
         HIPCHECK(hipGetLastError());
       }
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
+      if (dbg_sync) {  // TRAJOPT_SYNC_DEBUG=1: localise a device fault to a batch step
+        const hipError_t e = hipStreamSynchronize(h->stream);
+        std::fprintf(stderr, "[sync-debug] step %d B=%d Bp=%d level=%d store_x-path=%d: %s\n", step, a.P.B, a.P.Bp, h->rp_level, (int)(last_active), hipGetErrorString(e));
+        if (e != hipSuccess) return fail(TO_ERR_HIP, "device fault (sync debug)");
+      }
     }
     HIPCHECK(hipMemcpyAsync(&h->counter_host[launched], &a.counter[launched], sizeof(int) * chunk, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipEventRecord(cev[nchunks & 1], h->stream));
@@ -541,8 +636,25 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   if (const char* env = std::getenv("TRAJOPT_PN_EARLY_AT")) early_div = std::max(1, std::atoi(env));
   int early_thr = (al_mode && h->pn_early > 0) ? P.B / early_div : -1, early_left = h->pn_early;
   bool snapshot_pending = false;
+  // repacked working set (above): iLQR solves of the small models on the fused lane path with compaction
+  bool repack = !al_mode && h->fused_lane && a.compact && h->ops->write_through && h->rp_min > 0;
   if (max_steps > 0) TRY(enqueue_chunk());
   while (!done && waited < nchunks) {
+    if (repack && last_active >= 1 && (double)last_active <= h->rp_at * (double)a.P.B && a.P.B >= h->rp_min) {
+      // the exact count is needed on the host (B of every later launch): drain the queue once — a handful of times per solve
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      for (; checked < launched; ++checked) {
+        ++steps;
+        last_active = h->counter_host[checked];
+        if (last_active == 0) { done = true; break; }
+      }
+      waited = nchunks;
+      if (done) break;
+      a.step = launched - 1;   // (k_compact of that step built the list the move reads)
+      TRY(rp_move(h, last_active));
+      if (launched < max_steps) TRY(enqueue_chunk());
+      continue;
+    }
     if (launched < max_steps) TRY(enqueue_chunk());  // keep the queue one chunk ahead
     if (snapshot_pending) {  // taken before that chunk: the device keeps working while the host lists and launches
       TRY(early_polish_launch(h));
@@ -565,6 +677,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   }
   TRY(launch_accept(h));  // trajectories keep the slot of their last accepted step until here
   a.CW = h->cw_base; a.TW = h->tw_base;
+  TRY(rp_finish(h, true));  // a repacked working set goes home
   HIPCHECK(hipEventRecord(e1, h->stream));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -817,6 +930,8 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   h->roll_min_active = -1;
   if (const char* env = std::getenv("TRAJOPT_ACCEPT_ROLL_MIN")) h->roll_min_active = std::atoi(env);
   if (const char* env = std::getenv("TRAJOPT_ACCEPT_ROLL_FRAC")) h->roll_min_frac = std::atof(env);
+  if (const char* env = std::getenv("TRAJOPT_REPACK")) h->rp_min = std::atoi(env);  // 0: never; n: while the working set holds >= n trajectories
+  if (const char* env = std::getenv("TRAJOPT_REPACK_AT")) h->rp_at = std::min(0.95, std::max(0.05, std::atof(env)));
   h->fwd2 = 2;  // 0: one-wave forward pass only; 1: two-wave always (phase API included); 2: per batch step, by the active count
   if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env);
   if (h->fwd2 < 0 || h->fwd2 > 2) h->fwd2 = 2;
@@ -949,6 +1064,7 @@ int to_destroy(to_handle* h) {
   if (h->snap_cmax) hipHostFree(h->snap_cmax);
   for (hipEvent_t e : h->pn_ev) if (e) hipEventDestroy(e);
   if (h->pn_stream) hipStreamDestroy(h->pn_stream);
+  for (int w = 0; w < 2; ++w) { for (void* q : h->rp_work[w]) if (q) hipFree(q); if (h->rp_map[w]) hipFree(h->rp_map[w]); }
   if (h->counter_host) hipHostFree(h->counter_host);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   for (hipEvent_t e : h->sev) if (e) hipEventDestroy(e);
