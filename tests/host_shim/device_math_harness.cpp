@@ -70,6 +70,38 @@ void run(const char* name, const double* P) {
   printf("%s dual_vs_fd %.3e mdual_vs_dual %.3e left_inverse %.3e hess_sym %.3e\n", name, worst_fd, worst_md, worst_inv, worst_sym);
 }
 
+// cartpole_rk4_jac (the chain rule over hand-derived stage partials, models.h) against the chunk-mode dual-number RK4 Jacobian and
+// against central differences — small angles, large angles (the full sin / cos path of the later stages) and fast rotation
+static void cartpole_stage_jac(const double* P) {
+  double worst_dual = 0, worst_fd = 0, scale = 0;
+  for (int trial = 0; trial < 200; ++trial) {
+    double x[4], u[1], Mk[20];
+    const double amp = trial < 100 ? 0.4 : 6.0, wamp = trial % 3 == 0 ? 25.0 : 3.0;
+    x[0] = amp * rnd(); x[1] = amp * rnd(); x[2] = 3.0 * rnd(); x[3] = wamp * rnd(); u[0] = 4.0 * rnd();
+    const double h = trial % 2 ? 0.05 : 0.02;
+    cartpole_rk4_jac(P, x, u, h, Mk);
+    MDual<5> xm[4], um[1], xn[4];
+    for (int i = 0; i < 4; ++i) { xm[i].v = x[i]; xm[i].d[i] = 1.0; }
+    um[0].v = u[0]; um[0].d[4] = 1.0;
+    rk_step<CartpoleModel, MDual<5>, INTEG_RK4>(P, INTEG_RK4, xm, um, h, xn);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 5; ++j) {
+        worst_dual = std::fmax(worst_dual, std::fabs(Mk[i * 5 + j] - xn[i].d[j]));
+        scale = std::fmax(scale, std::fabs(xn[i].d[j]));
+      }
+    for (int j = 0; j < 5; ++j) {
+      double xp[4], xq[4], up[1] = {u[0]}, uq[1] = {u[0]}, fp[4], fq[4];
+      const double e = 1e-6;
+      for (int i = 0; i < 4; ++i) { xp[i] = x[i] + (i == j ? e : 0); xq[i] = x[i] - (i == j ? e : 0); }
+      if (j == 4) { up[0] += e; uq[0] -= e; }
+      rk_step<CartpoleModel, double, INTEG_RK4>(P, INTEG_RK4, xp, up, h, fp);
+      rk_step<CartpoleModel, double, INTEG_RK4>(P, INTEG_RK4, xq, uq, h, fq);
+      for (int i = 0; i < 4; ++i) worst_fd = std::fmax(worst_fd, std::fabs((fp[i] - fq[i]) / (2 * e) - Mk[i * 5 + j]));
+    }
+  }
+  printf("cartpole_stage_jac vs_dual %.3e vs_fd %.3e scale %.3e\n", worst_dual, worst_fd, scale);
+}
+
 int main() {
   srand(7);
   const double Pq[16] = {0.5, 0.0023, 0.0023, 0.004, 0, 0, -9.81, 0.175, 1.0, 0.0245, 0};
@@ -80,5 +112,6 @@ int main() {
   run<QuadrotorAttModel<ATT_RP>>("rp", Pq);
   run<CartpoleModel>("cartpole", Pc);
   run<DoubleIntegratorModel<2>>("di2", Pd);
+  cartpole_stage_jac(Pc);
   return 0;
 }

@@ -63,3 +63,13 @@ def test_device_dual_numbers(name, harness):
     assert s["mdual_vs_dual"] == 0.0       # chunk mode: every derivative component goes through the same operations
     assert s["left_inverse"] < 1e-14       # E(x) G(x) = I for quaternions (G'G = I) and for three-parameter attitudes (D^-1 D = I)
     assert s["hess_sym"] < 1e-15
+
+
+def test_cartpole_stage_jacobian_by_hand(harness):
+    """cartpole_rk4_jac — the RK4 Jacobian of the Cartpole by the chain rule over hand-derived stage partials, what the lane expansion of
+    large batches runs instead of chunk-mode dual numbers — is the same derivative of the same RK4 map: equal to the dual-number Jacobian
+    to rounding (200 states: small and large angles, fast rotation, two step sizes) and to central differences."""
+    _, summary = harness
+    s = summary["cartpole_stage_jac"]
+    assert s["vs_dual"] < 2e-14 * max(1.0, s["scale"])
+    assert s["vs_fd"] < 2e-7

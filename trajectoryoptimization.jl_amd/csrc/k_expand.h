@@ -342,6 +342,9 @@ __device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int l
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
   const DevProblem& P = a.P;
   const bool terminal = (k == P.N - 1);
+  if constexpr (has_stage_jac<M>::value && FIXED_INTEG == INTEG_RK4) {
+    if (!terminal) cartpole_rk4_jac(P.mp, x, u, P.dt[k], Mk);  // chain rule over hand-derived stage partials (models.h)
+  } else
   if (!terminal) {  // every column of [A B] in one pass
     MDual<nc> xd[n], ud[m], xn[n];
 #pragma unroll
@@ -361,6 +364,30 @@ __device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int l
   for (int i = 0; i < m; ++i) z[n + i] = u[i];
   const double* lam0 = a.lam + ((size_t)tile * (size_t)P.n_duals) * 64 + lane;
   const double* mu0 = a.mu + ((size_t)tile * (size_t)P.n_cons) * 64 + lane;
+  if constexpr (VAR == 0) {
+    // Plain DiagonalCost without constraints (C2 and the large-batch sweep): the block is diag(Q, R) and the gradient Q x + q, R u + r —
+    // ONE batch of scalar descriptor loads per knot.  The general loop below asks cost_grad_hvp for one column at a time, and each
+    // call re-reads the descriptor (five groups of scalar loads with a wait each per Cartpole knot: ~6 % of a knot at one wave per SIMD).
+    // Same products and sums as the general path computes for unit vectors (its multiplications by 0 and 1 are exact).
+    CostC& C = P.costs[P.cost_index[k]];
+    if (C.kind == TO_COST_DIAGONAL) {
+      const double sc = (P.opts.cost_dt_scaling && !terminal) ? P.dt[k] : 1.0;
+      double gr[nz];
+#pragma unroll
+      for (int i = 0; i < n; ++i) gr[i] = C.Q[i] * x[i] + C.q[i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) gr[n + i] = terminal ? 0.0 : C.R[i] * u[i] + C.r[i];
+      if (P.gl) goal_lin_grad<n, m>(P.gl + ((size_t)tile * (size_t)(P.n_costs * nz)) * 64 + lane, P.cost_index[k], terminal, gr);
+#pragma unroll
+      for (int j = 0; j < nc; ++j) {
+#pragma unroll
+        for (int i = 0; i <= j; ++i) H[j * (j + 1) / 2 + i] = 0.0;
+        H[j * (j + 1) / 2 + j] = (j < ne) ? C.Q[j] * sc : (terminal ? 0.0 : C.R[j - ne] * sc);
+        g[j] = gr[j < ne ? j : n + (j - ne)] * sc;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < nc; ++j) {
     double v[nz], gr[nz], y[nz];

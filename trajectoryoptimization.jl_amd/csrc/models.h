@@ -250,6 +250,9 @@ struct CartpoleModel {  // docs/src/model.md:34-50
   static constexpr bool mfma_backward = true, coop_backward = true;  // MFMA and cooperative backward passes stay built for A/B runs (TRAJOPT_BACKWARD)
   static constexpr bool lane_backward = true;  // default: one lane per trajectory
   static constexpr int trig_index = 1;  // the state entry whose sine / cosine the dynamics need (rk_step carries them from stage to stage)
+#ifndef TO_NO_STAGE_JAC  // (A/B builds: -DTO_NO_STAGE_JAC keeps the dual-number expansion everywhere)
+  static constexpr bool stage_jac = true;  // cartpole_rk4_jac: the RK4 Jacobian by the chain rule over hand-derived stage partials (lane expansion)
+#endif
   template <class T>
   __device__ __forceinline__ static void f(const double* P, const T* x, const T* u, T* xd) {
     T s, c;
@@ -541,6 +544,101 @@ __device__ __forceinline__ void rk_step(const double* P, int integrator_rt, cons
   M::f(P, xt, u, k);
 #pragma unroll
   for (int i = 0; i < n; ++i) { k[i] = k[i] * h; xn[i] = x[i] + (acc[i] + k[i]) * (1.0 / 6.0); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage Jacobians by hand where a model provides them (has_stage_jac): the RK4 Jacobian [A B] of the Cartpole by the chain rule
+// through the four stages, for the one-lane-per-trajectory expansion of large batches (k_expand.h expand_lane_knot).  Chunk-mode
+// dual numbers push 5 derivative components through EVERY operation of a stage (sin, cos, the 2 x 2 solve: ~700 FP64 instructions per
+// knot even with their structural zeros folded); here the accelerations' partials with respect to the three inputs they depend on
+// (theta, thetadot, u) are formed once per stage (~30 operations) and applied to the incoming 4 x 4 sensitivity block:
+//   k_i = h f(xt_i, u),  D_i = dk_i/dz = h [ Y_i[pdot,:]; Y_i[thetadot,:]; a_theta Y_i[theta,:] + a_omega Y_i[thetadot,:] + a_u e_u ],
+//   Y_1 = E (the inputs themselves), Y_2 = E + D_1/2, Y_3 = E + D_2/2, Y_4 = E + D_3,   d x+/dz = E + (D_1 + 2 D_2 + 2 D_3 + D_4)/6
+// with z = (theta, pdot, thetadot, u); nothing depends on the cart position p: d x+/dp = e_p exactly.  The same exact derivative of the same
+// RK4 map as the dual numbers give (tests/test_device_math_on_host.py: both against each other to rounding and against central
+// differences); every other kernel keeps the dual-number path, so the two still check each other on the GPU.
+template <class M, class = void>
+struct has_stage_jac : std::false_type {};
+template <class M>
+struct has_stage_jac<M, decltype((void)M::stage_jac)> : std::true_type {};
+
+// Cartpole accelerations a = (pddot, thetaddot) at (theta with sin s / cos c, thetadot w, u) and their partials Ja[2][3] w.r.t. (theta, w, u)
+__device__ __forceinline__ void cartpole_accel_jac(const double* P, double s, double c, double w, double u, double* a, double (*Ja)[3]) {
+  const double mc = P[0], mp = P[1], l = P[2], g = P[3];
+  const double h11 = mc + mp, h22 = mp * l * l, mpl = mp * l;
+  const double h12 = mpl * c;
+  const double c12 = -(mpl * w) * s;
+  const double b1 = c12 * w - u, b2 = (mpl * g) * s;
+  const double d = h11 * h22 - h12 * h12;
+  const double rd = rcp_fast(d);
+  const double s1 = (h22 * b1 - h12 * b2) * rd, s2 = (h11 * b2 - h12 * b1) * rd;
+  a[0] = -s1; a[1] = -s2;
+  // d/dtheta
+  const double dh12 = -mpl * s, db1 = -(mpl * c) * (w * w), db2 = (mpl * g) * c;
+  const double dd = -2.0 * h12 * dh12;
+  const double dN1 = h22 * db1 - dh12 * b2 - h12 * db2, dN2 = h11 * db2 - dh12 * b1 - h12 * db1;
+  Ja[0][0] = -((dN1 - s1 * dd) * rd); Ja[1][0] = -((dN2 - s2 * dd) * rd);
+  // d/dthetadot: b1 = -mp l s w^2 - u
+  const double wb1 = 2.0 * c12;
+  Ja[0][1] = -(h22 * wb1 * rd); Ja[1][1] = (h12 * wb1) * rd;
+  // d/du: b1' = -1
+  Ja[0][2] = h22 * rd; Ja[1][2] = -(h12 * rd);
+}
+// Mk[i*5 + j] = d x+_i / d [p, theta, pdot, thetadot, u]_j of one RK4 step of the Cartpole
+__device__ __forceinline__ void cartpole_rk4_jac(const double* P, const double* x, const double* u, double h, double* Mk) {
+  double s1, c1;
+  sincos_fast(x[1], &s1, &c1);
+  // rows: p, theta, pdot, thetadot; columns: theta, pdot, thetadot, u
+  double Y[4][4], acc[4][4], kprev[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) { Y[r][cc] = (r >= 1 && cc == r - 1) ? 1.0 : 0.0; acc[r][cc] = 0.0; }
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const double cf = (st == 0) ? 0.0 : (st == 3 ? 1.0 : 0.5);   // xt = x + cf * k_prev
+    const double th = x[1] + cf * kprev[1], w = x[3] + cf * kprev[3];
+    double s = s1, c = c1;
+    if (st > 0) {
+      const double delta = cf * kprev[1];
+      double sd, cd;
+      sincos_small(delta, &sd, &cd);
+      s = s1 * cd + c1 * sd; c = c1 * cd - s1 * sd;
+      const bool big = !(fabs(delta) <= TRIG_SMALL_MAX);
+      if (any_lane(big)) {
+        double sf, cf2;
+        sincos_fast(th, &sf, &cf2);
+        s = big ? sf : s; c = big ? cf2 : c;
+      }
+    }
+    double a[2], Ja[2][3];
+    cartpole_accel_jac(P, s, c, w, u[0], a, Ja);
+    const double k[4] = {h * (x[2] + cf * kprev[2]), h * w, h * a[0], h * a[1]};
+    double D[4][4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      D[0][cc] = h * Y[2][cc];
+      D[1][cc] = h * Y[3][cc];
+      D[2][cc] = h * (Ja[0][0] * Y[1][cc] + Ja[0][1] * Y[3][cc] + (cc == 3 ? Ja[0][2] : 0.0));
+      D[3][cc] = h * (Ja[1][0] * Y[1][cc] + Ja[1][1] * Y[3][cc] + (cc == 3 ? Ja[1][2] : 0.0));
+    }
+    const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, nf = (st == 2) ? 1.0 : 0.5;   // weight in the sum; factor of the NEXT stage's point
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        acc[r][cc] += wgt * D[r][cc];
+        Y[r][cc] = ((r >= 1 && cc == r - 1) ? 1.0 : 0.0) + nf * D[r][cc];
+      }
+      kprev[r] = k[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Mk[r * 5 + 0] = (r == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) Mk[r * 5 + 1 + cc] = ((r >= 1 && cc == r - 1) ? 1.0 : 0.0) + acc[r][cc] * (1.0 / 6.0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
