@@ -327,7 +327,7 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     prob._call("solver_path", info)
     path = {"backward": ("coop", "mfma", "lane")[info[0]], "fused_expansion": bool(info[1]), "compaction": bool(info[2]),
             "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4]), "scan_backward": bool(info[5]),
-            "accept_by_rollout": bool(info[6]), "line_search_repack": bool(info[7])}
+            "accept_by_rollout": bool(info[6]), "line_search_repack": bool(info[7] & 1), "repacked_working_set": bool(info[7] & 2)}
     gather, gather_note = None, None
     if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
         from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
@@ -413,7 +413,7 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
     value = iters_all / dt_max
     res = {"value": value, "unit": "trajectory-iterations/s", "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * dt_max / steps,
-           "config": {"workload": W["desc"], "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
+           "config": {"workload": W["desc"].replace(f"batch={W['batch']} per GPU", f"batch={batch} per GPU"), "batch_per_gpu": batch, "knot_points": N, "n": n, "m": m,
                       "trajectory_iterations_per_step": iters_all / steps, "batch_steps_per_solve": bsteps / steps,
                       "converged_fraction": float(np.mean(status == T.capi.SOLVE_SUCCEEDED)), "solver_path": path,
                       "projected_newton": None if W["solver"] != "altro" else {

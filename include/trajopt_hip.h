@@ -432,8 +432,9 @@ int to_discrete_jacobian(to_handle* h, double* F);
  * 0 is then empty and slot 1 covers both); info[2]: 1 = active-list compaction; info[3]: step sizes tried concurrently in the
  * first line-search round; info[4]: waves per forward-pass workgroup (2: roller + accountant, k_forward2); info[5]: 1 = the backward pass runs as a scan over the
  * horizon (one wave per trajectory, k_scan.h); info[6]: 1 = batch steps that fill the chip store only the controls of the line-search
- * candidates and roll the accepted ones out again (bit-identical states; k_accept_roll); info[7]: 1 = the last line-search round
- * is repacked (the trajectories of a wave that are still searching share all its lanes; bit-identical). */
+ * candidates and roll the accepted ones out again (bit-identical states; k_accept_roll); info[7]: bit 0 = the last line-search round
+ * is repacked (the trajectories of a wave that are still searching share all its lanes; bit-identical), bit 1 = iLQR solves move
+ * the trajectories still iterating into a dense working set as the batch converges (k_repack_*; bit-identical). */
 int to_solver_path(const to_handle* h, int32_t* info /* [8] */);
 /* Live state / control dimensions per knot, nx[N], nu[N] (RD.dims(models), src/dynamics.jl:15-31: the terminal knot carries the
  * last model's control dimension).  (n, m) on every knot unless the model is a hybrid model vector. */

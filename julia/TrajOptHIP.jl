@@ -691,7 +691,7 @@ function solver_path(p::BatchProblem)
     info = zeros(Int32, 8)
     check(ccall((:to_solver_path, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), p.handle, info))
     (backward = (:coop, :mfma, :lane)[info[1] + 1], fused_expansion = info[2] != 0, compaction = info[3] != 0, first_round = Int(info[4]),
-     forward_waves = Int(info[5]), scan_backward = info[6] != 0, accept_by_rollout = info[7] != 0, line_search_repack = info[8] != 0)
+     forward_waves = Int(info[5]), scan_backward = info[6] != 0, accept_by_rollout = info[7] != 0, line_search_repack = (info[8] & 1) != 0, repacked_working_set = (info[8] & 2) != 0)
 end
 
 """

@@ -117,15 +117,15 @@ struct PnLds {
 };
 template <class M>
 PN_HD long long pn_lds_doubles(int NB) {
-  constexpr int ne = M::ne, nc = M::ne + M::m;
-  return 3LL * NB * NB + (long long)ne * NB + ne * nc + 2LL * (NB - ne) * nc + 2 * nc + 2 * NB + 64;
+  constexpr int ne = M::ne, nc = M::ne + M::m, ncp = nc | 1;  // rows of F and C at an odd stride: lanes on different rows, different banks
+  return 3LL * NB * NB + (long long)ne * NB + ne * ncp + 2LL * (NB - ne) * ncp + 2 * nc + 2 * NB + 64;
 }
 template <class M>
 PN_FN PnLds pn_lds(double* p, int NB) {
-  constexpr int ne = M::ne, nc = M::ne + M::m;
+  constexpr int ne = M::ne, nc = M::ne + M::m, ncp = nc | 1;
   PnLds l; l.NB = NB;
-  l.LA = p; p += NB * NB; l.LB = p; p += NB * NB; l.LW = p; p += NB * NB; l.Lo = p; p += ne * NB; l.F = p; p += ne * nc;
-  l.Ca = p; p += (NB - ne) * nc; l.Cb = p; p += (NB - ne) * nc; l.Wa = p; p += nc; l.Wb = p; p += nc;
+  l.LA = p; p += NB * NB; l.LB = p; p += NB * NB; l.LW = p; p += NB * NB; l.Lo = p; p += ne * NB; l.F = p; p += ne * ncp;
+  l.Ca = p; p += (NB - ne) * ncp; l.Cb = p; p += (NB - ne) * ncp; l.Wa = p; p += nc; l.Wb = p; p += nc;
   l.va = p; p += NB; l.vb = p; p += NB; l.red = p;
   return l;
 }
@@ -201,6 +201,57 @@ PN_FN void pn_defect(const DevProblem& P, int k, const double* zprev, const doub
 #else
 #define PN_LANE_PARAM , int lane
 #define PN_LANE_ARG , lane
+#endif
+
+// -DTO_PN_TIMING (a diagnostic build of ops_pn.hip, never the product): the first workgroup of a k_pn_project launch prints where
+// its trajectory's time went, in microseconds of the 100 MHz wall clock.
+#if defined(TO_PN_TIMING) && !defined(TO_PN_HOST)
+__device__ long long pn_tacc[8];
+#define PN_TIC() const long long pn_tic_ = wall_clock64()
+#define PN_TOC(slot) do { if (blockIdx.x == 0 && lane == 0) pn_tacc[slot] += wall_clock64() - pn_tic_; } while (0)
+#define PN_MARK_DECL() long long pn_mark_ = wall_clock64()
+#define PN_MARK(slot) do { const long long t_ = wall_clock64(); if (blockIdx.x == 0 && lane == 0) pn_tacc[slot] += t_ - pn_mark_; pn_mark_ = t_; } while (0)
+#else
+#define PN_MARK_DECL() do { } while (0)
+#define PN_MARK(slot) do { } while (0)
+#define PN_TIC() do { } while (0)
+#define PN_TOC(slot) do { } while (0)
+#endif
+
+// ---- staged sweeps.  A phase that reads knot k's blocks straight from the workspace pays one memory round trip per knot of a
+// sweep that is nothing but a chain of such phases (~10 ms per trajectory and round on C5).  Blocks of up to 64 * PN_PF entries
+// (nbmax <= 21: every BASELINE problem) instead travel  workspace -> registers -> LDS  one knot AHEAD: the loads of knot k+1 are
+// issued before knot k is computed out of LDS, raw (record layout, sized by the host's candidate counts, so that nothing about the
+// active set has to be known to issue them), and the sweep's own stores are never waited for inside the sweep (PN_SYNC_LDS).
+// TO_PN_HOST runs the same index arithmetic with the "registers" being a plain array.
+#ifndef TO_PN_PF
+#define TO_PN_PF 7   // 0: no staging (diagnostic builds)
+#endif
+constexpr int PN_PF = TO_PN_PF, PN_PF_REGS = TO_PN_PF > 0 ? TO_PN_PF : 1;
+#ifdef TO_PN_HOST
+struct PnStage { double r[64 * PN_PF_REGS]; };
+PN_FN void pn_fetch(PnStage& s, const double* src, int cnt) { for (int e = 0; e < cnt; ++e) s.r[e] = src[e]; }
+PN_FN void pn_put(double* dst, const PnStage& s, int cnt) { for (int e = 0; e < cnt; ++e) dst[e] = s.r[e]; }
+PN_FN void pn_put_rows(double* dst, const PnStage& s, int cnt, int nc, int ncp) { for (int e = 0; e < cnt; ++e) dst[(e / nc) * ncp + e % nc] = s.r[e]; }
+PN_FN unsigned long long pn_uniform(unsigned long long v) { return v; }
+#else
+struct PnStage { double r[PN_PF_REGS]; };
+PN_FN void pn_fetch(PnStage& s, const double* src, int cnt, int lane) {
+#pragma unroll
+  for (int j = 0; j < PN_PF; ++j) if (j * 64 < cnt) { const int e = j * 64 + lane; s.r[j] = src[e < cnt ? e : cnt - 1]; }
+}
+PN_FN void pn_put(double* dst, const PnStage& s, int cnt, int lane) {
+#pragma unroll
+  for (int j = 0; j < PN_PF; ++j) if (j * 64 < cnt) { const int e = j * 64 + lane; dst[e < cnt ? e : cnt - 1] = s.r[j]; }
+}
+PN_FN void pn_put_rows(double* dst, const PnStage& s, int cnt, int nc, int ncp, int lane) {  // rows of nc entries land at stride ncp
+#pragma unroll
+  for (int j = 0; j < PN_PF; ++j) if (j * 64 < cnt) { int e = j * 64 + lane; e = e < cnt ? e : cnt - 1; dst[(e / nc) * ncp + e % nc] = s.r[j]; }
+}
+PN_FN unsigned long long pn_uniform(unsigned long long v) {  // every lane loaded the same word: make the compiler know it
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 #endif
 
 // max over the knots of loc[0] (NaN-aware): wave-uniform result
@@ -335,6 +386,54 @@ PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
 }
 #endif
 
+// e / d for 0 <= e < 4096, 2 <= d <= 64 by one multiplication: r = ceil(2^20 / d), e / d = (e r) >> 20  (the error e (r - 2^20 / d) < 4096
+// stays below 2^20 / d)
+PN_FN unsigned pn_recip(int d) { return ((1u << 20) + (unsigned)d - 1u) / (unsigned)d; }
+PN_FN int pn_div(int e, unsigned r) { return (int)(((unsigned)e * r) >> 20); }
+
+#ifndef TO_PN_HOST
+// Cholesky factor of an nb x nb block (nb <= PN_NBR; lower triangle in Lc, row stride NB) and the inverse of the factor into Mc, in
+// REGISTERS: lane i owns row i of L, then column i of L^-1; what the other lanes need of a row travels by v_readlane (the row
+// index is the loop counter: uniform).  The generic path below does the same arithmetic in the same order (column after column,
+// the terms of every entry in ascending order) through ~45 LDS phases per block — a third of a projection's time on C5.
+constexpr int PN_NBR = 21;
+PN_FN double pn_bcast(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+PN_FN bool pn_chol_inv_regs(const double* Lc, double* Mc, int nb, int NB, int lane) {
+  const int i = lane < nb ? lane : nb - 1;  // (a lane beyond the block repeats its last row / column)
+  double a[PN_NBR], x[PN_NBR];
+#pragma unroll
+  for (int t = 0; t < PN_NBR; ++t) {
+    const double val = Lc[i * NB + (t < nb ? t : 0)];
+    a[t] = (t <= i && t < nb) ? val : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < PN_NBR; ++j) {
+    if (j < nb) {
+      double v = a[j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) v -= a[t] * pn_bcast(a[t], j);
+      const double pj = pn_bcast(v, j);
+      if (!(pj > 0.0)) return false;
+      const double lj = sqrt(pj);
+      a[j] = (i == j) ? lj : (i > j ? v / lj : 0.0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < PN_NBR; ++r) {
+    if (r < nb) {
+      double v = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int t = 0; t < r; ++t) v -= pn_bcast(a[t], r) * x[t];
+      x[r] = (r < i) ? 0.0 : v / pn_bcast(a[r], r);
+      Mc[r * NB + i] = x[r];
+    }
+  }
+  return true;
+}
+#endif
+
 // Block-tridiagonal Cholesky factor of S + rho I, S = D W D': L_k,k-1 = S_k,k-1 L_k-1^-T, L_k = chol(S_kk + rho I - L_k,k-1 L_k,k-1').
 // What the records keep is what the SOLVES need — they run several times per factorisation and walk the horizon knot after
 // knot, so a knot must cost them one phase, not one per column: the INVERSE of every diagonal factor block,
@@ -344,48 +443,79 @@ PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
 // far inside what reg_solve's refinement corrects.)  false: a pivot was not positive.
 template <class M>
 PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_LANE_PARAM) {
-  constexpr int ne = M::ne, nc = M::ne + M::m;
+  constexpr int ne = M::ne, nc = M::ne + M::m, ncp = nc | 1;
   const int N = q.a.P.N, NB = L.NB;
   double *Mc = L.LA, *Mp = L.LB, *Lc = L.LW, *Cc = L.Ca, *Cp = L.Cb, *Wc = L.Wa, *Wp = L.Wb;
+  // The knot's Jacobian rows and metric come one knot ahead through registers when they fit (see PnStage), and no phase inside the
+  // sweep waits for the sweep's own stores (Pb, Mi, Nf are read by the solves, behind the barrier at the end).
+  const bool staged = ne * nc <= 64 * PN_PF && (NB - ne) * nc <= 64 * PN_PF;
+  PnStage sF, sC, sW;
+  unsigned long long rmask = 0;
+  if (staged) {
+    const PnRec<M> R = pn_rec<M>(q, w, 0);
+    pn_fetch(sC, R.C, (R.nbm - ne) * nc PN_LANE_ARG);
+    pn_fetch(sW, R.W, nc PN_LANE_ARG);
+    rmask = *R.mask;
+  }
   int nbp = 0;
+  PN_MARK_DECL();
   for (int k = 0; k < N; ++k) {
     const PnRec<M> R = pn_rec<M>(q, w, k);
-    const int pa = pn_popc(*R.mask), nb = ne + pa;
-    PN_FOR(e, ne * nc) L.F[e] = (k > 0) ? R.F[e] : 0.0;
-    PN_FOR(e, pa * nc) Cc[e] = R.C[e];
-    PN_FOR(e, nc) Wc[e] = R.W[e];
-    PN_SYNC();
+    int pa;
+    if (staged) {
+      pa = pn_popc(pn_uniform(rmask));
+      if (k > 0) pn_put_rows(L.F, sF, ne * nc, nc, ncp PN_LANE_ARG);
+      else PN_FOR(e, ne * ncp) L.F[e] = 0.0;
+      pn_put_rows(Cc, sC, (R.nbm - ne) * nc, nc, ncp PN_LANE_ARG);
+      pn_put(Wc, sW, nc PN_LANE_ARG);
+      if (k + 1 < N) {
+        const PnRec<M> Rn = pn_rec<M>(q, w, k + 1);
+        pn_fetch(sF, Rn.F, ne * nc PN_LANE_ARG);
+        pn_fetch(sC, Rn.C, (Rn.nbm - ne) * nc PN_LANE_ARG);
+        pn_fetch(sW, Rn.W, nc PN_LANE_ARG);
+        rmask = *Rn.mask;
+      }
+    } else {
+      pa = pn_popc(*R.mask);
+      PN_FOR(e, ne * nc) L.F[(e / nc) * ncp + e % nc] = (k > 0) ? R.F[e] : 0.0;
+      PN_FOR(e, pa * nc) Cc[(e / nc) * ncp + e % nc] = R.C[e];
+      PN_FOR(e, nc) Wc[e] = R.W[e];
+    }
+    const int nb = ne + pa;
+    const unsigned rnb = pn_recip(nb), rnbp = pn_recip(nbp > 0 ? nbp : 1);  // e / nb, e / nbp without the integer-division sequence
+    PN_SYNC_LDS();
+    PN_MARK(5);
     const double sg = (k == 0) ? 1.0 : -1.0, sgp = (k == 1) ? 1.0 : -1.0;  // coefficient of dx_k in its own arriving-defect row
     PN_FOR(e, nb * nb) {
-      const int i = e / nb, j = e % nb;
+      const int i = pn_div(e, rnb), j = e - i * nb;
       if (j <= i) {
         double v = 0.0;
         if (i < ne) {
-          if (k > 0) for (int c = 0; c < nc; ++c) v += L.F[i * nc + c] * Wp[c] * L.F[j * nc + c];
+          if (k > 0) for (int c = 0; c < nc; ++c) v += L.F[i * ncp + c] * Wp[c] * L.F[j * ncp + c];
           if (i == j) v += Wc[i];
-        } else if (j < ne) v = sg * Wc[j] * Cc[(i - ne) * nc + j];
-        else for (int c = 0; c < nc; ++c) v += Cc[(i - ne) * nc + c] * Wc[c] * Cc[(j - ne) * nc + c];
+        } else if (j < ne) v = sg * Wc[j] * Cc[(i - ne) * ncp + j];
+        else for (int c = 0; c < nc; ++c) v += Cc[(i - ne) * ncp + c] * Wc[c] * Cc[(j - ne) * ncp + c];
         Lc[i * NB + j] = v + (i == j ? rho : 0.0);
       }
     }
     if (k > 0) {  // S_k,k-1 (its ne defect rows) into R.Nf's place-holder in LDS: Mc is free until the inverse is formed
       PN_FOR(e, ne * nbp) {
-        const int i = e / nbp, j = e % nbp;
+        const int i = pn_div(e, rnbp), j = e - i * nbp;
         double v = 0.0;
-        if (j < ne) v = sgp * L.F[i * nc + j] * Wp[j];
-        else for (int c = 0; c < nc; ++c) v += L.F[i * nc + c] * Wp[c] * Cp[(j - ne) * nc + c];
+        if (j < ne) v = sgp * L.F[i * ncp + j] * Wp[j];
+        else for (int c = 0; c < nc; ++c) v += L.F[i * ncp + c] * Wp[c] * Cp[(j - ne) * ncp + c];
         Mc[i * NB + j] = v;
       }
     }
-    PN_SYNC();
+    PN_SYNC_LDS();
     if (k > 0) {
       PN_FOR(e, ne * nbp) {  // L_k,k-1 = S_k,k-1 Mi_k-1'  (Mi lower triangular: column j of Mi' is row j of Mi, entries t <= j)
-        const int i = e / nbp, j = e % nbp;
+        const int i = pn_div(e, rnbp), j = e - i * nbp;
         double v = 0.0;
         for (int t = 0; t <= j; ++t) v += Mc[i * NB + t] * Mp[j * NB + t];
         L.Lo[i * NB + j] = v;
       }
-      PN_SYNC();
+      PN_SYNC_LDS();
       PN_FOR(e, ne * ne) {
         const int i = e / ne, j = e % ne;
         if (j <= i) { double v = 0.0; for (int t = 0; t < nbp; ++t) v += L.Lo[i * NB + t] * L.Lo[j * NB + t]; Lc[i * NB + j] -= v; }
@@ -396,42 +526,127 @@ PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_L
         for (int t = j; t < nbp; ++t) v += Mp[t * NB + j] * L.Lo[i * NB + t];
         R.Pb[e] = v;
       }
-      PN_SYNC();
+      PN_SYNC_LDS();
     }
-    for (int j = 0; j < nb; ++j) {  // right-looking Cholesky of the block
-      const double pj = Lc[j * NB + j];
-      if (!(pj > 0.0)) return false;
-      const double lj = sqrt(pj);
-      PN_FOR(i, nb - j) { const int ii = j + i; Lc[ii * NB + j] = (i == 0) ? lj : Lc[ii * NB + j] / lj; }
-      PN_SYNC();
-      const int cnt = nb - j - 1;
-      PN_FOR(e, cnt * cnt) {
-        const int i = j + 1 + e / cnt, c = j + 1 + e % cnt;
-        if (c <= i) Lc[i * NB + c] -= Lc[i * NB + j] * Lc[c * NB + j];
+    PN_MARK(6);
+#ifndef TO_PN_HOST
+    if (NB <= PN_NBR) {
+      if (!pn_chol_inv_regs(Lc, Mc, nb, NB, lane)) return false;
+    } else
+#endif
+    {
+      for (int j = 0; j < nb; ++j) {  // right-looking Cholesky of the block
+        const double pj = Lc[j * NB + j];
+        if (!(pj > 0.0)) return false;
+        const double lj = sqrt(pj);
+        PN_FOR(i, nb - j) { const int ii = j + i; Lc[ii * NB + j] = (i == 0) ? lj : Lc[ii * NB + j] / lj; }
+        PN_SYNC_LDS();
+        const int cnt = nb - j - 1;
+        PN_FOR(e, cnt * cnt) {
+          const int i = j + 1 + e / cnt, c = j + 1 + e % cnt;
+          if (c <= i) Lc[i * NB + c] -= Lc[i * NB + j] * Lc[c * NB + j];
+        }
+        PN_SYNC_LDS();
       }
-      PN_SYNC();
-    }
-    PN_FOR(j, nb) {  // Mi_k = L_k^-1, one column per lane (forward substitution on e_j)
-      for (int i = 0; i < nb; ++i) {
-        double v = (i == j) ? 1.0 : 0.0;
-        for (int t = j; t < i; ++t) v -= Lc[i * NB + t] * Mc[t * NB + j];
-        Mc[i * NB + j] = (i < j) ? 0.0 : v / Lc[i * NB + i];
+      PN_FOR(j, nb) {  // Mi_k = L_k^-1, one column per lane (forward substitution on e_j)
+        for (int i = 0; i < nb; ++i) {
+          double v = (i == j) ? 1.0 : 0.0;
+          for (int t = j; t < i; ++t) v -= Lc[i * NB + t] * Mc[t * NB + j];
+          Mc[i * NB + j] = (i < j) ? 0.0 : v / Lc[i * NB + i];
+        }
       }
     }
-    PN_SYNC();
-    PN_FOR(e, nb * nb) R.Mi[e] = Mc[(e / nb) * NB + e % nb];
+    PN_SYNC_LDS();
+    PN_MARK(7);
+    PN_FOR(e, nb * nb) { const int i = pn_div(e, rnb); R.Mi[e] = Mc[i * NB + (e - i * nb)]; }
     if (k > 0) PN_FOR(e, nb * nbp) {  // Nf_k = Mi_k[:, 0:ne] L_k,k-1
-      const int i = e / nbp, j = e % nbp;
+      const int i = pn_div(e, rnbp), j = e - i * nbp;
       double v = 0.0;
       for (int t = 0; t < ne && t <= i; ++t) v += Mc[i * NB + t] * L.Lo[t * NB + j];
       R.Nf[e] = v;
     }
-    PN_SYNC();
+    PN_SYNC_LDS();
+    PN_MARK(5);
     double* t;
     t = Mc; Mc = Mp; Mp = t; t = Cc; Cc = Cp; Cp = t; t = Wc; Wc = Wp; Wp = t;
     nbp = nb;
   }
+  PN_SYNC();
   return true;
+}
+
+// The sweeps of pn_chol_solve (below) with the blocks staged one knot ahead (see PnStage); same arithmetic in the same order
+template <class M>
+PN_FN void pn_chol_solve_staged(const PnArgs& q, double* w, const PnLds& L, int which PN_LANE_PARAM) {
+  constexpr int ne = M::ne;
+  const int N = q.a.P.N;
+  double *yc = L.va, *yp = L.vb, *bM = L.LA, *bN = L.LB, *bv = L.LW;
+  PnStage sM, sN, sv;
+  unsigned long long rmask;
+  {
+    const PnRec<M> R = pn_rec<M>(q, w, 0);
+    pn_fetch(sM, R.Mi, R.nbm * R.nbm PN_LANE_ARG);
+    pn_fetch(sv, R.v(which), R.nbm PN_LANE_ARG);
+    rmask = *R.mask;
+  }
+  int nbp = 0, nbpm = 0;
+  for (int k = 0; k < N; ++k) {  // forward: y_k = Mi_k b_k - Nf_k y_k-1
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const int nbm = R.nbm, nb = ne + pn_popc(pn_uniform(rmask));
+    pn_put(bM, sM, nbm * nbm PN_LANE_ARG);
+    pn_put(bN, sN, nbm * nbpm PN_LANE_ARG);
+    pn_put(bv, sv, nbm PN_LANE_ARG);
+    if (k + 1 < N) {
+      const PnRec<M> Rn = pn_rec<M>(q, w, k + 1);
+      pn_fetch(sM, Rn.Mi, Rn.nbm * Rn.nbm PN_LANE_ARG);
+      pn_fetch(sN, Rn.Nf, Rn.nbm * nbm PN_LANE_ARG);
+      pn_fetch(sv, Rn.v(which), Rn.nbm PN_LANE_ARG);
+      rmask = *Rn.mask;
+    }
+    PN_SYNC_LDS();
+    double* v = R.v(which);
+    PN_FOR(i, nb) {
+      double s = 0.0;
+      for (int t = 0; t <= i; ++t) s += bM[i * nb + t] * bv[t];
+      if (k > 0) for (int t = 0; t < nbp; ++t) s -= bN[i * nbp + t] * yp[t];
+      yc[i] = s;
+      v[i] = s;
+    }
+    double* t = yc; yc = yp; yp = t;
+    nbp = nb; nbpm = nbm;
+  }
+  PN_SYNC();
+  {
+    const PnRec<M> R = pn_rec<M>(q, w, N - 1);
+    pn_fetch(sM, R.Mi, R.nbm * R.nbm PN_LANE_ARG);
+    pn_fetch(sv, R.v(which), R.nbm PN_LANE_ARG);
+    rmask = *R.mask;
+  }
+  for (int k = N - 1; k >= 0; --k) {  // backward: x_k = Mi_k' y_k - Pb_k+1 x_k+1[0:ne]
+    const PnRec<M> R = pn_rec<M>(q, w, k);
+    const int nbm = R.nbm, nb = ne + pn_popc(pn_uniform(rmask));
+    pn_put(bM, sM, nbm * nbm PN_LANE_ARG);
+    if (k < N - 1) pn_put(bN, sN, nbm * ne PN_LANE_ARG);
+    pn_put(bv, sv, nbm PN_LANE_ARG);
+    if (k > 0) {
+      const PnRec<M> Rn = pn_rec<M>(q, w, k - 1);
+      pn_fetch(sM, Rn.Mi, Rn.nbm * Rn.nbm PN_LANE_ARG);
+      pn_fetch(sN, R.Pb, Rn.nbm * ne PN_LANE_ARG);  // Pb_k couples knot k-1 to this one
+      pn_fetch(sv, Rn.v(which), Rn.nbm PN_LANE_ARG);
+      rmask = *Rn.mask;
+    }
+    PN_SYNC_LDS();
+    double* v = R.v(which);
+    PN_FOR(i, nb) {
+      double s = 0.0;
+      for (int t = i; t < nb; ++t) s += bM[t * nb + i] * bv[t];
+      if (k < N - 1) for (int t = 0; t < ne; ++t) s -= bN[i * ne + t] * yp[t];
+      yc[i] = s;
+      v[i] = s;
+    }
+    double* t = yc; yc = yp; yp = t;
+  }
+  PN_SYNC();
 }
 
 // (L L') x = b in place on vector `which` of the records: one phase per knot and direction (see pn_factor); inside a sweep only the
@@ -440,6 +655,7 @@ template <class M>
 PN_FN void pn_chol_solve(const PnArgs& q, double* w, const PnLds& L, int which PN_LANE_PARAM) {
   constexpr int ne = M::ne;
   const int N = q.a.P.N;
+  if (L.NB * L.NB <= 64 * PN_PF) { pn_chol_solve_staged<M>(q, w, L, which PN_LANE_ARG); return; }
   double *yc = L.va, *yp = L.vb;
   int nbp = 0;
   for (int k = 0; k < N; ++k) {  // forward: y_k = Mi_k b_k - Nf_k y_k-1
@@ -542,13 +758,14 @@ PN_FN void pn_reg_solve(const PnArgs& q, double* w, const PnLds& L PN_LANE_PARAM
   const int N = q.a.P.N, NB = L.NB;
   PN_FOR(it, N * NB) { const int k = it / NB, i = it % NB; const PnRec<M> R = pn_rec<M>(q, w, k); if (i < R.nbm) R.v(PN_VDL)[i] = R.v(PN_VD)[i]; }
   PN_SYNC();
-  pn_chol_solve<M>(q, w, L, PN_VDL PN_LANE_ARG);
+  { PN_TIC(); pn_chol_solve<M>(q, w, L, PN_VDL PN_LANE_ARG); PN_TOC(1); }
   for (int it = 0;; ++it) {
-    pn_step<M>(q, w, PN_VDL PN_LANE_ARG);
+    { PN_TIC(); pn_step<M>(q, w, PN_VDL PN_LANE_ARG); PN_TOC(3); }
     if (it >= PN_REG_SOLVE_ITERS) break;
-    const double nr = pn_residual<M>(q, w, L, PN_VD, PN_VR PN_LANE_ARG);
+    double nr;
+    { PN_TIC(); nr = pn_residual<M>(q, w, L, PN_VD, PN_VR PN_LANE_ARG); PN_TOC(4); }
     if (nr < PN_REG_SOLVE_TOL) break;
-    pn_chol_solve<M>(q, w, L, PN_VR PN_LANE_ARG);
+    { PN_TIC(); pn_chol_solve<M>(q, w, L, PN_VR PN_LANE_ARG); PN_TOC(1); }
     PN_FOR(e, N * NB) { const int k = e / NB, i = e % NB; const PnRec<M> R = pn_rec<M>(q, w, k); if (i < ne + pn_popc(*R.mask)) R.v(PN_VDL)[i] += R.v(PN_VR)[i]; }
     PN_SYNC();
   }
@@ -631,7 +848,13 @@ PN_FN void pn_project(const PnArgs& q, int b, double* w, double* lds_mem PN_LANE
   const double viol = w[PN_H_VIOL];
   PN_SYNC();  // every lane has read the header before lane 0 rewrites it
   PN_FOR(j, 1) w[PN_H_STEPS] += 1.0;
-  if (!pn_factor<M>(q, w, L, o.rho_chol PN_LANE_ARG)) {
+#if defined(TO_PN_TIMING) && !defined(TO_PN_HOST)
+  const long long pn_t_all = wall_clock64();
+  if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 8; ++i) pn_tacc[i] = 0;
+#endif
+  bool factored;
+  { PN_TIC(); factored = pn_factor<M>(q, w, L, o.rho_chol PN_LANE_ARG); PN_TOC(0); }
+  if (!factored) {
     PN_FOR(j, 1) w[PN_H_FAILED] = 1.0;
     PN_SYNC();
     return;
@@ -650,7 +873,7 @@ PN_FN void pn_project(const PnArgs& q, int b, double* w, double* lds_mem PN_LANE
         for (int j = 0; j < m; ++j) R.Zb[n + j] = (k < N - 1) ? R.Z[n + j] + alpha * R.dZ[ne + j] : 0.0;
       }
       PN_SYNC();
-      v = pn_eval<M>(q, w, L, x0, true, false, PN_VDN PN_LANE_ARG);
+      { PN_TIC(); v = pn_eval<M>(q, w, L, x0, true, false, PN_VDN PN_LANE_ARG); PN_TOC(2); }
       if (v < viol_prev) { accepted = true; break; }
       alpha *= 0.5;
     }
@@ -664,6 +887,12 @@ PN_FN void pn_project(const PnArgs& q, int b, double* w, double* lds_mem PN_LANE
     if (before < 1.0) { if (log10(v) / log10(before) < o.r_threshold) break; }
     else if (!(v < 0.5 * before)) break;
   }
+#if defined(TO_PN_TIMING) && !defined(TO_PN_HOST)
+  if (blockIdx.x == 0 && lane == 0)
+    printf("pn_project us: all %.1f factor %.1f (stage+store %.1f, products %.1f, chol+inverse %.1f) chol_solve %.1f eval %.1f step %.1f residual %.1f\n",
+           0.01 * (wall_clock64() - pn_t_all), 0.01 * pn_tacc[0], 0.01 * pn_tacc[5], 0.01 * pn_tacc[6], 0.01 * pn_tacc[7], 0.01 * pn_tacc[1], 0.01 * pn_tacc[2],
+           0.01 * pn_tacc[3], 0.01 * pn_tacc[4]);
+#endif
 }
 
 #ifndef TO_PN_HOST

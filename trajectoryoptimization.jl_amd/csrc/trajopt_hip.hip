@@ -1093,6 +1093,7 @@ int to_solver_path(const to_handle* h, int32_t* info) {
   info[5] = (h->scan && fcoop && P.expand_variant == 0 && !a.bwd_mfma && !a.bwd_lane) ? 1 : 0;
   info[6] = (h->ops->accept_roll && h->roll_min_active != 0) ? 1 : 0;  // full-chip batch steps store candidate controls only (k_accept_roll)
   info[7] = a.repack_block0 != 0 ? 1 : 0;                               // repacked last line-search round
+  if (h->fused_lane && h->compact && h->ops->write_through && h->rp_min > 0 && P.B >= h->rp_min) info[7] |= 2;  // repacked working set (iLQR solves)
   return TO_OK;
 }
 int to_knot_dims(const to_handle* h, int32_t* nx, int32_t* nu) {
