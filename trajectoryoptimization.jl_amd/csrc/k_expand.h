@@ -468,6 +468,155 @@ __global__ void __launch_bounds__(64) k_expand_lane(KArgs a) {
   }
 }
 
+// One knot of the lane Riccati recursion — k_backward_lane's knot, verbatim — on operands in registers: [A B] of the knot (Mk), its cost
+// block and gradient in the lane layout (H, g), the cost-to-go (S, s: updated in place).  Stores the gains row at pKk if `live`.
+// false: Quu + rho I is not positive definite (nothing stored, S and s untouched).
+template <class M>
+__device__ __forceinline__ bool lane_riccati_knot(const double (&Mk)[M::ne][M::ne + M::m], const double* H, const double* g, double (&S)[M::ne][M::ne],
+                                                  double (&s)[M::ne], double rho, bool live, double* pKk, double& dV0, double& dV1) {
+  constexpr int m = M::m, ne = M::ne, nc = ne + m;
+  using L = LaneLay<M>;
+    double T[ne][nc];
+#pragma unroll
+    for (int i = 0; i < ne; ++i)
+#pragma unroll
+      for (int j = 0; j < nc; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += S[i][r] * Mk[r][j];
+        T[i][j] = t;
+      }
+    double Qxx[ne][ne], Qux[m][ne], Quu[m][m], gq[nc];
+#pragma unroll
+    for (int j = 0; j < ne; ++j) {
+#pragma unroll
+      for (int i = 0; i < nc; ++i) {
+        double t = H[L::sym(i, j)];
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += Mk[r][i] * T[r][j];
+        if (i < ne) Qxx[i][j] = t; else Qux[i - ne][j] = t;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < m; ++q)
+#pragma unroll
+      for (int p = 0; p < m; ++p) {
+        double t = H[L::sym(ne + p, ne + q)];
+#pragma unroll
+        for (int r = 0; r < ne; ++r) t += Mk[r][ne + p] * T[r][ne + q];
+        Quu[p][q] = t;
+      }
+#pragma unroll
+    for (int j = 0; j < nc; ++j) {
+      double t = g[j];
+#pragma unroll
+      for (int r = 0; r < ne; ++r) t += Mk[r][j] * s[r];
+      gq[j] = t;
+    }
+    double Lc[m][m], iL[m];
+    bool pd_ok = true;
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+#pragma unroll
+      for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
+#pragma unroll
+    for (int q = 0; q < m; ++q) {
+      double sj = Lc[q][q];
+#pragma unroll
+      for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
+      if (not_positive(sj) && live) pd_ok = false;
+      iL[q] = rsqrt_fast(sj);
+      Lc[q][q] = sj * iL[q];
+#pragma unroll
+      for (int i = q + 1; i < m; ++i) {
+        double t = Lc[i][q];
+#pragma unroll
+        for (int r = 0; r < q; ++r) t -= Lc[i][r] * Lc[q][r];
+        Lc[i][q] = t * iL[q];
+      }
+    }
+    if (!pd_ok) return false;
+    double Kg[m][ne], dk[m];
+#pragma unroll
+    for (int cc = 0; cc <= ne; ++cc) {
+      double col[m];
+#pragma unroll
+      for (int i = 0; i < m; ++i) col[i] = (cc < ne) ? Qux[i][cc < ne ? cc : 0] : gq[ne + i];
+#pragma unroll
+      for (int i = 0; i < m; ++i) { double t = col[i];
+#pragma unroll
+        for (int r = 0; r < i; ++r) t -= Lc[i][r] * col[r];
+        col[i] = t * iL[i]; }
+#pragma unroll
+      for (int i = m - 1; i >= 0; --i) { double t = col[i];
+#pragma unroll
+        for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
+        col[i] = t * iL[i]; }
+#pragma unroll
+      for (int i = 0; i < m; ++i) { if (cc < ne) Kg[i][cc < ne ? cc : 0] = -col[i]; else dk[i] = -col[i]; }
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < m; ++r) {
+#pragma unroll
+        for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
+        pKk[r * (ne + 1) + ne] = dk[r];
+      }
+    }
+    double W[m][ne], qd[m];
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+#pragma unroll
+      for (int j = 0; j < ne; ++j) {
+        double t = Qux[r][j];
+#pragma unroll
+        for (int q = 0; q < m; ++q) t += Quu[r][q] * Kg[q][j];
+        W[r][j] = t;
+      }
+      double t2 = gq[ne + r];
+#pragma unroll
+      for (int q = 0; q < m; ++q) t2 += Quu[r][q] * dk[q];
+      qd[r] = t2;
+    }
+    double Sn[ne][ne], sn[ne];
+#pragma unroll
+    for (int j = 0; j < ne; ++j) {
+#pragma unroll
+      for (int i = 0; i < ne; ++i) {
+        double t = Qxx[i][j];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Kg[r][i] * W[r][j];
+#pragma unroll
+        for (int r = 0; r < m; ++r) t += Qux[r][i] * Kg[r][j];
+        Sn[i][j] = t;
+      }
+      double t = gq[j];
+#pragma unroll
+      for (int r = 0; r < m; ++r) t += Kg[r][j] * qd[r];
+#pragma unroll
+      for (int r = 0; r < m; ++r) t += Qux[r][j] * dk[r];
+      sn[j] = t;
+    }
+    double dv1 = 0.0, dv2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+      dv1 += dk[r] * gq[ne + r];
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
+      dv2 += dk[r] * t;
+    }
+    dV0 += dv1;
+    dV1 += 0.5 * dv2;
+#pragma unroll
+    for (int i = 0; i < ne; ++i) {
+#pragma unroll
+      for (int j = 0; j < ne; ++j) S[i][j] = 0.5 * (Sn[i][j] + Sn[j][i]);
+      s[i] = sn[i];
+    }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ fused lane expansion + Riccati
 // Large batches of the small models are HBM-bound (measured at B = 32 768: 13.9 M trajectory-iterations/s whichever
 // expansion kernel, backward-pass flavour or line-search width runs — 0.85 ms per batch step for ~3 GB of traffic), and two
@@ -569,149 +718,10 @@ __global__ void __launch_bounds__(64, TO_FUSED_LANE_WAVES) k_expand_backward_lan
       for (int i = 0; i < ne; ++i)
 #pragma unroll
         for (int j = 0; j < nc; ++j) Mk[i][j] = Me[i * nc + j];
-      // ---- from here on: k_backward_lane's knot, verbatim
-      double T[ne][nc];
-#pragma unroll
-      for (int i = 0; i < ne; ++i)
-#pragma unroll
-        for (int j = 0; j < nc; ++j) {
-          double t = 0.0;
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += S[i][r] * Mk[r][j];
-          T[i][j] = t;
-        }
-      double Qxx[ne][ne], Qux[m][ne], Quu[m][m], gq[nc];
-#pragma unroll
-      for (int j = 0; j < ne; ++j) {
-#pragma unroll
-        for (int i = 0; i < nc; ++i) {
-          double t = H[L::sym(i, j)];
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += Mk[r][i] * T[r][j];
-          if (i < ne) Qxx[i][j] = t; else Qux[i - ne][j] = t;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < m; ++q)
-#pragma unroll
-        for (int p = 0; p < m; ++p) {
-          double t = H[L::sym(ne + p, ne + q)];
-#pragma unroll
-          for (int r = 0; r < ne; ++r) t += Mk[r][ne + p] * T[r][ne + q];
-          Quu[p][q] = t;
-        }
-#pragma unroll
-      for (int j = 0; j < nc; ++j) {
-        double t = g[j];
-#pragma unroll
-        for (int r = 0; r < ne; ++r) t += Mk[r][j] * s[r];
-        gq[j] = t;
-      }
-      double Lc[m][m], iL[m];
-      bool pd_ok = true;
-#pragma unroll
-      for (int r = 0; r < m; ++r)
-#pragma unroll
-        for (int q = 0; q < m; ++q) Lc[r][q] = Quu[r][q] + ((r == q) ? rho : 0.0);
-#pragma unroll
-      for (int q = 0; q < m; ++q) {
-        double sj = Lc[q][q];
-#pragma unroll
-        for (int r = 0; r < q; ++r) sj -= Lc[q][r] * Lc[q][r];
-        if (not_positive(sj) && live) pd_ok = false;
-        iL[q] = rsqrt_fast(sj);
-        Lc[q][q] = sj * iL[q];
-#pragma unroll
-        for (int i = q + 1; i < m; ++i) {
-          double t = Lc[i][q];
-#pragma unroll
-          for (int r = 0; r < q; ++r) t -= Lc[i][r] * Lc[q][r];
-          Lc[i][q] = t * iL[q];
-        }
-      }
-      if (!pd_ok) {
+      if (!lane_riccati_knot<M>(Mk, H, g, S, s, rho, live, pK + (size_t)k * RSK, dV0, dV1)) {
         reg_increase(P.opts, rho, drho);
         if (rho > P.opts.bp_reg_max) failed = true; else restart = true;
         break;
-      }
-      double Kg[m][ne], dk[m];
-#pragma unroll
-      for (int cc = 0; cc <= ne; ++cc) {
-        double col[m];
-#pragma unroll
-        for (int i = 0; i < m; ++i) col[i] = (cc < ne) ? Qux[i][cc < ne ? cc : 0] : gq[ne + i];
-#pragma unroll
-        for (int i = 0; i < m; ++i) { double t = col[i];
-#pragma unroll
-          for (int r = 0; r < i; ++r) t -= Lc[i][r] * col[r];
-          col[i] = t * iL[i]; }
-#pragma unroll
-        for (int i = m - 1; i >= 0; --i) { double t = col[i];
-#pragma unroll
-          for (int r = i + 1; r < m; ++r) t -= Lc[r][i] * col[r];
-          col[i] = t * iL[i]; }
-#pragma unroll
-        for (int i = 0; i < m; ++i) { if (cc < ne) Kg[i][cc < ne ? cc : 0] = -col[i]; else dk[i] = -col[i]; }
-      }
-      if (live) {
-        double* pKk = pK + (size_t)k * RSK;
-#pragma unroll
-        for (int r = 0; r < m; ++r) {
-#pragma unroll
-          for (int j = 0; j < ne; ++j) pKk[r * (ne + 1) + j] = Kg[r][j];
-          pKk[r * (ne + 1) + ne] = dk[r];
-        }
-      }
-      double W[m][ne], qd[m];
-#pragma unroll
-      for (int r = 0; r < m; ++r) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) {
-          double t = Qux[r][j];
-#pragma unroll
-          for (int q = 0; q < m; ++q) t += Quu[r][q] * Kg[q][j];
-          W[r][j] = t;
-        }
-        double t2 = gq[ne + r];
-#pragma unroll
-        for (int q = 0; q < m; ++q) t2 += Quu[r][q] * dk[q];
-        qd[r] = t2;
-      }
-      double Sn[ne][ne], sn[ne];
-#pragma unroll
-      for (int j = 0; j < ne; ++j) {
-#pragma unroll
-        for (int i = 0; i < ne; ++i) {
-          double t = Qxx[i][j];
-#pragma unroll
-          for (int r = 0; r < m; ++r) t += Kg[r][i] * W[r][j];
-#pragma unroll
-          for (int r = 0; r < m; ++r) t += Qux[r][i] * Kg[r][j];
-          Sn[i][j] = t;
-        }
-        double t = gq[j];
-#pragma unroll
-        for (int r = 0; r < m; ++r) t += Kg[r][j] * qd[r];
-#pragma unroll
-        for (int r = 0; r < m; ++r) t += Qux[r][j] * dk[r];
-        sn[j] = t;
-      }
-      double dv1 = 0.0, dv2 = 0.0;
-#pragma unroll
-      for (int r = 0; r < m; ++r) {
-        dv1 += dk[r] * gq[ne + r];
-        double t = 0.0;
-#pragma unroll
-        for (int q = 0; q < m; ++q) t += Quu[r][q] * dk[q];
-        dv2 += dk[r] * t;
-      }
-      dV0 += dv1;
-      dV1 += 0.5 * dv2;
-#pragma unroll
-      for (int i = 0; i < ne; ++i) {
-#pragma unroll
-        for (int j = 0; j < ne; ++j) S[i][j] = 0.5 * (Sn[i][j] + Sn[j][i]);
-        s[i] = sn[i];
       }
     }
     if (!restart) break;
