@@ -109,23 +109,24 @@ PN_FN PnRec<M> pn_rec(const PnArgs& q, double* w, int k) {
   return r;
 }
 
-// LDS of one wave (doubles): three diagonal blocks (inverse factors of the previous and the current knot, work), the coupling block, the knot's Jacobian rows and metric, two vectors, a
+// LDS of one wave (doubles): three diagonal blocks (inverse factors of the previous and the current knot, work), the coupling block, the knot's Jacobian rows and metric (and the rows times the metric), two vectors, a
 // 64-entry reduction buffer
 struct PnLds {
-  double *LA, *LB, *LW, *Lo, *F, *Ca, *Cb, *Wa, *Wb, *va, *vb, *red;
+  double *LA, *LB, *LW, *Lo, *F, *Ca, *Cb, *FW, *CW, *Wa, *Wb, *va, *vb, *red;
   int NB;
 };
 template <class M>
 PN_HD long long pn_lds_doubles(int NB) {
   constexpr int ne = M::ne, nc = M::ne + M::m, ncp = nc | 1;  // rows of F and C at an odd stride: lanes on different rows, different banks
-  return 3LL * NB * NB + (long long)ne * NB + ne * ncp + 2LL * (NB - ne) * ncp + 2 * nc + 2 * NB + 64;
+  return 3LL * NB * NB + (long long)ne * NB + 2 * ne * ncp + 3LL * (NB - ne) * ncp + 2 * nc + 2 * NB + 64;
 }
 template <class M>
 PN_FN PnLds pn_lds(double* p, int NB) {
   constexpr int ne = M::ne, nc = M::ne + M::m, ncp = nc | 1;
   PnLds l; l.NB = NB;
   l.LA = p; p += NB * NB; l.LB = p; p += NB * NB; l.LW = p; p += NB * NB; l.Lo = p; p += ne * NB; l.F = p; p += ne * ncp;
-  l.Ca = p; p += (NB - ne) * ncp; l.Cb = p; p += (NB - ne) * ncp; l.Wa = p; p += nc; l.Wb = p; p += nc;
+  l.Ca = p; p += (NB - ne) * ncp; l.Cb = p; p += (NB - ne) * ncp; l.FW = p; p += ne * ncp; l.CW = p; p += (NB - ne) * ncp;
+  l.Wa = p; p += nc; l.Wb = p; p += nc;
   l.va = p; p += NB; l.vb = p; p += NB; l.red = p;
   return l;
 }
@@ -390,6 +391,13 @@ PN_FN void pn_lin_knot(const PnArgs& q, double* w, int k) {
 // stays below 2^20 / d)
 PN_FN unsigned pn_recip(int d) { return ((1u << 20) + (unsigned)d - 1u) / (unsigned)d; }
 PN_FN int pn_div(int e, unsigned r) { return (int)(((unsigned)e * r) >> 20); }
+// entry e of a lower triangle stored row after row: row i = the largest i with i (i + 1) / 2 <= e  (e < 2^20: the float estimate is off by one at most)
+PN_FN int pn_tri_row(int e) {
+  int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+  if ((i + 1) * (i + 2) / 2 <= e) ++i;
+  if (i * (i + 1) / 2 > e) --i;
+  return i;
+}
 
 #ifndef TO_PN_HOST
 // Cholesky factor of an nb x nb block (nb <= PN_NBR; lower triangle in Lc, row stride NB) and the inverse of the factor into Mc, in
@@ -408,26 +416,23 @@ PN_FN bool pn_chol_inv_regs(const double* Lc, double* Mc, int nb, int NB, int la
     const double val = Lc[i * NB + (t < nb ? t : 0)];
     a[t] = (t <= i && t < nb) ? val : 0.0;
   }
+  // column j of L, then row j of L^-1 (it needs rows <= j of L only): two chains that do not depend on each other until the division by
+  // L_jj, in one block so that the scheduler can interleave the square root / division sequence of the one with the dot products of the other
 #pragma unroll
   for (int j = 0; j < PN_NBR; ++j) {
     if (j < nb) {
       double v = a[j];
 #pragma unroll
       for (int t = 0; t < j; ++t) v -= a[t] * pn_bcast(a[t], j);
+      double w = (j == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int t = 0; t < j; ++t) w -= pn_bcast(a[t], j) * x[t];
       const double pj = pn_bcast(v, j);
       if (!(pj > 0.0)) return false;
       const double lj = sqrt(pj);
       a[j] = (i == j) ? lj : (i > j ? v / lj : 0.0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < PN_NBR; ++r) {
-    if (r < nb) {
-      double v = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-      for (int t = 0; t < r; ++t) v -= pn_bcast(a[t], r) * x[t];
-      x[r] = (r < i) ? 0.0 : v / pn_bcast(a[r], r);
-      Mc[r * NB + i] = x[r];
+      x[j] = (j < i) ? 0.0 : w / lj;
+      Mc[j * NB + i] = x[j];
     }
   }
   return true;
@@ -486,25 +491,39 @@ PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_L
     PN_SYNC_LDS();
     PN_MARK(5);
     const double sg = (k == 0) ? 1.0 : -1.0, sgp = (k == 1) ? 1.0 : -1.0;  // coefficient of dx_k in its own arriving-defect row
-    PN_FOR(e, nb * nb) {
-      const int i = pn_div(e, rnb), j = e - i * nb;
-      if (j <= i) {
-        double v = 0.0;
-        if (i < ne) {
-          if (k > 0) for (int c = 0; c < nc; ++c) v += L.F[i * ncp + c] * Wp[c] * L.F[j * ncp + c];
-          if (i == j) v += Wc[i];
-        } else if (j < ne) v = sg * Wc[j] * Cc[(i - ne) * ncp + j];
-        else for (int c = 0; c < nc; ++c) v += Cc[(i - ne) * ncp + c] * Wc[c] * Cc[(j - ne) * ncp + c];
-        Lc[i * NB + j] = v + (i == j ? rho : 0.0);
-      }
+    // rows times the metric, once: every product below is (row entry * metric entry) * row entry, left to right — FW / CW hold the
+    // rounded first product, so the sums are those of the three-factor expression, with two LDS reads per term instead of three
+    const int pap = nbp - ne;  // active constraint rows of the previous knot
+    if (k > 0) PN_FOR(e, ne * nc) { const int i = e / nc, c = e % nc; L.FW[i * ncp + c] = L.F[i * ncp + c] * Wp[c]; }
+    PN_FOR(e, pa * nc) { const int i = e / nc, c = e % nc; L.CW[i * ncp + c] = Cc[i * ncp + c] * Wc[c]; }
+    PN_SYNC_LDS();
+    // S_kk (lower triangle) region by region, so that no pass mixes the 16-term sums with the one-term entries: defect x defect,
+    // constraint x defect, constraint x constraint
+    PN_FOR(e, ne * (ne + 1) / 2) {
+      const int i = pn_tri_row(e), j = e - i * (i + 1) / 2;
+      double v = 0.0;
+      if (k > 0) for (int c = 0; c < nc; ++c) v += L.FW[i * ncp + c] * L.F[j * ncp + c];
+      if (i == j) v += Wc[i];
+      Lc[i * NB + j] = v + (i == j ? rho : 0.0);
+    }
+    PN_FOR(e, pa * ne) {
+      const int i = e / ne, j = e % ne;
+      Lc[(ne + i) * NB + j] = sg * L.CW[i * ncp + j] + 0.0;
+    }
+    PN_FOR(e, pa * (pa + 1) / 2) {
+      const int i = pn_tri_row(e), j = e - i * (i + 1) / 2;
+      double v = 0.0;
+      for (int c = 0; c < nc; ++c) v += L.CW[i * ncp + c] * Cc[j * ncp + c];
+      Lc[(ne + i) * NB + ne + j] = v + (i == j ? rho : 0.0);
     }
     if (k > 0) {  // S_k,k-1 (its ne defect rows) into R.Nf's place-holder in LDS: Mc is free until the inverse is formed
-      PN_FOR(e, ne * nbp) {
-        const int i = pn_div(e, rnbp), j = e - i * nbp;
+      PN_FOR(e, ne * ne) { const int i = e / ne, j = e % ne; Mc[i * NB + j] = sgp * L.FW[i * ncp + j]; }
+      const unsigned rpap = pn_recip(pap > 0 ? pap : 1);
+      PN_FOR(e, ne * pap) {
+        const int i = pn_div(e, rpap), j = e - i * pap;
         double v = 0.0;
-        if (j < ne) v = sgp * L.F[i * ncp + j] * Wp[j];
-        else for (int c = 0; c < nc; ++c) v += L.F[i * ncp + c] * Wp[c] * Cp[(j - ne) * ncp + c];
-        Mc[i * NB + j] = v;
+        for (int c = 0; c < nc; ++c) v += L.FW[i * ncp + c] * Cp[j * ncp + c];
+        Mc[i * NB + ne + j] = v;
       }
     }
     PN_SYNC_LDS();
@@ -516,9 +535,11 @@ PN_FN bool pn_factor(const PnArgs& q, double* w, const PnLds& L, double rho PN_L
         L.Lo[i * NB + j] = v;
       }
       PN_SYNC_LDS();
-      PN_FOR(e, ne * ne) {
-        const int i = e / ne, j = e % ne;
-        if (j <= i) { double v = 0.0; for (int t = 0; t < nbp; ++t) v += L.Lo[i * NB + t] * L.Lo[j * NB + t]; Lc[i * NB + j] -= v; }
+      PN_FOR(e, ne * (ne + 1) / 2) {
+        const int i = pn_tri_row(e), j = e - i * (i + 1) / 2;
+        double v = 0.0;
+        for (int t = 0; t < nbp; ++t) v += L.Lo[i * NB + t] * L.Lo[j * NB + t];
+        Lc[i * NB + j] -= v;
       }
       PN_FOR(e, nbp * ne) {  // Pb_k = Mi_k-1' L_k,k-1'  (nbp x ne)
         const int j = e / ne, i = e % ne;
