@@ -120,3 +120,18 @@ extern "C" int pn_host_solve(const to_problem_desc* desc, const to_solver_opts* 
   }
   return TO_OK;
 }
+
+// The integer helpers of the factorisation (k_pn.h): pn_div against /, pn_tri_row against the definition, over their whole domains.
+// Returns 0, or the first failing case encoded as 1000000 * which + value.
+extern "C" int pn_host_index_selftest() {
+  for (int d = 2; d <= 64; ++d) {
+    const unsigned r = pn_recip(d);
+    for (int e = 0; e < 4096; ++e)
+      if (pn_div(e, r) != e / d) return 1000000 + e;
+  }
+  for (int e = 0; e < 4096; ++e) {
+    const int i = pn_tri_row(e);
+    if (!(i * (i + 1) / 2 <= e && e < (i + 1) * (i + 2) / 2)) return 2000000 + e;
+  }
+  return 0;
+}

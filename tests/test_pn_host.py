@@ -106,3 +106,11 @@ def test_kernel_on_host_unconstrained_and_minimal_horizon(pn_host, oracle):
         assert np.array_equal(sth, s.stats["status"]) and np.array_equal(iph, s.stats["iterations_pn"]) and np.all(iph >= 1)
         np.testing.assert_allclose(Xh, T.states(prob), rtol=0, atol=1e-10)
         np.testing.assert_allclose(Uh, T.controls(prob), rtol=0, atol=1e-10)
+
+
+def test_index_helpers_of_the_factorisation(pn_host):
+    """pn_div (e / d by one multiplication) and pn_tri_row (row of a packed lower triangle from a float square root) are exact over
+    the domains the factorisation uses them on: e < 4096, d = 2 … 64."""
+    pn_host.pn_host_index_selftest.restype = C.c_int
+    assert pn_host.pn_host_index_selftest() == 0
+
