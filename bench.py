@@ -45,9 +45,17 @@ WORKLOADS = {
                               "solved as the reference's stack solves constrained problems: ALTRO = AL-iLQR to 1e-3 + projected-Newton "
                               "polish to constraint_tolerance 1e-6 (n_steps = 8); N=201, batch=8192 per GPU; the metric counts the "
                               "inner iLQR iterations, the time includes the polish"),
+    "quadrotor_altro_defaults": dict(batch=8192, N=201, solver="altro", opts={"n_steps": 2, "rho_chol": 1e-2},
+                         desc="C5 as quadrotor_altro but with Altro's own polish defaults (n_steps = 2, rho_chol = 1e-2): the fidelity line next to "
+                              "the tuned one; N=201, batch=8192 per GPU"),
     "quadrotor_al": dict(batch=8192, N=201, solver="al",
                          desc="C5 without the polish (AL-iLQR run to 1e-6 on its own: the definition of the rounds-1..3 records under this key)"),
 }
+
+
+# pipelined solves: the next solve is admitted when the one in flight has this fraction of its batch still iterating (measured per
+# workload: tools/ab/ab_pipeline.py, profiles/r06_ab/)
+ADMIT_FRAC = {"quadrotor": 0.5, "quadrotor_altro": 0.5, "quadrotor_altro_defaults": 0.5, "quadrotor_al": 0.5}
 
 
 def make_solver(T, configs, name, prob):
@@ -61,7 +69,7 @@ def build_problem(T, configs, name, batch, b_offset, device, lib):
         return configs.cartpole_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
     if name == "quadrotor":
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib)
-    if name in ("quadrotor_altro", "quadrotor_al"):
+    if name in ("quadrotor_altro", "quadrotor_altro_defaults", "quadrotor_al"):
         return configs.quadrotor_problem(batch=batch, b_offset=b_offset, device=device, lib=lib, constrained=True,
                                          goal_inds=configs.C5_GOAL_INDS)
     raise ValueError(name)
@@ -147,23 +155,38 @@ def cgroup_cpu_quota():
 
 
 def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
-    """Oracle (port) on the host cores, bounded sample of the same workload.  One OpenMP thread per PHYSICAL core, pinned
-    (OMP_PLACES=cores, OMP_PROC_BIND=close: set in main() before the OpenMP runtime starts)."""
+    """Oracle (port) on the host cores, bounded sample of the same workload.  One OpenMP thread per core the container may
+    actually USE: min(physical cores, cgroup CPU quota) — a box can show 128 cores and grant 16, and 128 threads under a 16-core
+    quota are throttled by the scheduler.  The one-thread-per-physical-core figure is reported beside it
+    (`all_physical_cores`).  Threads pinned (OMP_PLACES=cores, OMP_PROC_BIND=close: set in main() before the OpenMP runtime starts)."""
     from oracle_binding import load_oracle_native, set_threads
     o, flags = load_oracle_native()
     phys, logical = HOST_CORES   # taken at start-up: OMP_PROC_BIND binds the main thread later, which shrinks its own affinity mask
-    threads = max(1, min(o.max_threads(), phys))
+    quota = cgroup_cpu_quota()
+    all_threads = max(1, min(o.max_threads(), phys))
+    threads = max(1, min(all_threads, int(quota + 0.5))) if quota else all_threads
     sample = min(batch, 1024 if name == "cartpole" else 256 if name == "quadrotor" else 128)
     Solver = lambda pr: make_solver(T, configs, name, pr)
     prob = build_problem(T, configs, name, sample, 0, 0, o)
-    set_threads(prob, threads)
     u0 = initial_controls_value(T, prob, name)
     solver = Solver(prob)
-    solver.solve()                            # warm call: OpenMP team start-up, page faults
-    T.initial_controls(prob, u0)
-    t0 = time.perf_counter()
-    solver.solve()
-    dt = time.perf_counter() - t0
+
+    def timed(nthreads):
+        set_threads(prob, nthreads)
+        T.initial_controls(prob, u0)
+        solver.solve()                            # warm call: OpenMP team start-up, page faults
+        T.initial_controls(prob, u0)
+        t0 = time.perf_counter()
+        solver.solve()
+        return time.perf_counter() - t0
+
+    dt = timed(threads)
+    its = solver.total_iterations
+    over = None
+    if all_threads != threads:
+        dt_all = timed(all_threads)
+        over = {"threads": all_threads, "value": solver.total_iterations / dt_all,
+                "note": "one thread per physical core the box SHOWS: oversubscribes the cgroup quota (the r01-r05 records used this)"}
     # one trajectory on one core: the figure comparable to published single-core solver timings (SURVEY.md §8d);
     # best of 5 after a warm call (a single cold sample was 10x off in round 1)
     p1 = build_problem(T, configs, name, 1, 0, 0, o)
@@ -178,13 +201,13 @@ def cpu_baseline(T, configs, name, batch, seconds_budget=20.0):
         d1 = min(d1, time.perf_counter() - t1)
     single = {"value": s1.total_iterations / d1, "cores": 1,
               "sample": f"trajectory 0 alone, {s1.total_iterations} iterations in {d1 * 1e3:.1f} ms (best of 5 after a warm call)"}
-    return {"value": solver.total_iterations / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "build": flags, "single_thread": single,
-            "physical_cores": phys, "logical_cpus": logical, "cgroup_cpu_quota_cores": cgroup_cpu_quota(), "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core",
-            "parallel_speedup_over_one_thread": (solver.total_iterations / dt) / single["value"],
-            "effective_cores": (min(float(threads), cgroup_cpu_quota()) if cgroup_cpu_quota() else float(threads)),
+    return {"value": its / dt, "unit": "trajectory-iterations/s", "cores": threads, "kind": "port", "build": flags, "single_thread": single,
+            "physical_cores": phys, "logical_cpus": logical, "cgroup_cpu_quota_cores": quota,
+            "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close, one thread per core of the cgroup quota",
+            "parallel_speedup_over_one_thread": (its / dt) / single["value"], "all_physical_cores": over,
             "sample": f"{WORKLOADS[name]['desc']}: first {sample} trajectories of the batch, 1 solve after a warm call, "
-                      f"{solver.total_iterations} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories; {threads} threads on {phys} physical cores, "
-                      f"cgroup CPU quota {cgroup_cpu_quota()} cores: the quota, not the thread count, is the denominator of this number)"}
+                      f"{its} iterations in {dt:.2f} s (oracle/, OpenMP over trajectories; {threads} threads = the cgroup CPU quota "
+                      f"({quota} cores) on a box showing {phys} physical cores)"}
 
 
 def c1_cpu_line(T, configs):
@@ -286,6 +309,34 @@ def overlap_run(T, configs, lib, name, batch, parts, device):
             "trajectory_iterations": best[1], "note": "best of 3; sub-batches solved concurrently through to_*_solve_async on separate streams"}
 
 
+def pipelined_run(T, configs, lib, name, batch, depth, steps, warmup, admit_frac, device, prob0, solver0, u0):
+    """`steps` solves of the workload's batch, pipelined over `depth` handles (to_solve_progress / to_solve_wait_below; api.SolvePipeline):
+    step i runs on handle i % depth — every handle holds the SAME batch, so every step is the unpipelined step, bit for bit — and is
+    admitted when the step in front has at most admit_frac * batch trajectories still iterating.  The drained tail of one solve (C3: 52 of
+    141 batch steps on a handful of stragglers, chip empty) runs under the dense first steps of the next.  Timed from the first submit to
+    the last wait: the ramp-up and the final, un-overlapped drain are inside the figure."""
+    probs = [prob0] + [build_problem(T, configs, name, batch, 0, device, lib) for _ in range(depth - 1)]
+    solvers = [solver0] + [make_solver(T, configs, name, p) for p in probs[1:]]
+    for s_ in solvers[1:]:
+        T.initial_controls(s_.prob, u0)
+        s_.solve()                       # warm every handle (allocations of the first solve: polish workspace, event pools)
+    prep = lambda p: T.initial_controls(p, u0)
+    best = None
+    for rep in range(1 + warmup):        # the warm-up repetitions run the same pipelined sequence
+        pipe = T.SolvePipeline(solvers, admit_below=int(admit_frac * batch))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit(prep)
+        pipe.drain()
+        dt = time.perf_counter() - t0
+        best = (dt, pipe.total_iterations, sum(r[2] for r in pipe.results))
+    dt, its, bsteps = best
+    return {"depth": depth, "admit_below": int(admit_frac * batch), "steps": steps, "value": its / dt, "ms_per_step": 1e3 * dt / steps,
+            "trajectory_iterations": its, "batch_steps_per_solve": bsteps / steps,
+            "note": "value = trajectory-iterations of `steps` solves / wall time from the first submit to the last wait (ramp-up and final drain included); "
+                    "every solve is the unpipelined solve bit for bit (tests/test_gpu_pipeline.py)"}
+
+
 class Watchdog:
     """A collective that never returns (a peer that died inside ncclCommInitRank, a rank that took another branch) must end as a
     LABELLED failure of this rank, not as the driver's wall-clock limit: `with Watchdog("what", seconds)` exits the process with code 3
@@ -315,8 +366,11 @@ class Watchdog:
         return False
 
 
-def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True):
-    """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings."""
+def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True, pipeline=0, pipeline_steps=0,
+                 admit_frac=0.5):
+    """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings.  pipeline = d > 1 (one
+    rank only): a third pass of `pipeline_steps` solves pipelined over d handles becomes the line's value; the unpipelined figure stays
+    beside it under "unpipelined"."""
     W = WORKLOADS[name]
     prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
     solver = make_solver(T, configs, name, prob)
@@ -424,6 +478,18 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
                                      "ranks the RCCL communicator saw: %d, shards %s" % (len(gather.counts), gather.counts))
                       if gather is not None and gather_note is None else (gather_note or "none")},
            "roofline": roofline_block(configs, name, batch, dims, iters_prof, value / world, kms, kln, lib.build_id(), path) if profile else None}
+    if pipeline > 1 and dist is None:
+        pr = pipelined_run(T, configs, lib, name, batch, pipeline, pipeline_steps or max(steps, 2 * pipeline), warmup, admit_frac, local_rank, prob, solver, u0)
+        res["unpipelined"] = {"value": res["value"], "ms_per_step": res["ms_per_step"], "steps": res["steps"]}
+        res["value"], res["ms_per_step"], res["steps"] = pr["value"], pr["ms_per_step"], pr["steps"]
+        res["config"]["workload"] += (f"; PIPELINED over {pipeline} handles: {pr['steps']} solves of the same batch, the next admitted when the one in flight "
+                                      f"has <= {pr['admit_below']} trajectories still iterating")
+        res["config"]["pipeline"] = pr
+        if res["roofline"] is not None:  # kernel timings: the unpipelined profiled pass; the whole-iteration figure: the pipelined value
+            wi = res["roofline"]["whole_iteration"]
+            wi["achieved"] = wi["algorithmic_bytes_per_unit"] * res["value"] / 1e9
+            wi["frac"] = wi["achieved"] / HBM_PEAK_GBS
+            wi["note"] = "from the pipelined value; the per-kernel figures above are the unpipelined profiled pass"
     return res, prob, u0
 
 
@@ -441,6 +507,12 @@ def main():
                     help="skip the batch sweep (2x ... 64x the probe batch) that locates the throughput plateau")
     ap.add_argument("--no-profile", action="store_true", help="skip the separate hipEvent-profiled pass (no roofline object)")
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
+    ap.add_argument("--pipeline", type=int, default=-1,
+                    help="pipeline the solves over this many handles (the next solve is admitted when the one in flight has drained below "
+                         "--admit of its batch); default: 2 for the Quadrotor workloads (the extra C3 / C5 lines included), 0 for the Cartpole "
+                         "headline (two host threads driving 100 us batch steps lose: DESIGN.md §4.10)")
+    ap.add_argument("--pipeline-steps", type=int, default=0, help="solves of the pipelined pass (default max(steps, 2 x depth))")
+    ap.add_argument("--admit", type=float, default=-1.0, help="admit the next solve at this fraction of the batch still iterating (default per workload)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="also solve the workload as this many sub-batches on as many handles / streams in flight at once (to_*_solve_async): "
                          "what overlapping the drained tails recovers; reported separately under \"overlap\", never the headline")
@@ -480,8 +552,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: libtrajopt_hip.so has no CPU fallback")
     name = args.workload
     batch = args.batch or WORKLOADS[name]["batch"]
+    depth = args.pipeline if args.pipeline >= 0 else (0 if name == "cartpole" else 2)
     res, prob, u0 = run_workload(T, configs, lib, name, batch, args.steps, args.warmup, rank, local_rank, world, dist, torch,
-                                 profile=not args.no_profile)
+                                 profile=not args.no_profile, pipeline=depth, pipeline_steps=args.pipeline_steps,
+                                 admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(name, 0.5))
 
     if rank == 0:
         out = {"metric": "iLQR iterations/sec (batched trajectories)", "value": res["value"], "unit": res["unit"],
@@ -538,12 +612,16 @@ def main():
     # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
     if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:
         extra = {}
-        for key, wname in (("C3", "quadrotor"), ("C5", "quadrotor_altro")):
+        for key, wname, pdepth, psteps in (("C3", "quadrotor", 2, 8), ("C5", "quadrotor_altro", 2, 6), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
             try:
+                if args.pipeline >= 0:
+                    pdepth = args.pipeline if pdepth else 0
                 r, p2, _ = run_workload(T, configs, lib, wname, WORKLOADS[wname]["batch"], 2, 1, 0, local_rank, 1, None, torch,
-                                        profile=not args.no_profile)
+                                        profile=(not args.no_profile) and key != "C5_altro_defaults",
+                                        pipeline=pdepth, pipeline_steps=psteps,
+                                        admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(wname, 0.5))
                 del p2
-                if not args.no_cpu_baseline:
+                if not args.no_cpu_baseline and key != "C5_altro_defaults":
                     r["cpu_baseline"] = cpu_baseline(T, configs, wname, WORKLOADS[wname]["batch"])
                 extra[key] = r
             except Exception as e:

@@ -53,8 +53,9 @@ extern "C" {
  * points to_pn_solve, to_altro_solve, to_dynamics_defect and the asynchronous to_*_solve_async / to_solve_wait; TO_MODEL_VECTOR with
  * to_problem_desc::step_models (general model vectors).  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
- * a descriptor stamped with another version. */
-#define TO_ABI_VERSION 5
+ * a descriptor stamped with another version.  5: TO_MODEL_INFEASIBLE, to_infeasible_controls, to_set_cost_linear_batch, to_get_cost_to_go.
+ * 6: to_solve_progress / to_solve_wait_below (pipelined solves over several handles). */
+#define TO_ABI_VERSION 6
 
 #define TO_MAX_N 16       /* max state dimension            */
 #define TO_MAX_M 8        /* max control dimension          */
@@ -396,6 +397,16 @@ int to_ilqr_solve_async(to_handle* h, to_solve_stats* stats);
 int to_al_solve_async(to_handle* h, to_solve_stats* stats);
 int to_altro_solve_async(to_handle* h, to_solve_stats* stats);
 int to_solve_wait(to_handle* h);
+/* Pipelined solves (round 6).  A solve is batch-synchronous and its batch drains unevenly: C3 spends 52 of its 141 batch steps on a
+ * handful of stragglers with the chip empty.  Trajectories are independent (one Z per problem, src/problem.jl:330-340: no cross
+ * terms), so a host that has MORE work — the next MPC batch, the next shard of a sweep — starts it on a second handle while the
+ * first drains; the two streams share the device.  to_solve_progress reports what the solve loop of the solve in flight last saw:
+ * *active = trajectories still iterating (B right after to_*_solve_async, 0 once the iLQR / AL stage has ended — a polish may still
+ * be running: to_solve_wait is the completion), *batch_steps = batch steps whose counters have been read, *in_flight = 1 until
+ * to_solve_wait has returned.  to_solve_wait_below blocks until *active <= active_max (at once when nothing is in flight).  Both may
+ * be called while a solve is in flight (they are the only ones besides the pure descriptor getters); any pointer may be NULL. */
+int to_solve_progress(to_handle* h, int32_t* active, int32_t* batch_steps, int32_t* in_flight);
+int to_solve_wait_below(to_handle* h, int32_t active_max);
 
 /* expansion / gain getters (parity + solver introspection); host layouts column-major:
  *   A[ne,ne,N-1,B]  Bm[ne,m,N-1,B]  Qxx[ne,ne,N,B] Quu[m,m,N,B] Qux[m,ne,N,B] qx[ne,N,B] qu[m,N,B]

@@ -20,7 +20,7 @@ const TO = TrajectoryOptimization
 const lib = get(ENV, "TRAJOPT_HIP_LIBRARY", "libtrajopt_hip")   # trajectoryoptimization.jl_amd/csrc/libtrajopt_hip.so
 
 # ------------------------------------------------------------------------------------------------ header mirrors
-const TO_ABI_VERSION = Int32(5)
+const TO_ABI_VERSION = Int32(6)
 const MAXN, MAXM, MAXP, MAXPAR, MAXIND = 16, 8, 40, 400, 48
 const PROFILE_SLOTS = 4
 
@@ -529,6 +529,49 @@ function wait_solve!(s::PendingSolve)
     check(ccall((:to_solve_wait, lib), Cint, (Ptr{Cvoid},), s.p.handle))
     st = s.stats[]
     merge(s.bufs, (status = SolverStatus.(s.bufs.status), total_iterations = st.total_iterations, batch_steps = st.batch_steps, solve_ms = st.solve_ms))
+end
+
+"""
+    solve_progress(s::PendingSolve) -> (active, batch_steps, in_flight)
+    wait_below!(s::PendingSolve, active_max)
+What the solve loop of the solve in flight last saw (`to_solve_progress`), and a blocking wait until at most `active_max` trajectories
+are still iterating (`to_solve_wait_below`).  A host with more work than one batch pipelines it over two `BatchProblem`s: the next
+solve is admitted when the one in flight has drained (`solve_pipelined!`).
+"""
+function solve_progress(s::PendingSolve)
+    a, b, f = Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+    check(ccall((:to_solve_progress, lib), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), s.p.handle, a, b, f))
+    (active = a[], batch_steps = b[], in_flight = f[] != 0)
+end
+wait_below!(s::PendingSolve, active_max::Integer) =
+    check(ccall((:to_solve_wait_below, lib), Cint, (Ptr{Cvoid}, Int32), s.p.handle, Int32(active_max)))
+"""
+    solve_pipelined!(problems, jobs; which = :ilqr, admit_below = B ÷ 2, prepare! = (p, job) -> nothing)
+`jobs` solves over `length(problems)` handles of the same shape: job i runs on `problems[mod1(i, depth)]`, is prepared with
+`prepare!(p, i)` (new x0 / goal / initial controls) once that handle's previous solve has been collected, and is admitted as soon as the
+job in front of it has at most `admit_below` trajectories still iterating.  Returns the statistics of every job, in order.
+"""
+function solve_pipelined!(problems::Vector{BatchProblem}, jobs::Integer; which::Symbol = :ilqr,
+                          admit_below::Integer = problems[1].B ÷ 2, prepare! = (p, job) -> nothing)
+    depth = length(problems)
+    pending = Vector{Union{Nothing,PendingSolve}}(nothing, depth)
+    out = Vector{Any}(undef, jobs)
+    slotjob = zeros(Int, depth)
+    last = nothing
+    for job in 1:jobs
+        slot = mod1(job, depth)
+        if pending[slot] !== nothing
+            out[slotjob[slot]] = wait_solve!(pending[slot]); pending[slot] = nothing
+        end
+        prepare!(problems[slot], job)
+        last === nothing || wait_below!(last, admit_below)
+        last = pending[slot] = solve_async!(problems[slot], which)
+        slotjob[slot] = job
+    end
+    for slot in 1:depth
+        pending[slot] === nothing || (out[slotjob[slot]] = wait_solve!(pending[slot]))
+    end
+    out
 end
 
 # ---- expansion / gains (error-state blocks; examples/Internal API.ipynb)

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-TO_ABI_VERSION = 5
+TO_ABI_VERSION = 6
 TO_MAX_N, TO_MAX_M, TO_MAX_P = 16, 8, 40
 TO_MAX_CON_PARAMS, TO_MAX_CON_INDS = 400, 48
 
@@ -218,6 +218,8 @@ HIP_ONLY = {
     "al_solve_async": [_H, C.POINTER(SolveStats)],
     "altro_solve_async": [_H, C.POINTER(SolveStats)],
     "solve_wait": [_H],
+    "solve_progress": [_H, _PI, _PI, _PI],
+    "solve_wait_below": [_H, C.c_int32],
 }
 
 

@@ -45,7 +45,7 @@ __all__ = [
     "KnotPoint", "Problem", "rollout", "cost", "states", "controls", "initial_controls", "initial_states",
     "set_initial_state", "set_goal_state", "update_trajectory", "get_constraints", "get_objective", "get_model",
     "get_initial_state", "get_final_state", "get_trajectory", "gettimes",
-    "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "ProjectedNewtonSolver", "dynamics_defect", "solve", "iterations", "status", "max_violation",
+    "SolverOptions", "iLQRSolver", "ALSolver", "ALTROSolver", "ProjectedNewtonSolver", "dynamics_defect", "solve", "SolvePipeline", "iterations", "status", "max_violation",
     "evaluate_constraints", "constraint_jacobians", "sense", "upper_bound", "lower_bound", "is_bound",
     "DimensionMismatch", "ArgumentError", "UnsupportedError",
 ]
@@ -1416,6 +1416,8 @@ def set_goal_state(prob, xf, objective=True, constraint=True):
                 d = con._desc(a, b)
                 prob._call("set_constraint", i, C.byref(d))
     prob.xf = xf.copy()
+    if objective:
+        prob.xf_batch = None  # to_set_cost starts every cost's per-trajectory terms over: the batch goals are gone
 
 
 def _set_goal_state_batch(prob, Xf, objective=True, constraint=True):
@@ -1579,6 +1581,17 @@ class _Solver:
         self.total_iterations, self.batch_steps, self.solve_ms = st.total_iterations, st.batch_steps, st.solve_ms
         return self
 
+    def progress(self):
+        """(active, batch_steps, in_flight) of the solve in flight as its solve loop last saw it (to_solve_progress)."""
+        a, b, f = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.prob._call("solve_progress", C.byref(a), C.byref(b), C.byref(f))
+        return a.value, b.value, bool(f.value)
+
+    def wait_below(self, active_max):
+        """Block until at most ``active_max`` trajectories of the solve in flight are still iterating (to_solve_wait_below)."""
+        self.prob._call("solve_wait_below", int(active_max))
+        return self
+
 
 class iLQRSolver(_Solver):
     """Altro.iLQRSolver(prob, opts): unconstrained iLQR on the batch (examples/Cartpole.ipynb cell 25)."""
@@ -1615,6 +1628,68 @@ class ALTROSolver(_Solver):
 def solve(solver):
     """solve!(solver)."""
     return solver.solve()
+
+
+class SolvePipeline:
+    """Pipelined solves over ``depth = len(solvers)`` handles of the same shape (to_solve_progress / to_solve_wait_below).
+
+    A solve is batch-synchronous and its batch drains unevenly (C3: 52 of 141 batch steps run on a handful of stragglers with the chip
+    empty).  Trajectories are independent — one ``Z`` per problem, no cross terms (src/problem.jl:330-340) — so a host with more work
+    than one batch (the next MPC batch, the next shard of a sweep) starts the next solve on another handle while the one in flight
+    drains.  ``submit(prepare)``: job i runs on handle ``i % depth``; that handle's previous job is collected first (``wait``), then
+    ``prepare(prob)`` sets the job's inputs (x0 / goal / initial controls), and the solve is admitted once the job in front has at most
+    ``admit_below`` trajectories still iterating.  Every trajectory's result equals that of an unpipelined solve bit for bit
+    (tests/test_gpu_pipeline.py).  ``results`` holds (job, total_iterations, batch_steps, stats copy or None) in completion order."""
+
+    def __init__(self, solvers, admit_below=None, keep_stats=False, on_done=None):
+        self.solvers = list(solvers)
+        self.depth = len(self.solvers)
+        B = self.solvers[0].prob.B
+        self.admit_below = B // 2 if admit_below is None else int(admit_below)
+        self.keep_stats = keep_stats
+        self.on_done = on_done
+        self._job = [None] * self.depth
+        self._last = None
+        self.jobs = 0
+        self.results = []
+
+    def _collect(self, slot):
+        if self._job[slot] is None:
+            return
+        s = self.solvers[slot]
+        s.wait()
+        if self.on_done is not None:
+            self.on_done(self._job[slot], s)
+        self.results.append((self._job[slot], int(s.total_iterations), int(s.batch_steps),
+                             {k: v.copy() for k, v in s.stats.items()} if self.keep_stats else None))
+        if self._last is s:
+            self._last = None
+        self._job[slot] = None
+
+    def submit(self, prepare=None):
+        slot = self.jobs % self.depth
+        self._collect(slot)
+        s = self.solvers[slot]
+        if prepare is not None:
+            prepare(s.prob)
+        if self._last is not None:
+            self._last.wait_below(self.admit_below)
+        s.solve_async()
+        self._job[slot] = self.jobs
+        self._last = s
+        self.jobs += 1
+        return slot
+
+    def drain(self):
+        """Collect everything in flight (oldest first)."""
+        order = sorted((j, i) for i, j in enumerate(self._job) if j is not None)
+        for _, slot in order:
+            self._collect(slot)
+        return self
+
+    @property
+    def total_iterations(self):
+        return sum(r[1] for r in self.results)
 
 
 def iterations(solver):

@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,6 +72,7 @@ struct to_handle_s {
   double* d_dt = nullptr;
   int* d_cost_index = nullptr;
   int* d_crow = nullptr;    // [64] compact_row table of the model (tangent-matrix getters)
+  std::vector<char> gl_set; // [n_costs] cost i carries per-trajectory linear terms (all clear: DevProblem::gl goes back to null)
   double* d_gl = nullptr;   // per-trajectory linear cost terms (DevProblem::gl), tiled, L = n_costs * (n + m); allocated on first use
   double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
   double* d_tmp2 = nullptr;
@@ -114,6 +117,12 @@ struct to_handle_s {
   std::atomic<bool> inflight{false};
   int async_rc = 0;
   std::string async_err;
+  // progress of the solve in flight, as the solve loop last saw it (to_solve_progress / to_solve_wait_below: a host that
+  // pipelines solves over several handles admits the next one when the one in flight has drained)
+  std::atomic<int> prog_active{0};   // trajectories still iterating (B when a solve starts, 0 once its iLQR / AL stage has ended)
+  std::atomic<int> prog_steps{0};    // batch steps whose counters have been read
+  std::mutex prog_mu;
+  std::condition_variable prog_cv;
   int last_steps = 0;     // batch steps and device time of the last solve (fill_stats)
   double last_ms = 0.0;
   // measurement

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(1024) k_compact_write(KArgs a, int per) {
 constexpr int RP_MAX = 32;
 struct RpArgs {
   int n;                // arrays
-  int kind[RP_MAX];     // 0: tiled doubles, L per trajectory; 1: plain double [B]; 2: plain int [B]
+  int kind[RP_MAX];     // 0: tiled doubles, L per trajectory; 1: plain double [B]; 2: plain int [B]; 3: tiled doubles a solve only READS (moved, never copied home)
   int L[RP_MAX];
   const void* src[RP_MAX];
   void* dst[RP_MAX];
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64) k_repack_move(RpArgs r, const int* __restr
   if (j >= count) return;
   const int p = list[j];
   if (ai == 0) omap_new[j] = omap_old ? omap_old[p] : p;
-  if (r.kind[ai] == 0) {
+  if (r.kind[ai] == 0 || r.kind[ai] == 3) {
     const int L = r.L[ai];
     const double* s = (const double*)r.src[ai] + ((size_t)(p >> 6) * (size_t)L) * 64 + (p & 63);
     double* d = (double*)r.dst[ai] + ((size_t)(j >> 6) * (size_t)L) * 64 + (j & 63);
@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(64) k_repack_home(RpArgs r, const int* __restr
   if (j >= count) return;
   if (!all && active[j] != 0) return;
   const int q = omap[j];
+  if (r.kind[ai] == 3) return;
   if (r.kind[ai] == 0) {
     const int L = r.L[ai];
     const double* s = (const double*)r.src[ai] + ((size_t)(j >> 6) * (size_t)L) * 64 + (j & 63);

@@ -258,12 +258,16 @@ int rp_setup(to_handle* h) {
   };
   add(&a.Xs, 0, P.N * P.n); add(&a.Us, 0, (P.N - 1) * P.m); add(&a.x0, 0, P.n);
   if (a.P.gl) add(&a.P.gl, 0, P.n_costs * (P.n + P.m));
+  // duals and penalties: an iLQR solve (the only kind that repacks) never writes them, but its expansion, forward pass and cost read
+  // them through the tile of the WORKING position whenever the problem has constraints (a hand-built AL loop, to_set_duals, an iLQR
+  // re-solve behind an AL solve: per-trajectory values) — moved along, never copied home
+  if (P.n_cons > 0) { add(&a.lam, 3, (int)P.n_duals); add(&a.mu, 3, P.n_cons); }
   for (double** f : {&a.J, &a.dJ, &a.grad, &a.rho, &a.drho, &a.cmax}) add(f, 1, 1);
   for (int** f : {&a.status, &a.iterations, &a.it_inner, &a.outer, &a.dJzero, &a.ls_index, &a.active, &a.budget, &a.bpfail, &a.acc, &a.accp}) add(f, 2, 1);
   if ((int)h->rp_arr.size() > RP_MAX) return fail(TO_ERR_UNSUPPORTED, "repack table too long");
   return TO_OK;
 }
-size_t rp_bytes(const to_handle::RpArr& r, int Bp) { return r.kind == 0 ? sizeof(double) * (size_t)r.L * Bp : (r.kind == 1 ? sizeof(double) : sizeof(int)) * (size_t)Bp; }
+size_t rp_bytes(const to_handle::RpArr& r, int Bp) { return (r.kind == 0 || r.kind == 3) ? sizeof(double) * (size_t)r.L * Bp : (r.kind == 1 ? sizeof(double) : sizeof(int)) * (size_t)Bp; }
 // move the `count` active trajectories (list of the NEXT step, built by k_compact) into the other working set and go on there
 int rp_move(to_handle* h, int count) {
   KArgs& a = h->a;
@@ -279,9 +283,17 @@ int rp_move(to_handle* h, int count) {
     for (void* q : h->rp_work[w]) if (q) HIPCHECK(hipFree(q));
     h->rp_work[w].assign(h->rp_arr.size(), nullptr);
     if (h->rp_map[w]) HIPCHECK(hipFree(h->rp_map[w]));
+    h->rp_map[w] = nullptr; h->rp_cap[w] = 0;
     // (+ one spare tile, like the home arrays: k_accept_roll's lanes without an accepted step store into the tile behind the batch)
-    for (size_t i = 0; i < h->rp_arr.size(); ++i) HIPCHECK(hipMalloc(&h->rp_work[w][i], rp_bytes(h->rp_arr[i], Bp_new + 64)));
-    HIPCHECK(hipMalloc((void**)&h->rp_map[w], sizeof(int) * Bp_new));
+    bool ok = true;
+    for (size_t i = 0; ok && i < h->rp_arr.size(); ++i) ok = hipMalloc(&h->rp_work[w][i], rp_bytes(h->rp_arr[i], Bp_new + 64)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&h->rp_map[w], sizeof(int) * Bp_new) == hipSuccess;
+    if (!ok) {  // no memory for a working set: the repack is an optimisation — the solve goes on where it is (return value 1: declined)
+      (void)hipGetLastError();
+      for (void*& q : h->rp_work[w]) { if (q) hipFree(q); q = nullptr; }
+      if (h->rp_map[w]) { hipFree(h->rp_map[w]); h->rp_map[w] = nullptr; }
+      return 1;
+    }
     h->rp_cap[w] = Bp_new;
   }
   RpArgs mv, hm;
@@ -334,9 +346,16 @@ int rp_finish(to_handle* h, bool copy) {
   return rc;
 }
 
+// what the solve loop knows about its batch, published for to_solve_progress / to_solve_wait_below
+void publish_progress(to_handle* h, int active, int steps) {
+  const int before = h->prog_active.exchange(active);
+  h->prog_steps = steps;
+  if (active < before) { std::lock_guard<std::mutex> lk(h->prog_mu); h->prog_cv.notify_all(); }
+}
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
   const int rc = solve_impl(h, st, al_mode);
+  publish_progress(h, 0, h->prog_steps);  // on every exit path: nobody may wait for a count that will not come
   rp_finish(h, false);   // (an error path may leave the handle on a working set: back to the home arrays, without the copy)
   h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
   h->a.compact = 0;  // ... nor take its trajectories from a solve's active list
@@ -542,6 +561,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   const hipEvent_t cev[2] = {h->sev[2], h->sev[3]};
   int launched = 0, checked = 0, nchunks = 0, last_active = P.B;
   bool done = false;
+  h->prog_active = P.B; h->prog_steps = 0;
   const bool dbg_sync = std::getenv("TRAJOPT_SYNC_DEBUG") != nullptr;
   auto enqueue_chunk = [&]() -> int {
     const int chunk = std::min(CHECK_EVERY, max_steps - launched);
@@ -649,9 +669,14 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
         if (last_active == 0) { done = true; break; }
       }
       waited = nchunks;
+      publish_progress(h, last_active, steps);
       if (done) break;
       a.step = launched - 1;   // (k_compact of that step built the list the move reads)
-      TRY(rp_move(h, last_active));
+      {
+        const int mrc = rp_move(h, last_active);
+        if (mrc > 0) repack = false;  // declined (out of memory): no further attempts in this solve
+        else TRY(mrc);
+      }
       if (launched < max_steps) TRY(enqueue_chunk());
       continue;
     }
@@ -668,6 +693,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       if (h->counter_host[checked] == 0) { done = true; break; }
     }
     ++waited;
+    publish_progress(h, last_active, steps);
     if (!done && early_left > 0 && last_active <= early_thr) {
       TRY(early_polish_snapshot(h));
       snapshot_pending = true;
@@ -1195,6 +1221,10 @@ int to_set_cost(to_handle* h, int32_t id, const to_cost_desc* c) {
     const int nz = h->a.P.n + h->a.P.m, L = (int)h->costs.size() * nz;
     std::vector<double> zero((size_t)nz * h->a.P.B, 0.0);
     TRY(upload_vec(h, zero.data(), h->d_gl, nz, L, id * nz));
+    h->gl_set[id] = 0;
+    bool any = false;
+    for (char f : h->gl_set) any = any || f;
+    if (!any) h->a.P.gl = nullptr;  // every cost is back on its shared descriptor: the default forward variants again
   }
   return upload_tables(h);
 }
@@ -1219,6 +1249,8 @@ int to_set_cost_linear_batch(to_handle* h, int32_t id, const double* q, const do
     TRY(upload_vec(h, delta.data(), h->d_gl, m, L, id * nz + n));
   }
   P.gl = h->d_gl;
+  h->gl_set.resize(h->costs.size(), 0);
+  h->gl_set[id] = 1;
   return TO_OK;
 }
 int to_clear_cost_linear_batch(to_handle* h) {
@@ -1228,6 +1260,7 @@ int to_clear_cost_linear_batch(to_handle* h) {
     HIPCHECK(hipStreamSynchronize(h->stream));
   }
   h->a.P.gl = nullptr;
+  h->gl_set.assign(h->costs.size(), 0);
   return TO_OK;
 }
 int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
@@ -1310,6 +1343,7 @@ static int solve_async(to_handle* h, to_solve_stats* st, int kind) {
   if (h->inflight) return fail(TO_ERR_ARGUMENT, "a solve is already in flight on this handle (call to_solve_wait first)");
   h->inflight = true;
   h->async_rc = TO_OK;
+  h->prog_active = h->a.P.B; h->prog_steps = 0;  // (before the worker exists: a to_solve_wait_below right behind this call must block)
   try {  // no exception may cross the C ABI (std::system_error: out of threads)
     h->worker = std::thread([h, st, kind] {
       h->async_rc = kind == 0 ? solve(h, st, 0) : kind == 1 ? solve(h, st, 1) : altro_solve(h, st);
@@ -1317,6 +1351,7 @@ static int solve_async(to_handle* h, to_solve_stats* st, int kind) {
     });
   } catch (const std::exception& e) {
     h->inflight = false;
+    h->prog_active = 0;
     return fail(TO_ERR_HIP, std::string("could not start the solve thread: ") + e.what());
   }
   return TO_OK;
@@ -1331,6 +1366,20 @@ int to_solve_wait(to_handle* h) {
   h->inflight = false;
   if (h->async_rc != TO_OK) g_err = h->async_err;
   return h->async_rc;
+}
+int to_solve_progress(to_handle* h, int32_t* active, int32_t* batch_steps, int32_t* in_flight) {
+  CHECK_H(h);
+  if (active) *active = h->prog_active.load();
+  if (batch_steps) *batch_steps = h->prog_steps.load();
+  if (in_flight) *in_flight = h->inflight ? 1 : 0;
+  return TO_OK;
+}
+int to_solve_wait_below(to_handle* h, int32_t active_max) {
+  CHECK_H(h);
+  if (active_max < 0) return fail(TO_ERR_ARGUMENT, "to_solve_wait_below: the threshold must be >= 0");
+  std::unique_lock<std::mutex> lk(h->prog_mu);
+  h->prog_cv.wait(lk, [&] { return h->prog_active.load() <= active_max; });
+  return TO_OK;
 }
 int to_dynamics_defect(to_handle* h, double* defect) {
   CHECK_H(h); CHECK_IDLE(h); CHECK_P(defect);
