@@ -83,8 +83,9 @@ typedef enum {
   TO_MAX_ITERATIONS = 3,
   TO_MAX_ITERATIONS_OUTER = 4,
   TO_MAXIMUM_COST = 5,
-  TO_STATE_LIMIT = 6,   /* reserved (Altro order); never emitted: a rollout that leaves |x| <= max_state_value /  */
-  TO_CONTROL_LIMIT = 7, /* |u| <= max_control_value is rejected as a line-search candidate, not reported as a status */
+  TO_STATE_LIMIT = 6,   /* the INITIAL rollout of a solve left |x| <= max_state_value (checked knot by knot, the state first — Altro's   */
+  TO_CONTROL_LIMIT = 7, /* rollout!) / |u| <= max_control_value: the solve ends there, no iteration performed.  Inside a line search such a
+                           candidate is rejected like any other failed step size and no status is reported */
   TO_NO_PROGRESS = 8,
   TO_COST_INCREASE = 9,
   TO_REGULARIZATION_MAX = 10,

@@ -863,6 +863,16 @@ void ilqr_solve(const Problem& P, Traj& t, double cost_tol, int max_iters) {
   rollout(P, t);
   double J_prev = total_cost(P, t, t.X.data(), t.U.data(), true);
   t.J = J_prev;
+  /* Altro's rollout! checks every knot it simulates — the state it arrives at first, then the control that took it there — and
+   * reports STATE_LIMIT / CONTROL_LIMIT.  Inside a line search such a candidate is simply rejected (rollout_closed_loop); the
+   * INITIAL rollout of a solve has nothing to fall back on: the solve ends there with that status, no iteration performed. */
+  for (int k = 0; k < P.N - 1; ++k) {
+    double mx = 0.0, mu = 0.0;
+    for (int i = 0; i < P.n; ++i) { double a = std::fabs(t.X[(size_t)(k + 1) * P.n + i]); if (!(a <= mx)) mx = a; }
+    for (int j = 0; j < P.m; ++j) { double a = std::fabs(t.U[(size_t)k * P.m + j]); if (!(a <= mu)) mu = a; }
+    if (!(mx <= P.opts.max_state_value)) { t.status = TO_STATE_LIMIT; return; }
+    if (!(mu <= P.opts.max_control_value)) { t.status = TO_CONTROL_LIMIT; return; }
+  }
   if (max_iters <= 0) { t.status = TO_MAX_ITERATIONS; return; }
   int it = 0;
   while (true) {

@@ -77,3 +77,48 @@ def test_two_rank_bootstrap_on_one_gpu(hip, tmp_path):
         assert "to_comm_init_rank" in log and "HipError" in log, log[-2000:]                  # ... and failed through the C-ABI's error path
         assert "Duplicate GPU detected" in log or "invalid usage" in log, log[-2000:]
         assert "communicator up" not in log
+
+
+def build_rccl_stub(dst):
+    """tests/rccl_stub/rccl_stub.cpp -> dst (g++; links the HIP runtime the process already has)."""
+    src = ROOT / "tests" / "rccl_stub" / "rccl_stub.cpp"
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-o", str(dst),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread", "-Wno-format-truncation"], check=True, capture_output=True)
+    return dst
+
+
+@pytest.mark.parametrize("world,total", [(2, 12), (2, 13), (3, 14), (4, 64)])
+def test_multi_rank_collectives_on_one_gpu_through_the_stub(world, total, hip, tmp_path):
+    """The N > 1 code of the C-ABI on a ONE-GPU box: RCCL refuses two ranks on one device, so the ranks' collective
+    library is the shared-memory stand-in of tests/rccl_stub (TRAJOPT_RCCL_LIB) — same eight entry points, same signatures.  `world`
+    processes, all on device 0, each with its contiguous shard: to_comm_init_rank(nranks = world) exchanges the shard sizes with
+    ncclAllGather, to_allgather gathers (X, U) — in place with equal shards (12 = 6 + 6, 64 = 4 x 16), by grouped ncclBroadcast with
+    unequal ones (13 = 7 + 6, 14 = 5 + 5 + 4) — and to_allgather_stats the per-trajectory integers and costs.  Every rank's result must
+    equal the one-handle solve of the whole batch bit for bit (shards are solved independently; inputs come from the GLOBAL index)."""
+    import os
+    stub = build_rccl_stub(tmp_path / "librccl_stub.so")
+    id_file, out = tmp_path / "nccl_id.bin", tmp_path / "gather"
+    env = dict(os.environ, TRAJOPT_WORKER_SAME_DEVICE="1", TRAJOPT_RCCL_LIB=str(stub))
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "multi_gpu_worker.py"), str(r), str(world), str(total),
+                               str(id_file), str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        assert p.returncode == 0, log.decode()[-3000:]
+        assert "communicator up" in log.decode()
+    ref = configs.cartpole_problem(batch=total, N=41, tf=2.0, lib=hip)
+    sv = T.iLQRSolver(ref, iterations=25).solve()
+    X, U = T.states(ref), T.controls(ref)
+    base, extra = divmod(total, world)
+    for r in range(world):
+        g = np.load(str(out) + f".rank{r}.npz")
+        assert int(g["total"]) == total and list(g["counts"]) == [base + (1 if q < extra else 0) for q in range(world)]
+        np.testing.assert_array_equal(g["X"], X)
+        np.testing.assert_array_equal(g["U"], U)
+        np.testing.assert_array_equal(g["its"], sv.stats["iterations"])
+        np.testing.assert_array_equal(g["st"], sv.stats["status"])
+        np.testing.assert_array_equal(g["J"], sv.stats["cost"])

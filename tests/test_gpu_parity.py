@@ -1630,3 +1630,42 @@ def test_scan_backward_pass_horizons(N, hip, oracle, monkeypatch):
         ph, po = build(hip), build(oracle)
         sh, so = T.iLQRSolver(ph, iterations=25).solve(), T.iLQRSolver(po, iterations=25).solve()
         assert_solve_parity(sh, so, ph, po, unconverged_rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["cartpole", "cartpole_big", "quadrotor", "quadrotor_al"])
+def test_state_and_control_limits_of_the_initial_rollout(kind, hip, oracle):
+    """TO_STATE_LIMIT / TO_CONTROL_LIMIT (Altro's rollout! check, knot by knot: the state first, then the control): trajectories whose
+    INITIAL rollout leaves the limits end with that status and no iteration, on every solver path — cooperative / scan (small batch),
+    fused lane with compaction (large batch), MFMA with compaction (Quadrotor), AL — and the rest of the batch solves as if they were
+    not there (integers bit-exact against the oracle)."""
+    def mk(lib):
+        if kind == "cartpole":
+            return configs.cartpole_problem(batch=70, N=41, tf=2.0, lib=lib)
+        if kind == "cartpole_big":
+            return configs.cartpole_problem(batch=40000, N=21, tf=1.0, lib=lib)
+        return configs.quadrotor_problem(batch=48, N=41, tf=1.0, constrained=(kind == "quadrotor_al"), u_norm_max=2.6, lib=lib)
+    ph, po = mk(hip), mk(oracle)
+    B, N, m = ph.B, ph.N, ph.m
+    U = T.controls(ph).copy()
+    bad_u, bad_x, bad_nan = [1, B // 2, B - 1], [3, B // 2 + 1], [5]
+    cart = kind.startswith("cartpole")
+    lim = dict(max_control_value=50.0, max_state_value=30.0 if cart else 500.0)
+    for b in bad_u:
+        U[b, 7, 0] = 60.0        # beyond max_control_value at knot 8; the state it produces stays inside
+    for b in bad_x:
+        U[b, :, 0] = 40.0        # legal, and drives a velocity through max_state_value within ten knots
+    U[bad_nan[0], 2, m - 1] = float("nan")
+    for p in (ph, po):
+        T.initial_controls(p, U)
+    Solver = T.ALSolver if kind == "quadrotor_al" else T.iLQRSolver
+    kw = dict(iterations=12, **lim) if kind == "cartpole_big" else dict(lim)
+    sh, so = Solver(ph, **kw).solve(), Solver(po, **kw).solve()
+    for k in ("status", "iterations", "iterations_outer"):
+        np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
+    st = sh.stats["status"]
+    assert (st[bad_u] == T.capi.CONTROL_LIMIT).all() and (st[bad_x] == T.capi.STATE_LIMIT).all() and st[bad_nan[0]] == T.capi.STATE_LIMIT
+    assert sh.stats["iterations"][bad_u + bad_x + bad_nan].max() == 0
+    ok = np.ones(B, bool); ok[bad_u + bad_x + bad_nan] = False
+    assert sh.stats["iterations"][ok].min() >= 1
+    np.testing.assert_allclose(T.states(ph)[ok], T.states(po)[ok], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(T.controls(ph)[ok], T.controls(po)[ok], rtol=1e-6, atol=1e-8)

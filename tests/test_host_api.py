@@ -366,3 +366,20 @@ def test_committed_bench_line_follows_the_contract():
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in c, k
         assert c["kind"] == "port" and w["value"] > 0
+
+
+def test_rccl_stub_builds_and_exports_what_the_library_binds(tmp_path):
+    """tests/rccl_stub (the shared-memory stand-in that lets several ranks share one GPU in the -m gpu suite) must export every nccl*
+    entry point csrc/trajopt_hip.hip dlsym()s — checked here so that the GPU test cannot silently skip a symbol."""
+    import re
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    src = (root / "trajectoryoptimization.jl_amd" / "csrc" / "trajopt_hip.hip").read_text()
+    wanted = set(re.findall(r'dlsym\(g_rccl\.lib, "(nccl\w+)"\)', src))
+    assert len(wanted) == 8
+    so = tmp_path / "librccl_stub.so"
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(root / "tests" / "rccl_stub" / "rccl_stub.cpp"),
+                    "-o", str(so), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread", "-Wno-format-truncation"], check=True, capture_output=True)
+    out = subprocess.run(["nm", "-D", "--defined-only", str(so)], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (nccl\w+)", out))
+    assert wanted <= exported, sorted(wanted - exported)

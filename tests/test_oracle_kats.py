@@ -545,3 +545,33 @@ def test_al_full_newton_hessian_matches_finite_differences(oracle):
     T.initial_states(pf, X0)
     np.testing.assert_allclose(Hf[k], fd, rtol=1e-5, atol=1e-5 * np.abs(fd).max())
     assert np.abs(Hg[k] - fd).max() > 1e-2 * np.abs(fd).max()  # Gauss-Newton drops the curvature term
+
+
+def test_initial_rollout_beyond_the_limits_ends_the_solve(oracle):
+    """Altro's rollout! reports STATE_LIMIT / CONTROL_LIMIT for the knot it cannot accept — the state it arrives at first, then the
+    control that took it there.  A line search rejects such a candidate; the INITIAL rollout of a solve has nothing to fall back on:
+    the solve ends with that status, no iteration performed, the other trajectories of the batch untouched."""
+    from trajectoryoptimization_jl_amd import configs
+    lim = dict(max_control_value=50.0, max_state_value=30.0)
+    p = configs.cartpole_problem(batch=6, N=41, tf=2.0, lib=oracle)
+    U = np.full((6, 40, 1), 0.01)
+    U[1, 7, 0] = 60.0          # beyond max_control_value at knot 8 (the state it produces stays small)
+    U[3, :, 0] = 40.0          # a legal control that drives the state through max_state_value a few knots later
+    U[4, 0, 0] = float("nan")  # NaN fails `<=`: the state it produces is reported first
+    T.initial_controls(p, U)
+    s = T.iLQRSolver(p, iterations=30, **lim).solve()
+    st = s.stats["status"]
+    assert st[1] == T.capi.CONTROL_LIMIT and st[3] == T.capi.STATE_LIMIT and st[4] == T.capi.STATE_LIMIT
+    assert all(st[b] in (T.capi.SOLVE_SUCCEEDED, T.capi.MAX_ITERATIONS) for b in (0, 2, 5))
+    assert s.stats["iterations"][[1, 3, 4]].tolist() == [0, 0, 0] and s.stats["iterations"][[0, 2, 5]].min() > 3
+    np.testing.assert_array_equal(T.controls(p)[[1, 3]], U[[1, 3]])   # nothing was changed
+    # a tighter state limit stops the nominal swing-up guess itself
+    s2 = T.iLQRSolver(configs.cartpole_problem(batch=2, N=41, tf=2.0, lib=oracle), max_state_value=1e-4).solve()
+    assert (s2.stats["status"] == T.capi.STATE_LIMIT).all()
+    # AL / ALTRO solves stop the same way (one outer iteration counted)
+    pc = configs.cartpole_problem(batch=3, constrained=True, lib=oracle)
+    Uc = np.full((3, 100, 1), 0.01); Uc[2, 5, 0] = -60.0
+    T.initial_controls(pc, Uc)
+    sc = T.ALTROSolver(pc, **lim).solve()
+    assert sc.stats["status"][2] == T.capi.CONTROL_LIMIT and sc.stats["iterations"][2] == 0 and sc.stats["iterations_outer"][2] == 1
+    assert (sc.stats["status"][:2] == T.capi.SOLVE_SUCCEEDED).all()

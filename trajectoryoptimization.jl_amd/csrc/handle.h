@@ -125,6 +125,16 @@ struct to_handle_s {
   std::condition_variable prog_cv;
   int last_steps = 0;     // batch steps and device time of the last solve (fill_stats)
   double last_ms = 0.0;
+  // TRAJOPT_GUARD=1 (read at to_create): every device array of the handle sits between two red zones filled with a pattern, checked after
+  // every batch step of a solve and every phase-API call — an out-of-bounds store of a kernel is reported where it happens, by array name,
+  // instead of surfacing as a fault at whatever batch size happens to cross a mapping boundary (sanitizer hook; GPU ASan is
+  // not available on this pool)
+  bool guard = false;
+  struct GuardRec { void* base; void* payload; size_t bytes; std::string name; };
+  std::vector<GuardRec> guards;
+  void* guard_tab = nullptr;   // device copy of the zone addresses (rebuilt when `guards` changes)
+  int* guard_bad = nullptr;    // device: index of the first damaged zone, else INT_MAX
+  bool guard_dirty = true;
   // measurement
   bool profile = false;
   std::vector<hipEvent_t> ev;  // event pool, 4 per batch step
@@ -199,6 +209,11 @@ void fill_ops_pn(ModelOps* table);
 void fill_ops_vector(ModelOps* table);
 void fill_ops_infeasible_a(ModelOps* table);
 void fill_ops_infeasible_b(ModelOps* table);
+
+// handle-owned device memory (red zones around it in guard mode); g_free accepts what g_malloc returned
+int g_malloc(to_handle* h, void** p, size_t bytes, const char* name);
+void g_free(to_handle* h, void* p);
+int check_guards(to_handle* h, const char* where);
 
 inline dim3 grid_b(const to_handle* h, int y = 1, int z = 1) { return dim3(h->a.P.Bp / BLOCK, y, z); }
 

@@ -18,12 +18,24 @@ __global__ void __launch_bounds__(64) k_rollout(KArgs a) {  // src/problem.jl:33
   double x[n], u[m], xn[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) { x[i] = EL(x0, i); EL(X, i) = x[i]; }
+  int lim = 0;  // first knot beyond max_state_value / max_control_value: the state it arrives at first, then the control (Altro's rollout!)
+  const double max_x = P.opts.max_state_value, max_u = P.opts.max_control_value;
   for (int k = 0; k < P.N - 1; ++k) {
 #pragma unroll
     for (int i = 0; i < m; ++i) u[i] = EL(U, k * m + i);
     model_step<M, double, FIXED_INTEG>(P.mp, P.integrator, k, x, u, P.dt[k], xn);
+    double mx = 0.0, mu = 0.0;
 #pragma unroll
-    for (int i = 0; i < n; ++i) { x[i] = xn[i]; EL(X, (k + 1) * n + i) = x[i]; }
+    for (int i = 0; i < n; ++i) { x[i] = xn[i]; EL(X, (k + 1) * n + i) = x[i]; const double v = fabs(x[i]); mx = !(v <= mx) ? v : mx; }
+#pragma unroll
+    for (int i = 0; i < m; ++i) { const double v = fabs(u[i]); mu = !(v <= mu) ? v : mu; }
+    if (lim == 0) lim = !(mx <= max_x) ? TO_STATE_LIMIT : !(mu <= max_u) ? TO_CONTROL_LIMIT : 0;
+  }
+  // the initial rollout of a solve (KArgs::control): a trajectory beyond the limits ends right here — TO_STATE_LIMIT / TO_CONTROL_LIMIT,
+  // no iteration performed (inside a line search such a candidate is simply rejected, k_forward.h); the phase API only simulates
+  if (a.control && lim != 0 && a.active[b] != 0) {
+    a.status[b] = lim; a.active[b] = 0;
+    if (a.al_mode) a.outer[b] = 1;  // (the AL loop counts the outer iteration its first inner solve belongs to)
   }
 }
 

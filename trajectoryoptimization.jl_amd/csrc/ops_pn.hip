@@ -38,21 +38,21 @@ int op_pn_prepare(to_handle* h, int want) {
   const int cap = (int)std::min<size_t>((size_t)want, std::max<size_t>(1, (size_t)(gb * 1073741824.0) / per));
   if (h->pn_ws_bytes < per * cap) {
     HIPCHECK(hipDeviceSynchronize());  // the polish may still be running on its own stream
-    if (h->pn_ws) { HIPCHECK(hipFree(h->pn_ws)); h->pn_ws = nullptr; h->pn_ws_bytes = 0; }
-    HIPCHECK(hipMalloc((void**)&h->pn_ws, per * cap));
+    if (h->pn_ws) { g_free(h, h->pn_ws); h->pn_ws = nullptr; h->pn_ws_bytes = 0; }
+    TRY(g_malloc(h, (void**)&h->pn_ws, per * cap, "pn_ws"));
     h->pn_ws_bytes = per * cap;
   }
   h->pn_cap = (int)(h->pn_ws_bytes / per);
   h->pn_per = (long long)koff[N];
   if (h->pn_tab_len < N + 1) {
     HIPCHECK(hipDeviceSynchronize());
-    if (h->pn_pak) HIPCHECK(hipFree(h->pn_pak));
-    if (h->pn_koff) HIPCHECK(hipFree(h->pn_koff));
-    if (h->pn_list) HIPCHECK(hipFree(h->pn_list));
+    if (h->pn_pak) g_free(h, h->pn_pak);
+    if (h->pn_koff) g_free(h, h->pn_koff);
+    if (h->pn_list) g_free(h, h->pn_list);
     if (h->pn_list_host) HIPCHECK(hipHostFree(h->pn_list_host));
-    HIPCHECK(hipMalloc((void**)&h->pn_pak, sizeof(int) * (N + 1)));
-    HIPCHECK(hipMalloc((void**)&h->pn_koff, sizeof(long long) * (N + 1)));
-    HIPCHECK(hipMalloc((void**)&h->pn_list, sizeof(int) * P.Bp));
+    TRY(g_malloc(h, (void**)&h->pn_pak, sizeof(int) * (N + 1), "pn_pak"));
+    TRY(g_malloc(h, (void**)&h->pn_koff, sizeof(long long) * (N + 1), "pn_koff"));
+    TRY(g_malloc(h, (void**)&h->pn_list, sizeof(int) * P.Bp, "pn_list"));
     HIPCHECK(hipHostMalloc((void**)&h->pn_list_host, sizeof(int) * P.Bp));
     h->pn_tab_len = N + 1;
   }

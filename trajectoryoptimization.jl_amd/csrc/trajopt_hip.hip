@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <time.h>
 
 #include <mutex>
 #include <thread>
@@ -27,6 +28,78 @@ thread_local std::string g_err;
 namespace to {
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 }
+
+namespace to {
+// ---- guard mode (handle.h): red zones around every handle-owned device array ---------------------------------------------------------
+constexpr size_t GUARD_BYTES = 4096;                          // per zone: half a tile row of the batch-fastest layout and then some
+constexpr unsigned long long GUARD_WORD = 0xA5C3A5C3DEADBEEFull;
+struct GuardZones { unsigned long long* front; unsigned long long* back; };
+__global__ void k_guard_fill(unsigned long long* z) { z[blockIdx.x * 64 + threadIdx.x] = GUARD_WORD; }
+__global__ void k_guard_check(const GuardZones* tab, int* bad) {
+  const GuardZones g = tab[blockIdx.x];
+  constexpr int words = (int)(GUARD_BYTES / 8);
+  bool hit = false;
+  for (int i = threadIdx.x; i < words; i += 64) hit = hit || g.front[i] != GUARD_WORD || g.back[i] != GUARD_WORD;
+  if (hit) atomicMin(bad, (int)blockIdx.x);
+}
+__global__ void k_guard_poke(double* p, long long off) { p[off] = 1.0; }  // TRAJOPT_GUARD_SELFTEST: the overrun the check must find
+
+int g_malloc(to_handle* h, void** p, size_t bytes, const char* name) {
+  if (!h->guard) {
+    HIPCHECK(hipMalloc(p, bytes));
+    return TO_OK;
+  }
+  const size_t payload = (bytes + 255) / 256 * 256;  // the back zone starts right behind the (rounded-up) payload
+  void* base = nullptr;
+  HIPCHECK(hipMalloc(&base, payload + 2 * GUARD_BYTES));
+  char* q = (char*)base + GUARD_BYTES;
+  hipLaunchKernelGGL(k_guard_fill, dim3(GUARD_BYTES / 8 / 64), dim3(64), 0, h->stream, (unsigned long long*)base);
+  hipLaunchKernelGGL(k_guard_fill, dim3(GUARD_BYTES / 8 / 64), dim3(64), 0, h->stream, (unsigned long long*)(q + payload));
+  if (payload > bytes) HIPCHECK(hipMemsetAsync(q + bytes, 0, payload - bytes, h->stream));
+  HIPCHECK(hipGetLastError());
+  h->guards.push_back({base, q, payload, name ? name : ""});
+  h->guard_dirty = true;
+  *p = q;
+  return TO_OK;
+}
+void g_free(to_handle* h, void* p) {
+  if (!p) return;
+  if (h->guard)
+    for (size_t i = 0; i < h->guards.size(); ++i)
+      if (h->guards[i].payload == p) {
+        hipFree(h->guards[i].base);
+        h->guards.erase(h->guards.begin() + i);
+        h->guard_dirty = true;
+        return;
+      }
+  hipFree(p);
+}
+// every red zone of the handle intact?  Synchronises the stream (a debugging mode).
+int check_guards(to_handle* h, const char* where) {
+  if (!h->guard || h->guards.empty()) return TO_OK;
+  if (!h->guard_bad) HIPCHECK(hipMalloc((void**)&h->guard_bad, sizeof(int)));
+  if (h->guard_dirty) {
+    std::vector<GuardZones> tab;
+    for (const auto& g : h->guards) tab.push_back({(unsigned long long*)g.base, (unsigned long long*)((char*)g.payload + g.bytes)});
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->guard_tab) HIPCHECK(hipFree(h->guard_tab));
+    HIPCHECK(hipMalloc(&h->guard_tab, tab.size() * sizeof(GuardZones)));
+    HIPCHECK(hipMemcpy(h->guard_tab, tab.data(), tab.size() * sizeof(GuardZones), hipMemcpyHostToDevice));
+    h->guard_dirty = false;
+  }
+  int bad = 0x7fffffff;
+  HIPCHECK(hipMemcpyAsync(h->guard_bad, &bad, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_guard_check, dim3((unsigned)h->guards.size()), dim3(64), 0, h->stream, (const GuardZones*)h->guard_tab, h->guard_bad);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(&bad, h->guard_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  if (bad != 0x7fffffff) {
+    const auto& g = h->guards[bad];
+    return fail(TO_ERR_HIP, "guard: a red zone of device array '" + g.name + "' (" + std::to_string(g.bytes) + " bytes) was overwritten — first seen after " + where);
+  }
+  return TO_OK;
+}
+}  // namespace to
 
 namespace {
 
@@ -51,19 +124,20 @@ const ModelOps* model_ops(int key) {
 }
 
 template <class T>
-int dev_alloc(to_handle* h, T** p, size_t count, bool zero = true) {
+int dev_alloc_named(to_handle* h, const char* name, T** p, size_t count, bool zero = true) {
   void* q = nullptr;
-  HIPCHECK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  TRY(g_malloc(h, &q, std::max<size_t>(count, 1) * sizeof(T), name));
   h->allocs.push_back(q);
   if (zero) HIPCHECK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
   *p = (T*)q;
   return TO_OK;
 }
+#define dev_alloc(h, p, ...) dev_alloc_named(h, #p, p, __VA_ARGS__)
 
 int ensure_stage(to_handle* h, size_t bytes) {
   if (h->stage_bytes >= bytes) return TO_OK;
-  if (h->stage) { HIPCHECK(hipStreamSynchronize(h->stream)); HIPCHECK(hipFree(h->stage)); h->stage = nullptr; h->stage_bytes = 0; }
-  HIPCHECK(hipMalloc((void**)&h->stage, bytes));
+  if (h->stage) { HIPCHECK(hipStreamSynchronize(h->stream)); g_free(h, h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+  TRY(g_malloc(h, (void**)&h->stage, bytes, "stage"));
   h->stage_bytes = bytes;
   return TO_OK;
 }
@@ -280,18 +354,18 @@ int rp_move(to_handle* h, int count) {
     h->rp_B = a.P.B; h->rp_Bp = a.P.Bp;
   }
   if (h->rp_cap[w] < Bp_new || h->rp_work[w].size() != h->rp_arr.size()) {  // (sized once per handle: the first move of a solve is the largest for this working set)
-    for (void* q : h->rp_work[w]) if (q) HIPCHECK(hipFree(q));
+    for (void* q : h->rp_work[w]) if (q) g_free(h, q);
     h->rp_work[w].assign(h->rp_arr.size(), nullptr);
-    if (h->rp_map[w]) HIPCHECK(hipFree(h->rp_map[w]));
+    if (h->rp_map[w]) g_free(h, h->rp_map[w]);
     h->rp_map[w] = nullptr; h->rp_cap[w] = 0;
     // (+ one spare tile, like the home arrays: k_accept_roll's lanes without an accepted step store into the tile behind the batch)
     bool ok = true;
-    for (size_t i = 0; ok && i < h->rp_arr.size(); ++i) ok = hipMalloc(&h->rp_work[w][i], rp_bytes(h->rp_arr[i], Bp_new + 64)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&h->rp_map[w], sizeof(int) * Bp_new) == hipSuccess;
+    for (size_t i = 0; ok && i < h->rp_arr.size(); ++i) ok = g_malloc(h, &h->rp_work[w][i], rp_bytes(h->rp_arr[i], Bp_new + 64), "repacked working set") == TO_OK;
+    ok = ok && g_malloc(h, (void**)&h->rp_map[w], sizeof(int) * Bp_new, "repack map") == TO_OK;
     if (!ok) {  // no memory for a working set: the repack is an optimisation — the solve goes on where it is (return value 1: declined)
       (void)hipGetLastError();
-      for (void*& q : h->rp_work[w]) { if (q) hipFree(q); q = nullptr; }
-      if (h->rp_map[w]) { hipFree(h->rp_map[w]); h->rp_map[w] = nullptr; }
+      for (void*& q : h->rp_work[w]) { if (q) g_free(h, q); q = nullptr; }
+      if (h->rp_map[w]) { g_free(h, h->rp_map[w]); h->rp_map[w] = nullptr; }
       return 1;
     }
     h->rp_cap[w] = Bp_new;
@@ -347,14 +421,30 @@ int rp_finish(to_handle* h, bool copy) {
 }
 
 // what the solve loop knows about its batch, published for to_solve_progress / to_solve_wait_below
+// TRAJOPT_TRACE=<file>: every progress report of every solve loop as one line "<handle> <seconds> <batch steps> <active> <tag>" (host clock,
+// CLOCK_MONOTONIC) — the timeline of pipelined solves over several handles (tools/ab/pipeline_timeline.py)
+void trace_line(to_handle* h, int active, int steps, const char* tag) {
+  static const char* path = std::getenv("TRAJOPT_TRACE");
+  if (!path) return;
+  static std::mutex mu;
+  static FILE* f = std::fopen(path, "a");
+  if (!f) return;
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  std::lock_guard<std::mutex> lk(mu);
+  std::fprintf(f, "%p %.6f %d %d %s\n", (void*)h, ts.tv_sec + 1e-9 * ts.tv_nsec, steps, active, tag);
+  std::fflush(f);
+}
 void publish_progress(to_handle* h, int active, int steps) {
+  trace_line(h, active, steps, "step");
   const int before = h->prog_active.exchange(active);
   h->prog_steps = steps;
   if (active < before) { std::lock_guard<std::mutex> lk(h->prog_mu); h->prog_cv.notify_all(); }
 }
 int solve_impl(to_handle* h, to_solve_stats* st, int al_mode);
 int solve(to_handle* h, to_solve_stats* st, int al_mode) {
-  const int rc = solve_impl(h, st, al_mode);
+  int rc = solve_impl(h, st, al_mode);
+  if (rc == TO_OK && h->guard) rc = check_guards(h, "the end of a solve (final accept, working set home, statistics)");
   publish_progress(h, 0, h->prog_steps);  // on every exit path: nobody may wait for a count that will not come
   rp_finish(h, false);   // (an error path may leave the handle on a working set: back to the home arrays, without the copy)
   h->a.control = 0;  // on every exit path: the phase API must never find the state machine armed
@@ -384,6 +474,7 @@ int pn_run(to_handle* h, const std::vector<int>& list, const to_solver_opts& opt
   HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
   h->last_ms += ms;
   if (h->profile) { h->prof_ms[3] += ms; h->prof_launches[3] += 1; }  // slot 3: the polish (all its launches of one solve)
+  if (h->guard) TRY(check_guards(h, "the projected-Newton polish"));
   return TO_OK;
 }
 int ensure_solve_events(to_handle* h) {
@@ -516,7 +607,9 @@ int altro_solve(to_handle* h, to_solve_stats* st) {
     if (status[b] == TO_SOLVE_SUCCEEDED && cmax[b] > user.constraint_tolerance && !(had_early && h->pn_done_early[b])) list.push_back(b);
   // A problem outside the polish's limits (PN_NB_LIMIT rows on one knot) keeps the result of its AL stage: the call succeeds, the
   // trajectories keep their AL status / violation and to_last_error() says why nothing was polished
+  trace_line(h, (int)list.size(), h->last_steps, "polish");
   const int prc = pn_run(h, list, user);
+  trace_line(h, 0, h->last_steps, "polish_done");
   if (prc != TO_OK && prc != TO_ERR_UNSUPPORTED) return prc;
   if (st) { const std::string note = prc == TO_OK ? std::string() : g_err; TRY(fill_stats(h, st, true)); if (!note.empty()) g_err = "polish skipped: " + note; }
   return TO_OK;
@@ -533,7 +626,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   const int max_steps = (al_mode ? P.opts.iterations_total : P.opts.iterations) + 1;
   if (h->counter_len < max_steps) {
     int* c = nullptr;
-    HIPCHECK(hipMalloc((void**)&c, sizeof(int) * max_steps));
+    TRY(g_malloc(h, (void**)&c, sizeof(int) * max_steps, "step counters"));
     h->allocs.push_back(c);
     a.counter = c;
     if (h->counter_host) HIPCHECK(hipHostFree(h->counter_host));
@@ -549,6 +642,19 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   HIPCHECK(hipGetLastError());
   TRY(launch_rollout(h));
   TRY(launch_cost(h, 1, a.J, nullptr));
+  if (a.compact) {  // the initial rollout may have ended trajectories (TO_STATE_LIMIT / TO_CONTROL_LIMIT): the list of step 0 without them
+    a.step = -1;
+    if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
+    else {
+      int per = ((P.Bp + 255) / 256 + 1023) / 1024 * 1024;
+      if (per > 65536) per = 65536;
+      const int nb = (P.Bp + per - 1) / per;
+      if (nb > 256) return fail(TO_ERR_UNSUPPORTED, "batch too large for the compaction kernels (16 777 216 trajectories)");
+      hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(1024), 0, h->stream, a, per);
+      hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(1024), 0, h->stream, a, per);
+    }
+    HIPCHECK(hipGetLastError());
+  }
   int steps = 0;
   if (h->profile) {
     while ((int)h->ev.size() < 4 * max_steps) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); h->ev.push_back(e); }
@@ -638,6 +744,11 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
         HIPCHECK(hipGetLastError());
       }
       if (h->profile) HIPCHECK(hipEventRecord(h->ev[4 * step + 3], h->stream));
+      if (h->guard) {
+        if (step == 0) if (const char* env = std::getenv("TRAJOPT_GUARD_SELFTEST")) if (std::atoi(env))  // one double behind the nominal states
+          hipLaunchKernelGGL(k_guard_poke, dim3(1), dim3(1), 0, h->stream, a.Xs, (long long)P.N * P.n * (P.Bp + 64) + 3);
+        TRY(check_guards(h, ("batch step " + std::to_string(step) + " of a solve").c_str()));
+      }
       if (dbg_sync) {  // TRAJOPT_SYNC_DEBUG=1: localise a device fault to a batch step
         const hipError_t e = hipStreamSynchronize(h->stream);
         std::fprintf(stderr, "[sync-debug] step %d B=%d Bp=%d level=%d store_x-path=%d: %s\n", step, a.P.B, a.P.Bp, h->rp_level, (int)(last_active), hipGetErrorString(e));
@@ -676,6 +787,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
         const int mrc = rp_move(h, last_active);
         if (mrc > 0) repack = false;  // declined (out of memory): no further attempts in this solve
         else TRY(mrc);
+        if (h->guard) TRY(check_guards(h, "a move into a repacked working set"));
       }
       if (launched < max_steps) TRY(enqueue_chunk());
       continue;
@@ -741,10 +853,14 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 int load_rccl() {
   std::call_once(g_rccl_once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (g_rccl.lib) break;
-    }
+    // TRAJOPT_RCCL_LIB names the collective library outright (any library exporting these eight nccl* entry points: a site build of
+    // RCCL, or the shared-memory stand-in of tests/rccl_stub that lets several ranks share one GPU); nothing else is tried then
+    if (const char* env = std::getenv("TRAJOPT_RCCL_LIB")) g_rccl.lib = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    else
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+      }
     if (!g_rccl.lib) return;
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
@@ -850,6 +966,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   to_handle* h = new to_handle();
   h->device = device;
   h->model_key = key;
+  if (const char* env = std::getenv("TRAJOPT_GUARD")) h->guard = std::atoi(env) != 0;
   h->R = (ne + m) <= 4 ? 4 : (ne + m) <= 8 ? 8 : 16;
   h->G = 64 / h->R;
   h->ops = model_ops(key);
@@ -1078,19 +1195,21 @@ int to_destroy(to_handle* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  for (void* p : h->allocs) hipFree(p);
-  if (h->stage) hipFree(h->stage);
-  if (h->pn_ws) hipFree(h->pn_ws);
-  if (h->pn_pak) hipFree(h->pn_pak);
-  if (h->pn_koff) hipFree(h->pn_koff);
-  if (h->pn_list) hipFree(h->pn_list);
+  for (void* p : h->allocs) g_free(h, p);
+  g_free(h, h->stage);
+  g_free(h, h->pn_ws);
+  g_free(h, h->pn_pak);
+  g_free(h, h->pn_koff);
+  g_free(h, h->pn_list);
+  if (h->guard_tab) hipFree(h->guard_tab);
+  if (h->guard_bad) hipFree(h->guard_bad);
   if (h->pn_list_host) hipHostFree(h->pn_list_host);
   if (h->snap_status) hipHostFree(h->snap_status);
   if (h->snap_active) hipHostFree(h->snap_active);
   if (h->snap_cmax) hipHostFree(h->snap_cmax);
   for (hipEvent_t e : h->pn_ev) if (e) hipEventDestroy(e);
   if (h->pn_stream) hipStreamDestroy(h->pn_stream);
-  for (int w = 0; w < 2; ++w) { for (void* q : h->rp_work[w]) if (q) hipFree(q); if (h->rp_map[w]) hipFree(h->rp_map[w]); }
+  for (int w = 0; w < 2; ++w) { for (void* q : h->rp_work[w]) g_free(h, q); g_free(h, h->rp_map[w]); }
   if (h->counter_host) hipHostFree(h->counter_host);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   for (hipEvent_t e : h->sev) if (e) hipEventDestroy(e);
@@ -1275,7 +1394,7 @@ int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
   return upload_tables(h);
 }
 
-int to_rollout(to_handle* h) { CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h)); TRY(launch_rollout(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return TO_OK; }
+int to_rollout(to_handle* h) { CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h)); TRY(launch_rollout(h)); HIPCHECK(hipStreamSynchronize(h->stream)); return check_guards(h, "to_rollout"); }
 int to_cost(to_handle* h, double* J) {
   CHECK_H(h); CHECK_IDLE(h); CHECK_P(J); TRY(use_device(h));
   TRY(launch_cost(h, 0, h->d_tmp, nullptr));
@@ -1304,7 +1423,7 @@ int to_expand(to_handle* h) {
   CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
   TRY(launch_set_active(h, 1)); TRY(launch_expand(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
-  return TO_OK;
+  return check_guards(h, "to_expand");
 }
 int to_backward(to_handle* h) {
   CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
@@ -1316,7 +1435,7 @@ int to_backward(to_handle* h) {
     TRY(h->ops->expand_backward_scan(h));
   } else TRY(launch_backward(h));
   HIPCHECK(hipStreamSynchronize(h->stream));
-  return TO_OK;
+  return check_guards(h, "to_backward");
 }
 int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
   CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
@@ -1329,7 +1448,7 @@ int to_forward(to_handle* h, int32_t* ls_index, double* J_new) {
   TRY(download_int(h, ls_index, h->a.ls_index));
   TRY(download_scalar(h, J_new, h->a.Jout));
   HIPCHECK(hipStreamSynchronize(h->stream));
-  return TO_OK;
+  return check_guards(h, "to_forward");
 }
 int to_ilqr_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); CHECK_IDLE(h); return solve(h, st, 0); }
 int to_al_solve(to_handle* h, to_solve_stats* st) { CHECK_H(h); CHECK_IDLE(h); return solve(h, st, 1); }
