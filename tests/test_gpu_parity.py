@@ -1643,13 +1643,15 @@ def test_state_and_control_limits_of_the_initial_rollout(kind, hip, oracle):
             return configs.cartpole_problem(batch=70, N=41, tf=2.0, lib=lib)
         if kind == "cartpole_big":
             return configs.cartpole_problem(batch=40000, N=21, tf=1.0, lib=lib)
-        return configs.quadrotor_problem(batch=48, N=41, tf=1.0, constrained=(kind == "quadrotor_al"), u_norm_max=2.6, lib=lib)
+        if kind == "quadrotor_al":  # (the C5 shape of test_al_solve_quadrotor_soc: tolerance 1e-4 keeps the AL solve out of its chaotic tail)
+            return configs.quadrotor_problem(batch=24, N=101, tf=5.0, constrained=True, lib=lib, options=T.SolverOptions(lib=lib, constraint_tolerance=1e-4))
+        return configs.quadrotor_problem(batch=48, N=41, tf=1.0, lib=lib)
     ph, po = mk(hip), mk(oracle)
     B, N, m = ph.B, ph.N, ph.m
     U = T.controls(ph).copy()
     bad_u, bad_x, bad_nan = [1, B // 2, B - 1], [3, B // 2 + 1], [5]
     cart = kind.startswith("cartpole")
-    lim = dict(max_control_value=50.0, max_state_value=30.0 if cart else 500.0)
+    lim = dict(max_control_value=50.0, max_state_value=30.0 if cart else 2000.0)  # (2000: far from anything a line-search candidate of the healthy trajectories reaches — the limit test is a sharp threshold)
     for b in bad_u:
         U[b, 7, 0] = 60.0        # beyond max_control_value at knot 8; the state it produces stays inside
     for b in bad_x:
@@ -1660,7 +1662,7 @@ def test_state_and_control_limits_of_the_initial_rollout(kind, hip, oracle):
     Solver = T.ALSolver if kind == "quadrotor_al" else T.iLQRSolver
     kw = dict(iterations=12, **lim) if kind == "cartpole_big" else dict(lim)
     sh, so = Solver(ph, **kw).solve(), Solver(po, **kw).solve()
-    for k in ("status", "iterations", "iterations_outer"):
+    for k in ("status", "iterations", "iterations_outer", "iterations_pn"):
         np.testing.assert_array_equal(sh.stats[k], so.stats[k], err_msg=k)
     st = sh.stats["status"]
     assert (st[bad_u] == T.capi.CONTROL_LIMIT).all() and (st[bad_x] == T.capi.STATE_LIMIT).all() and st[bad_nan[0]] == T.capi.STATE_LIMIT
