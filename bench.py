@@ -55,7 +55,7 @@ WORKLOADS = {
 
 # pipelined solves: the next solve is admitted when the one in flight has this fraction of its batch still iterating (measured per
 # workload: tools/ab/ab_pipeline.py, profiles/r06_ab/)
-ADMIT_FRAC = {"quadrotor": 0.5, "quadrotor_altro": 0.5, "quadrotor_altro_defaults": 0.5, "quadrotor_al": 0.5}
+ADMIT_FRAC = {"quadrotor": 1.0, "quadrotor_altro": 1.0, "quadrotor_altro_defaults": 1.0, "quadrotor_al": 1.0}
 
 
 def make_solver(T, configs, name, prob):
@@ -317,9 +317,9 @@ def pipelined_run(T, configs, lib, name, batch, depth, steps, warmup, admit_frac
     the last wait: the ramp-up and the final, un-overlapped drain are inside the figure."""
     probs = [prob0] + [build_problem(T, configs, name, batch, 0, device, lib) for _ in range(depth - 1)]
     solvers = [solver0] + [make_solver(T, configs, name, p) for p in probs[1:]]
-    for s_ in solvers[1:]:
-        T.initial_controls(s_.prob, u0)
-        s_.solve()                       # warm every handle (allocations of the first solve: polish workspace, event pools)
+    for i in range(1, depth):
+        T.initial_controls(probs[i], u0)
+        solvers[i].solve()               # warm every handle (allocations of the first solve: polish workspace, event pools)
     prep = lambda p: T.initial_controls(p, u0)
     best = None
     for rep in range(1 + warmup):        # the warm-up repetitions run the same pipelined sequence
@@ -331,6 +331,10 @@ def pipelined_run(T, configs, lib, name, batch, depth, steps, warmup, admit_frac
         dt = time.perf_counter() - t0
         best = (dt, pipe.total_iterations, sum(r[2] for r in pipe.results))
     dt, its, bsteps = best
+    prob0._call("set_shared_device", 0)
+    del pipe, solvers, probs      # the extra handles go NOW: idle streams take hardware-queue slots from whatever runs next
+    import gc
+    gc.collect()
     return {"depth": depth, "admit_below": int(admit_frac * batch), "steps": steps, "value": its / dt, "ms_per_step": 1e3 * dt / steps,
             "trajectory_iterations": its, "batch_steps_per_solve": bsteps / steps,
             "note": "value = trajectory-iterations of `steps` solves / wall time from the first submit to the last wait (ramp-up and final drain included); "
@@ -509,7 +513,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     ap.add_argument("--pipeline", type=int, default=-1,
                     help="pipeline the solves over this many handles (the next solve is admitted when the one in flight has drained below "
-                         "--admit of its batch); default: 2 for the Quadrotor workloads (the extra C3 / C5 lines included), 0 for the Cartpole "
+                         "--admit of its batch); default: 3 for the Quadrotor workloads (the extra C3 / C5 lines included), 0 for the Cartpole "
                          "headline (two host threads driving 100 us batch steps lose: DESIGN.md §4.10)")
     ap.add_argument("--pipeline-steps", type=int, default=0, help="solves of the pipelined pass (default max(steps, 2 x depth))")
     ap.add_argument("--admit", type=float, default=-1.0, help="admit the next solve at this fraction of the batch still iterating (default per workload)")
@@ -552,10 +556,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: libtrajopt_hip.so has no CPU fallback")
     name = args.workload
     batch = args.batch or WORKLOADS[name]["batch"]
-    depth = args.pipeline if args.pipeline >= 0 else (0 if name == "cartpole" else 2)
+    depth = args.pipeline if args.pipeline >= 0 else (0 if name == "cartpole" else 3)
     res, prob, u0 = run_workload(T, configs, lib, name, batch, args.steps, args.warmup, rank, local_rank, world, dist, torch,
                                  profile=not args.no_profile, pipeline=depth, pipeline_steps=args.pipeline_steps,
-                                 admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(name, 0.5))
+                                 admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(name, 1.0))
 
     if rank == 0:
         out = {"metric": "iLQR iterations/sec (batched trajectories)", "value": res["value"], "unit": res["unit"],
@@ -609,18 +613,22 @@ def main():
                 except Exception as e:
                     out["c1_cpu"] = {"error": repr(e)}
     del prob
+    import gc
+    gc.collect()
     # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
     if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:
         extra = {}
-        for key, wname, pdepth, psteps in (("C3", "quadrotor", 2, 8), ("C5", "quadrotor_altro", 2, 6), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
+        for key, wname, pdepth, psteps in (("C3", "quadrotor", 3, 12), ("C5", "quadrotor_altro", 3, 9), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
             try:
                 if args.pipeline >= 0:
                     pdepth = args.pipeline if pdepth else 0
                 r, p2, _ = run_workload(T, configs, lib, wname, WORKLOADS[wname]["batch"], 2, 1, 0, local_rank, 1, None, torch,
                                         profile=(not args.no_profile) and key != "C5_altro_defaults",
                                         pipeline=pdepth, pipeline_steps=psteps,
-                                        admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(wname, 0.5))
+                                        admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(wname, 1.0))
                 del p2
+                import gc
+                gc.collect()
                 if not args.no_cpu_baseline and key != "C5_altro_defaults":
                     r["cpu_baseline"] = cpu_baseline(T, configs, wname, WORKLOADS[wname]["batch"])
                 extra[key] = r

@@ -54,7 +54,8 @@ def main():
                                   "ms_per_solve": 1e3 * dt / steps}), flush=True)
         v, ms = unpipelined()
         print(json.dumps({"workload": name, "depth": 1, "value": v, "ms_per_solve": ms, "when": "after"}), flush=True)
-        del solvers, probs
+        del solvers, probs, pipe, s
+        import gc; gc.collect()
 
 
 if __name__ == "__main__":
