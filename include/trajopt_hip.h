@@ -54,7 +54,8 @@ extern "C" {
  * to_problem_desc::step_models (general model vectors).  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version.  5: TO_MODEL_INFEASIBLE, to_infeasible_controls, to_set_cost_linear_batch, to_get_cost_to_go.
- * 6: to_solve_progress / to_solve_wait_below / to_set_shared_device (pipelined solves over several handles); TO_STATE_LIMIT / TO_CONTROL_LIMIT are
+ * 6: to_solve_progress / to_solve_wait_below / to_set_shared_device (pipelined solves over several handles), to_set_constraint_params_batch /
+ * to_clear_constraint_params_batch (one GoalConstraint target per trajectory); TO_STATE_LIMIT / TO_CONTROL_LIMIT are
  * emitted; TRAJOPT_RCCL_LIB, TRAJOPT_GUARD. */
 #define TO_ABI_VERSION 6
 
@@ -362,12 +363,20 @@ int to_set_constraint(to_handle* h, int32_t con_id, const to_constraint_desc* co
  * either may be NULL) REPLACE the linear terms of cost `cost_id` for trajectory b; Q, R, H, c stay the descriptor's.  The host mirrors
  * compute q_b = -Q xf_b (set_goal_state!(prob, Xf::Matrix), src/problem.jl:294-310).  Kinds DIAGONAL, QUADRATIC, DIAGONAL_QUAT (its
  * quaternion reference q_ref stays shared); TO_ERR_UNSUPPORTED for ERROR_QUADRATIC.  to_set_cost on a cost resets its per-trajectory
- * terms; to_clear_cost_linear_batch returns the whole handle to shared descriptors.  Constraint parameters (GoalConstraint's xf) stay
- * shared by the batch: hard per-trajectory goals need one handle per goal.  The projected-Newton polish builds its metric from the
+ * terms; to_clear_cost_linear_batch returns the whole handle to shared descriptors.  A GoalConstraint's target per trajectory:
+ * to_set_constraint_params_batch (below).  The projected-Newton polish builds its metric from the
  * descriptors alone (per-trajectory q does not enter a Hessian except through the attitude term of quaternion states, which the polish
  * then takes from the shared q). */
 int to_set_cost_linear_batch(to_handle* h, int32_t cost_id, const double* q /* [n*B] or NULL */, const double* r /* [m*B] or NULL */);
 int to_clear_cost_linear_batch(to_handle* h);
+/* One constraint-parameter set per TRAJECTORY (round 6): set_goal_state!(prob, xf; constraint = true) updates the GoalConstraints too
+ * (src/problem.jl:303-309, src/constraints.jl:22-87) — here for every trajectory of the batch at once.  con_id must be a GOAL constraint;
+ * params[p, B] (column-major) = xf_b[inds], the target of trajectory b.  Everything that evaluates the constraint — AL terms and their
+ * expansion, violation, dual update, the projected-Newton polish, to_evaluate_constraints — then uses the trajectory's own target (the
+ * solves run the general kernel variants while any constraint carries per-trajectory parameters).  to_set_constraint on the
+ * constraint returns it to shared parameters, to_clear_constraint_params_batch all of them.  Other kinds: TO_ERR_UNSUPPORTED. */
+int to_set_constraint_params_batch(to_handle* h, int32_t con_id, const double* params /* [p*B] */);
+int to_clear_constraint_params_batch(to_handle* h);
 
 /* ---- the hot path, phase by phase ----------------------------------------------------------- */
 int to_rollout(to_handle* h);                                   /* rollout!  src/problem.jl:330-340 */

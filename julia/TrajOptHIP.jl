@@ -598,23 +598,36 @@ end
 """
     TO.set_goal_state!(p::BatchProblem, Xf::Matrix)        # Xf :: (n, B): one goal per trajectory
 `set_LQR_goal!(cost, xf_b)` (src/cost_functions.jl:249-252: q = -Q xf, nothing else) on every cost of the objective for every
-trajectory of the batch — batched MPC / goal sweeps on one handle (SURVEY §8b).  Constraint parameters (a GoalConstraint's xf) stay
-shared; `clear_goal_state_batch!` returns to the shared descriptors.
+trajectory of the batch — batched MPC / goal sweeps on one handle (SURVEY §8b) — and, with `constraint = true` (the reference's default,
+src/problem.jl:303-309), the target `xf_b[inds]` of every GoalConstraint (`to_set_constraint_params_batch`); `clear_goal_state_batch!`
+returns to the shared descriptors.
 """
-function TO.set_goal_state!(p::BatchProblem, Xf::Matrix{Float64})
+function TO.set_goal_state!(p::BatchProblem, Xf::Matrix{Float64}; objective::Bool = true, constraint::Bool = true)
     size(Xf) == (p.n, p.B) || throw(DimensionMismatch("Xf must be (n, B)"))
-    costs = Any[]
-    for c in p.prob.obj.cost
-        any(x -> x === c, costs) || push!(costs, c)
+    if objective
+        costs = Any[]
+        for c in p.prob.obj.cost
+            any(x -> x === c, costs) || push!(costs, c)
+        end
+        for (i, c) in enumerate(costs)
+            c isa TO.QuadraticCostFunction || throw(MethodError(TO.set_LQR_goal!, (c, Xf)))
+            q = -(c.Q * Xf)                                   # (n, B), column-major
+            check(ccall((:to_set_cost_linear_batch, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), p.handle, i - 1, q, C_NULL))
+        end
     end
-    for (i, c) in enumerate(costs)
-        c isa TO.QuadraticCostFunction || throw(MethodError(TO.set_LQR_goal!, (c, Xf)))
-        q = -(c.Q * Xf)                                   # (n, B), column-major
-        check(ccall((:to_set_cost_linear_batch, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}), p.handle, i - 1, q, C_NULL))
+    if constraint   # src/problem.jl:303-309: every GoalConstraint of the list gets the new target — here one per trajectory
+        for (i, con) in enumerate(p.prob.constraints)
+            con isa TO.GoalConstraint || continue
+            par = Xf[collect(con.inds), :]                    # (p, B), column-major
+            check(ccall((:to_set_constraint_params_batch, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), p.handle, i - 1, par))
+        end
     end
     nothing
 end
-clear_goal_state_batch!(p::BatchProblem) = check(ccall((:to_clear_cost_linear_batch, lib), Cint, (Ptr{Cvoid},), p.handle))
+function clear_goal_state_batch!(p::BatchProblem)
+    check(ccall((:to_clear_cost_linear_batch, lib), Cint, (Ptr{Cvoid},), p.handle))
+    check(ccall((:to_clear_constraint_params_batch, lib), Cint, (Ptr{Cvoid},), p.handle))
+end
 "Cost-to-go of the last backward pass: S[ne,ne,N,B], s[ne,N,B] (S_N = Qxx_N; S_k = Qxx + K'Quu K + K'Qux + Qux'K)."
 function cost_to_go(p::BatchProblem)
     S, s = zeros(p.ne, p.ne, p.N, p.B), zeros(p.ne, p.N, p.B)

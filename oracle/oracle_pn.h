@@ -61,14 +61,16 @@ int pn_candidate_count(const Problem& P, int k) {
 }
 
 /* values (and gradients with respect to z = [x; u], row-major [q][nz]) of every candidate row of knot k */
-int pn_candidates(const Problem& P, const double* X, const double* U, int k, double* val, double* grad) {
+int pn_candidates(const Problem& P, const Traj& t, const double* X, const double* U, int k, double* val, double* grad) {
   const int n = P.n, m = P.m, nz = n + m;
   double z[MAXZ], c[TO_MAX_P], jac[TO_MAX_P * MAXZ];
   knot_z(P, X, U, k, z);
   int q = 0;
-  for (const ConInfo& ci : P.cons) {
+  for (size_t ic = 0; ic < P.cons.size(); ++ic) {
+    const ConInfo& ci = P.cons[ic];
     if (k < ci.k1 || k > ci.k2) continue;
-    constraint_evaluate(ci.d, n, m, z, c, grad ? jac : nullptr);
+    EffDesc ed;
+    constraint_evaluate(ed.get(t, ic, ci), n, m, z, c, grad ? jac : nullptr);
     if (ci.d.sense == TO_CONE_SECOND_ORDER) { /* [v; s] in the cone <=> |v| - s <= 0 */
       const int p = ci.p;
       double a2 = 0.0; for (int i = 0; i < p - 1; ++i) a2 += c[i] * c[i];
@@ -129,7 +131,7 @@ double pn_residual(const Problem& P, const Traj& t, const double* X, const doubl
   if (refresh) {
     s.mask.assign(N, 0); s.goff.assign(N + 1, 0);
     for (int k = 0; k < N; ++k) {
-      const int nq = pn_candidates(P, X, U, k, val, grad);
+      const int nq = pn_candidates(P, t, X, U, k, val, grad);
       pn_candidate_senses(P, k, eq);
       errstate_jacobian(P.M, &X[(size_t)k * n], G);
       uint64_t mk = 0; int pa = 0;
@@ -151,7 +153,7 @@ double pn_residual(const Problem& P, const Traj& t, const double* X, const doubl
   for (int k = 0; k < N; ++k) {
     double* dk = &d[s.goff[k]];
     pn_defect(P, t, X, U, k, dk);
-    const int nq = pn_candidates(P, X, U, k, val, nullptr);
+    const int nq = pn_candidates(P, t, X, U, k, val, nullptr);
     int a = 0;
     for (int q = 0; q < nq; ++q) if (s.mask[k] >> q & 1) dk[ne + a++] = val[q];
     for (int i = 0; i < ne + a; ++i) { const double v = std::fabs(dk[i]); if (v > viol || std::isnan(v)) viol = v; }
@@ -186,7 +188,7 @@ void pn_linearise(const Problem& P, const Traj& t, const double* X, const double
       }
     }
     /* active constraint rows, in error-state coordinates */
-    const int nq = pn_candidates(P, X, U, k, val, grad);
+    const int nq = pn_candidates(P, t, X, U, k, val, grad);
     errstate_jacobian(P.M, &X[(size_t)k * n], G);
     int a = 0;
     for (int q = 0; q < nq; ++q) {

@@ -70,6 +70,8 @@ struct Traj {
   std::vector<double> Sall, sall;             /* [N] ne*ne, ne: cost-to-go of the last backward pass (oracle_get_cost_to_go) */
   std::vector<double> gl;                     /* per-trajectory linear cost terms, [n_costs] (n + m): what q, r differ by from the descriptor (empty: none) */
   std::vector<double> lambda, mu;             /* duals (n_duals), penalties (ncons) */
+  std::vector<std::vector<double>> cpar;      /* per-trajectory constraint parameters (oracle_set_constraint_params_batch): cpar[i] replaces the
+                                                 leading parameters of constraint i's descriptor for THIS trajectory (empty: the shared ones) */
   double dV[2] = {0, 0};
   double rho = 0, drho = 0;
   double J = 0, dJ = 0, grad = 0, c_max = 0;
@@ -310,10 +312,22 @@ double objective_knot(const Problem& P, const double* X, const double* U, int k,
   return J;
 }
 
+/* The descriptor constraint i has for trajectory t: the shared one, or — set_goal_state!(prob, Xf; constraint = true) with one goal per
+ * trajectory, src/problem.jl:303-309 — a copy whose leading parameters are the trajectory's own. */
+struct EffDesc {
+  to_constraint_desc tmp;
+  const to_constraint_desc& get(const Traj& t, size_t i, const ConInfo& ci) {
+    if (i >= t.cpar.size() || t.cpar[i].empty()) return ci.d;
+    tmp = ci.d;
+    for (size_t r = 0; r < t.cpar[i].size(); ++r) tmp.params[r] = t.cpar[i][r];
+    return tmp;
+  }
+};
+
 /* AL penalty of constraint ci at one knot; lambda points at the p duals of that knot */
-double al_term(const ConInfo& ci, int n, int m, const double* z, const double* lambda, double mu) {
+double al_term(const ConInfo& ci, const to_constraint_desc& D, int n, int m, const double* z, const double* lambda, double mu) {
   double c[TO_MAX_P];
-  constraint_evaluate(ci.d, n, m, z, c, nullptr);
+  constraint_evaluate(D, n, m, z, c, nullptr);
   const int p = ci.p;
   double J = 0.0;
   if (ci.d.sense == TO_CONE_ZERO) {
@@ -340,7 +354,8 @@ double al_knot(const Problem& P, const Traj& t, const double* X, const double* U
   for (size_t i = 0; i < P.cons.size(); ++i) {
     const ConInfo& ci = P.cons[i];
     if (k < ci.k1 || k > ci.k2) continue;
-    J += al_term(ci, P.n, P.m, z, &t.lambda[ci.dual_off + (size_t)(k - ci.k1) * ci.p], t.mu[i]);
+    EffDesc ed;
+    J += al_term(ci, ed.get(t, i, ci), P.n, P.m, z, &t.lambda[ci.dual_off + (size_t)(k - ci.k1) * ci.p], t.mu[i]);
   }
   return J;
 }
@@ -357,10 +372,13 @@ double total_cost(const Problem& P, const Traj& t, const double* X, const double
 
 double max_violation(const Problem& P, const Traj& t) {
   double cmax = 0.0, z[MAXZ], c[TO_MAX_P], pc[TO_MAX_P];
-  for (const ConInfo& ci : P.cons)
+  EffDesc ed;
+  for (size_t ic = 0; ic < P.cons.size(); ++ic) {
+    const ConInfo& ci = P.cons[ic];
+    const to_constraint_desc& D = ed.get(t, ic, ci);
     for (int k = ci.k1; k <= ci.k2; ++k) {
       knot_z(P, t.X.data(), t.U.data(), k, z);
-      constraint_evaluate(ci.d, P.n, P.m, z, c, nullptr);
+      constraint_evaluate(D, P.n, P.m, z, c, nullptr);
       for (int i = 0; i < ci.p; ++i) {
         double v;
         if (ci.d.sense == TO_CONE_ZERO) v = std::fabs(c[i]);
@@ -369,6 +387,7 @@ double max_violation(const Problem& P, const Traj& t) {
         if (v > cmax || std::isnan(v)) cmax = v;
       }
     }
+  }
   return cmax;
 }
 
@@ -377,9 +396,11 @@ void dual_update(const Problem& P, Traj& t) {
   for (size_t i = 0; i < P.cons.size(); ++i) {
     const ConInfo& ci = P.cons[i];
     double mu = t.mu[i];
+    EffDesc ed;
+    const to_constraint_desc& D = ed.get(t, i, ci);
     for (int k = ci.k1; k <= ci.k2; ++k) {
       knot_z(P, t.X.data(), t.U.data(), k, z);
-      constraint_evaluate(ci.d, P.n, P.m, z, c, nullptr);
+      constraint_evaluate(D, P.n, P.m, z, c, nullptr);
       double* lam = &t.lambda[ci.dual_off + (size_t)(k - ci.k1) * ci.p];
       if (ci.d.sense == TO_CONE_ZERO) {
         for (int r = 0; r < ci.p; ++r) lam[r] = std::fmax(-P.opts.dual_max, std::fmin(P.opts.dual_max, lam[r] + mu * c[r]));
@@ -411,7 +432,9 @@ void knot_expansion_full(const Problem& P, const Traj& t, const double* X, const
     if (k < ci.k1 || k > ci.k2) continue;
     const int p = ci.p; const double mu = t.mu[i];
     const double* lam = &t.lambda[ci.dual_off + (size_t)(k - ci.k1) * p];
-    constraint_evaluate(ci.d, n, m, z, c, jac);
+    EffDesc ed;
+    const to_constraint_desc& D = ed.get(t, i, ci);
+    constraint_evaluate(D, n, m, z, c, jac);
     std::memset(W, 0, sizeof(double) * p * p);
     if (ci.d.sense == TO_CONE_ZERO) {
       for (int r = 0; r < p; ++r) { y[r] = lam[r] + mu * c[r]; W[r * p + r] = mu; }
@@ -435,7 +458,7 @@ void knot_expansion_full(const Problem& P, const Traj& t, const double* X, const
     }
     /* full Newton (opts.al_full_newton): + sum_r y_r d2c_r/dz2 with the multiplier estimate y; the SOC branch already carries the
        curvature of the projection and its constraints are linear in z */
-    if (P.opts.al_full_newton && ci.d.sense != TO_CONE_SECOND_ORDER) constraint_hessian_add(ci.d, n, m, z, y, hess, nz);
+    if (P.opts.al_full_newton && ci.d.sense != TO_CONE_SECOND_ORDER) constraint_hessian_add(D, n, m, z, y, hess, nz);
     /* grad += jac' y ; hess += jac' W jac */
     for (int a = 0; a < nz; ++a) { double s = 0.0; for (int r = 0; r < p; ++r) s += jac[r * nz + a] * y[r]; grad[a] += s; }
     double WJ[TO_MAX_P * MAXZ];
@@ -1062,7 +1085,28 @@ int oracle_set_constraint(oracle_handle* h, int32_t id, const to_constraint_desc
   ConInfo ci; int r = validate_constraint(h->P, *c, &ci); if (r) return r;
   const ConInfo& old = h->P.cons[id];
   if (ci.p != old.p || ci.k1 != old.k1 || ci.k2 != old.k2) return fail(TO_ERR_DIMENSION_MISMATCH, "replacement constraint must keep p and the knot range");
-  ci.dual_off = old.dual_off; h->P.cons[id] = ci; return TO_OK;
+  ci.dual_off = old.dual_off; h->P.cons[id] = ci;
+  for (Traj& t : h->T) if ((size_t)id < t.cpar.size()) t.cpar[id].clear();  /* its per-trajectory parameters start over */
+  return TO_OK;
+}
+/* One parameter set per TRAJECTORY for constraint id (to_set_constraint_params_batch): params[n_params, B] column-major.  GOAL: xf[inds]. */
+int oracle_set_constraint_params_batch(oracle_handle* h, int32_t id, const double* params) {
+  CHECK_H(h); CHECK_P(params);
+  if (id < 0 || id >= (int)h->P.cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  const ConInfo& ci = h->P.cons[id];
+  if (ci.d.kind != TO_CON_GOAL) return fail(TO_ERR_UNSUPPORTED, "per-trajectory constraint parameters: GoalConstraint only");
+  const int np = ci.p;
+  for (int b = 0; b < h->P.B; ++b) {
+    Traj& t = h->T[b];
+    if (t.cpar.size() < h->P.cons.size()) t.cpar.resize(h->P.cons.size());
+    t.cpar[id].assign(params + (size_t)np * b, params + (size_t)np * (b + 1));
+  }
+  return TO_OK;
+}
+int oracle_clear_constraint_params_batch(oracle_handle* h) {
+  CHECK_H(h);
+  for (Traj& t : h->T) t.cpar.clear();
+  return TO_OK;
 }
 
 int oracle_rollout(oracle_handle* h) { CHECK_H(h); for_batch(h, [&](Traj& t, int) { rollout(h->P, t); }); return TO_OK; }
@@ -1252,7 +1296,8 @@ int oracle_evaluate_constraints(oracle_handle* h, int32_t id, double* vals) {
   double z[MAXZ], c[TO_MAX_P];
   for (int b = 0; b < h->P.B; ++b) for (int k = ci.k1; k <= ci.k2; ++k) {
     knot_z(h->P, h->T[b].X.data(), h->T[b].U.data(), k, z);
-    constraint_evaluate(ci.d, h->P.n, h->P.m, z, c, nullptr);
+    EffDesc ed;
+    constraint_evaluate(ed.get(h->T[b], id, ci), h->P.n, h->P.m, z, c, nullptr);
     for (int r = 0; r < ci.p; ++r) vals[r + ci.p * ((k - ci.k1) + (size_t)nk * b)] = c[r];
   }
   return TO_OK;
@@ -1264,7 +1309,8 @@ int oracle_constraint_jacobians(oracle_handle* h, int32_t id, double* jac) {
   double z[MAXZ], c[TO_MAX_P], J[TO_MAX_P * MAXZ];
   for (int b = 0; b < h->P.B; ++b) for (int k = ci.k1; k <= ci.k2; ++k) {
     knot_z(h->P, h->T[b].X.data(), h->T[b].U.data(), k, z);
-    constraint_evaluate(ci.d, h->P.n, h->P.m, z, c, J);
+    EffDesc ed;
+    constraint_evaluate(ed.get(h->T[b], id, ci), h->P.n, h->P.m, z, c, J);
     size_t kb = (k - ci.k1) + (size_t)nk * b;
     for (int r = 0; r < ci.p; ++r) for (int j = 0; j < w; ++j) jac[r + ci.p * (j + (size_t)w * kb)] = J[r * nz + j];
   }
@@ -1278,7 +1324,8 @@ int oracle_constraint_hessians(oracle_handle* h, int32_t id, const double* lambd
   for (int b = 0; b < h->P.B; ++b) for (int k = ci.k1; k <= ci.k2; ++k) {
     knot_z(h->P, h->T[b].X.data(), h->T[b].U.data(), k, z);
     const size_t kb = (k - ci.k1) + (size_t)nk * b;
-    constraint_hessian_add(ci.d, h->P.n, h->P.m, z, lambda + (size_t)ci.p * kb, H + (size_t)w * w * kb, w);
+    EffDesc ed;
+    constraint_hessian_add(ed.get(h->T[b], id, ci), h->P.n, h->P.m, z, lambda + (size_t)ci.p * kb, H + (size_t)w * w * kb, w);
   }
   return TO_OK;
 }

@@ -57,9 +57,67 @@ def test_per_trajectory_goal_checks(oracle):
     p = configs.cartpole_problem(batch=3, constrained=True, lib=oracle)
     with pytest.raises(T.DimensionMismatch):
         T.set_goal_state(p, np.zeros((2, 4)))
-    with pytest.raises(T.UnsupportedError):        # the GoalConstraint's target is shared by the batch
-        T.set_goal_state(p, np.zeros((3, 4)))
+    T.set_goal_state(p, np.zeros((3, 4)))                      # objective and GoalConstraint, one target per trajectory
     T.set_goal_state(p, np.zeros((3, 4)), constraint=False)
+    with pytest.raises(T.UnsupportedError, match="GoalConstraint only"):
+        p._call("set_constraint_params_batch", 0, p._pd(np.zeros((3, 1))))      # constraint 0 is the control bound
+    with pytest.raises(T.ArgumentError):
+        p._call("set_constraint_params_batch", 7, p._pd(np.zeros((3, 4))))
+
+
+def test_per_trajectory_goal_constraints_equal_single_trajectory_problems(oracle):
+    """set_goal_state!(prob, xf; constraint = true) retargets the GoalConstraint as well (src/problem.jl:303-309, src/constraints.jl:22-87).
+    With one goal per trajectory (to_set_constraint_params_batch) every trajectory of the batch must behave exactly like a
+    single-trajectory problem retargeted with the reference's scalar verb: constraint values and Jacobians, violation, AL cost, the
+    expansion's gains, whole AL and ALTRO solves (integers equal, the cart at ITS goal to the constraint tolerance)."""
+    B = 5
+    Xf = cartpole_goals(B, seed=11)
+    Xf[:, 0] *= 0.5
+    pb = configs.cartpole_problem(batch=B, constrained=True, lib=oracle)
+    x0 = np.empty((B, 4)); pb._call("get_initial_state", pb._pd(x0))
+    T.set_goal_state(pb, Xf)
+    T.rollout(pb)
+    I.dual_update(pb); I.dual_update(pb)
+    gi = len(pb.constraints) - 1                               # the GoalConstraint
+    cb, jb = T.evaluate_constraints(pb, gi), T.constraint_jacobians(pb, gi)
+    vb, ab = T.max_violation(pb), I.al_cost(pb)
+    I.expand(pb); I.backwardpass(pb)
+    gb = I.gains(pb)
+    singles = []
+    for b in range(B):
+        p1 = configs.cartpole_problem(batch=1, constrained=True, lib=oracle)
+        p1.set_initial_state(x0[b])
+        T.set_goal_state(p1, Xf[b])                            # the reference's scalar verb: objective + GoalConstraint
+        T.rollout(p1)
+        I.dual_update(p1); I.dual_update(p1)
+        np.testing.assert_allclose(T.evaluate_constraints(p1, gi)[0], cb[b], rtol=1e-13, atol=1e-14)
+        np.testing.assert_array_equal(T.constraint_jacobians(p1, gi)[0], jb[b])
+        np.testing.assert_allclose(T.max_violation(p1)[0], vb[b], rtol=1e-13)
+        np.testing.assert_allclose(I.al_cost(p1)[0], ab[b], rtol=1e-12)
+        I.expand(p1); I.backwardpass(p1)
+        g1 = I.gains(p1)
+        np.testing.assert_allclose(g1["d"][0], gb["d"][b], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(g1["K"][0], gb["K"][b], rtol=1e-9, atol=1e-10)
+        singles.append(p1)
+    assert np.ptp(cb[:, 0, 0]) > 0.1                           # the targets do differ
+    for Solver in (T.ALSolver, T.ALTROSolver):
+        for p in [pb] + singles:
+            T.initial_controls(p, np.full(1, 0.01)); I.reset_duals(p)
+        sb = Solver(pb).solve()
+        Xb = T.states(pb)
+        for b, p1 in enumerate(singles):
+            s1 = Solver(p1).solve()
+            for k in ("iterations", "iterations_outer", "iterations_pn", "status"):
+                assert int(s1.stats[k][0]) == int(sb.stats[k][b]), (Solver.__name__, k, b)
+            np.testing.assert_allclose(T.states(p1)[0], Xb[b], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(s1.stats["c_max"][0], sb.stats["c_max"][b], rtol=1e-5, atol=1e-12)
+        assert (sb.stats["status"] == T.capi.SOLVE_SUCCEEDED).all() and sb.stats["c_max"].max() < 1e-6
+        assert np.abs(Xb[:, -1, :] - Xf).max() < 1e-5          # every cart AT its own goal, to the constraint tolerance
+    # to_set_constraint returns a constraint to shared parameters; the scalar verb does exactly that
+    T.set_goal_state(pb, Xf[0])
+    T.rollout(pb)
+    c0 = T.evaluate_constraints(pb, gi)
+    np.testing.assert_allclose(c0[:, 0, :], T.states(pb)[:, -1, :] - Xf[0][None, :], rtol=0, atol=1e-14)
 
 
 @pytest.mark.gpu
@@ -126,3 +184,46 @@ def test_per_trajectory_goals_quadrotor_and_constraints_on_gpu(hip, oracle):
     (sh, ph, G), (so, po, _) = out
     assert_solve_parity(sh, so, ph, po)
     assert np.all(sh.stats["status"] == T.capi.SOLVE_SUCCEEDED) and np.abs(T.states(ph)[:, -1, :2] - G[:, :2]).max() < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cartpole", "cartpole_lane", "quadrotor"])
+def test_per_trajectory_goal_constraints_on_gpu(kind, hip, oracle, monkeypatch):
+    """One GoalConstraint target per trajectory (to_set_constraint_params_batch) on the GPU against the oracle: constraint values, the AL
+    expansion's gains, the forward pass, then whole AL and ALTRO solves with integers bit-exact — Cartpole on the cooperative path and on
+    the lane path with compaction, the Quadrotor with the C5 constraint set (goal on position + velocities, SOC on the controls)."""
+    from test_gpu_parity import assert_solve_parity
+    if kind == "cartpole_lane":
+        monkeypatch.setenv("TRAJOPT_BACKWARD", "lane"); monkeypatch.setenv("TRAJOPT_ACCEPT_ROLL_MIN", "1")
+    def mk(lib):
+        if kind == "quadrotor":
+            p = configs.quadrotor_problem(batch=24, N=61, tf=3.0, constrained=True, goal_inds=configs.C5_GOAL_INDS, lib=lib)
+            Xf = np.tile(p.xf, (p.B, 1)); Xf[:, :3] += np.random.default_rng(4).uniform(-0.6, 0.6, (p.B, 3))
+        else:
+            p = configs.cartpole_problem(batch=300 if kind == "cartpole_lane" else 70, constrained=True, lib=lib)
+            Xf = cartpole_goals(p.B, seed=3); Xf[:, 0] *= 0.5
+        T.set_goal_state(p, Xf)
+        return p, Xf
+    (ph, Xf), (po, _) = mk(hip), mk(oracle)
+    gi = len(ph.constraints) - 1 if kind != "quadrotor" else next(i for i, c in enumerate(ph.constraints.constraints) if isinstance(c, T.GoalConstraint))
+    for p in (ph, po):
+        T.rollout(p); I.dual_update(p); I.dual_update(p)
+    np.testing.assert_allclose(T.evaluate_constraints(ph, gi), T.evaluate_constraints(po, gi), rtol=1e-11, atol=1e-12)
+    np.testing.assert_array_equal(T.constraint_jacobians(ph, gi), T.constraint_jacobians(po, gi))
+    np.testing.assert_allclose(T.max_violation(ph), T.max_violation(po), rtol=1e-11)
+    np.testing.assert_allclose(I.al_cost(ph), I.al_cost(po), rtol=1e-11)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-6, atol=1e-8); np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-6, atol=1e-8)
+    lh, Jh = I.forwardpass(ph); lo, Jo = I.forwardpass(po)
+    np.testing.assert_array_equal(lh, lo); np.testing.assert_allclose(Jh, Jo, rtol=1e-9)
+    for Solver, kw in ((T.ALTROSolver, dict(n_steps=configs.C5_PN_STEPS) if kind == "quadrotor" else {}),
+                       (T.ALSolver, dict(constraint_tolerance=1e-4))):
+        (ph, Xf), (po, _) = mk(hip), mk(oracle)
+        sh, so = Solver(ph, **kw).solve(), Solver(po, **kw).solve()
+        assert_solve_parity(sh, so, ph, po, rtol=1e-5 if Solver is T.ALSolver else 1e-6)
+        ok = sh.stats["status"] == T.capi.SOLVE_SUCCEEDED
+        assert ok.mean() > 0.9
+        inds = [j - 1 for j in ph.constraints.constraints[gi].inds]
+        assert np.abs(T.states(ph)[ok][:, -1, inds] - Xf[ok][:, inds]).max() < (2e-4 if Solver is T.ALSolver else 1e-5)

@@ -167,6 +167,8 @@ SIGNATURES = {
     "set_constraint": [_H, C.c_int32, C.POINTER(ConstraintDesc)],
     "set_cost_linear_batch": [_H, C.c_int32, _PD, _PD],
     "clear_cost_linear_batch": [_H],
+    "set_constraint_params_batch": [_H, C.c_int32, _PD],
+    "clear_constraint_params_batch": [_H],
     "rollout": [_H],
     "cost": [_H, _PD],
     "stage_costs": [_H, _PD],

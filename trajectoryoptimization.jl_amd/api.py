@@ -1423,14 +1423,16 @@ def set_goal_state(prob, xf, objective=True, constraint=True):
 def _set_goal_state_batch(prob, Xf, objective=True, constraint=True):
     """set_goal_state!(prob, Xf) with ONE GOAL PER TRAJECTORY, Xf [B, n] (batched MPC / goal sweeps on one handle):
     set_LQR_goal!(cost, xf_b) on every cost for every trajectory — q_b = -Q xf_b, nothing else changes (src/cost_functions.jl:249-252)
-    — through to_set_cost_linear_batch.  A GoalConstraint's target stays shared by the batch (constraint parameters are not
-    per-trajectory): pass ``constraint=False`` on problems that carry one."""
+    — through to_set_cost_linear_batch, and with ``constraint=True`` the target of every GoalConstraint, xf_b[inds], through
+    to_set_constraint_params_batch."""
     Xf = np.ascontiguousarray(np.asarray(Xf, dtype=np.float64))
     if Xf.shape != (prob.B, prob.n):
         raise DimensionMismatch(f"Xf must be [B, n] = {(prob.B, prob.n)}; got {Xf.shape}")
-    if constraint and any(isinstance(c, GoalConstraint) for c in prob.constraints.constraints):
-        raise UnsupportedError("per-trajectory goals act on the objective; a GoalConstraint's xf is shared by the batch "
-                               "(pass constraint=False, or use one Problem per goal)")
+    if constraint:  # (src/problem.jl:303-309: every GoalConstraint of the list gets the new target — here trajectory by trajectory)
+        for i, con in enumerate(prob.constraints.constraints):
+            if isinstance(con, GoalConstraint):
+                par = np.ascontiguousarray(Xf[:, [j - 1 for j in con.inds]])      # [B, p] = column-major (p, B)
+                prob._call("set_constraint_params_batch", i, prob._pd(par))
     if objective:
         for i, c in enumerate(prob._cost_objs):
             if c.kind == capi.COST_ERROR_QUADRATIC:
@@ -1441,8 +1443,9 @@ def _set_goal_state_batch(prob, Xf, objective=True, constraint=True):
 
 
 def clear_goal_state_batch(prob):
-    """Back to the shared descriptors (to_clear_cost_linear_batch)."""
+    """Back to the shared descriptors (to_clear_cost_linear_batch, to_clear_constraint_params_batch)."""
     prob._call("clear_cost_linear_batch")
+    prob._call("clear_constraint_params_batch")
     prob.xf_batch = None
 
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ double* slot_ptr(double* nominal, double* cand, const
 // gl0: this lane's pointer into DevProblem::gl (per-trajectory linear cost terms; nullptr: none)
 template <class M, bool GEN = true>
 __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
-                                            const double* mu0, bool with_al, const double* gl0 = nullptr) {
+                                            const double* mu0, bool with_al, const double* gl0 = nullptr, const double* cp0 = nullptr) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   const int cidx = P.cost_index[k];
   double Jk = cost_eval<n, m, GEN>(P.costs[cidx], x, u);
@@ -126,6 +126,13 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
       ConC& K = P.cons[ci];
       if (k < K.k1 || k > K.k2) continue;
       const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+      if constexpr (GEN) {  // (per-trajectory constraint parameters: general variants only)
+        double zc[nz];
+#pragma unroll
+        for (int i = 0; i < nz; ++i) zc[i] = z[i];
+        con_shift<n>(P, K, cp0, zc);
+        Ja += al_term<n, m, GEN>(K, zc, lam, (size_t)64, EL(mu0, ci));
+      } else
       Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
     }
     Jk += Ja;
@@ -138,7 +145,7 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
 // descriptor-table path.  Terms are summed in constraint order, like knot_al.
 template <class M, bool GEN, class CS>
 __device__ __forceinline__ double knot_al_cached(const DevProblem& P, int k, const double* x, const double* u, const double* lam0,
-                                                 const double* mu0, int ncs, const CS& c0, const CS& c1) {
+                                                 const double* mu0, int ncs, const CS& c0, const CS& c1, const double* cp0 = nullptr) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   double Ja = 0.0;
   for (int ci = 0; ci < P.n_cons; ++ci) {
@@ -152,6 +159,7 @@ __device__ __forceinline__ double knot_al_cached(const DevProblem& P, int k, con
 #pragma unroll
     for (int i = 0; i < m; ++i) z[n + i] = u[i];
     const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+    if constexpr (GEN) con_shift<n>(P, K, cp0, z);  // (z is rebuilt for every table constraint)
     Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
   }
   return Ja;
@@ -176,7 +184,7 @@ __device__ __forceinline__ double knot_al(const DevProblem& P, int k, const doub
 }
 
 template <class M>
-__device__ __forceinline__ double knot_violation(const DevProblem& P, int k, const double* x, const double* u) {
+__device__ __forceinline__ double knot_violation(const DevProblem& P, int k, const double* x, const double* u, const double* cp0 = nullptr) {
   constexpr int n = M::n, m = M::m, nz = n + m;
   double z[nz];
 #pragma unroll
@@ -187,7 +195,11 @@ __device__ __forceinline__ double knot_violation(const DevProblem& P, int k, con
   for (int ci = 0; ci < P.n_cons; ++ci) {
     ConC& K = P.cons[ci];
     if (k < K.k1 || k > K.k2) continue;
-    const double v = con_violation<nz>(K, z);
+    double zc[nz];
+#pragma unroll
+    for (int i = 0; i < nz; ++i) zc[i] = z[i];
+    con_shift<n>(P, K, cp0, zc);
+    const double v = con_violation<nz>(K, zc);
     if (!(v <= vmax)) vmax = v;
   }
   return vmax;
@@ -204,6 +216,7 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int la
   const double* U = U_SLOT_PTR(a, tile * 64 + lane, c);
   double* lam0 = TILE_PTR(a.lam, P.n_duals);
   double* mu0 = TILE_PTR(a.mu, P.n_cons);
+  const double* cp0 = TILE_PTR(P.cp, P.n_cp);
   double J = 0.0, cmax = 0.0;
   for (int k = 0; k < N; ++k) {
     double x[n], u[m];
@@ -221,11 +234,15 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int la
         ConC& K = P.cons[ci];
         if (k < K.k1 || k > K.k2) continue;
         double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-        con_dual_update<nz>(K, z, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
+        double zc[nz];
+#pragma unroll
+        for (int i = 0; i < nz; ++i) zc[i] = z[i];
+        con_shift<n>(P, K, cp0, zc);
+        con_dual_update<nz>(K, zc, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
       }
     }
-    if (cmax_out && P.n_cons > 0) { const double v = knot_violation<M>(P, k, x, u); if (!(v <= cmax)) cmax = v; }
-    if (J_out) J += knot_cost<M>(P, k, x, u, lam0, mu0, with_al, TILE_PTR(P.gl, P.n_costs * nz));
+    if (cmax_out && P.n_cons > 0) { const double v = knot_violation<M>(P, k, x, u, cp0); if (!(v <= cmax)) cmax = v; }
+    if (J_out) J += knot_cost<M>(P, k, x, u, lam0, mu0, with_al, TILE_PTR(P.gl, P.n_costs * nz), cp0);
   }
   if (J_out) *J_out = J;
   if (cmax_out) *cmax_out = cmax;

@@ -122,6 +122,7 @@ inline int validate_constraint(int n, int m, int N, const to_constraint_desc& d,
   DevCon ci;
   std::memset(&ci, 0, sizeof(ci));
   ci.d = d;
+  ci.cp_off = -1;  // shared parameters (to_set_constraint_params_batch flags a constraint later)
   if (d.k_first < 1 || d.k_last > N || d.k_first > d.k_last)
     return fail(TO_ERR_ASSERTION, "Invalid inds, inds[end] must be less than number of knotpoints");  // src/constraint_list.jl:112
   if (d.n_inds < 0 || d.n_inds > TO_MAX_CON_INDS || d.n_params < 0 || d.n_params > TO_MAX_CON_PARAMS)

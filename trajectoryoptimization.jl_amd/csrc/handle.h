@@ -75,6 +75,7 @@ struct to_handle_s {
   int* d_crow = nullptr;    // [64] compact_row table of the model (tangent-matrix getters)
   std::vector<char> gl_set; // [n_costs] cost i carries per-trajectory linear terms (all clear: DevProblem::gl goes back to null)
   double* d_gl = nullptr;   // per-trajectory linear cost terms (DevProblem::gl), tiled, L = n_costs * (n + m); allocated on first use
+  double* d_cp = nullptr;   // per-trajectory constraint parameters (DevProblem::cp), tiled, L = n * n_cons; allocated on first use
   double* d_tmp = nullptr;  // [Bp] scratch for reductions / outputs
   double* d_tmp2 = nullptr;
   // multi-GPU: RCCL communicator of the batch shards (to_comm_*; librccl is dlopen'ed on first use)

@@ -117,6 +117,13 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
         ConC& K = P.cons[ci];
         if (k < K.k1 || k > K.k2) continue;
         const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        if constexpr ((VAR & 4) != 0) {  // per-trajectory constraint parameters (DevProblem::cp): the general variant only
+          double zc[nz];
+#pragma unroll
+          for (int i = 0; i < nz; ++i) zc[i] = z[i];
+          con_shift<n>(P, K, P.cp + ((size_t)tile * (size_t)P.n_cp) * 64 + lane64, zc);
+          al_grad_hvp<n, m, true>(K, zc, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
+        } else
         al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
       }
     }
@@ -405,6 +412,13 @@ __device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int l
         ConC& K = P.cons[ci];
         if (k < K.k1 || k > K.k2) continue;
         const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
+        if constexpr ((VAR & 4) != 0) {  // per-trajectory constraint parameters (DevProblem::cp): the general variant only
+          double zc[nz];
+#pragma unroll
+          for (int i = 0; i < nz; ++i) zc[i] = z[i];
+          con_shift<n>(P, K, P.cp + ((size_t)tile * (size_t)P.n_cp) * 64 + lane, zc);
+          al_grad_hvp<n, m, true>(K, zc, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
+        } else
         al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
       }
     }

@@ -104,6 +104,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
   typename std::conditional<KLDS, StageCostLds<n, m>, StageCostDiag<n, m>>::type sc;
   const bool has_gl = P.gl != nullptr;  // wave-uniform (a kernel argument): the branches on it are scalar
   const double* gl0 = TILE_PTR(P.gl, P.n_costs * (n + m));
+  const double* cp0 = TILE_PTR(P.cp, P.n_cp);  // per-trajectory constraint parameters (general variants)
   const int ci0 = P.cost_index[0];
   double h0 = 0.0;
   if constexpr (SIMPLE) {
@@ -191,7 +192,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
         if (ncs > 0) Ja += cs0.term(ub);
         if (ncs > 1) Ja += cs1.term(ub);
         Jk += Ja;
-      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1);
+      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1, cp0);
     }
     J += Jk;
     model_step<M, double, (MODE & 4) ? INTEG_RK4 : -1>(mp, integrator, k, xb, ub, h, xn);
@@ -213,7 +214,7 @@ __device__ __forceinline__ void forward_candidate(const KArgs& a, int tile, int 
     double u0[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
-    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true, gl0);
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true, gl0, cp0);
   }
   if constexpr (KLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be in flight when the next pass refills the buffers
   J_out = J; g_out = gsum / (N - 1); ok_out = ok;
@@ -675,6 +676,7 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
   typename std::conditional<M::lds_gains, StageCostLds<n, m>, StageCostDiag<n, m>>::type sc;
   const bool has_gl = P.gl != nullptr;  // wave-uniform (a kernel argument): the branches on it are scalar
   const double* gl0 = TILE_PTR(P.gl, P.n_costs * (n + m));
+  const double* cp0 = TILE_PTR(P.cp, P.n_cp);  // per-trajectory constraint parameters (general variants)
   const int ci0 = P.cost_index[0];
   double h0 = 0.0;
   if constexpr (SIMPLE) {
@@ -736,7 +738,7 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
         if (ncs > 0) Ja += cs0.term(ub);
         if (ncs > 1) Ja += cs1.term(ub);
         Jk += Ja;
-      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1);
+      } else Jk += knot_al_cached<M, GEN>(P, k, xb, ub, lam0, mu0, ncs, cs0, cs1, cp0);
     }
     J += Jk;
     // admissibility (k_forward checks x_{k+1} and u_k in iteration k: the same set of values, seen one knot later here)
@@ -764,7 +766,7 @@ __device__ __forceinline__ void fwd2_account(const KArgs& a, int tile, int lane,
     double u0[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) u0[j] = 0.0;
-    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true, gl0);
+    J += knot_cost<M, GEN>(P, N - 1, xb, u0, lam0, mu0, true, gl0, cp0);
   }
   J_out = J; g_out = gsum / (N - 1); ok_out = ok;
 }

@@ -76,7 +76,7 @@ PN_FN void pn_upd_max(double& m, double v) { if (v > m || v != v) m = v; }  // N
 PN_FN int pn_popc(unsigned long long m) { int c = 0; while (m) { m &= m - 1; ++c; } return c; }
 
 // header of a trajectory's workspace
-enum { PN_H_STATE = 0, PN_H_STEPS = 1, PN_H_VIOL = 2, PN_H_FAILED = 3, PN_HEADER = 8 };
+enum { PN_H_STATE = 0, PN_H_STEPS = 1, PN_H_VIOL = 2, PN_H_FAILED = 3, PN_H_TRAJ = 4 /* the trajectory this slot polishes */, PN_HEADER = 8 };
 enum { PN_FRESH = 0, PN_ACTIVE = 1, PN_DONE = 2 };
 
 // vectors of a knot record: d (rhs on the active set), dn (candidate's), dl (multiplier step), r (residual), t (scratch)
@@ -133,14 +133,22 @@ PN_FN PnLds pn_lds(double* p, int NB) {
 
 // ---- candidate rows of a knot: f(q, value, gradient over z = [x; u] (nz), equality?) for every row that may take part.
 // A second-order cone [v; s] contributes the ONE row |v| - s.
+// lane pointer into DevProblem::cp (per-trajectory constraint parameters) of the trajectory whose workspace w is
+PN_FN const double* pn_cp0(const DevProblem& P, const double* w) {
+  if (!P.cp) return nullptr;
+  const int b = (int)w[PN_H_TRAJ];
+  return P.cp + ((size_t)(b >> 6) * (size_t)P.n_cp) * 64 + (b & 63);
+}
 template <class M, bool GRAD, class Fn>
-PN_FN void pn_for_candidates(const DevProblem& P, int k, const double* z, Fn&& f) {
+PN_FN void pn_for_candidates(const DevProblem& P, int k, const double* zin, const double* cp0, Fn&& f) {
   constexpr int nz = M::n + M::m;
   int qi = 0;
-  double gz[nz], coef[nz];
+  double gz[nz], coef[nz], z[nz];
   for (int ci = 0; ci < P.n_cons; ++ci) {
     ConC& K = P.cons[ci];
     if (k < K.k1 || k > K.k2) continue;
+    for (int i = 0; i < nz; ++i) z[i] = zin[i];
+    con_shift<M::n>(P, K, cp0, z);  // the state as this constraint sees it (a shift: values change, gradients do not)
     const int p = K.p;
     if (K.d.sense == TO_CONE_SECOND_ORDER) {
       double a2 = 0.0;
@@ -292,7 +300,7 @@ PN_FN double pn_eval(const PnArgs& q, double* w, const PnLds& L, const double* x
     int na = 0;
     const bool terminal = (k == N - 1);
     if (refresh) {
-      pn_for_candidates<M, true>(P, k, z, [&](int qi, double val, const double* gz, bool eq) {
+      pn_for_candidates<M, true>(P, k, z, pn_cp0(P, w), [&](int qi, double val, const double* gz, bool eq) {
         if (!(eq || val >= -tol_a)) return;
         double ge[nc], g2 = 0.0;
         pn_project_row<M>(z, gz, terminal, ge);
@@ -303,7 +311,7 @@ PN_FN double pn_eval(const PnArgs& q, double* w, const PnLds& L, const double* x
       });
       *R.mask = mask;
     } else {
-      pn_for_candidates<M, false>(P, k, z, [&](int qi, double val, const double*, bool) {
+      pn_for_candidates<M, false>(P, k, z, pn_cp0(P, w), [&](int qi, double val, const double*, bool) {
         if (!(mask >> qi & 1ull)) return;
         dst[ne + na++] = val; pn_upd_max(mx, fabs(val));
       });
@@ -371,7 +379,7 @@ PN_FN void pn_lin_rows(const PnArgs& q, double* w, int k) {
   const bool terminal = (k == P.N - 1);
   const unsigned long long mask = *R.mask;
   int na = 0;
-  pn_for_candidates<M, true>(P, k, R.Z, [&](int qi, double, const double* gz, bool) {
+  pn_for_candidates<M, true>(P, k, R.Z, pn_cp0(P, w), [&](int qi, double, const double* gz, bool) {
     if (!(mask >> qi & 1ull)) return;
     pn_project_row<M>(R.Z, gz, terminal, R.C + (size_t)na * nc);
     ++na;
@@ -816,7 +824,7 @@ PN_FN void pn_begin(const PnArgs& q, int b, double* w, double* lds_mem, int roun
       const int k = e / nz, i = e % nz;
       pn_rec<M>(q, w, k).Z[i] = i < n ? EL(Xn, k * n + i) : (k < N - 1 ? EL(Un, k * m + (i - n)) : 0.0);
     }
-    PN_FOR(j, 1) { w[PN_H_STEPS] = 0.0; w[PN_H_FAILED] = 0.0; }
+    PN_FOR(j, 1) { w[PN_H_STEPS] = 0.0; w[PN_H_FAILED] = 0.0; w[PN_H_TRAJ] = (double)b; }
     PN_SYNC();
   }
   const bool failed = w[PN_H_FAILED] != 0.0;
@@ -832,7 +840,7 @@ PN_FN void pn_begin(const PnArgs& q, int b, double* w, double* lds_mem, int roun
     double e[ne], mx = 0.0;
     pn_defect<M>(P, k, zp, R.Z, x0, e);
     for (int i = 0; i < ne; ++i) pn_upd_max(mx, fabs(e[i]));
-    if (P.n_cons > 0) pn_upd_max(mx, knot_violation<M>(P, k, R.Z, R.Z + n));
+    if (P.n_cons > 0) pn_upd_max(mx, knot_violation<M>(P, k, R.Z, R.Z + n, pn_cp0(P, w)));
     R.loc[0] = mx;
   }
   PN_SYNC();

@@ -22,6 +22,8 @@ struct DevCon {
   int sidx[TO_MAX_P];       // selector rows: 0-based index into z, or -1 for a constant row (value = soff)
   double ssgn[TO_MAX_P];
   double soff[TO_MAX_P];
+  int cp_off;               // >= 0: this constraint sees the STATE shifted by the per-trajectory block DevProblem::cp[cp_off .. cp_off + n)
+                            // (to_set_constraint_params_batch: one GoalConstraint target per trajectory); -1: shared parameters only
 };
 
 // Read-only descriptor tables are addressed through the CONSTANT address space: with a wave-uniform address the
@@ -51,7 +53,23 @@ struct DevProblem {
   // src/cost_functions.jl:249-258, src/problem.jl:294-310): tiled array, L = n_costs * (n + m); entry ci*(n+m) + i of trajectory b is
   // what its q_i (i < n) / r_{i-n} differs by from cost ci's descriptor.  NULL (the default): every trajectory shares the descriptors.
   const double* gl;
+  // Per-trajectory constraint parameters (to_set_constraint_params_batch: set_goal_state!(prob, Xf; constraint = true) with one goal per
+  // trajectory, src/problem.jl:303-309): tiled array, L = n_cp = n * n_cons; block ci holds what trajectory b's GoalConstraint target
+  // differs by from the descriptor's, scattered onto the state indices — the constraint with target xf + d IS the shared constraint
+  // evaluated at x - d (same value, same Jacobian), so every evaluation site shifts the state it hands to a flagged constraint
+  // (con_shift).  NULL (the default): every trajectory shares the descriptors.  Read by the GENERAL kernel variants only.
+  const double* cp;
+  int n_cp;
 };
+
+// z as constraint K sees it for this lane's trajectory (cp0: the lane's pointer to entry 0 of DevProblem::cp)
+template <int n>
+__device__ __forceinline__ void con_shift(const DevProblem& P, ConC& K, const double* cp0, double* z) {
+  if (P.cp != nullptr && K.cp_off >= 0) {  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < n; ++i) z[i] -= cp0[(size_t)(K.cp_off + i) * 64];
+  }
+}
 
 // cost of the per-trajectory linear terms of cost ci at (x, u), and their gradient (added to g); gl0 = this lane's pointer to entry 0
 template <int n, int m>

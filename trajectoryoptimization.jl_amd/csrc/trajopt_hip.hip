@@ -226,6 +226,7 @@ int upload_tables(to_handle* h) {
     bool dense = false, generic = false;
     for (const auto& c : h->costs) dense = dense || c.kind == TO_COST_QUADRATIC || c.kind == TO_COST_ERROR_QUADRATIC;
     for (const auto& c : h->cons) generic = generic || !c.selector;
+    for (const auto& c : h->cons) generic = generic || c.cp_off >= 0;  // per-trajectory parameters are read by the general variants only
     P.expand_variant = (dense ? 1 : 0) | (h->cons.empty() ? 0 : 2) | (generic ? 4 : 0);
     // unit-SOC forward-pass variants (problem_dev.h unit_soc_desc): at least one control-block constraint, and all of them unit
     bool any_ctrl = false, all_unit = true;
@@ -270,7 +271,7 @@ int launch_accept(to_handle* h) {  // materialise accepted candidate slots on sl
 int launch_forward(to_handle* h, bool accept = true, bool two_wave = false) {
   const KArgs& a = h->a;
   // (bit3 also with per-trajectory linear cost terms, DevProblem::gl: only the general variants read them)
-  int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | (((a.P.expand_variant & 5) || a.P.gl) ? 8 : 0);
+  int mode = (a.P.simple_stage ? 1 : 0) | (a.P.n_cons > 0 ? 2 : 0) | (a.P.integrator == INTEG_RK4 ? 4 : 0) | (((a.P.expand_variant & 5) || a.P.gl || a.P.cp) ? 8 : 0);
   if (!h->ops->forward[mode]) mode &= ~4;  // the model does not pin RK4
   if (a.P.unit_soc && h->ops->forward[mode | 16]) mode |= 16;
   if (!h->ops->forward[mode]) mode = (mode | 8) & ~1 & ~16;  // the general variant (any cost kind, stage cost read per knot): a superset
@@ -336,6 +337,7 @@ int rp_setup(to_handle* h) {
   // them through the tile of the WORKING position whenever the problem has constraints (a hand-built AL loop, to_set_duals, an iLQR
   // re-solve behind an AL solve: per-trajectory values) — moved along, never copied home
   if (P.n_cons > 0) { add(&a.lam, 3, (int)P.n_duals); add(&a.mu, 3, P.n_cons); }
+  if (a.P.cp) add(&a.P.cp, 3, P.n_cp);
   for (double** f : {&a.J, &a.dJ, &a.grad, &a.rho, &a.drho, &a.cmax}) add(f, 1, 1);
   for (int** f : {&a.status, &a.iterations, &a.it_inner, &a.outer, &a.dJzero, &a.ls_index, &a.active, &a.budget, &a.bpfail, &a.acc, &a.accp}) add(f, 2, 1);
   if ((int)h->rp_arr.size() > RP_MAX) return fail(TO_ERR_UNSUPPORTED, "repack table too long");
@@ -1393,7 +1395,34 @@ int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
   const DevCon& old = h->cons[id];
   if (ci.p != old.p || ci.k1 != old.k1 || ci.k2 != old.k2) return fail(TO_ERR_DIMENSION_MISMATCH, "replacement constraint must keep p and the knot range");
   ci.dual_off = old.dual_off;
-  h->cons[id] = ci;
+  h->cons[id] = ci;  // (cp_off = -1: the replaced constraint starts on shared parameters again)
+  bool any = false;
+  for (const DevCon& c : h->cons) any = any || c.cp_off >= 0;
+  if (!any) h->a.P.cp = nullptr;
+  return upload_tables(h);
+}
+// One parameter set per TRAJECTORY for constraint con_id.  GOAL: params[p, B] = xf_b[inds].  Stored as the state shift the constraint
+// sees (DevProblem::cp): the GoalConstraint with target xf + d is the shared one evaluated at x - d.
+int to_set_constraint_params_batch(to_handle* h, int32_t id, const double* params) {
+  CHECK_H(h); CHECK_IDLE(h); CHECK_P(params); TRY(use_device(h));
+  if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
+  DevCon& ci = h->cons[id];
+  if (ci.d.kind != TO_CON_GOAL) return fail(TO_ERR_UNSUPPORTED, "per-trajectory constraint parameters: GoalConstraint only");
+  DevProblem& P = h->a.P;
+  const int n = P.n, B = P.B, p = ci.p, L = n * (int)h->cons.size();
+  if (!h->d_cp) TRY(dev_alloc(h, &h->d_cp, (size_t)L * P.Bp));  // zero-filled
+  std::vector<double> shift((size_t)n * B, 0.0);
+  for (int b = 0; b < B; ++b)
+    for (int r = 0; r < p; ++r) shift[(size_t)(ci.d.inds[r] - 1) + (size_t)n * b] = params[r + (size_t)p * b] - ci.d.params[r];
+  TRY(upload_vec(h, shift.data(), h->d_cp, n, L, id * n));
+  ci.cp_off = id * n;
+  P.cp = h->d_cp; P.n_cp = L;
+  return upload_tables(h);
+}
+int to_clear_constraint_params_batch(to_handle* h) {
+  CHECK_H(h); CHECK_IDLE(h); TRY(use_device(h));
+  for (DevCon& c : h->cons) c.cp_off = -1;
+  h->a.P.cp = nullptr;
   return upload_tables(h);
 }
 
