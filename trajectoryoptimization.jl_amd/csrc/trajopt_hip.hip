@@ -239,7 +239,9 @@ int upload_tables(to_handle* h) {
       }
     P.unit_soc = (any_ctrl && all_unit) ? 1 : 0;
     if (const char* env = std::getenv("TRAJOPT_UNIT_SOC")) if (!std::atoi(env)) P.unit_soc = 0;  // A/B knob
-    h->a.h_compact = (h->a.bwd_mfma && compact_cost_blocks(h)) ? 1 : 0;
+    // (the compact cost block exists for the variants 0 and 2 of the tangent-matrix expansion; the general variant 7 — dense costs, generic
+    // constraints, per-trajectory constraint parameters — writes the full block)
+    h->a.h_compact = (h->a.bwd_mfma && compact_cost_blocks(h) && (P.expand_variant == 0 || P.expand_variant == 2)) ? 1 : 0;
     h->a.h_diag = (!h->a.bwd_mfma && !h->a.bwd_lane && diagonal_cost_blocks(h)) ? 1 : 0;
     if (const char* env = std::getenv("TRAJOPT_FULL_COST_BLOCKS")) if (std::atoi(env)) { h->a.h_compact = 0; h->a.h_diag = 0; }  // testing knob
   }
