@@ -331,7 +331,6 @@ def pipelined_run(T, configs, lib, name, batch, depth, steps, warmup, admit_frac
         dt = time.perf_counter() - t0
         best = (dt, pipe.total_iterations, sum(r[2] for r in pipe.results))
     dt, its, bsteps = best
-    prob0._call("set_shared_device", 0)
     del pipe, solvers, probs      # the extra handles go NOW: idle streams take hardware-queue slots from whatever runs next
     import gc
     gc.collect()

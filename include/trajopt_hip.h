@@ -54,7 +54,7 @@ extern "C" {
  * to_problem_desc::step_models (general model vectors).  Policy: the version changes whenever a struct field changes meaning or a symbol is added; a
  * host checks to_abi_version() == TO_ABI_VERSION right after dlopen (the Python and Julia shims do) and to_create rejects
  * a descriptor stamped with another version.  5: TO_MODEL_INFEASIBLE, to_infeasible_controls, to_set_cost_linear_batch, to_get_cost_to_go.
- * 6: to_solve_progress / to_solve_wait_below / to_set_shared_device (pipelined solves over several handles), to_set_constraint_params_batch /
+ * 6: to_solve_progress / to_solve_wait_below (pipelined solves over several handles), to_set_constraint_params_batch /
  * to_clear_constraint_params_batch (one GoalConstraint target per trajectory); TO_STATE_LIMIT / TO_CONTROL_LIMIT are
  * emitted; TRAJOPT_RCCL_LIB, TRAJOPT_GUARD. */
 #define TO_ABI_VERSION 6
@@ -417,13 +417,9 @@ int to_solve_wait(to_handle* h);
  * to_solve_wait has returned.  to_solve_wait_below blocks until *active <= active_max (at once when nothing is in flight).  Both may
  * be called while a solve is in flight (they are the only ones besides the pure descriptor getters); any pointer may be NULL. */
 int to_solve_progress(to_handle* h, int32_t* active, int32_t* batch_steps, int32_t* in_flight);
-/* Tell the handle that other solves run on the device while its own do (pipelined handles): the per-batch-step choices of the solve
- * loop that assume a chip of their own — whether a step stores whole line-search candidates or only their controls and rolls the accepted
- * ones out again — then go for throughput.  Every choice is between bit-identical kernels: results do not change.  Note for hosts: a
- * handle that is no longer needed should be destroyed — HIP multiplexes streams onto a few hardware queues, and idle handles' streams
- * take slots that concurrent solves then have to share (measured: three pipelined C5 solves 1.24 instead of 1.40 M it/s next to
- * three stale handles). */
-int to_set_shared_device(to_handle* h, int32_t shared);
+/* Note for hosts that pipeline: a handle that is no longer needed should be destroyed — HIP multiplexes streams onto a few hardware
+ * queues, and idle handles' streams take slots that concurrent solves then have to share (measured: three pipelined C5 solves 1.24
+ * instead of 1.40 M it/s next to three stale handles). */
 int to_solve_wait_below(to_handle* h, int32_t active_max);
 
 /* expansion / gain getters (parity + solver introspection); host layouts column-major:

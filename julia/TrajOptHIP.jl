@@ -551,12 +551,9 @@ wait_below!(s::PendingSolve, active_max::Integer) =
 `prepare!(p, i)` (new x0 / goal / initial controls) once that handle's previous solve has been collected, and is admitted as soon as the
 job in front of it has at most `admit_below` trajectories still iterating.  Returns the statistics of every job, in order.
 """
-set_shared_device!(p::BatchProblem, shared::Bool = true) =
-    check(ccall((:to_set_shared_device, lib), Cint, (Ptr{Cvoid}, Int32), p.handle, Int32(shared)))
 function solve_pipelined!(problems::Vector{BatchProblem}, jobs::Integer; which::Symbol = :ilqr,
                           admit_below::Integer = problems[1].B, prepare! = (p, job) -> nothing)
     depth = length(problems)
-    foreach(p -> set_shared_device!(p, depth > 1), problems)
     pending = Vector{Union{Nothing,PendingSolve}}(nothing, depth)
     out = Vector{Any}(undef, jobs)
     slotjob = zeros(Int, depth)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profile one bench workload on the GPU box: kernel-trace stats, then one PMC pass per HBM counter (never combined with
-# tracing), then the plain bench line.  Usage: tools/run_profiles.sh <tag> <bench args...>; results in gpurun_out/<tag>/.
+# tracing) — all of them on UNPIPELINED solves (--pipeline 0: one handle, per-kernel figures undisturbed) — then the plain bench line
+# (pipelined where that is the workload's default).  Usage: tools/run_profiles.sh <tag> <bench args...>; results in gpurun_out/<tag>/.
 set -u
 tag=$1; shift
 repo=$(pwd)
@@ -8,12 +9,12 @@ out=$repo/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python "$repo/bench.py" "$@" --no-cpu-baseline --no-extra --throughput-probe 0 --no-probe-sweep > "$out/bench_under_trace.json" 2> "$out/kt.log"
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/fetch.log"
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/write.log"
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$out/valu" -o valu --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/valu.log"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python "$repo/bench.py" "$@" --no-cpu-baseline --no-extra --throughput-probe 0 --no-probe-sweep --pipeline 0 > "$out/bench_under_trace.json" 2> "$out/kt.log"
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep --pipeline 0 > /dev/null 2> "$out/fetch.log"
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o write --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep --pipeline 0 > /dev/null 2> "$out/write.log"
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$out/valu" -o valu --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep --pipeline 0 > /dev/null 2> "$out/valu.log"
 # matrix-core pass (k_backward_mfma runs v_mfma_f64_16x16x4_f64): instructions, MOPS (units of 512 flops), pipe-busy cycles
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d "$out/mfma" -o mfma --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep > /dev/null 2> "$out/mfma.log"
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d "$out/mfma" -o mfma --output-format csv -- python "$repo/bench.py" "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-extra --throughput-probe 0 --no-probe-sweep --pipeline 0 > /dev/null 2> "$out/mfma.log"
 cd "$repo"
 bid=$(python -c "import trajopt_amd as T; print(T.load_hip_library().build_id())")
 python tools/pmc_traffic.py "$out/hbm_traffic_pmc.json" "$bid" $(find "$out/fetch" "$out/write" "$out/valu" "$out/mfma" -name '*counter_collection.csv')

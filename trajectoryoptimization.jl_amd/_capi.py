@@ -222,7 +222,6 @@ HIP_ONLY = {
     "solve_wait": [_H],
     "solve_progress": [_H, _PI, _PI, _PI],
     "solve_wait_below": [_H, C.c_int32],
-    "set_shared_device": [_H, C.c_int32],
 }
 
 

@@ -1651,8 +1651,6 @@ class SolvePipeline:
         # (measured, C3 / C5 over 2-4 handles, admission at 100 % ... 6 % of the batch: the earliest admission always won — the dense steps of a
         # batch of 4096 do not fill the chip either, so two dense solves side by side already gain; profiles/r06_ab/)
         self.admit_below = B if admit_below is None else int(admit_below)
-        for s in self.solvers:
-            s.prob._call("set_shared_device", 1 if self.depth > 1 else 0)
         self.keep_stats = keep_stats
         self.on_done = on_done
         self._job = [None] * self.depth

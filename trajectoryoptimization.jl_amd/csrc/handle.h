@@ -62,7 +62,6 @@ struct to_handle_s {
   int roll_min_active = -1;  // solve loop: batch steps with at least this many active trajectories store candidate controls only and accept
                              // by k_accept_roll (-1: the measured default per solver, 0: never; TRAJOPT_ACCEPT_ROLL_MIN)
   int roll_min_small = 32768;  // ... the default of the small (write-through) models
-  int shared_device = 0;       // to_set_shared_device: other solves run on the device at the same time (pipelined handles): throughput choices
   double roll_min_frac = 0.25;  // ... which also need at least this fraction of the batch active (TRAJOPT_ACCEPT_ROLL_FRAC)
   int ls2_cwa = 0, ls2_cwb = 2;  // two-launch line search (common.h ls_phase): step sizes per round of launch A (0: off) / launch B (TRAJOPT_LS_TWO=a,b)
   int ls2_blkA = 0, ls2_dump = 0;  // candidate blocks of launch A; the dump block behind launch B's

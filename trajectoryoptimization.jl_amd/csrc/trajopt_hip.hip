@@ -704,10 +704,10 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       // Small models (write-through; 4 step sizes x 16 trajectories per wave): at the large-batch plateau the forward pass wrote 19 KB per
       // active trajectory for 4 KB of result and the next expansion gathered the accepted candidate through 4x-amplified sectors;
       // with the controls only and the re-roll both kernels stream the nominal (TRAJOPT_ACCEPT_ROLL_MIN overrides every default)
-      // (a handle that SHARES the device with other solves — to_set_shared_device, pipelined handles — takes the re-roll from 2048 on in
-      // iLQR solves too: the break-even above assumes the chip idles while this batch drains; with another solve's dense steps filling it the
-      // candidate-state stores and k_accept's copy cost the others bandwidth: C3 pipelined over 3 handles 1.57 -> 1.70 M it/s, alone 1.12 either way)
-      const int roll_min = h->roll_min_active >= 0 ? h->roll_min_active : h->ops->write_through ? h->roll_min_small : ((al_mode || h->shared_device) ? 2048 : 8192);
+      // (round 6: 2048 for iLQR solves too — alone, C3 at B = 4096 runs 1.12 M it/s with either threshold, and next to other solves on
+      // the device (pipelined handles) the candidate-state stores and k_accept's copy cost the others bandwidth: 1.57 -> 1.70 M it/s over three
+      // handles; the forward phase's counter traffic drops with it)
+      const int roll_min = h->roll_min_active >= 0 ? h->roll_min_active : h->ops->write_through ? h->roll_min_small : 2048;
       // ... and, for those models, only while the batch is still DENSE: the active list is in index order, so once half of the batch has
       // converged a wave's 64 trajectories sit in several tiles and every store of the re-roll becomes scattered 8-byte writes (r05 trace,
       // Cartpole at B = 1 048 576: the re-roll takes 0.9 ms with every trajectory active and 1.8 ms with a quarter of them); the
@@ -1520,7 +1520,6 @@ int to_solve_wait(to_handle* h) {
   if (h->async_rc != TO_OK) g_err = h->async_err;
   return h->async_rc;
 }
-int to_set_shared_device(to_handle* h, int32_t shared) { CHECK_H(h); CHECK_IDLE(h); h->shared_device = shared != 0; return TO_OK; }
 int to_solve_progress(to_handle* h, int32_t* active, int32_t* batch_steps, int32_t* in_flight) {
   CHECK_H(h);
   if (active) *active = h->prog_active.load();
