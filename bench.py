@@ -512,7 +512,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     ap.add_argument("--pipeline", type=int, default=-1,
                     help="pipeline the solves over this many handles (the next solve is admitted when the one in flight has drained below "
-                         "--admit of its batch); default: 3 for the Quadrotor workloads (the extra C3 / C5 lines included), 0 for the Cartpole "
+                         "--admit of its batch); default: 4 for the Quadrotor workloads (the extra C3 / C5 lines included), 0 for the Cartpole "
                          "headline (two host threads driving 100 us batch steps lose: DESIGN.md §4.10)")
     ap.add_argument("--pipeline-steps", type=int, default=0, help="solves of the pipelined pass (default max(steps, 2 x depth))")
     ap.add_argument("--admit", type=float, default=-1.0, help="admit the next solve at this fraction of the batch still iterating (default per workload)")
@@ -555,7 +555,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: libtrajopt_hip.so has no CPU fallback")
     name = args.workload
     batch = args.batch or WORKLOADS[name]["batch"]
-    depth = args.pipeline if args.pipeline >= 0 else (0 if name == "cartpole" else 3)
+    depth = args.pipeline if args.pipeline >= 0 else (0 if name == "cartpole" else 4)
     res, prob, u0 = run_workload(T, configs, lib, name, batch, args.steps, args.warmup, rank, local_rank, world, dist, torch,
                                  profile=not args.no_profile, pipeline=depth, pipeline_steps=args.pipeline_steps,
                                  admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(name, 1.0))
@@ -617,7 +617,7 @@ def main():
     # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
     if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:
         extra = {}
-        for key, wname, pdepth, psteps in (("C3", "quadrotor", 3, 12), ("C5", "quadrotor_altro", 3, 9), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
+        for key, wname, pdepth, psteps in (("C3", "quadrotor", 4, 12), ("C5", "quadrotor_altro", 4, 12), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
             try:
                 if args.pipeline >= 0:
                     pdepth = args.pipeline if pdepth else 0

@@ -236,7 +236,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
 }
 
 #ifndef TO_EXPAND_KC_CONS
-#define TO_EXPAND_KC_CONS 0  // 0: the model's expand_knots for every variant
+#define TO_EXPAND_KC_CONS 4  // knots per wave of the CONSTRAINED variants of models that pipeline at all (0: the model's expand_knots for every variant)
 #endif
 template <class M, int VAR>
 __host__ __device__ constexpr int expand_kc() {

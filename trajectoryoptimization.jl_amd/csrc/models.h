@@ -288,9 +288,13 @@ struct QuadrotorModel {  // RigidBody dynamics, world-frame velocity; state [r(3
   static constexpr int att = ATT_QUAT;
   static constexpr bool pin_rk4 = false;  // compile-time RK4 costs registers here: measured slower than the runtime switch
 #ifndef TO_QUAD_EXPAND_KNOTS
-#define TO_QUAD_EXPAND_KNOTS 4
+#define TO_QUAD_EXPAND_KNOTS 2
 #endif
-  static constexpr int expand_knots = TO_QUAD_EXPAND_KNOTS;  // knots one expansion wave walks (software-pipelined loads)
+  // knots one expansion wave walks (software-pipelined loads).  Round 6: 2 for the unconstrained variant, 4 (k_expand.h TO_EXPAND_KC_CONS) for
+  // the constrained ones — interleaved A/B of library builds, depth-4 pipelined / alone, M it/s (profiles/r06_ab/ab_expand_occupancy.jsonl):
+  // C3 1.73-1.77 / 1.12 with 4, 1.83 / 1.12 with 2, 1.68 / 1.08 with 1, 1.80 / 1.08 with 1 knot at two waves per SIMD;
+  // C5 1.42-1.43 / 1.14 with 4, 1.42 / 1.12 with 2, 1.37 / 1.10 with 1, 1.34 / 1.07 with 1 knot at two waves per SIMD
+  static constexpr int expand_knots = TO_QUAD_EXPAND_KNOTS;
   static constexpr bool accept_write_through = false;  // accepted steps are copied onto slot 0 by k_accept after every forward pass
   static constexpr bool lds_gains = true;  // forward pass: the 52-double gains row of a knot comes through LDS (DMA), not prefetch VGPRs
   static constexpr int ls_first_round = 16;  // accepted step sizes sit at 2^-5 .. 2^-12 late in these solves (tools/ls_hist.py): a deep first round
