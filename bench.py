@@ -617,7 +617,7 @@ def main():
     # The other single-GPU BASELINE configurations, driver-visible in the same JSON line (2 steps each; C4 is C3 sharded)
     if world == 1 and name == "cartpole" and not args.batch and not args.no_extra:
         extra = {}
-        for key, wname, pdepth, psteps in (("C3", "quadrotor", 4, 12), ("C5", "quadrotor_altro", 4, 12), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
+        for key, wname, pdepth, psteps in (("C3", "quadrotor", 4, 16), ("C5", "quadrotor_altro", 4, 12), ("C5_altro_defaults", "quadrotor_altro_defaults", 0, 0)):
             try:
                 if args.pipeline >= 0:
                     pdepth = args.pipeline if pdepth else 0

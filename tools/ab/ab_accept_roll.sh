@@ -3,7 +3,7 @@
 # 0 = never): bench lines of C3 / C5 at several batch sizes.  Run on the GPU box: gpurun -- 'bash tools/ab/ab_accept_roll.sh'
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
-for spec in "quadrotor_al 4096" "quadrotor_al 2048" "quadrotor_al 16384" "quadrotor 8192" "quadrotor 16384" "quadrotor 2048"; do
+for spec in "quadrotor_altro 4096" "quadrotor_altro 2048" "quadrotor_altro 16384" "quadrotor 8192" "quadrotor 16384" "quadrotor 2048"; do
   set -- $spec
   for w in 0 1; do
     TRAJOPT_ACCEPT_ROLL_MIN=$w python bench.py --workload $1 --batch $2 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/roll_$1_$2_$w.json

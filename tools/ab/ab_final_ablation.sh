@@ -11,11 +11,11 @@ import json; d=json.load(open("gpurun_out/ablation/${tag}.json")); k=d["roofline
 PY
 }
 for rep in 1 2; do
-  run c5_all_on_$rep quadrotor_al X=1
-  run c5_no_early_polish_$rep quadrotor_al TRAJOPT_PN_EARLY=0
-  run c5_no_repack_$rep quadrotor_al TRAJOPT_LS_REPACK=0
-  run c5_no_accept_roll_$rep quadrotor_al TRAJOPT_ACCEPT_ROLL_MIN=0
-  run c5_all_off_$rep quadrotor_al TRAJOPT_PN_EARLY=0 TRAJOPT_LS_REPACK=0 TRAJOPT_ACCEPT_ROLL_MIN=0
+  run c5_all_on_$rep quadrotor_altro X=1
+  run c5_no_early_polish_$rep quadrotor_altro TRAJOPT_PN_EARLY=0
+  run c5_no_repack_$rep quadrotor_altro TRAJOPT_LS_REPACK=0
+  run c5_no_accept_roll_$rep quadrotor_altro TRAJOPT_ACCEPT_ROLL_MIN=0
+  run c5_all_off_$rep quadrotor_altro TRAJOPT_PN_EARLY=0 TRAJOPT_LS_REPACK=0 TRAJOPT_ACCEPT_ROLL_MIN=0
 done
 run c3_all_on quadrotor X=1
 run c3_all_off quadrotor TRAJOPT_LS_REPACK=0 TRAJOPT_ACCEPT_ROLL_MIN=0
