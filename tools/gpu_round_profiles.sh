@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: the profiles of the round (tools/run_profiles.sh per BASELINE workload, with the PMC file handed to bench.py),
 # the large-batch points of the throughput sweep under the counters, then the driver-format line.  Usage: tools/gpu_round_profiles.sh r04
-r=${1:-r04}
+r=${1:-r06}
 FINAL_FLAGS=--no-cpu-baseline PROFILE_COPY=${r}_cartpole_b1024 bash tools/run_profiles.sh ${r}_cartpole_b1024 --workload cartpole > /dev/null 2>&1
 FINAL_FLAGS=--no-cpu-baseline PROFILE_COPY=${r}_quadrotor_b4096 bash tools/run_profiles.sh ${r}_quadrotor_b4096 --workload quadrotor --steps 2 > /dev/null 2>&1
 FINAL_FLAGS=--no-cpu-baseline PROFILE_COPY=${r}_quadrotor_altro_b8192 bash tools/run_profiles.sh ${r}_quadrotor_altro_b8192 --workload quadrotor_altro --steps 1 > /dev/null 2>&1

@@ -65,49 +65,38 @@ __global__ void k_solve_init(KArgs a, int reset_duals) {
 }
 
 // Stable compaction of the active flags into alist[(step+1)&1] (ascending trajectory index) and acount[(step+1)&1].
-// ONE workgroup of 256 threads: wave w owns the contiguous segment [w*seg, (w+1)*seg) of the batch, seg a multiple of 64;
-// pass 1 counts (ballot + popcount, eight independent loads in flight per lane), a 4-entry scan in LDS gives every wave its offset,
-// pass 2 writes the indices.  Four waves, not sixteen (round 6): a 1024-thread workgroup needs a compute unit with four free wave slots
-// and ~100 free registers on EVERY SIMD at the same moment; next to another handle's dense k_expand launch (one 450-register wave per
-// SIMD, re-dispatched continuously) the sixteen-wave version sat 580 us per launch in the trace of pipelined C5 solves (10 us alone).
-// That wait was not the bottleneck — the chip is saturated in that regime and the pipelined throughput is the same with either version
-// (1.418 vs 1.42 M it/s; the time shows up in k_expand's durations instead) — but the small workgroup no longer reserves a whole
-// compute unit for a 10 us job, and a solve that shares the device sees its own batch step end sooner.
-constexpr int COMPACT_THREADS = 256;
-__global__ void __launch_bounds__(COMPACT_THREADS) k_compact(KArgs a) {
-  constexpr int NW = COMPACT_THREADS / 64, UN = 8;
-  __shared__ int wcount[NW];
+// ONE workgroup of 1024 threads: wave w owns the contiguous segment [w*seg, (w+1)*seg) of the batch, seg a multiple of 64;
+// pass 1 counts (ballot + popcount), a 16-entry scan in LDS gives every wave its offset, pass 2 writes the indices.
+__global__ void __launch_bounds__(1024) k_compact(KArgs a) {
+  __shared__ int wcount[16];
   const int Bp = a.P.Bp, B = a.P.B;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int seg = (((Bp + NW - 1) / NW) + 63) / 64 * 64;
+  const int seg = (((Bp + 15) / 16) + 63) / 64 * 64;
   const int lo = wave * seg, hi = min(Bp, lo + seg);
   int cnt = 0;
-  for (int i0 = lo; i0 < hi; i0 += 64 * UN) {
-    int f[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) { const int b = i0 + u * 64 + lane; f[u] = (b < hi && b < B) ? a.active[b] : 0; }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) cnt += __popcll(__ballot(f[u] != 0));
+  for (int i = lo; i < hi; i += 64) {
+    const int b = i + lane;
+    cnt += __popcll(__ballot(b < B && a.active[b] != 0));
   }
   if (lane == 0) wcount[wave] = cnt;
   __syncthreads();
   int off = 0, total = 0;
-  for (int w = 0; w < NW; ++w) { off += (w < wave) ? wcount[w] : 0; total += wcount[w]; }
+  for (int w = 0; w < 16; ++w) { off += (w < wave) ? wcount[w] : 0; total += wcount[w]; }
   int* out = a.alist + (size_t)((a.step + 1) & 1) * Bp;
-  for (int i0 = lo; i0 < hi; i0 += 64 * UN) {
-    int f[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) { const int b = i0 + u * 64 + lane; f[u] = (b < hi && b < B) ? a.active[b] : 0; }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const bool on = f[u] != 0;
-      const unsigned long long m = __ballot(on);
-      if (on) out[off + __popcll(m & ((1ull << lane) - 1ull))] = i0 + u * 64 + lane;
-      off += __popcll(m);
-    }
+  for (int i = lo; i < hi; i += 64) {
+    const int b = i + lane;
+    const bool on = b < B && a.active[b] != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) out[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    off += __popcll(m);
   }
   if (threadIdx.x == 0) a.acount[(a.step + 1) & 1] = total;
 }
+// (Round 6 tried this kernel as FOUR waves instead of sixteen — a 1024-thread workgroup needs a compute unit with four free wave slots on
+// every SIMD at once, and next to another handle's dense k_expand launch it sat 580 us per launch in the trace of pipelined C5 solves.
+// That wait was not a bottleneck: the chip is saturated in that regime, the pipelined throughput was the same with either version
+// (1.418 vs 1.42 M it/s; the time moved into k_expand's durations), and alone the four-wave version is slower — 10 vs 5 us per launch at
+// B = 4096, 24 vs 9 us at 16 384: -4 % at the B = 32 768 sweep point.  Reverted; profiles/r06_ab/.)
 
 // The same for large batches, in two launches of NB workgroups (the single workgroup takes 87 us for 131 072 flags, 9 % of a
 // batch step of the large-batch sweep): k_compact_count leaves every workgroup's number of active trajectories in ccount[],

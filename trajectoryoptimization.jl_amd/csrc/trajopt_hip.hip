@@ -648,7 +648,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
   TRY(launch_cost(h, 1, a.J, nullptr));
   if (a.compact) {  // the initial rollout may have ended trajectories (TO_STATE_LIMIT / TO_CONTROL_LIMIT): the list of step 0 without them
     a.step = -1;
-    if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(COMPACT_THREADS), 0, h->stream, a);
+    if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
     else {
       int per = ((P.Bp + 255) / 256 + 1023) / 1024 * 1024;
       if (per > 65536) per = 65536;
@@ -739,7 +739,7 @@ int solve_impl(to_handle* h, to_solve_stats* st, int al_mode) {
       a.store_x = 1;
       if (al_mode) TRY(launch_outer(h));
       if (a.compact) {  // the list of the trajectories that go on, for the next step's kernels
-        if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(COMPACT_THREADS), 0, h->stream, a);
+        if (P.Bp <= 16384) hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, a);
         else {  // two launches of up to 256 workgroups, each owning `per` flags (a multiple of 1024, at most 64 slices of 1024)
           int per = ((P.Bp + 255) / 256 + 1023) / 1024 * 1024;
           if (per > 65536) per = 65536;
