@@ -1671,3 +1671,43 @@ def test_state_and_control_limits_of_the_initial_rollout(kind, hip, oracle):
     assert sh.stats["iterations"][ok].min() >= 1
     np.testing.assert_allclose(T.states(ph)[ok], T.states(po)[ok], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(T.controls(ph)[ok], T.controls(po)[ok], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("integration", [T.RK4, T.RK3, T.Euler])
+@pytest.mark.parametrize("constrained", [False, True])
+def test_packed_quadrotor_expansion_is_bit_identical(integration, constrained, hip, monkeypatch):
+    """The packed expansion of the quaternion rigid body (k_expand.h PACK: six trajectories x the ten differentiated columns per wave, the six
+    constant columns of [A B] written once per handle, their cost entries delivered through a superposed direction) against the 4 x 16 kernel
+    (TRAJOPT_EXPAND_PACK=0): every block the backward pass reads — A, B, the compact cost block, the gradients — and whole iLQR / ALTRO solves
+    must be EQUAL, for every integrator (the constant column mirrors the dual numbers' roundings), with ragged batches (41 = 6 x 6 + 5) and
+    after the constraint list was switched to the general variant and back (which overwrites the constant columns in between)."""
+    out = []
+    for pack in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_EXPAND_PACK", pack)
+        p = configs.quadrotor_problem(batch=41, N=52, tf=2.0, constrained=constrained, goal_inds=configs.C5_GOAL_INDS, integration=integration, lib=hip)
+        perturb_controls((p,), 0.05)
+        T.rollout(p)
+        if constrained:
+            I.dual_update(p); I.dual_update(p)
+            Xf = np.tile(p.xf, (p.B, 1)); Xf[:, 0] += 0.1
+            T.set_goal_state(p, Xf)            # general variant (full cost block, 4 x 16 kernel) ...
+            I.expand(p)
+            T.set_goal_state(p, p.xf)          # ... and back to the compact block: the constant columns are restored
+        I.expand(p)
+        A, Bm = I.dynamics_jacobians(p)
+        ce = I.cost_expansion(p)
+        I.backwardpass(p)
+        g = I.gains(p)
+        s = (T.ALTROSolver(p, n_steps=configs.C5_PN_STEPS) if constrained else T.iLQRSolver(p, iterations=40)).solve()
+        out.append((A, Bm, ce, g, {k: v.copy() for k, v in s.stats.items()}, T.states(p), T.controls(p)))
+    (A0, B0, c0, g0, s0, X0, U0), (A1, B1, c1, g1, s1, X1, U1) = out
+    np.testing.assert_array_equal(A0, A1); np.testing.assert_array_equal(B0, B1)
+    assert np.all(A1[:, :, :3, :3] == np.eye(3)) and np.all(A1[:, :, 6:9, 6:9] == np.eye(3)) and np.all(A1[:, :, 3:, :3] == 0)
+    for k in c0:
+        np.testing.assert_array_equal(c0[k], c1[k], err_msg=k)
+    for k in ("K", "d"):
+        np.testing.assert_array_equal(g0[k], g1[k], err_msg=k)
+    for k in s0:
+        np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+    np.testing.assert_array_equal(X0, X1); np.testing.assert_array_equal(U0, U1)
+    assert s1["iterations"].min() >= 3

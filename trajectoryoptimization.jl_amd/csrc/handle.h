@@ -58,6 +58,7 @@ struct to_handle_s {
   int fused_coop = 0;     // solve loop, cooperative path with diagonal cost blocks: one k_expand_backward_coop launch (TRAJOPT_FUSED_COOP=0 to split)
   int fused_lane = 0;     // solve loop: one k_expand_backward_lane launch instead of expansion + backward pass (lane path; TRAJOPT_FUSED_LANE=0 to split)
   int compact = 0;        // solves run with active-list compaction (KArgs::compact; TRAJOPT_COMPACT=0 switches it off)
+  int expand_pack = 1;    // packed tangent-matrix expansion of the quaternion rigid body (k_expand.h PACK; TRAJOPT_EXPAND_PACK=0: the 4 x 16 kernel)
   int expand_lane = 1;    // lane layout: expansion by k_expand_lane (one lane per (trajectory, knot)); 0 = column-per-lane kernel (A/B knob TRAJOPT_EXPAND_LANE)
   int roll_min_active = -1;  // solve loop: batch steps with at least this many active trajectories store candidate controls only and accept
                              // by k_accept_roll (-1: the measured default per solver, 0: never; TRAJOPT_ACCEPT_ROLL_MIN)
@@ -169,6 +170,7 @@ struct ModelOps {
   int (*constraint_eval)(to_handle*, int ci, double* vals, double* jac) = nullptr;
   int (*constraint_hessian)(to_handle*, int ci, const double* lambda, double* H) = nullptr;
   int (*expand)(to_handle*) = nullptr;
+  int (*expand_const)(to_handle*) = nullptr;     // packed expansion: the constant columns of [A B], written once per handle (k_expand_const_columns)
   int (*backward)(to_handle*) = nullptr;
   int (*expand_lane_k)(to_handle*) = nullptr;    // lane-layout expansion, one lane per (trajectory, knot) (ops_lane.h; null: column-per-lane kernel)
   int (*expand_backward)(to_handle*) = nullptr;  // fused lane expansion + Riccati (small models; null elsewhere)

@@ -16,11 +16,20 @@ namespace to {
 // one knot of the expansion for lane (g, j): x = x_k, u = u_k (zeros at the terminal knot), x1 = x_{k+1}
 // LAY: where the columns go.  0: column layout (cooperative backward pass); 1: tangent-matrix layout, full cost block;
 // 2: tangent-matrix layout, compact cost block; 3: lane layout (one lane per trajectory backward pass) — all in k_backward.h.
-template <class M, int FIXED_INTEG, int VAR, int LAY>
+// PACK (rigid body with a quaternion attitude, compact cost block): six of the sixteen columns of [Ā B̄] are CONSTANTS — the dynamics do
+// not read the position, and the (world-frame) velocity only as ṙ = v, so ∂x⁺/∂r = [I; 0; 0; 0] and ∂x⁺/∂v = [h I; 0; I; 0] for every
+// Runge-Kutta scheme — and live in Mt from k_expand_const_columns on.  A wave then holds SIX trajectories x the TEN differentiated
+// columns (attitude, ω, controls) instead of four x sixteen; the lanes of the first six of them also deliver the cost entries of one
+// constant column each (jc >= 0): the cost (+AL) Hessian-vector product is taken with the direction of the own column PLUS e_jc — the
+// compact cost block is block-diagonal with r and v on 1 x 1 blocks (KArgs::h_compact), so entry jc of the product is exactly the diagonal
+// entry of column jc and every other entry is what the own direction alone gives — and the gradient does not depend on the direction.
+template <class M> struct ExpandPack { static constexpr bool ok = M::lie && M::att == ATT_QUAT && M::ne == 12 && M::m == 4 && Tm<M>::fits; };
+template <class M, int FIXED_INTEG, int VAR, int LAY, bool PACK = false>
 __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane, int tile, int lane64, int b, int j, int k, bool valid,
                                             const double* x, const double* u, const double* x1, const ConExp<M::m>& ce0,
-                                            const ConExp<M::m>& ce1, bool table_cons) {
+                                            const ConExp<M::m>& ce1, bool table_cons, int jc = -1, bool valid_c = false) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
+  static_assert(!PACK || (LAY == 2 && ExpandPack<M>::ok), "packed expansion: compact tangent-matrix layout of the quaternion rigid body");
   constexpr int NEP = Tm<M>::NEP, RS = Tm<M>::RS, NR = Tm<M>::NR;
   const int ct = j < ne ? j : NEP + (j - ne);  // tangent index of this lane's column
   const DevProblem& P = a.P;
@@ -90,6 +99,11 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   }
   // ---- cost (+AL) gradient and Hessian-vector product on the full state
   double gr[nz], y[nz];
+  const int sc = jc < 3 ? jc : jc + 1;  // state index of the constant column this lane serves (error index 6..8 = state 7..9); PACK only
+  if constexpr (PACK) {  // (from here on v carries e_sc as well; the own column's dot products below skip that entry)
+#pragma unroll
+    for (int i = 0; i < n; ++i) v[i] = (jc >= 0 && i == sc) ? 1.0 : v[i];
+  }
   cost_grad_hvp<n, m, (VAR & 1) != 0>(P.costs[P.cost_index[k]], x, u, terminal, v, gr, y);
   if (P.gl) goal_lin_grad<n, m>(P.gl + ((size_t)tile * (size_t)(P.n_costs * nz)) * 64 + lane64, P.cost_index[k], terminal, gr);  // per-trajectory q, r
   if (P.opts.cost_dt_scaling && !terminal) {
@@ -135,10 +149,22 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
     // exactly nothing, so the values are those of picking entry j out of G'y / G'g — without the 16-deep select chains per
     // picked entry that were half of this kernel's non-FP64 instructions (profiles/r03: 49 % of its VALU instructions).
     double gj = 0.0, dj = 0.0;
+    if constexpr (PACK) {  // the own direction has a zero at sc: its terms are left out, not multiplied by the 1 planted there
+#pragma unroll
+      for (int i = 0; i < nz; ++i) gj += ((jc >= 0 && i == sc) ? 0.0 : v[i]) * gr[i];
+#pragma unroll
+      for (int i = 0; i < n; ++i) dj += ((jc >= 0 && i == sc) ? 0.0 : v[i]) * y[i];
+      if (jc >= 0 && valid_c) {  // cost entries of the constant column jc: diagonal entry of the block, gradient component
+        const double dc = pick<n>(y, sc), gc = pick<n>(gr, sc);
+        a.Ht[((size_t)b * N + k) * 64 + (jc & 3) * 16 + jc] = dc;
+        a.gt[((size_t)b * N + k) * 16 + jc] = gc;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < nz; ++i) gj += v[i] * gr[i];
 #pragma unroll
     for (int i = 0; i < n; ++i) dj += v[i] * y[i];
+    }
     double col[ne];
     errstate_tmul<M>(x, y, col);  // (only the attitude rows 3..5 are used below)
     if constexpr (M::att == ATT_QUAT) {  // second-order term of the attitude map: −I₃ (qᵀ ∂J/∂q) on the attitude diagonal
@@ -249,12 +275,18 @@ __host__ __device__ constexpr int expand_kc() {
 #ifndef TO_EXPAND_WAVES
 #define TO_EXPAND_WAVES 1  // minimum waves per SIMD k_expand is compiled for (register cap 512 / waves)
 #endif
-template <class M, int FIXED_INTEG, int VAR, int LAY>
+constexpr int EXPAND_PACK_G = 6, EXPAND_PACK_R = 10;  // packed expansion: trajectories per wave x differentiated columns (lanes 60..63 idle)
+template <class M, int FIXED_INTEG, int VAR, int LAY, bool PACK = false>
 __global__ void __launch_bounds__(64, TO_EXPAND_WAVES) k_expand(KArgs a) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nc = ne + m, KC = expand_kc<M, VAR>();
-  constexpr int R = Coop<M>::R, G = Coop<M>::G;
+  constexpr int R = PACK ? EXPAND_PACK_R : Coop<M>::R, G = PACK ? EXPAND_PACK_G : Coop<M>::G;
   const int gtile = blockIdx.x, lane = threadIdx.x;
-  const int g = lane / R, j = lane % R;
+  // PACK: lane jj of a trajectory's ten owns column 3..5 (attitude), 9..11 (ω) or 12..15 (controls); the first six also serve the cost
+  // entries of constant column 0..2 (r) / 6..8 (v); lanes 60..63 ride along on the last trajectory without storing anything
+  const int g = PACK ? (lane < G * R ? lane / R : G - 1) : lane / R, jj = PACK ? (lane < G * R ? lane % R : R - 1) : lane % R;
+  const int j = PACK ? (jj < 3 ? 3 + jj : jj < 6 ? 6 + jj : 6 + jj) : jj;   // 0,1,2 -> 3,4,5;  3,4,5 -> 9,10,11;  6..9 -> 12..15
+  const int jc = PACK ? (jj < 3 ? jj : jj < 6 ? 3 + jj : -1) : -1;            // 0,1,2 -> 0,1,2;  3,4,5 -> 6,7,8
+  const bool lane_live = !PACK || lane < G * R;
   const DevProblem& P = a.P;
   const int N = P.N;
   const int k0 = blockIdx.y * KC;
@@ -273,7 +305,7 @@ __global__ void __launch_bounds__(64, TO_EXPAND_WAVES) k_expand(KArgs a) {
   }
   // idle lanes (padding columns, finished trajectories) compute along with EXEC full — partially masked FP64 issues
   // ~1.3x slower on gfx950 — and only their stores are predicated; a wave without any work leaves
-  const bool lane_ok = inrange && j < nc && a.active[inrange ? b : 0];
+  const bool lane_ok = lane_live && inrange && j < nc && a.active[inrange ? b : 0];
   if (__ballot(lane_ok) == 0) return;
   // Inside a solve the step accepted by the previous forward pass still sits in its candidate slot (acc != 0): the
   // expansion reads it there and writes it through to slot 0, so the separate k_accept copy (and its re-read of every
@@ -321,13 +353,37 @@ __global__ void __launch_bounds__(64, TO_EXPAND_WAVES) k_expand(KArgs a) {
         for (int i = 0; i < m; ++i) EL(U0, k * m + i) = u[i];
       }
     }
-    expand_knot<M, FIXED_INTEG, VAR, LAY>(a, gtile, lane, tile, lane64, b, j, k, valid, x, u, x1, ce0, ce1, table_cons);
+    expand_knot<M, FIXED_INTEG, VAR, LAY, PACK>(a, gtile, lane, tile, lane64, b, j, k, valid, x, u, x1, ce0, ce1, table_cons, jc, lane_ok);
     if (KC > 1) {
 #pragma unroll
       for (int i = 0; i < n; ++i) { x[i] = x1[i]; x1[i] = x2[i]; }
 #pragma unroll
       for (int i = 0; i < m; ++i) u[i] = un[i];
     }
+  }
+}
+
+// The constant columns of [Ā B̄] of the packed expansion (above), written ONCE per handle (the time steps never change): position columns
+// e_c, velocity columns [h_k e_d; 0; e_d; 0], every other row zero.  grid (B, ceil((N-1)/4)), 64 lanes = 4 knots x 16 rows/columns slots.
+template <class M>
+__global__ void __launch_bounds__(64) k_expand_const_columns(KArgs a) {
+  constexpr int ne = M::ne, RS = Tm<M>::RS;
+  const DevProblem& P = a.P;
+  const int b = blockIdx.x, k = blockIdx.y * 4 + (threadIdx.x >> 4), t = threadIdx.x & 15;
+  if (b >= P.B || k >= P.N - 1 || t >= ne) return;
+  const int i = t;  // row
+  double* Mt = a.Mt + (((size_t)b * (P.N - 1) + k) * RS) * 64 + (i / 4) * 64 + (i % 4) * 16;
+  const double h = P.dt[k];
+  // ∂r⁺/∂v is h in exact arithmetic; the value stored is the one the dual numbers produce when they run through rk_step (models.h) —
+  // k_i.d = h, acc = k1 + 2 k2 + 2 k3 (RK3: k1 + 4 k2), x + (acc + k_last) (1/6), with the roundings of those operations — so that the packed
+  // kernel and the 4 x 16 one agree to the last bit (the zig-zag solve is chaotic enough to amplify one ulp of this entry to 1e-6)
+  double dv = h;
+  if (P.integrator == INTEG_RK3) { double acc = h; acc = fma(4.0, h, acc); dv = (acc + h) * (1.0 / 6.0); }
+  else if (P.integrator != INTEG_EULER) { double acc = h; acc = fma(2.0, h, acc); acc = fma(2.0, h, acc); dv = (acc + h) * (1.0 / 6.0); }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    Mt[c] = (i == c) ? 1.0 : 0.0;                                   // ∂x⁺/∂r_c
+    Mt[6 + c] = (i == c) ? dv : (i == 6 + c) ? 1.0 : 0.0;           // ∂x⁺/∂v_c
   }
 }
 

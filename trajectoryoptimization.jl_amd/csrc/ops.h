@@ -108,6 +108,15 @@ int op_expand_fi(to_handle* h) {
   if (lay == 3 && h->expand_lane && h->ops->expand_lane_k) return h->ops->expand_lane_k(h);
 #define TO_EXPAND_CASE(V, LY) \
   if (var == V && lay == LY) { hipLaunchKernelGGL((k_expand<M, FI, V, LY>), grid, dim3(BLOCK), 0, h->stream, h->a); HIPCHECK(hipGetLastError()); return TO_OK; }
+  if constexpr (M::mfma_backward && ExpandPack<M>::ok) {  // compact cost block of the quaternion rigid body: the packed expansion (k_expand.h)
+    if (lay == 2 && h->expand_pack && (var == 0 || var == 2)) {
+      const dim3 pgrid((P.B + EXPAND_PACK_G - 1) / EXPAND_PACK_G, (P.N + kc - 1) / kc);
+      if (var == 0) hipLaunchKernelGGL((k_expand<M, FI, 0, 2, true>), pgrid, dim3(BLOCK), 0, h->stream, h->a);
+      else hipLaunchKernelGGL((k_expand<M, FI, 2, 2, true>), pgrid, dim3(BLOCK), 0, h->stream, h->a);
+      HIPCHECK(hipGetLastError());
+      return TO_OK;
+    }
+  }
   if constexpr (M::mfma_backward) {
     TO_EXPAND_CASE(0, 1) TO_EXPAND_CASE(0, 2) TO_EXPAND_CASE(2, 1) TO_EXPAND_CASE(2, 2) TO_EXPAND_CASE(7, 1)
   }
@@ -119,6 +128,13 @@ int op_expand_fi(to_handle* h) {
   }
 #undef TO_EXPAND_CASE
   return fail(TO_ERR_UNSUPPORTED, "expansion variant not compiled for this model");
+}
+template <class M>
+int op_expand_const(to_handle* h) {
+  const DevProblem& P = h->a.P;
+  hipLaunchKernelGGL(k_expand_const_columns<M>, dim3(P.B, (P.N - 1 + 3) / 4), dim3(BLOCK), 0, h->stream, h->a);
+  HIPCHECK(hipGetLastError());
+  return TO_OK;
 }
 template <class M>
 int op_expand(to_handle* h) {

@@ -2,5 +2,5 @@
 #include "ops.h"
 
 namespace to {
-void fill_ops_quad_expand(ModelOps* t) { t[4].expand = op_expand<QuadrotorModel>; }
+void fill_ops_quad_expand(ModelOps* t) { t[4].expand = op_expand<QuadrotorModel>; t[4].expand_const = op_expand_const<QuadrotorModel>; }
 }  // namespace to

@@ -245,6 +245,9 @@ int upload_tables(to_handle* h) {
     h->a.h_diag = (!h->a.bwd_mfma && !h->a.bwd_lane && diagonal_cost_blocks(h)) ? 1 : 0;
     if (const char* env = std::getenv("TRAJOPT_FULL_COST_BLOCKS")) if (std::atoi(env)) { h->a.h_compact = 0; h->a.h_diag = 0; }  // testing knob
   }
+  // packed expansion (k_expand.h): whenever the compact cost block is (back) in use, the constant columns of [A B] are in place —
+  // another variant of the expansion (general: full cost block) writes them from its dual numbers, equal to rounding only
+  if (h->a.Mt && h->a.h_compact && h->expand_pack && h->ops->expand_const) TRY(h->ops->expand_const(h));
   HIPCHECK(hipMemcpyAsync(h->d_costs, h->costs.data(), h->costs.size() * sizeof(to_cost_desc), hipMemcpyHostToDevice, h->stream));
   if (!h->cons.empty()) HIPCHECK(hipMemcpyAsync(h->d_cons, h->cons.data(), h->cons.size() * sizeof(DevCon), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -1082,6 +1085,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
   if (const char* env = std::getenv("TRAJOPT_ACCEPT_ROLL_FRAC")) h->roll_min_frac = std::atof(env);
   if (const char* env = std::getenv("TRAJOPT_REPACK")) h->rp_min = std::atoi(env);  // 0: never; n: while the working set holds >= n trajectories
   if (const char* env = std::getenv("TRAJOPT_REPACK_AT")) h->rp_at = std::min(0.95, std::max(0.05, std::atof(env)));
+  if (const char* env = std::getenv("TRAJOPT_EXPAND_PACK")) h->expand_pack = std::atoi(env) != 0;
   h->fwd2 = 2;  // 0: one-wave forward pass only; 1: two-wave always (phase API included); 2: per batch step, by the active count
   if (const char* env = std::getenv("TRAJOPT_FWD2")) h->fwd2 = std::atoi(env);
   if (h->fwd2 < 0 || h->fwd2 > 2) h->fwd2 = 2;
@@ -1189,6 +1193,7 @@ int to_create(const to_problem_desc* desc, const to_solver_opts* opts, int devic
       HIPB(hipStreamSynchronize(h->stream));
     }
   }
+  if (a.Mt && a.h_compact && h->expand_pack && h->ops->expand_const) TRYB(h->ops->expand_const(h));
   HIPB(hipStreamSynchronize(h->stream));
 #undef TRYB
 #undef HIPB
