@@ -12,7 +12,12 @@ batch=1024 trajectories.  Every rank owns its own 1024-trajectory shard (weak sc
 from the global trajectory index so shards are disjoint); with N>1 each step ends with the north-star's
 RCCL all-gather of the converged trajectories.
 
-value = total trajectory-iterations of all ranks over the K timed steps / max-over-ranks wall time.
+The K steps are timed twice: one after the other on one handle ("unpipelined" in the line), and — the line's value — PIPELINED over
+four handles per rank (--pipeline): step i on handle i mod 4, every handle holding the same batch, the next solve admitted while the one
+in flight drains (to_solve_progress / to_solve_wait_below).  A solve is batch-synchronous and its batch drains unevenly (C2: half of its
+300 batch steps serve five trajectories), and every solve of the pipelined pass equals the unpipelined one bit for bit.
+
+value = total trajectory-iterations of all ranks over the timed steps / max-over-ranks wall time between barriers.
 roofline: algorithmic bytes (48 064 B per Cartpole trajectory-iteration, split per kernel as
 DESIGN.md §4 states) / kernel time from hipEvents recorded on the library's own stream inside the timed
 region.  cpu_baseline: the CPU oracle (a port; the Julia reference cannot run here) on the same workload.
@@ -136,6 +141,7 @@ def physical_cores():
 
 
 HOST_CORES = physical_cores()
+START_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
 
 def cgroup_cpu_quota():
@@ -309,35 +315,52 @@ def overlap_run(T, configs, lib, name, batch, parts, device):
             "trajectory_iterations": best[1], "note": "best of 3; sub-batches solved concurrently through to_*_solve_async on separate streams"}
 
 
-def pipelined_run(T, configs, lib, name, batch, depth, steps, warmup, admit_frac, device, prob0, solver0, u0):
+def pipelined_run(T, configs, lib, name, batch, b_offset, depth, steps, warmup, admit_frac, device, prob0, solver0, u0, gather0, make_gather_fn, barrier):
     """`steps` solves of the workload's batch, pipelined over `depth` handles (to_solve_progress / to_solve_wait_below; api.SolvePipeline):
     step i runs on handle i % depth — every handle holds the SAME batch, so every step is the unpipelined step, bit for bit — and is
     admitted when the step in front has at most admit_frac * batch trajectories still iterating.  The drained tail of one solve (C3: 52 of
-    141 batch steps on a handful of stragglers, chip empty) runs under the dense first steps of the next.  Timed from the first submit to
-    the last wait: the ramp-up and the final, un-overlapped drain are inside the figure."""
-    probs = [prob0] + [build_problem(T, configs, name, batch, 0, device, lib) for _ in range(depth - 1)]
+    141 batch steps on a handful of stragglers, chip empty; C2: half of its 300 batch steps serve five trajectories) runs under the dense
+    first steps of the next.  Timed between barriers from the first submit to the last wait: the ramp-up and the final, un-overlapped
+    drain are inside the figure.  With several ranks every handle has its own communicator and gathers when its solve is collected (the
+    collectives come in submit order on every rank).  -> (seconds, trajectory-iterations, batch steps, admit_below, gather_note)"""
+    probs = [prob0] + [build_problem(T, configs, name, batch, b_offset, device, lib) for _ in range(depth - 1)]
     solvers = [solver0] + [make_solver(T, configs, name, p) for p in probs[1:]]
+    gathers, note = [gather0], None
     for i in range(1, depth):
+        g, gn = make_gather_fn(probs[i])
+        gathers.append(g)
+        note = note or gn
         T.initial_controls(probs[i], u0)
         solvers[i].solve()               # warm every handle (allocations of the first solve: polish workspace, event pools)
+    slot_of = {id(sv): i for i, sv in enumerate(solvers)}
+
+    def on_done(job, sv):
+        g = gathers[slot_of[id(sv)]]
+        if g is not None:
+            with Watchdog("all-gather of the converged trajectories and stats (%s, pipelined job %d)" % (name, job)):
+                g()
+                g.stats(sv)
+
     prep = lambda p: T.initial_controls(p, u0)
     best = None
     for rep in range(1 + warmup):        # the warm-up repetitions run the same pipelined sequence
-        pipe = T.SolvePipeline(solvers, admit_below=int(admit_frac * batch))
+        pipe = T.SolvePipeline(solvers, admit_below=int(admit_frac * batch), on_done=on_done)
+        barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             pipe.submit(prep)
         pipe.drain()
+        barrier()
         dt = time.perf_counter() - t0
         best = (dt, pipe.total_iterations, sum(r[2] for r in pipe.results))
     dt, its, bsteps = best
-    del pipe, solvers, probs      # the extra handles go NOW: idle streams take hardware-queue slots from whatever runs next
+    for g in gathers[1:]:
+        if g is not None:
+            g.close()
+    del pipe, solvers, probs, gathers      # the extra handles go NOW: idle streams take hardware-queue slots from whatever runs next
     import gc
     gc.collect()
-    return {"depth": depth, "admit_below": int(admit_frac * batch), "steps": steps, "value": its / dt, "ms_per_step": 1e3 * dt / steps,
-            "trajectory_iterations": its, "batch_steps_per_solve": bsteps / steps,
-            "note": "value = trajectory-iterations of `steps` solves / wall time from the first submit to the last wait (ramp-up and final drain included); "
-                    "every solve is the unpipelined solve bit for bit (tests/test_gpu_pipeline.py)"}
+    return dt, its, bsteps, int(admit_frac * batch), note
 
 
 class Watchdog:
@@ -369,22 +392,9 @@ class Watchdog:
         return False
 
 
-def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True, pipeline=0, pipeline_steps=0,
-                 admit_frac=0.5):
-    """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings.  pipeline = d > 1 (one
-    rank only): a third pass of `pipeline_steps` solves pipelined over d handles becomes the line's value; the unpipelined figure stays
-    beside it under "unpipelined"."""
-    W = WORKLOADS[name]
-    prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
-    solver = make_solver(T, configs, name, prob)
-    u0 = initial_controls_value(T, prob, name)
-    n, m, N = prob.dims()
-    dims = (n, m, prob.errstate_dim, N, sum(prob.constraints.p))
-    info = (C.c_int32 * 8)()
-    prob._call("solver_path", info)
-    path = {"backward": ("coop", "mfma", "lane")[info[0]], "fused_expansion": bool(info[1]), "compaction": bool(info[2]),
-            "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4]), "scan_backward": bool(info[5]),
-            "accept_by_rollout": bool(info[6]), "line_search_repack": bool(info[7] & 1), "repacked_working_set": bool(info[7] & 2)}
+def make_gather(lib, prob, dist, torch, rank, local_rank, world, name):
+    """RCCL all-gather of the converged trajectories of `prob`'s handle (device-to-device, the library's own communicator) -> (gather,
+    note); (None, None) without torch.distributed.  Collective: every rank calls it for its handles in the same order."""
     gather, gather_note = None, None
     if dist is not None:  # RCCL all-gather of the converged trajectories, device-to-device
         from trajectoryoptimization_jl_amd.distributed import TrajectoryGather
@@ -419,6 +429,35 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
                 gather.close()
             gather = TrajectoryGather(prob, dist, device=None)
             gather_note = "torch.distributed all_gather of host-staged arrays (the library's RCCL communicator did not come up: %s)" % (err or "on another rank")
+
+    return gather, gather_note
+
+
+def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, world, dist, torch, profile=True, pipeline=0, pipeline_steps=0,
+                 admit_frac=0.5):
+    """Timed (event-free) pass of `steps` solves, then a profiled pass of the same steps for the per-phase timings.  pipeline = d > 1: a
+    third pass of `pipeline_steps` solves pipelined over d handles becomes the line's value (with several ranks: every handle with its own
+    communicator, gathering when its solve is collected); the unpipelined figure stays beside it under "unpipelined"."""
+    W = WORKLOADS[name]
+    # The cpu_baseline leg pins its OpenMP threads (OMP_PROC_BIND=close): once that runtime has started, THIS thread is bound to one core, and
+    # the solve threads the library starts (one per handle in flight) would inherit a one-core mask — four of them driving 100 us batch steps
+    # of the pipelined Cartpole solves from one core (5.4 instead of 8.8 M it/s).  Back to the mask the process started with.
+    if hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, START_AFFINITY)
+        except OSError:
+            pass
+    prob = build_problem(T, configs, name, batch, rank * batch, local_rank, lib)
+    solver = make_solver(T, configs, name, prob)
+    u0 = initial_controls_value(T, prob, name)
+    n, m, N = prob.dims()
+    dims = (n, m, prob.errstate_dim, N, sum(prob.constraints.p))
+    info = (C.c_int32 * 8)()
+    prob._call("solver_path", info)
+    path = {"backward": ("coop", "mfma", "lane")[info[0]], "fused_expansion": bool(info[1]), "compaction": bool(info[2]),
+            "first_round_step_sizes": int(info[3]), "forward_waves_per_workgroup": int(info[4]), "scan_backward": bool(info[5]),
+            "accept_by_rollout": bool(info[6]), "line_search_repack": bool(info[7] & 1), "repacked_working_set": bool(info[7] & 2)}
+    gather, gather_note = make_gather(lib, prob, dist, torch, rank, local_rank, world, name)
 
     def one_step():
         T.initial_controls(prob, u0)          # device-side reset of the batch to the initial guess
@@ -481,16 +520,33 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
                                      "ranks the RCCL communicator saw: %d, shards %s" % (len(gather.counts), gather.counts))
                       if gather is not None and gather_note is None else (gather_note or "none")},
            "roofline": roofline_block(configs, name, batch, dims, iters_prof, value / world, kms, kln, lib.build_id(), path) if profile else None}
-    if pipeline > 1 and dist is None:
-        pr = pipelined_run(T, configs, lib, name, batch, pipeline, pipeline_steps or max(steps, 2 * pipeline), warmup, admit_frac, local_rank, prob, solver, u0)
+    if pipeline > 1:
+        psteps = pipeline_steps or max(steps, 2 * pipeline)
+        pdt, pits, pbsteps, admit_below, pnote = pipelined_run(
+            T, configs, lib, name, batch, rank * batch, pipeline, psteps, warmup, admit_frac, local_rank, prob, solver, u0, gather,
+            lambda p: make_gather(lib, p, dist, torch, rank, local_rank, world, name), barrier)
+        if dist is not None:
+            t = torch.tensor([pdt, float(pits)], dtype=torch.float64, device="cuda")
+            tmax, tsum = t.clone(), t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            pdt, pits_all = float(tmax[0]), float(tsum[1])
+        else:
+            pits_all = float(pits)
+        pr = {"depth": pipeline, "admit_below": admit_below, "steps": psteps, "value": pits_all / pdt, "ms_per_step": 1e3 * pdt / psteps,
+              "trajectory_iterations": pits_all, "batch_steps_per_solve": pbsteps / psteps,
+              "note": "value = trajectory-iterations of `steps` solves (all ranks) / max-over-ranks wall time between barriers, from the first submit to the "
+                      "last wait (ramp-up and final drain included); every solve is the unpipelined solve bit for bit (tests/test_gpu_pipeline.py)"}
         res["unpipelined"] = {"value": res["value"], "ms_per_step": res["ms_per_step"], "steps": res["steps"]}
         res["value"], res["ms_per_step"], res["steps"] = pr["value"], pr["ms_per_step"], pr["steps"]
         res["config"]["workload"] += (f"; PIPELINED over {pipeline} handles: {pr['steps']} solves of the same batch, the next admitted when the one in flight "
                                       f"has <= {pr['admit_below']} trajectories still iterating")
         res["config"]["pipeline"] = pr
+        if pnote and res["config"].get("collective"):
+            res["config"]["collective"] += " | pipelined handles: " + pnote
         if res["roofline"] is not None:  # kernel timings: the unpipelined profiled pass; the whole-iteration figure: the pipelined value
             wi = res["roofline"]["whole_iteration"]
-            wi["achieved"] = wi["algorithmic_bytes_per_unit"] * res["value"] / 1e9
+            wi["achieved"] = wi["algorithmic_bytes_per_unit"] * res["value"] / world / 1e9
             wi["frac"] = wi["achieved"] / HBM_PEAK_GBS
             wi["note"] = "from the pipelined value; the per-kernel figures above are the unpipelined profiled pass"
     return res, prob, u0
@@ -499,7 +555,8 @@ def run_workload(T, configs, lib, name, batch, steps, warmup, rank, local_rank, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0, help="timed solves (default 24 / 16 / 12 for cartpole / quadrotor / the constrained workloads): the unpipelined pass "
+                                                          "and the pipelined pass both time exactly this many")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cartpole", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/scaling studies only)")
@@ -512,9 +569,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="do not append the C3 / C5 lines (extra_workloads) to the default C2 run")
     ap.add_argument("--pipeline", type=int, default=-1,
                     help="pipeline the solves over this many handles (the next solve is admitted when the one in flight has drained below "
-                         "--admit of its batch); default: 4 for the Quadrotor workloads (the extra C3 / C5 lines included), 0 for the Cartpole "
-                         "headline (two host threads driving 100 us batch steps lose: DESIGN.md §4.10)")
-    ap.add_argument("--pipeline-steps", type=int, default=0, help="solves of the pipelined pass (default max(steps, 2 x depth))")
+                         "--admit of its batch); default 4 for every workload (0 / 1: unpipelined only); the unpipelined figure of the same run "
+                         "is always reported beside it")
+    ap.add_argument("--pipeline-steps", type=int, default=0, help="solves of the pipelined pass (default: --steps)")
     ap.add_argument("--admit", type=float, default=-1.0, help="admit the next solve at this fraction of the batch still iterating (default per workload)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="also solve the workload as this many sub-batches on as many handles / streams in flight at once (to_*_solve_async): "
@@ -554,17 +611,20 @@ def main():
     if lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libtrajopt_hip.so has no CPU fallback")
     name = args.workload
+    if args.steps <= 0:
+        args.steps = {"cartpole": 24, "quadrotor": 16}.get(name, 12)
     batch = args.batch or WORKLOADS[name]["batch"]
-    depth = args.pipeline if args.pipeline >= 0 else (0 if name == "cartpole" else 4)
+    depth = args.pipeline if args.pipeline >= 0 else (0 if args.batch else 4)   # (--batch: scaling studies of one handle)
     res, prob, u0 = run_workload(T, configs, lib, name, batch, args.steps, args.warmup, rank, local_rank, world, dist, torch,
-                                 profile=not args.no_profile, pipeline=depth, pipeline_steps=args.pipeline_steps,
+                                 profile=not args.no_profile, pipeline=depth,
+                                 pipeline_steps=args.pipeline_steps or args.steps,
                                  admit_frac=args.admit if args.admit >= 0 else ADMIT_FRAC.get(name, 1.0))
 
     if rank == 0:
         out = {"metric": "iLQR iterations/sec (batched trajectories)", "value": res["value"], "unit": res["unit"],
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": res["config"], "roofline": res["roofline"], "build_id": lib.build_id()}
+               "config": res["config"], "roofline": res["roofline"], "unpipelined": res.get("unpipelined"), "build_id": lib.build_id()}
         probe = args.throughput_probe
         if probe < 0:
             probe = 32768 if (name == "cartpole" and world == 1) else 0
@@ -638,7 +698,7 @@ def main():
     # workload sharded 4096 trajectories per GPU (with 8 ranks: exactly C4's 32 768), same weak-scaling protocol, same RCCL gathers.
     if dist is not None and name == "cartpole" and not args.batch and not args.no_extra:
         r4, p4, _ = run_workload(T, configs, lib, "quadrotor", WORKLOADS["quadrotor"]["batch"], 2, 1, rank, local_rank, world, dist, torch,
-                                 profile=False)
+                                 profile=False, pipeline=(args.pipeline if args.pipeline >= 0 else 4), pipeline_steps=16, admit_frac=1.0)
         del p4
         if rank == 0:
             r4["config"]["workload"] = "C4: " + r4["config"]["workload"] + f" x {world} ranks = {world * WORKLOADS['quadrotor']['batch']} trajectories, RCCL all-gather per solve"

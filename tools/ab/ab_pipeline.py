@@ -24,7 +24,7 @@ def main():
     lib = T.load_hip_library()
     for name in names:
         batch = bench.WORKLOADS[name]["batch"]
-        steps = int(os.environ.get("AB_STEPS", "12" if name == "quadrotor" else "8"))
+        steps = int(os.environ.get("AB_STEPS", "12" if name == "quadrotor" else "24" if name == "cartpole" else "8"))
         grid = [(int(g.split(":")[0]), float(g.split(":")[1])) for g in os.environ.get("AB_GRID", "").split(",") if g] or \
                [(d, a) for d in (2, 3) for a in (1.0, 0.75, 0.5, 0.35, 0.25, 0.125, 0.06)]
         probs = [bench.build_problem(T, configs, name, batch, 0, 0, lib) for _ in range(max(d for d, _ in grid))]
