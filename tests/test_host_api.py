@@ -368,6 +368,28 @@ def test_committed_bench_line_follows_the_contract():
         assert c["kind"] == "port" and w["value"] > 0
 
 
+def test_committed_r06_bench_line_names_its_pipelining():
+    """profiles/r06_bench_default.json (a plain `python bench.py` of round 6): every pipelined line says so in config.workload, carries the
+    depth / admission rule / step count under config.pipeline and the UNPIPELINED figure of the same run beside its value; both passes time
+    exactly `steps` solves; no roofline fraction exceeds 1."""
+    import json
+    from pathlib import Path
+    d = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "r06_bench_default.json").read_text().strip())
+    assert d["metric"] == "iLQR iterations/sec (batched trajectories)" and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    lines = [("C2", d)] + [(k, v) for k, v in d["extra_workloads"].items() if "config" in v and "pipeline" in v["config"]]
+    assert [k for k, _ in lines] == ["C2", "C3", "C5"]
+    for key, w in lines:
+        pl, un = w["config"]["pipeline"], w["unpipelined"]
+        assert "PIPELINED over %d handles" % pl["depth"] in w["config"]["workload"] and pl["depth"] == 4
+        assert abs(w["value"] - pl["value"]) < 1e-6 * w["value"] and w["value"] > un["value"] > 0 and w["steps"] == pl["steps"]
+        r = w["roofline"]
+        assert 0 < r["frac"] < 1 and 0 < r["whole_iteration"]["frac"] < 1 and r["traffic"] is not None
+        assert w["cpu_baseline"]["cores"] <= (w["cpu_baseline"]["cgroup_cpu_quota_cores"] or 1e9) + 0.5
+    assert d["steps"] == d["unpipelined"]["steps"] == 24
+    alt = d["extra_workloads"]["C5_altro_defaults"]
+    assert "n_steps = 2" in alt["config"]["workload"] and 0.9 < alt["config"]["converged_fraction"] < d["extra_workloads"]["C5"]["config"]["converged_fraction"]
+
+
 def test_rccl_stub_builds_and_exports_what_the_library_binds(tmp_path):
     """tests/rccl_stub (the shared-memory stand-in that lets several ranks share one GPU in the -m gpu suite) must export every nccl*
     entry point csrc/trajopt_hip.hip dlsym()s — checked here so that the GPU test cannot silently skip a symbol."""
