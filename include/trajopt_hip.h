@@ -370,11 +370,15 @@ int to_set_constraint(to_handle* h, int32_t con_id, const to_constraint_desc* co
 int to_set_cost_linear_batch(to_handle* h, int32_t cost_id, const double* q /* [n*B] or NULL */, const double* r /* [m*B] or NULL */);
 int to_clear_cost_linear_batch(to_handle* h);
 /* One constraint-parameter set per TRAJECTORY (round 6): set_goal_state!(prob, xf; constraint = true) updates the GoalConstraints too
- * (src/problem.jl:303-309, src/constraints.jl:22-87) — here for every trajectory of the batch at once.  con_id must be a GOAL constraint;
- * params[p, B] (column-major) = xf_b[inds], the target of trajectory b.  Everything that evaluates the constraint — AL terms and their
- * expansion, violation, dual update, the projected-Newton polish, to_evaluate_constraints — then uses the trajectory's own target (the
- * solves run the general kernel variants while any constraint carries per-trajectory parameters).  to_set_constraint on the
- * constraint returns it to shared parameters, to_clear_constraint_params_batch all of them.  Other kinds: TO_ERR_UNSUPPORTED. */
+ * (src/problem.jl:303-309, src/constraints.jl:22-87) — here for every trajectory of the batch at once.  con_id names a GOAL constraint,
+ * params[p, B] (column-major) = xf_b[inds], the target of trajectory b — or a LINEAR constraint (src/constraints.jl:103-150), params[p, B] =
+ * b_b, its right-hand side for trajectory b (the rows of A must be linearly independent: TO_ERR_UNSUPPORTED otherwise).  Everything that
+ * evaluates the constraint — AL terms and their expansion, violation, dual update, the projected-Newton polish, to_evaluate_constraints —
+ * then uses the trajectory's own parameters (the solves run the general kernel variants while any constraint carries them).  On the
+ * device the difference from the descriptor is a shift of z = [x; u] as that constraint sees it: the GoalConstraint with target xf + d is
+ * the shared one at x - d; A z = b + db is the shared one at z - A'(A A')^-1 db (values agree with the direct evaluation to rounding,
+ * Jacobians exactly).  to_set_constraint on the constraint returns it to shared parameters, to_clear_constraint_params_batch all of
+ * them.  Other kinds: TO_ERR_UNSUPPORTED. */
 int to_set_constraint_params_batch(to_handle* h, int32_t con_id, const double* params /* [p*B] */);
 int to_clear_constraint_params_batch(to_handle* h);
 

@@ -621,6 +621,13 @@ function TO.set_goal_state!(p::BatchProblem, Xf::Matrix{Float64}; objective::Boo
     end
     nothing
 end
+"""
+    set_constraint_params_batch!(p, con_id, params)       # params :: (p_rows, B)
+One parameter set per trajectory for constraint `con_id` (1-based position in the ConstraintList): a `GoalConstraint`'s target `xf_b[inds]`
+or a `LinearConstraint`'s right-hand side `b_b` (`to_set_constraint_params_batch`).
+"""
+set_constraint_params_batch!(p::BatchProblem, con_id::Integer, params::Matrix{Float64}) =
+    check(ccall((:to_set_constraint_params_batch, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), p.handle, Int32(con_id - 1), params))
 function clear_goal_state_batch!(p::BatchProblem)
     check(ccall((:to_clear_cost_linear_batch, lib), Cint, (Ptr{Cvoid},), p.handle))
     check(ccall((:to_clear_constraint_params_batch, lib), Cint, (Ptr{Cvoid},), p.handle))

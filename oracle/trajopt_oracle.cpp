@@ -70,8 +70,9 @@ struct Traj {
   std::vector<double> Sall, sall;             /* [N] ne*ne, ne: cost-to-go of the last backward pass (oracle_get_cost_to_go) */
   std::vector<double> gl;                     /* per-trajectory linear cost terms, [n_costs] (n + m): what q, r differ by from the descriptor (empty: none) */
   std::vector<double> lambda, mu;             /* duals (n_duals), penalties (ncons) */
-  std::vector<std::vector<double>> cpar;      /* per-trajectory constraint parameters (oracle_set_constraint_params_batch): cpar[i] replaces the
-                                                 leading parameters of constraint i's descriptor for THIS trajectory (empty: the shared ones) */
+  std::vector<std::vector<double>> cpar;      /* per-trajectory constraint parameters (oracle_set_constraint_params_batch): cpar[i] replaces
+                                                 parameters of constraint i's descriptor for THIS trajectory — a GoalConstraint's target (the
+                                                 leading p), a LinearConstraint's b (behind A) — (empty: the shared ones) */
   double dV[2] = {0, 0};
   double rho = 0, drho = 0;
   double J = 0, dJ = 0, grad = 0, c_max = 0;
@@ -319,7 +320,8 @@ struct EffDesc {
   const to_constraint_desc& get(const Traj& t, size_t i, const ConInfo& ci) {
     if (i >= t.cpar.size() || t.cpar[i].empty()) return ci.d;
     tmp = ci.d;
-    for (size_t r = 0; r < t.cpar[i].size(); ++r) tmp.params[r] = t.cpar[i][r];
+    const size_t off = (ci.d.kind == TO_CON_LINEAR) ? (size_t)ci.p * ci.d.n_inds : 0;
+    for (size_t r = 0; r < t.cpar[i].size(); ++r) tmp.params[off + r] = t.cpar[i][r];
     return tmp;
   }
 };
@@ -1089,12 +1091,13 @@ int oracle_set_constraint(oracle_handle* h, int32_t id, const to_constraint_desc
   for (Traj& t : h->T) if ((size_t)id < t.cpar.size()) t.cpar[id].clear();  /* its per-trajectory parameters start over */
   return TO_OK;
 }
-/* One parameter set per TRAJECTORY for constraint id (to_set_constraint_params_batch): params[n_params, B] column-major.  GOAL: xf[inds]. */
+/* One parameter set per TRAJECTORY for constraint id (to_set_constraint_params_batch): params[p, B] column-major.  GOAL: xf[inds]; LINEAR: b. */
 int oracle_set_constraint_params_batch(oracle_handle* h, int32_t id, const double* params) {
   CHECK_H(h); CHECK_P(params);
   if (id < 0 || id >= (int)h->P.cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   const ConInfo& ci = h->P.cons[id];
-  if (ci.d.kind != TO_CON_GOAL) return fail(TO_ERR_UNSUPPORTED, "per-trajectory constraint parameters: GoalConstraint only");
+  if (ci.d.kind != TO_CON_GOAL && ci.d.kind != TO_CON_LINEAR)
+    return fail(TO_ERR_UNSUPPORTED, "per-trajectory constraint parameters: GoalConstraint (its target) and LinearConstraint (its b) only");
   const int np = ci.p;
   for (int b = 0; b < h->P.B; ++b) {
     Traj& t = h->T[b];

@@ -59,7 +59,7 @@ def test_per_trajectory_goal_checks(oracle):
         T.set_goal_state(p, np.zeros((2, 4)))
     T.set_goal_state(p, np.zeros((3, 4)))                      # objective and GoalConstraint, one target per trajectory
     T.set_goal_state(p, np.zeros((3, 4)), constraint=False)
-    with pytest.raises(T.UnsupportedError, match="GoalConstraint only"):
+    with pytest.raises(T.UnsupportedError, match="GoalConstraint .its target. and LinearConstraint"):
         p._call("set_constraint_params_batch", 0, p._pd(np.zeros((3, 1))))      # constraint 0 is the control bound
     with pytest.raises(T.ArgumentError):
         p._call("set_constraint_params_batch", 7, p._pd(np.zeros((3, 4))))
@@ -119,6 +119,66 @@ def test_per_trajectory_goal_constraints_equal_single_trajectory_problems(oracle
     c0 = T.evaluate_constraints(pb, gi)
     np.testing.assert_allclose(c0[:, 0, :], T.states(pb)[:, -1, :] - Xf[0][None, :], rtol=0, atol=1e-14)
 
+
+def linear_problem(lib, B, bvals=None):
+    """2-D double integrator to a goal with a half-plane keep-out  a'p <= b  on every stage knot and a coupled control row
+    u1 + 2 u2 <= c  (one LinearConstraint with two rows over [x; u]); optionally one right-hand side per trajectory."""
+    model = T.DoubleIntegrator(1.0, 2)
+    n, m, N = 4, 2, 31
+    xf = np.array([1.0, 2.0, 0.0, 0.0])
+    obj = T.LQRObjective(np.ones(n), 0.1 * np.ones(m), 100 * np.ones(n), xf, N)
+    cons = T.ConstraintList(n, m, N)
+    A = np.array([[1.0, -0.5, 0.0, 0.0], [0.0, 0.0, 1.0, 2.0]])         # over z[inds], inds = (x1, x2, u1, u2)
+    T.add_constraint(cons, T.LinearConstraint(n, m, A, np.array([0.6, 3.0]), T.Inequality(), inds=[1, 2, 5, 6]), (1, N - 1))
+    T.add_constraint(cons, T.GoalConstraint(xf), N)
+    p = T.Problem(model, obj, np.zeros(n), 3.0, xf=xf, constraints=cons, batch=B, lib=lib)
+    x0 = np.zeros((B, n)); x0[:, :2] = np.random.default_rng(3).uniform(-0.2, 0.2, (B, 2)); x0[0] = 0
+    p.set_initial_state(x0)
+    if bvals is not None:
+        T.set_constraint_params_batch(p, 0, bvals)
+    return p, x0
+
+
+def linear_rhs(B, seed=2):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.uniform(0.45, 0.9, B), rng.uniform(2.4, 3.6, B)], axis=1)      # [B, p]
+
+
+def test_per_trajectory_linear_rhs_equals_single_trajectory_problems(oracle):
+    """One right-hand side b per trajectory for a LinearConstraint (to_set_constraint_params_batch; src/constraints.jl:103-150): every trajectory
+    of the oracle's batch against a single-trajectory problem BUILT with that b — values, Jacobians, violation, AL cost, gains, AL solves."""
+    B = 5
+    bv = linear_rhs(B)
+    pb, x0 = linear_problem(oracle, B, bv)
+    T.initial_controls(pb, np.array([0.3, 0.5])); T.rollout(pb)
+    I.dual_update(pb); I.dual_update(pb)
+    cb, jb, vb, ab = T.evaluate_constraints(pb, 0), T.constraint_jacobians(pb, 0), T.max_violation(pb), I.al_cost(pb)
+    I.expand(pb); I.backwardpass(pb)
+    gb = I.gains(pb)
+    sb = T.ALSolver(pb).solve()
+    Xb = T.states(pb)
+    for b in range(B):
+        p1, _ = linear_problem(oracle, 1)
+        con = p1.constraints.constraints[0]
+        con.b = bv[b].copy()                                   # the descriptor itself carries this trajectory's b
+        d = con._desc(*p1.constraints.inds[0])
+        p1._call("set_constraint", 0, __import__("ctypes").byref(d))
+        p1.set_initial_state(x0[b])
+        T.initial_controls(p1, np.array([0.3, 0.5])); T.rollout(p1)
+        I.dual_update(p1); I.dual_update(p1)
+        np.testing.assert_allclose(T.evaluate_constraints(p1, 0)[0], cb[b], rtol=1e-13, atol=1e-14)
+        np.testing.assert_array_equal(T.constraint_jacobians(p1, 0)[0], jb[b])
+        np.testing.assert_allclose(T.max_violation(p1)[0], vb[b], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(I.al_cost(p1)[0], ab[b], rtol=1e-12)
+        I.expand(p1); I.backwardpass(p1)
+        g1 = I.gains(p1)
+        np.testing.assert_allclose(g1["K"][0], gb["K"][b], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(g1["d"][0], gb["d"][b], rtol=1e-9, atol=1e-10)
+        s1 = T.ALSolver(p1).solve()
+        for k in ("iterations", "iterations_outer", "status"):
+            assert int(s1.stats[k][0]) == int(sb.stats[k][b]), (k, b)
+        np.testing.assert_allclose(T.states(p1)[0], Xb[b], rtol=1e-6, atol=1e-7)
+    assert (sb.stats["status"] == T.capi.SOLVE_SUCCEEDED).all() and np.ptp(cb[:, 0, 0]) > 0.05
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["default", "lane", "fwd1"])
@@ -227,3 +287,43 @@ def test_per_trajectory_goal_constraints_on_gpu(kind, hip, oracle, monkeypatch):
         assert ok.mean() > 0.9
         inds = [j - 1 for j in ph.constraints.constraints[gi].inds]
         assert np.abs(T.states(ph)[ok][:, -1, inds] - Xf[ok][:, inds]).max() < (2e-4 if Solver is T.ALSolver else 1e-5)
+
+
+@pytest.mark.gpu
+def test_per_trajectory_linear_rhs_on_gpu(hip, oracle):
+    """One LinearConstraint right-hand side per trajectory on the GPU (stored as the minimum-norm shift of z: A (z - A^+ db) - b) against the oracle
+    (which replaces b in a per-trajectory copy of the descriptor): values to rounding, Jacobians exactly, gains, forward pass, then AL and ALTRO solves
+    with integers bit-exact.  Linearly dependent rows are refused."""
+    from test_gpu_parity import assert_solve_parity
+    B = 40
+    bv = linear_rhs(B)
+    (ph, _), (po, _) = linear_problem(hip, B, bv), linear_problem(oracle, B, bv)
+    for p in (ph, po):
+        T.initial_controls(p, np.array([0.3, 0.5])); T.rollout(p); I.dual_update(p); I.dual_update(p)
+    np.testing.assert_allclose(T.evaluate_constraints(ph, 0), T.evaluate_constraints(po, 0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(T.constraint_jacobians(ph, 0), T.constraint_jacobians(po, 0))
+    np.testing.assert_allclose(T.max_violation(ph), T.max_violation(po), rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(I.al_cost(ph), I.al_cost(po), rtol=1e-11)
+    for p in (ph, po):
+        I.expand(p); I.backwardpass(p)
+    gh, go = I.gains(ph), I.gains(po)
+    np.testing.assert_allclose(gh["K"], go["K"], rtol=1e-7, atol=1e-9); np.testing.assert_allclose(gh["d"], go["d"], rtol=1e-7, atol=1e-9)
+    lh, Jh = I.forwardpass(ph); lo, Jo = I.forwardpass(po)
+    np.testing.assert_array_equal(lh, lo); np.testing.assert_allclose(Jh, Jo, rtol=1e-10)
+    for Solver in (T.ALSolver, T.ALTROSolver):
+        (ph, _), (po, _) = linear_problem(hip, B, bv), linear_problem(oracle, B, bv)
+        sh, so = Solver(ph).solve(), Solver(po).solve()
+        assert_solve_parity(sh, so, ph, po)
+        assert (sh.stats["status"] == T.capi.SOLVE_SUCCEEDED).all()
+        X, U = T.states(ph), T.controls(ph)
+        c0 = X[:, :-1, 0] - 0.5 * X[:, :-1, 1] - bv[:, None, 0]
+        c1 = U[:, :, 0] + 2 * U[:, :, 1] - bv[:, None, 1]
+        assert max(c0.max(), c1.max()) < 2e-6 and (np.abs(c1).min(axis=1) < 1e-3).mean() > 0.2     # every trajectory inside ITS half-planes; the control row binds for some
+    model = T.DoubleIntegrator(1.0, 2)
+    cons = T.ConstraintList(4, 2, 11)
+    T.add_constraint(cons, T.LinearConstraint(4, 2, np.array([[1.0, 2.0], [2.0, 4.0]]), np.zeros(2), T.Inequality(), inds=[1, 2]), (1, 10))
+    obj = T.LQRObjective(np.ones(4), np.ones(2), np.ones(4), np.zeros(4), 11)
+    for lib in (hip,):
+        pd = T.Problem(model, obj, np.zeros(4), 1.0, constraints=cons, batch=3, lib=lib)
+        with pytest.raises(T.UnsupportedError, match="linearly independent"):
+            T.set_constraint_params_batch(pd, 0, np.zeros((3, 2)))

@@ -1711,3 +1711,44 @@ def test_packed_quadrotor_expansion_is_bit_identical(integration, constrained, h
         np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
     np.testing.assert_array_equal(X0, X1); np.testing.assert_array_equal(U0, U1)
     assert s1["iterations"].min() >= 3
+
+
+@pytest.mark.parametrize("rot", ["mrp", "rp"])
+def test_packed_expansion_three_parameter_attitudes(rot, hip, oracle, monkeypatch):
+    """The packed expansion also serves RigidBody{MRP} / RigidBody{RodriguesParam} with a compact cost block (DiagonalCost): the same six
+    constant columns.  Equal to the 4 x 16 kernel bit for bit, and equal to the oracle as before."""
+    def mk(lib):
+        model = T.Quadrotor(rotation=rot)
+        n, m = model.dims()
+        x0 = np.zeros(n); x0[:3] = [0.4, -0.3, 1.0]
+        xf = np.zeros(n); xf[:3] = [0.0, 0.0, 1.5]
+        obj = T.LQRObjective(np.full(n, 0.1), np.full(m, 0.01), np.full(n, 10.0), xf, 31)
+        p = T.Problem(model, obj, x0, 1.0, xf=xf, lib=lib, batch=23)
+        X0 = np.tile(x0, (23, 1)); X0[:, :3] += np.random.default_rng(6).uniform(-0.3, 0.3, (23, 3)); X0[:, 3:6] = np.random.default_rng(7).uniform(-0.1, 0.1, (23, 3))
+        p.set_initial_state(X0)
+        T.initial_controls(p, model.hover_control())
+        return p
+    out = []
+    for pack in ("0", "1"):
+        monkeypatch.setenv("TRAJOPT_EXPAND_PACK", pack)
+        p = mk(hip)
+        perturb_controls((p,), 0.05)
+        T.rollout(p); I.expand(p)
+        A, Bm = I.dynamics_jacobians(p)
+        ce = I.cost_expansion(p)
+        s = T.iLQRSolver(p, iterations=25).solve()
+        out.append((A, Bm, ce, s.stats["iterations"].copy(), T.states(p), T.controls(p)))
+    np.testing.assert_array_equal(out[0][0], out[1][0]); np.testing.assert_array_equal(out[0][1], out[1][1])
+    for k in out[0][2]:
+        np.testing.assert_array_equal(out[0][2][k], out[1][2][k], err_msg=k)
+    np.testing.assert_array_equal(out[0][3], out[1][3]); np.testing.assert_array_equal(out[0][4], out[1][4]); np.testing.assert_array_equal(out[0][5], out[1][5])
+    monkeypatch.setenv("TRAJOPT_EXPAND_PACK", "1")
+    ph, po = mk(hip), mk(oracle)
+    perturb_controls((ph, po), 0.05)
+    for p in (ph, po):
+        T.rollout(p); I.expand(p)
+    Ah, Bh = I.dynamics_jacobians(ph); Ao, Bo = I.dynamics_jacobians(po)
+    np.testing.assert_allclose(Ah, Ao, rtol=1e-9, atol=1e-11); np.testing.assert_allclose(Bh, Bo, rtol=1e-9, atol=1e-11)
+    info = (ctypes.c_int32 * 8)()
+    ph._call("solver_path", info)
+    assert info[0] == 1          # MFMA backward pass: the tangent-matrix (packed) expansion ran

@@ -33,7 +33,7 @@ from ._capi import (ArgumentError, DimensionMismatch, ConstraintDesc, CostDesc, 
                     SolverOpts, SolveStats, UnsupportedError)
 
 __all__ = [
-    "clear_goal_state_batch", "InfeasibleModel", "InfeasibleConstraint", "InfeasibleProblem", "infeasible_controls",
+    "clear_goal_state_batch", "set_constraint_params_batch", "InfeasibleModel", "InfeasibleConstraint", "InfeasibleProblem", "infeasible_controls",
     "DoubleIntegrator", "Cartpole", "Quadrotor", "DiscreteMap", "LinearMap", "ModelVector", "HybridDoubleIntegrator", "pad_cost", "dims", "RK4", "RK3", "Euler",
     "DiagonalCost", "QuadraticCost", "LQRCost", "DiagonalQuatCost", "ErrorQuadratic", "QuatLQRCost",
     "Objective", "LQRObjective", "TrackingObjective",
@@ -1440,6 +1440,17 @@ def _set_goal_state_batch(prob, Xf, objective=True, constraint=True):
             q = -(Xf @ c.Q.T) if c.kind == capi.COST_QUADRATIC else -(Xf * c.Q[None, :])   # [B, n] = column-major (n, B)
             prob._call("set_cost_linear_batch", i, prob._pd(np.ascontiguousarray(q)), None)
     prob.xf_batch = Xf.copy()
+
+
+def set_constraint_params_batch(prob, con_id, params):
+    """One parameter set per TRAJECTORY for constraint ``con_id`` (0-based position in the ConstraintList): ``params`` [B, p] — a
+    GoalConstraint's target xf_b[inds], or a LinearConstraint's right-hand side b_b (to_set_constraint_params_batch).  ``set_goal_state``
+    with a matrix calls this for every GoalConstraint; ``clear_goal_state_batch`` returns every constraint to its shared parameters."""
+    con = prob.constraints.constraints[con_id]
+    par = np.ascontiguousarray(np.asarray(params, dtype=np.float64))
+    if par.shape != (prob.B, con.p):
+        raise DimensionMismatch(f"params must be [B, p] = {(prob.B, con.p)}; got {par.shape}")
+    prob._call("set_constraint_params_batch", int(con_id), prob._pd(par))
 
 
 def clear_goal_state_batch(prob):

@@ -130,7 +130,7 @@ __device__ __forceinline__ double knot_cost(const DevProblem& P, int k, const do
         double zc[nz];
 #pragma unroll
         for (int i = 0; i < nz; ++i) zc[i] = z[i];
-        con_shift<n>(P, K, cp0, zc);
+        con_shift<nz>(P, K, cp0, zc);
         Ja += al_term<n, m, GEN>(K, zc, lam, (size_t)64, EL(mu0, ci));
       } else
       Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
@@ -159,7 +159,7 @@ __device__ __forceinline__ double knot_al_cached(const DevProblem& P, int k, con
 #pragma unroll
     for (int i = 0; i < m; ++i) z[n + i] = u[i];
     const double* lam = lam0 + (size_t)(K.dual_off + (long long)(k - K.k1) * K.p) * 64;
-    if constexpr (GEN) con_shift<n>(P, K, cp0, z);  // (z is rebuilt for every table constraint)
+    if constexpr (GEN) con_shift<nz>(P, K, cp0, z);  // (z is rebuilt for every table constraint)
     Ja += al_term<n, m, GEN>(K, z, lam, (size_t)64, EL(mu0, ci));
   }
   return Ja;
@@ -198,7 +198,7 @@ __device__ __forceinline__ double knot_violation(const DevProblem& P, int k, con
     double zc[nz];
 #pragma unroll
     for (int i = 0; i < nz; ++i) zc[i] = z[i];
-    con_shift<n>(P, K, cp0, zc);
+    con_shift<nz>(P, K, cp0, zc);
     const double v = con_violation<nz>(K, zc);
     if (!(v <= vmax)) vmax = v;
   }
@@ -237,7 +237,7 @@ __device__ __forceinline__ void trajectory_pass(const KArgs& a, int tile, int la
         double zc[nz];
 #pragma unroll
         for (int i = 0; i < nz; ++i) zc[i] = z[i];
-        con_shift<n>(P, K, cp0, zc);
+        con_shift<nz>(P, K, cp0, zc);
         con_dual_update<nz>(K, zc, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
       }
     }

@@ -16,20 +16,20 @@ namespace to {
 // one knot of the expansion for lane (g, j): x = x_k, u = u_k (zeros at the terminal knot), x1 = x_{k+1}
 // LAY: where the columns go.  0: column layout (cooperative backward pass); 1: tangent-matrix layout, full cost block;
 // 2: tangent-matrix layout, compact cost block; 3: lane layout (one lane per trajectory backward pass) — all in k_backward.h.
-// PACK (rigid body with a quaternion attitude, compact cost block): six of the sixteen columns of [Ā B̄] are CONSTANTS — the dynamics do
+// PACK (rigid body — quaternion, MRP or Rodrigues attitude —, compact cost block): six of the sixteen columns of [Ā B̄] are CONSTANTS — the dynamics do
 // not read the position, and the (world-frame) velocity only as ṙ = v, so ∂x⁺/∂r = [I; 0; 0; 0] and ∂x⁺/∂v = [h I; 0; I; 0] for every
 // Runge-Kutta scheme — and live in Mt from k_expand_const_columns on.  A wave then holds SIX trajectories x the TEN differentiated
 // columns (attitude, ω, controls) instead of four x sixteen; the lanes of the first six of them also deliver the cost entries of one
 // constant column each (jc >= 0): the cost (+AL) Hessian-vector product is taken with the direction of the own column PLUS e_jc — the
 // compact cost block is block-diagonal with r and v on 1 x 1 blocks (KArgs::h_compact), so entry jc of the product is exactly the diagonal
 // entry of column jc and every other entry is what the own direction alone gives — and the gradient does not depend on the direction.
-template <class M> struct ExpandPack { static constexpr bool ok = M::lie && M::att == ATT_QUAT && M::ne == 12 && M::m == 4 && Tm<M>::fits; };
+template <class M> struct ExpandPack { static constexpr bool ok = M::lie && (M::att == ATT_QUAT || M::att == ATT_MRP || M::att == ATT_RP) && M::ne == 12 && M::m == 4 && Tm<M>::fits; };
 template <class M, int FIXED_INTEG, int VAR, int LAY, bool PACK = false>
 __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane, int tile, int lane64, int b, int j, int k, bool valid,
                                             const double* x, const double* u, const double* x1, const ConExp<M::m>& ce0,
                                             const ConExp<M::m>& ce1, bool table_cons, int jc = -1, bool valid_c = false) {
   constexpr int n = M::n, m = M::m, ne = M::ne, nz = n + m, nc = ne + m;
-  static_assert(!PACK || (LAY == 2 && ExpandPack<M>::ok), "packed expansion: compact tangent-matrix layout of the quaternion rigid body");
+  static_assert(!PACK || (LAY == 2 && ExpandPack<M>::ok), "packed expansion: compact tangent-matrix layout of the rigid body");
   constexpr int NEP = Tm<M>::NEP, RS = Tm<M>::RS, NR = Tm<M>::NR;
   const int ct = j < ne ? j : NEP + (j - ne);  // tangent index of this lane's column
   const DevProblem& P = a.P;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
   }
   // ---- cost (+AL) gradient and Hessian-vector product on the full state
   double gr[nz], y[nz];
-  const int sc = jc < 3 ? jc : jc + 1;  // state index of the constant column this lane serves (error index 6..8 = state 7..9); PACK only
+  const int sc = (n == 13 && jc >= 3) ? jc + 1 : jc;  // state index of the constant column this lane serves (quaternion states: error index 6..8 = state 7..9); PACK only
   if constexpr (PACK) {  // (from here on v carries e_sc as well; the own column's dot products below skip that entry)
 #pragma unroll
     for (int i = 0; i < n; ++i) v[i] = (jc >= 0 && i == sc) ? 1.0 : v[i];
@@ -135,7 +135,7 @@ __device__ __forceinline__ void expand_knot(const KArgs& a, int gtile, int lane,
           double zc[nz];
 #pragma unroll
           for (int i = 0; i < nz; ++i) zc[i] = z[i];
-          con_shift<n>(P, K, P.cp + ((size_t)tile * (size_t)P.n_cp) * 64 + lane64, zc);
+          con_shift<nz>(P, K, P.cp + ((size_t)tile * (size_t)P.n_cp) * 64 + lane64, zc);
           al_grad_hvp<n, m, true>(K, zc, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
         } else
         al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
@@ -472,7 +472,7 @@ __device__ __forceinline__ void expand_lane_knot(const KArgs& a, int tile, int l
           double zc[nz];
 #pragma unroll
           for (int i = 0; i < nz; ++i) zc[i] = z[i];
-          con_shift<n>(P, K, P.cp + ((size_t)tile * (size_t)P.n_cp) * 64 + lane, zc);
+          con_shift<nz>(P, K, P.cp + ((size_t)tile * (size_t)P.n_cp) * 64 + lane, zc);
           al_grad_hvp<n, m, true>(K, zc, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);
         } else
         al_grad_hvp<n, m, (VAR & 4) != 0>(K, z, lam, (size_t)64, EL(mu0, ci), v, gr, y, P.opts.al_full_newton != 0);

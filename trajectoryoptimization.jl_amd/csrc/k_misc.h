@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) k_outer_update(KArgs a) {
     double zc[nz];
 #pragma unroll
     for (int i = 0; i < nz; ++i) zc[i] = z[i];
-    con_shift<n>(P, K, TILE_PTR(P.cp, P.n_cp), zc);
+    con_shift<nz>(P, K, TILE_PTR(P.cp, P.n_cp), zc);
     con_dual_update<nz>(K, zc, lam, (size_t)64, EL(mu0, ci), P.opts.dual_max);
   }
   EL(TILE_PTR(a.knotbuf, N), k) = knot_cost<M>(P, k, x, u, lam0, mn0, true, TILE_PTR(P.gl, P.n_costs * nz), TILE_PTR(P.cp, P.n_cp));
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64) k_constraint_eval(KArgs a, int ci, double*
   for (int i = 0; i < n; ++i) z[i] = EL(X, k * n + i);
 #pragma unroll
   for (int i = 0; i < m; ++i) z[n + i] = (k < N - 1) ? EL(U, k * m + i) : 0.0;
-  con_shift<n>(P, K, TILE_PTR(P.cp, P.n_cp), z);
+  con_shift<nz>(P, K, TILE_PTR(P.cp, P.n_cp), z);
   const size_t kb = (size_t)kk + (size_t)nk * b;
   const int p = K.p, w = K.width;
   double coef[nz];

@@ -148,7 +148,7 @@ PN_FN void pn_for_candidates(const DevProblem& P, int k, const double* zin, cons
     ConC& K = P.cons[ci];
     if (k < K.k1 || k > K.k2) continue;
     for (int i = 0; i < nz; ++i) z[i] = zin[i];
-    con_shift<M::n>(P, K, cp0, z);  // the state as this constraint sees it (a shift: values change, gradients do not)
+    con_shift<nz>(P, K, cp0, z);  // the state as this constraint sees it (a shift: values change, gradients do not)
     const int p = K.p;
     if (K.d.sense == TO_CONE_SECOND_ORDER) {
       double a2 = 0.0;

@@ -22,7 +22,7 @@ struct DevCon {
   int sidx[TO_MAX_P];       // selector rows: 0-based index into z, or -1 for a constant row (value = soff)
   double ssgn[TO_MAX_P];
   double soff[TO_MAX_P];
-  int cp_off;               // >= 0: this constraint sees the STATE shifted by the per-trajectory block DevProblem::cp[cp_off .. cp_off + n)
+  int cp_off;               // >= 0: this constraint sees z = [x; u] shifted by the per-trajectory block DevProblem::cp[cp_off .. cp_off + n + m)
                             // (to_set_constraint_params_batch: one GoalConstraint target per trajectory); -1: shared parameters only
 };
 
@@ -54,20 +54,20 @@ struct DevProblem {
   // what its q_i (i < n) / r_{i-n} differs by from cost ci's descriptor.  NULL (the default): every trajectory shares the descriptors.
   const double* gl;
   // Per-trajectory constraint parameters (to_set_constraint_params_batch: set_goal_state!(prob, Xf; constraint = true) with one goal per
-  // trajectory, src/problem.jl:303-309): tiled array, L = n_cp = n * n_cons; block ci holds what trajectory b's GoalConstraint target
+  // trajectory, src/problem.jl:303-309): tiled array, L = n_cp = (n + m) * n_cons; block ci holds what trajectory b's GoalConstraint target
   // differs by from the descriptor's, scattered onto the state indices — the constraint with target xf + d IS the shared constraint
-  // evaluated at x - d (same value, same Jacobian), so every evaluation site shifts the state it hands to a flagged constraint
-  // (con_shift).  NULL (the default): every trajectory shares the descriptors.  Read by the GENERAL kernel variants only.
+  // evaluated at x - d (same value, same Jacobian), so every evaluation site shifts the z it hands to a flagged constraint
+  // (con_shift).  A LinearConstraint A z = b + db is the shared one seen from z - A^+ db (the host forms the minimum-norm A^+ db).  NULL (the default): every trajectory shares the descriptors.  Read by the GENERAL kernel variants only.
   const double* cp;
   int n_cp;
 };
 
-// z as constraint K sees it for this lane's trajectory (cp0: the lane's pointer to entry 0 of DevProblem::cp)
-template <int n>
+// z = [x; u] as constraint K sees it for this lane's trajectory (cp0: the lane's pointer to entry 0 of DevProblem::cp; blocks of nz = n + m)
+template <int nz>
 __device__ __forceinline__ void con_shift(const DevProblem& P, ConC& K, const double* cp0, double* z) {
   if (P.cp != nullptr && K.cp_off >= 0) {  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < n; ++i) z[i] -= cp0[(size_t)(K.cp_off + i) * 64];
+    for (int i = 0; i < nz; ++i) z[i] -= cp0[(size_t)(K.cp_off + i) * 64];
   }
 }
 

@@ -1408,21 +1408,51 @@ int to_set_constraint(to_handle* h, int32_t id, const to_constraint_desc* c) {
   if (!any) h->a.P.cp = nullptr;
   return upload_tables(h);
 }
-// One parameter set per TRAJECTORY for constraint con_id.  GOAL: params[p, B] = xf_b[inds].  Stored as the state shift the constraint
-// sees (DevProblem::cp): the GoalConstraint with target xf + d is the shared one evaluated at x - d.
+// One parameter set per TRAJECTORY for constraint con_id.  GOAL: params[p, B] = xf_b[inds]; LINEAR: params[p, B] = b_b.  Stored as the shift of
+// z = [x; u] the constraint sees (DevProblem::cp): the GoalConstraint with target xf + d is the shared one evaluated at x - d, the
+// LinearConstraint with b + db the shared one at z - A^+ db.
 int to_set_constraint_params_batch(to_handle* h, int32_t id, const double* params) {
   CHECK_H(h); CHECK_IDLE(h); CHECK_P(params); TRY(use_device(h));
   if (id < 0 || id >= (int)h->cons.size()) return fail(TO_ERR_ARGUMENT, "constraint id out of range");
   DevCon& ci = h->cons[id];
-  if (ci.d.kind != TO_CON_GOAL) return fail(TO_ERR_UNSUPPORTED, "per-trajectory constraint parameters: GoalConstraint only");
+  if (ci.d.kind != TO_CON_GOAL && ci.d.kind != TO_CON_LINEAR)
+    return fail(TO_ERR_UNSUPPORTED, "per-trajectory constraint parameters: GoalConstraint (its target) and LinearConstraint (its b) only");
   DevProblem& P = h->a.P;
-  const int n = P.n, B = P.B, p = ci.p, L = n * (int)h->cons.size();
+  const int n = P.n, nz = P.n + P.m, B = P.B, p = ci.p, L = nz * (int)h->cons.size();
+  std::vector<double> shift((size_t)nz * B, 0.0);
+  if (ci.d.kind == TO_CON_GOAL) {
+    for (int b = 0; b < B; ++b)
+      for (int r = 0; r < p; ++r) shift[(size_t)(ci.d.inds[r] - 1) + (size_t)nz * b] = params[r + (size_t)p * b] - ci.d.params[r];
+  } else {
+    // A z[inds] - (b + db) = A (z[inds] - dz) - b with the minimum-norm dz = A'(A A')^-1 db: needs linearly independent rows
+    const int D = ci.d.n_inds;
+    const double* A = ci.d.params;          // p x D, column-major
+    const double* b0 = ci.d.params + (size_t)p * D;
+    std::vector<double> G((size_t)p * p, 0.0), Lc((size_t)p * p, 0.0), w(p), y(p);
+    double gmax = 0.0;
+    for (int i = 0; i < p; ++i)
+      for (int j = 0; j < p; ++j) { double t = 0.0; for (int c = 0; c < D; ++c) t += A[i + (size_t)p * c] * A[j + (size_t)p * c]; G[i + (size_t)p * j] = t; if (i == j) gmax = std::fmax(gmax, t); }
+    for (int j = 0; j < p; ++j) {  // Cholesky of A A'
+      double d = G[j + (size_t)p * j];
+      for (int k = 0; k < j; ++k) d -= Lc[j + (size_t)p * k] * Lc[j + (size_t)p * k];
+      if (!(d > 1e-12 * gmax)) return fail(TO_ERR_UNSUPPORTED, "per-trajectory b of a LinearConstraint: the rows of A must be linearly independent");
+      Lc[j + (size_t)p * j] = std::sqrt(d);
+      for (int i = j + 1; i < p; ++i) {
+        double t = G[i + (size_t)p * j];
+        for (int k = 0; k < j; ++k) t -= Lc[i + (size_t)p * k] * Lc[j + (size_t)p * k];
+        Lc[i + (size_t)p * j] = t / Lc[j + (size_t)p * j];
+      }
+    }
+    for (int b = 0; b < B; ++b) {
+      for (int i = 0; i < p; ++i) { double t = params[i + (size_t)p * b] - b0[i]; for (int k = 0; k < i; ++k) t -= Lc[i + (size_t)p * k] * y[k]; y[i] = t / Lc[i + (size_t)p * i]; }
+      for (int i = p - 1; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < p; ++k) t -= Lc[k + (size_t)p * i] * w[k]; w[i] = t / Lc[i + (size_t)p * i]; }
+      for (int c = 0; c < D; ++c) { double t = 0.0; for (int i = 0; i < p; ++i) t += A[i + (size_t)p * c] * w[i]; shift[(size_t)(ci.d.inds[c] - 1) + (size_t)nz * b] += t; }
+    }
+    (void)n;
+  }
   if (!h->d_cp) TRY(dev_alloc(h, &h->d_cp, (size_t)L * P.Bp));  // zero-filled
-  std::vector<double> shift((size_t)n * B, 0.0);
-  for (int b = 0; b < B; ++b)
-    for (int r = 0; r < p; ++r) shift[(size_t)(ci.d.inds[r] - 1) + (size_t)n * b] = params[r + (size_t)p * b] - ci.d.params[r];
-  TRY(upload_vec(h, shift.data(), h->d_cp, n, L, id * n));
-  ci.cp_off = id * n;
+  TRY(upload_vec(h, shift.data(), h->d_cp, nz, L, id * nz));
+  ci.cp_off = id * nz;
   P.cp = h->d_cp; P.n_cp = L;
   return upload_tables(h);
 }
