@@ -405,3 +405,54 @@ def test_rccl_stub_builds_and_exports_what_the_library_binds(tmp_path):
     out = subprocess.run(["nm", "-D", "--defined-only", str(so)], check=True, capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (nccl\w+)", out))
     assert wanted <= exported, sorted(wanted - exported)
+
+
+def test_solve_pipeline_host_logic():
+    """api.SolvePipeline without a GPU: mock solvers record what the pipeline does to them.  Job i runs on handle i % depth; a handle's previous
+    job is collected (wait, on_done, results) before the handle is prepared again; the job in front is asked to drain below the admission
+    threshold before the next solve is started; drain() collects what is in flight oldest first; every job is reported exactly once."""
+    log = []
+
+    class FakeProb:
+        def __init__(self, name):
+            self.name, self.B = name, 100
+
+    class FakeSolver:
+        def __init__(self, name):
+            self.prob, self.stats = FakeProb(name), {"iterations": np.zeros(3, np.int32)}
+            self.total_iterations, self.batch_steps, self.inflight = 0, 0, None
+
+        def solve_async(self):
+            assert self.inflight is None, "a handle was restarted before its previous job was collected"
+            self.inflight = len([e for e in log if e[0] == "start"])
+            log.append(("start", self.prob.name, self.inflight))
+
+        def wait(self):
+            assert self.inflight is not None
+            log.append(("wait", self.prob.name, self.inflight))
+            self.total_iterations, self.batch_steps = 10 + self.inflight, 3
+            self.stats["iterations"][:] = self.inflight
+            self.inflight = None
+
+        def wait_below(self, thr):
+            log.append(("wait_below", self.prob.name, thr))
+
+    solvers = [FakeSolver("h%d" % i) for i in range(3)]
+    done = []
+    pipe = T.SolvePipeline(solvers, admit_below=40, keep_stats=True, on_done=lambda job, s: done.append((job, s.prob.name)))
+    prepared = []
+    for _ in range(8):
+        pipe.submit(lambda p: prepared.append(p.name))
+    pipe.drain()
+    assert prepared == ["h0", "h1", "h2", "h0", "h1", "h2", "h0", "h1"]
+    assert [d[0] for d in done] == list(range(8)) and [d[1] for d in done] == prepared       # every job once, in order, on its handle
+    assert [r[0] for r in pipe.results] == list(range(8)) and pipe.total_iterations == sum(10 + j for j in range(8))
+    assert all(int(r[3]["iterations"][0]) == r[0] for r in pipe.results)                      # the stats snapshot is the job's own
+    starts = [e for e in log if e[0] == "start"]
+    assert [e[1] for e in starts] == prepared
+    # before start k (k >= 1) the job in front (on the previous handle) was asked to drain below the threshold
+    for k in range(1, 8):
+        i = log.index(starts[k])
+        assert ("wait_below", prepared[k - 1], 40) in log[:i]
+    # default admission: at once (threshold = the whole batch)
+    assert T.SolvePipeline([FakeSolver("x"), FakeSolver("y")]).admit_below == 100
