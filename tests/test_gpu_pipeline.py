@@ -106,3 +106,29 @@ def test_repacked_working_set_carries_duals(hip, monkeypatch):
     _assert_same(out[0][:3], out[1][:3])
     np.testing.assert_array_equal(out[0][3], out[1][3])
     assert len(set(out[0][0]["iterations"])) > 3
+
+
+@pytest.mark.parametrize("workload", ["C2", "C3"])
+def test_pipelined_full_size_baseline_shapes(workload, hip):
+    """bench.py's pipelined lines at BASELINE's own sizes — C2 (Cartpole N=101, B=1024) and C3 (Quadrotor N=201, B=4096), four handles, earliest
+    admission: every one of the jobs equals the unpipelined solve bit for bit (iterations, status, states, controls of all trajectories)."""
+    def mk():
+        p = configs.cartpole_problem(batch=1024, lib=hip) if workload == "C2" else configs.quadrotor_problem(batch=4096, lib=hip)
+        return T.iLQRSolver(p)
+    ref = mk()
+    u0 = T.controls(ref.prob)[0, 0].copy()
+    ref.solve()
+    want = _snapshot(ref)
+    solvers = [ref] + [mk() for _ in range(3)]
+    bad = []
+    def check(job, s):
+        got = _snapshot(s)
+        ok = all(np.array_equal(want[0][k], got[0][k]) for k in want[0]) and np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
+        if not ok:
+            bad.append(job)
+    pipe = T.SolvePipeline(solvers, on_done=check)
+    for _ in range(9):
+        pipe.submit(lambda p: T.initial_controls(p, u0))
+    pipe.drain()
+    assert not bad, f"pipelined jobs {bad} differ from the unpipelined solve"
+    assert pipe.total_iterations == 9 * int(want[0]["iterations"].sum())
